@@ -1,0 +1,209 @@
+"""ORACLE (test infrastructure) -- restatement of the multi-speaker generate() loop.
+
+Follows vibevoice/modular/modeling_vibevoice_inference.py:
+  _process_speech_inputs (voice-prompt prefill)     :149-163
+  setup (max_steps, valid tokens, negative prompt)   :372-422
+  hot loop                                            :432-675
+  sample_speech_tokens                                :697-710
+with the HF-GenerationMixin plumbing (DynamicCache, attention masks,
+cache_position) replaced by its arithmetic meaning on *compact per-utterance
+caches* (SURVEY.md 8c): a left-padded row's pads carry no information, position
+ids are cumsum(mask)-1 == index in the compact cache.
+
+Negative (CFG) branch, compact form of :379-386, :549-565, :576-624:
+  * the negative cache of utterance b only ever grows on steps where b emits
+    <speech_diffusion>; the reference forwards all rows and then masks the
+    spurious entry back out (:594-624) -- net effect "nothing appended";
+  * the appended token is the SAME embedding the positive pass consumed at
+    this step (:579-581), or the lone <speech_start> prompt token on step 0;
+  * on <speech_start> (:549-565) everything but the first entry is dropped
+    (mask := 0 except last; K/V[last] := K/V[0]) -> compact length 1.
+    (Exact whenever an utterance's first negative step is the batch's first
+    negative step, which the processor's prompt guarantees: every prompt ends
+    in <speech_start>, so step 0 emits <speech_diffusion> for every row.)
+
+PARITY UNPINNED for the orchestration itself (the reference generate() does
+not run under transformers 5.x); every arithmetic stage called from here is
+pinned by tests/golden.
+"""
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import codec, connector, dpm, head
+
+
+@dataclass
+class TokenIds:
+    speech_start_id: int
+    speech_end_id: int
+    speech_diffusion_id: int
+    eos_token_id: int
+    bos_token_id: Optional[int] = None
+    pad_token_id: Optional[int] = None
+
+
+@dataclass
+class OracleModel:
+    lm: object                      # oracle.lm.Qwen2Oracle
+    lm_head: torch.Tensor           # [V, H]
+    head_w: dict
+    head_layers: int
+    ac_w: dict                      # acoustic tokenizer weights (encoder.* / decoder.*)
+    sem_w: dict                     # semantic tokenizer weights (encoder.*)
+    ac_conn: dict
+    sem_conn: dict
+    ratios: list                    # [8,5,5,4,2,2]
+    enc_depths: list                # [3,3,3,3,3,3,8]
+    dec_depths: list                # reversed
+    sem_depths: list
+    scaling: float
+    bias: float
+    fix_std: float = 0.5
+    max_position_embeddings: int = 65536
+    head_eps: float = 1e-5
+    codec_eps: float = 1e-5
+    t_cast_dtype: Optional[torch.dtype] = None
+
+
+@dataclass
+class Trace:
+    pos_hidden: list = field(default_factory=list)
+    neg_hidden: list = field(default_factory=list)
+    latents: list = field(default_factory=list)
+    semantic: list = field(default_factory=list)
+    next_embeds: list = field(default_factory=list)
+    tokens: list = field(default_factory=list)
+
+
+def process_speech_inputs(m: OracleModel, speech_tensors, speech_masks, prefill_noise):
+    """:149-163.  prefill_noise = (randn[n_spk], randn[n_spk, T, 64]) replaces the
+    two device-RNG draws of VibeVoiceTokenizerEncoderOutput.sample('gaussian')
+    (modular_vibevoice_tokenizer.py:980-989)."""
+    lat = codec.encoder_forward(m.ac_w, speech_tensors.unsqueeze(1), m.ratios, m.enc_depths,
+                                state=None, eps=m.codec_eps)
+    mean = lat.permute(0, 2, 1)                                  # [n_spk, T, 64]
+    std = prefill_noise[0] * (m.fix_std / 0.8)
+    x = mean + std[:, None, None] * prefill_noise[1]
+    feats = (x + m.bias) * m.scaling
+    connected = connector.connector_forward(m.ac_conn, feats)[speech_masks]
+    return feats, connected
+
+
+def oracle_generate(m: OracleModel, tok: TokenIds, input_ids, attention_mask,
+                    speech_tensors=None, speech_masks=None, speech_input_mask=None,
+                    cfg_scale=1.3, num_steps=10, max_new_tokens=None, max_length_times=2,
+                    noise_fn: Callable = None, prefill_noise=None,
+                    forced_tokens: Optional[List[List[int]]] = None,
+                    do_sample=False, trace: Optional[Trace] = None):
+    """Returns (sequences [B, L0+steps], speech_outputs list, reach_max_step_sample)."""
+    B, L0 = input_ids.shape
+    if max_new_tokens is None:
+        max_new_tokens = m.max_position_embeddings - L0
+    max_length = L0 + max_new_tokens
+    init_len = attention_mask.sum(-1)
+    max_steps = min(max_length - L0, int(max_length_times * L0))
+    max_step_per_sample = torch.min(max_length - init_len, (max_length_times * init_len).long())
+    valid = [tok.speech_start_id, tok.speech_end_id, tok.speech_diffusion_id, tok.eos_token_id]
+    if tok.bos_token_id is not None:
+        valid.append(tok.bos_token_id)
+
+    finished = torch.zeros(B, dtype=torch.bool)
+    reach_max = torch.zeros(B, dtype=torch.bool)
+    pos_cache = [m.lm.new_cache() for _ in range(B)]
+    neg_cache = [m.lm.new_cache() for _ in range(B)]
+    ac_state = [dict() for _ in range(B)]
+    sem_state = [dict() for _ in range(B)]
+    audio_chunks = [[] for _ in range(B)]
+    seq = input_ids.clone()
+    inputs_embeds = None                     # [B, H] embeds the NEXT positive pass consumes
+
+    for step in range(max_steps):
+        if finished.all():
+            break
+        if seq.shape[-1] >= max_length:
+            reach_max[~finished] = True
+            break
+        # ---- positive LM pass (:466-485) ----
+        hidden = []
+        if step == 0:
+            emb = m.lm.embed(input_ids)                       # [B, L0, H]
+            if speech_tensors is not None:
+                _, sp = process_speech_inputs(m, speech_tensors, speech_masks, prefill_noise)
+                emb[speech_input_mask] = sp
+            for b in range(B):
+                e = emb[b][attention_mask[b].bool()]
+                hidden.append(m.lm.forward(e, pos_cache[b])[-1])
+        else:
+            for b in range(B):
+                hidden.append(m.lm.forward(inputs_embeds[b][None], pos_cache[b])[-1])
+        hidden = torch.stack(hidden)                          # [B, H]
+        consumed = inputs_embeds
+        # ---- token selection (:488-501) ----
+        logits = F.linear(hidden, m.lm_head).float()
+        mask = torch.full_like(logits, float("-inf"))
+        mask[:, valid] = 0
+        scores = logits + mask
+        if forced_tokens is not None:
+            nxt = torch.tensor([forced_tokens[b][step] if step < len(forced_tokens[b])
+                                else tok.eos_token_id for b in range(B)])
+        elif do_sample:
+            nxt = torch.multinomial(torch.softmax(scores, -1), 1).squeeze(1)
+        else:
+            nxt = torch.argmax(scores, dim=-1)
+        nxt[finished] = tok.eos_token_id
+        seq = torch.cat([seq, nxt[:, None]], dim=-1)
+        if trace is not None:
+            trace.pos_hidden.append(hidden.clone())
+            trace.tokens.append(nxt.clone())
+        # ---- bookkeeping (:518-539) ----
+        finished = finished | (nxt == tok.eos_token_id)
+        hit = (step >= max_step_per_sample) & ~finished
+        finished = finished | hit
+        reach_max = reach_max | hit
+        # ---- <speech_end>: zero both conv caches (:542-546) ----
+        for b in (nxt == tok.speech_end_id).nonzero().flatten().tolist():
+            codec.zero_state(ac_state[b])
+            codec.zero_state(sem_state[b])
+        # ---- <speech_start>: reset the negative branch (:549-565) ----
+        for b in (~finished & (nxt == tok.speech_start_id)).nonzero().flatten().tolist():
+            if neg_cache[b].length > 0:
+                neg_cache[b].truncate(1)
+        next_embeds = m.lm.embed(nxt)                          # [B, H]
+        diff = (~finished & (nxt == tok.speech_diffusion_id)).nonzero().flatten().tolist()
+        if diff:
+            n = len(diff)
+            neg_hidden = []
+            for b in diff:
+                e = m.lm.embed(torch.tensor([tok.speech_start_id])) if consumed is None else consumed[b][None]
+                neg_hidden.append(m.lm.forward(e, neg_cache[b])[-1])
+            neg_hidden = torch.stack(neg_hidden)
+            pos_cond = hidden[diff]
+            noise = noise_fn(step, 2 * n)
+            lat = dpm.sample_speech_tokens(
+                lambda x, t, c: head.head_forward(m.head_w, x, t, c, m.head_layers, m.head_eps),
+                pos_cond, neg_hidden, cfg_scale, num_steps, noise, m.t_cast_dtype)
+            scaled = lat / m.scaling - m.bias
+            sem_list = []
+            for j, b in enumerate(diff):
+                chunk = codec.decoder_forward(m.ac_w, scaled[j][None, :, None], m.ratios, m.dec_depths,
+                                              state=ac_state[b], eps=m.codec_eps)      # [1,1,3200]
+                audio_chunks[b].append(chunk[0])
+                sem = codec.encoder_forward(m.sem_w, chunk, m.ratios, m.sem_depths,
+                                            state=sem_state[b], eps=m.codec_eps)        # [1,128,1]
+                sem_list.append(sem[0, :, 0])
+            sem_feat = torch.stack(sem_list)
+            emb = connector.connector_forward(m.ac_conn, lat) + connector.connector_forward(m.sem_conn, sem_feat)
+            next_embeds[diff] = emb
+            if trace is not None:
+                trace.neg_hidden.append(neg_hidden.clone())
+                trace.latents.append(lat.clone())
+                trace.semantic.append(sem_feat.clone())
+        if trace is not None:
+            trace.next_embeds.append(next_embeds.clone())
+        inputs_embeds = next_embeds
+
+    outs = [torch.cat(c, dim=-1) if c else None for c in audio_chunks]
+    return seq, outs, reach_max
