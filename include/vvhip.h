@@ -1,0 +1,130 @@
+/* vvhip.h -- C ABI of libvvhip.so, the MI355X (gfx950) engine behind
+ * VibeVoiceForConditionalGenerationInference.generate().
+ *
+ * The reference (vibevoice-community/VibeVoice) is pure Python: its "operator
+ * interface" for this path is the set of nn.Module calls generate() makes per
+ * step.  Each entry point below replaces one of those calls (file:line into
+ * /root/reference/vibevoice/modular/); INTEGRATION.md shows the ctypes binding a
+ * maintainer would add to modeling_vibevoice_inference.py.
+ *
+ * Conventions: plain C, opaque context, no torch types.  Pointers suffixed _dev
+ * are device pointers (e.g. tensor.data_ptr()); the caller keeps them alive until
+ * the stream has consumed them.  `stream` is a hipStream_t passed as void*
+ * (0 = default stream).  Every function returns 0 on success, <0 on error
+ * (vv_last_error() gives the text).  No hidden syncs except where stated; no
+ * allocation after vv_create() except lazily-built hipGraphs and scratch on the
+ * first call of a given shape.
+ */
+#ifndef VVHIP_H
+#define VVHIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vv_ctx vv_ctx;
+
+typedef struct vv_config {
+    /* Qwen2 decoder (configs/qwen2.5_*.json "decoder_config") */
+    int lm_hidden, lm_layers, lm_heads, lm_kv_heads, lm_head_dim, lm_inter, lm_vocab;
+    float lm_eps;
+    /* diffusion head ("diffusion_head_config") */
+    int head_layers, head_ffn, latent_dim;
+    float head_eps;
+    /* tokenizers ("acoustic_tokenizer_config", "semantic_tokenizer_config") */
+    int n_filters, n_ratios, ratios[8];
+    int n_stages, enc_depths[8]; /* encoder order; decoder uses the reverse */
+    int sem_dim;                 /* semantic vae_dim (0 = no semantic tokenizer) */
+    int has_acoustic_encoder;    /* voice-prompt path */
+    float codec_eps;
+    /* runtime */
+    int n_slots;       /* concurrent utterances: 2 KV caches (cond/uncond) + 2 conv states each */
+    int max_ctx;       /* KV positions per cache (rounded up to 128) */
+    int max_rows;      /* max LM rows per step (<=16) */
+    int xsplit;        /* activation precision inside MFMA: 1 bf16, 2 ~fp24, 3 fp32-exact */
+    int attn_splits;   /* flash-decoding splits along the sequence */
+    int enc_frames;    /* frames per chunk of the voice-prompt encoder (>=1) */
+    int use_graph;     /* replay captured hipGraphs for repeated shapes */
+} vv_config;
+
+int vv_create(const vv_config* cfg, vv_ctx** out);
+void vv_destroy(vv_ctx* ctx);
+const char* vv_last_error(vv_ctx* ctx);
+
+/* ---- parameters.  Names are the reference state_dict keys with the prefixes
+ * model.language_model.->"lm."  model.prediction_head.->"head."
+ * model.acoustic_tokenizer.decoder.->"dec."  model.acoustic_tokenizer.encoder.->"aenc."
+ * model.semantic_tokenizer.encoder.->"senc."  model.acoustic_connector.->"ac_conn."
+ * model.semantic_connector.->"sem_conn."  lm_head.weight (optional: tied -> embed_tokens),
+ * plus "lm.rope.inv_freq" (fp32 [head_dim/2], the table HF computes in Qwen2RotaryEmbedding).
+ * The engine repacks every matrix into MFMA-fragment tiles (bf16). */
+int vv_num_weights(vv_ctx* ctx);
+int vv_weight_info(vv_ctx* ctx, int idx, char* name, int name_cap, int64_t* nelem, int* loaded);
+/* src may be a host or a device pointer; src_dtype 0 = fp32, 1 = bf16. Synchronous. */
+int vv_upload(vv_ctx* ctx, const char* name, const void* src, int src_dtype, int64_t nelem);
+/* scalar buffers speech_scaling_factor / speech_bias_factor (modeling_vibevoice.py:131-132) */
+int vv_set_speech_factors(vv_ctx* ctx, float scaling, float bias);
+/* ids the constrained sampler may emit (VibeVoiceTokenConstraintProcessor, modeling_vibevoice_inference.py:53-66,405-419) */
+int vv_set_valid_tokens(vv_ctx* ctx, const int* ids, int n);
+/* DPM-Solver++ table for N steps: t[N] (the timestep values fed to the head) and coef[N][5] =
+ * {alpha_i, sigma_i, sigma_{i+1}/sigma_i, -alpha_{i+1}(e^{-h}-1), second-order term}
+ * (dpm_solver.py:321-423,581-584,669-677,738-764) -- computed by vibevoice_amd/schedule.py */
+int vv_set_schedule(vv_ctx* ctx, int n_steps, const float* t, const float* coef, void* stream);
+
+/* ---- KV caches: cache id = 2*slot (+1 for the CFG-negative branch) */
+typedef struct vv_row { int cache; int pos; } vv_row;
+
+/* One Qwen2 forward over n_rows tokens, each appended to its cache at rows[i].pos
+ * (== the cache length before this token).  Replaces self(**model_inputs, ...)
+ * (modeling_vibevoice_inference.py:480-482 -> modeling_vibevoice.py:187-199 -> HF Qwen2Model)
+ * for the positive rows and :583-585 for the negative rows -- both in ONE pass
+ * over the weights.  hidden_out = last_hidden_state (after the final RMSNorm). */
+int vv_lm_forward(vv_ctx* ctx, void* stream, int n_rows, const vv_row* rows,
+                  const float* x_in_dev, float* hidden_out_dev);
+/* embed_tokens lookup (modeling_vibevoice_inference.py:218,569); ids on host */
+int vv_embed(vv_ctx* ctx, void* stream, int n, const int* ids, float* out_dev);
+/* logits restricted to the valid ids: replaces lm_head + constraint mask (:241-242,488-490).
+ * logits_out_dev [n][n_valid] fp32 in the order given to vv_set_valid_tokens. */
+int vv_lm_logits(vv_ctx* ctx, void* stream, int n, const float* hidden_dev, float* logits_out_dev);
+
+/* sample_speech_tokens (:697-710): cond_dev [2n][H] = n positive then n negative
+ * conditions, noise_dev [n][latent], -> latent_out_dev [n][latent] */
+int vv_diffusion_sample(vv_ctx* ctx, void* stream, int n, const float* cond_dev, const float* noise_dev,
+                        float cfg_scale, float* latent_out_dev);
+/* one prediction_head forward (modular_vibevoice_diffusion_head.py:254-280) for tests:
+ * noisy [n][latent], t[n] (host), cond [n][H] -> out [n][latent].  Synchronous. */
+int vv_head_forward(vv_ctx* ctx, void* stream, int n, const float* noisy_dev, const float* t_host,
+                    const float* cond_dev, float* out_dev);
+
+/* acoustic_tokenizer.decode(latent/scale - bias, cache, use_cache=True) (:636-643) for one
+ * utterance slot: latent_dev [frames][latent] -> audio_out_dev [frames*hop]. */
+int vv_codec_decode(vv_ctx* ctx, void* stream, int slot, int frames, const float* latent_dev,
+                    float* audio_out_dev, int apply_speech_factors);
+/* semantic_tokenizer.encode(audio, cache, use_cache=True).mean (:658-664) */
+int vv_semantic_encode(vv_ctx* ctx, void* stream, int slot, int frames, const float* audio_dev,
+                       float* sem_out_dev);
+/* acoustic_tokenizer.encode(wav).mean, non-streaming (:154; modular_vibevoice_tokenizer.py:1081-1085):
+ * wav_dev [frames*hop] -> mean_out_dev [frames][latent] */
+int vv_acoustic_encode(vv_ctx* ctx, void* stream, int frames, const float* wav_dev, float* mean_out_dev);
+/* acoustic_cache.set_to_zero + semantic_cache.set_to_zero for a slot (:542-546) */
+int vv_codec_reset(vv_ctx* ctx, void* stream, int slot);
+/* acoustic_connector(latent) [+ semantic_connector(sem)] (:667-669, :161); sem_dev may be NULL */
+int vv_connect(vv_ctx* ctx, void* stream, int n, const float* latent_dev, const float* sem_dev,
+               float* embeds_out_dev);
+
+/* ---- low-level entry points (tests, microbenchmarks) */
+/* pack a row-major fp32 [N][K] matrix into fragment tiles; dst needs vv_packed_bytes(N,K) */
+int64_t vv_packed_bytes(int N, int K);
+int vv_pack_matrix(void* stream, const float* src_dev, void* dst_dev, int N, int K);
+/* Y[T][N] = X[T][K] . W^T with the given prologue/epilogue ids (vv_common.h) */
+int vv_gemm_raw(void* stream, const void* w_packed_dev, const void* w2_packed_dev, const float* x_dev,
+                float* y_dev, int T, int N, int K, int ldx, int ldy, int pro, int epi,
+                const float* nw_dev, float eps, const float* bias_dev, const float* nscale_dev,
+                int xsplit, int ksplit, int nontemporal);
+/* number of kernel launches issued by the last engine call (graph nodes when replayed) */
+int64_t vv_stat(vv_ctx* ctx, int what);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

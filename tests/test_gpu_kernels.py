@@ -1,0 +1,307 @@
+"""GPU parity: every HIP stage (through the C ABI) against the oracle on seeded inputs.
+
+Tolerances (stated, fp32-class): with xsplit=3 the engine multiplies exact bf16
+weights by exact fp32 activations and accumulates in fp32, so the only
+differences from the fp32 oracle are summation order and libm ulps:
+rel-L2 <= 2e-5 per GEMM, <= 1e-4 per composed stage; the LM additionally
+keeps a bf16 KV cache, which the oracle mirrors with kv_round_bf16=True.
+xsplit=1 (bf16 activations inside the MFMA, the reference's GPU numerics):
+rel-L2 <= 2e-2.
+"""
+import numpy as np
+import pytest
+import torch
+
+import synth
+from gpu_util import build_small, max_err, rel_err
+from oracle import codec, connector, dpm, head
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sm():
+    s = build_small(synth.LMCfg(), xsplit=3)
+    yield s
+    s.eng.close()
+
+
+def dev(t, eng):
+    out = t.to(eng.device, torch.float32).contiguous()
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("T,N,K", [(1, 64, 64), (2, 48, 96), (2, 4608, 3584), (16, 200, 72), (2, 64, 18944),
+                                   (37, 130, 40), (200, 128, 32), (5, 20, 7)])
+@pytest.mark.parametrize("xs,tol", [(3, 2e-5), (2, 2e-4), (1, 2e-2)])
+def test_gemm_plain(sm, T, N, K, xs, tol):
+    eng = sm.eng
+    g = synth.Gen(T * 1000 + N + K)
+    w = g.normal((N, K), 1.0 / np.sqrt(K))
+    x = g.normal((T, K), 1.0, mat=False)
+    ref = x @ w.t()
+    wp = eng.pack_matrix(w)
+    xd = dev(x, eng)
+    for ks in (0, 1, 2, 4):
+        y = eng.new(T, N)
+        with torch.cuda.stream(eng.stream):
+            eng.gemm_raw(wp, xd, y, N, K, xsplit=xs, ksplit=ks, nontemporal=ks & 1)
+        eng.sync()
+        assert rel_err(y, ref) <= tol, (ks, rel_err(y, ref))
+
+
+def test_gemm_transpose_detecting(sm):
+    # A = identity-like weights, asymmetric x: catches row/col swaps in the MFMA layout
+    eng = sm.eng
+    N = K = 64
+    w = torch.eye(N)
+    x = torch.arange(3 * K, dtype=torch.float32).reshape(3, K) / 7.0
+    wp = eng.pack_matrix(w)
+    y = eng.new(3, N)
+    with torch.cuda.stream(eng.stream):
+        eng.gemm_raw(wp, dev(x, eng), y, N, K, xsplit=3)
+    eng.sync()
+    assert max_err(y, x) < 1e-6
+
+
+@pytest.mark.parametrize("pro,epi", [(1, 1), (1, 2), (0, 4), (1, 3), (0, 0)])
+def test_gemm_fused(sm, pro, epi):
+    eng = sm.eng
+    T, N, K = 3, 96, 160
+    g = synth.Gen(77 + pro * 10 + epi)
+    w = g.normal((N, K), 1.0 / np.sqrt(K))
+    w2 = g.normal((N, K), 1.0 / np.sqrt(K))
+    x = g.normal((T, K), 1.0, mat=False)
+    nw = g.vec(K, 0.1, 1.0)
+    bias = g.vec(N, 0.3)
+    nscale = g.uniform((N,), 0.5, 1.5)
+    y0 = g.normal((T, N), 1.0, mat=False)
+    xin = x
+    if pro == 1:
+        xin = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-5) * nw
+    acc = xin @ w.t()
+    if epi == 1:
+        ref = acc + bias
+    elif epi == 2:
+        ref = torch.nn.functional.gelu(acc + bias)
+    elif epi == 3:
+        ref = torch.nn.functional.silu(acc) * (xin @ w2.t())
+    elif epi == 4:
+        ref = y0 + nscale * (acc + bias)
+    else:
+        ref = acc
+    y = dev(y0.clone(), eng)
+    with torch.cuda.stream(eng.stream):
+        eng.gemm_raw(eng.pack_matrix(w), dev(x, eng), y, N, K, pro=pro, epi=epi,
+                     w2p=eng.pack_matrix(w2) if epi == 3 else None, nw=dev(nw, eng), eps=1e-5,
+                     bias=dev(bias, eng), nscale=dev(nscale, eng), xsplit=3)
+    eng.sync()
+    assert rel_err(y, ref) <= 2e-5, rel_err(y, ref)
+
+
+def test_head_forward(sm):
+    eng = sm.eng
+    g = synth.Gen(100)
+    noisy = g.normal((4, 64), 1.0, mat=False)
+    cond = g.normal((4, sm.hc.hidden), 1.0, mat=False)
+    for t in (999.0, 500.0, 3.0):
+        ref = head.head_forward(sm.head_w, noisy, torch.full((4,), t), cond, sm.hc.layers, sm.hc.eps)
+        out = eng.new(4, 64)
+        with torch.cuda.stream(eng.stream):
+            eng.head_forward(dev(noisy, eng), t, dev(cond, eng), out)
+        eng.sync()
+        assert rel_err(out, ref) <= 1e-4, (t, rel_err(out, ref))
+
+
+@pytest.mark.parametrize("n_steps", [5, 10, 20])
+@pytest.mark.parametrize("n", [1, 2])
+def test_sampler(sm, n_steps, n):
+    eng = sm.eng
+    g = synth.Gen(200 + n_steps + n)
+    pos = g.normal((n, sm.hc.hidden), 1.0, mat=False)
+    neg = g.normal((n, sm.hc.hidden), 1.0, mat=False)
+    noise = g.normal((2 * n, 64), 1.0, mat=False)
+    ref = dpm.sample_speech_tokens(lambda x, t, c: head.head_forward(sm.head_w, x, t, c, sm.hc.layers, sm.hc.eps),
+                                   pos, neg, 1.3, n_steps, noise)
+    eng.set_num_steps(n_steps)
+    out = eng.new(n, 64)
+    with torch.cuda.stream(eng.stream):
+        eng.diffusion_sample(n, dev(torch.cat([pos, neg]), eng), dev(noise[:n], eng), 1.3, out)
+    eng.sync()
+    assert rel_err(out, ref) <= 5e-4, rel_err(out, ref)
+
+
+def test_connectors(sm):
+    eng = sm.eng
+    g = synth.Gen(400)
+    lat = g.normal((3, 64), 1.0, mat=False)
+    sem = g.normal((3, 128), 1.0, mat=False)
+    ref = connector.connector_forward(sm.ac_conn, lat) + connector.connector_forward(sm.sem_conn, sem)
+    out = eng.new(3, sm.lmcfg.hidden)
+    with torch.cuda.stream(eng.stream):
+        eng.connect(3, dev(lat, eng), dev(sem, eng), out)
+    eng.sync()
+    assert rel_err(out, ref) <= 5e-5
+    ref2 = connector.connector_forward(sm.ac_conn, lat)
+    with torch.cuda.stream(eng.stream):
+        eng.connect(3, dev(lat, eng), None, out)
+    eng.sync()
+    assert rel_err(out, ref2) <= 5e-5
+
+
+def test_codec_decode_stream_reset(sm):
+    eng = sm.eng
+    cc = sm.cc
+    g = synth.Gen(300)
+    nfr = 7
+    lat = g.normal((nfr, 64), 1.0, mat=False)
+    st = {}
+    slot = 1
+    with torch.cuda.stream(eng.stream):
+        eng.codec_reset(slot)
+    for t in range(nfr):
+        scaled = lat[t] / sm.scaling - sm.bias
+        ref = codec.decoder_forward(sm.ac_w, scaled[None, :, None], cc.ratios, cc.dec_depths, st, cc.eps)[0, 0]
+        out = eng.new(3200)
+        with torch.cuda.stream(eng.stream):
+            eng.codec_decode(slot, dev(lat[t:t + 1], eng), out)
+        eng.sync()
+        assert rel_err(out, ref) <= 2e-4, (t, rel_err(out, ref))
+        if t == 3:
+            codec.zero_state(st)
+            with torch.cuda.stream(eng.stream):
+                eng.codec_reset(slot)
+
+
+def test_semantic_encode_stream(sm):
+    eng = sm.eng
+    sc = sm.sc
+    g = synth.Gen(301)
+    nfr = 5
+    audio = g.uniform((nfr, 3200), -0.5, 0.5)
+    st = {}
+    for t in range(nfr):
+        ref = codec.encoder_forward(sm.sem_w, audio[t][None, None], sc.ratios, sc.enc_depths, st, sc.eps)[0, :, 0]
+        out = eng.new(128)
+        with torch.cuda.stream(eng.stream):
+            eng.semantic_encode(0, dev(audio[t], eng), out)
+        eng.sync()
+        assert rel_err(out, ref) <= 2e-4, (t, rel_err(out, ref))
+        if t == 2:
+            codec.zero_state(st)
+            with torch.cuda.stream(eng.stream):
+                eng.codec_reset(0)
+
+
+def test_acoustic_encode_nonstream(sm):
+    eng = sm.eng
+    cc = sm.cc
+    g = synth.Gen(302)
+    nfr = 5                                  # enc_frames=2 -> chunks of 2,2,1
+    wav = g.uniform((nfr * 3200,), -0.5, 0.5)
+    ref = codec.encoder_forward(sm.ac_w, wav[None, None], cc.ratios, cc.enc_depths, None, cc.eps)[0].t()
+    out = eng.new(nfr, 64)
+    with torch.cuda.stream(eng.stream):
+        eng.acoustic_encode(nfr, dev(wav, eng), out)
+    eng.sync()
+    assert rel_err(out, ref) <= 2e-4, rel_err(out, ref)
+
+
+LM_CASES = {"d64": synth.LMCfg(), "d128": synth.LMCfg(hidden=256, heads=2, kv_heads=1, inter=384),
+            "gqa": synth.LMCfg(hidden=256, heads=4, kv_heads=2, inter=320, layers=3)}
+
+
+@pytest.mark.parametrize("tag", ["d64", "d128", "gqa"])
+def test_lm_prefill_decode_and_logits(tag):
+    s = build_small(LM_CASES[tag], xsplit=3, max_ctx=1024)
+    eng = s.eng
+    try:
+        H = s.lmcfg.hidden
+        m = s.oracle_lm(kv_round_bf16=True)
+        g = synth.Gen(500)
+        L0 = 37
+        ids = torch.from_numpy(g.rng.integers(0, s.lmcfg.vocab, (L0,)))
+        oc = m.new_cache()
+        ref_pre = m.forward(m.embed(ids), oc)
+        emb = eng.new(L0, H)
+        for i0 in range(0, L0, 16):
+            with torch.cuda.stream(eng.stream):
+                eng.embed(ids[i0:i0 + 16].tolist(), emb[i0:])
+        eng.sync()
+        assert max_err(emb, m.embed(ids)) == 0.0
+        hid = eng.new(L0, H)
+        for i0 in range(0, L0, 16):
+            n = min(16, L0 - i0)
+            with torch.cuda.stream(eng.stream):
+                eng.lm_forward([(2, i0 + j) for j in range(n)], emb[i0:i0 + n], hid[i0:i0 + n])
+        eng.sync()
+        assert rel_err(hid, ref_pre) <= 3e-4, rel_err(hid, ref_pre)
+        # decode steps on cache 2 plus an independent short cache 1 in the same pass
+        oc2 = m.new_cache()
+        x = g.normal((6, 2, H), 1.0, mat=False)
+        for i in range(6):
+            r1 = m.forward(x[i, 0:1], oc)
+            r2 = m.forward(x[i, 1:2], oc2)
+            out = eng.new(2, H)
+            with torch.cuda.stream(eng.stream):
+                eng.lm_forward([(2, L0 + i), (1, i)], dev(x[i], eng), out)
+            eng.sync()
+            assert rel_err(out[0], r1[0]) <= 3e-4, (i, rel_err(out[0], r1[0]))
+            assert rel_err(out[1], r2[0]) <= 3e-4, (i, rel_err(out[1], r2[0]))
+        # restricted logits
+        valid = [5, 17, 300 % s.lmcfg.vocab, 2]
+        eng.set_valid_tokens(valid)
+        lg = eng.new(2, len(valid))
+        with torch.cuda.stream(eng.stream):
+            eng.lm_logits(2, out, lg)
+        eng.sync()
+        ref_lg = torch.nn.functional.linear(torch.stack([r1[0], r2[0]]), s.lm_head)[:, valid]
+        assert rel_err(lg, ref_lg) <= 5e-4
+    finally:
+        eng.close()
+
+
+def test_lm_long_context_split_attention():
+    # many positions -> every flash-decoding split and the tail masking are exercised
+    s = build_small(LM_CASES["gqa"], xsplit=3, max_ctx=2048)
+    eng = s.eng
+    try:
+        H = s.lmcfg.hidden
+        m = s.oracle_lm(kv_round_bf16=True)
+        g = synth.Gen(501)
+        L0 = 700
+        x = g.normal((L0, H), 1.0, mat=False)
+        oc = m.new_cache()
+        ref = m.forward(x, oc)
+        hid = eng.new(L0, H)
+        xd = dev(x, eng)
+        for i0 in range(0, L0, 16):
+            n = min(16, L0 - i0)
+            with torch.cuda.stream(eng.stream):
+                eng.lm_forward([(0, i0 + j) for j in range(n)], xd[i0:i0 + n], hid[i0:i0 + n])
+        eng.sync()
+        assert rel_err(hid[-50:], ref[-50:]) <= 5e-4, rel_err(hid[-50:], ref[-50:])
+        assert rel_err(hid, ref) <= 5e-4
+    finally:
+        eng.close()
+
+
+def test_bf16_activation_mode_tolerance():
+    s = build_small(synth.LMCfg(), xsplit=1)
+    eng = s.eng
+    try:
+        g = synth.Gen(600)
+        pos = g.normal((1, s.hc.hidden), 1.0, mat=False)
+        neg = g.normal((1, s.hc.hidden), 1.0, mat=False)
+        noise = g.normal((2, 64), 1.0, mat=False)
+        ref = dpm.sample_speech_tokens(lambda x, t, c: head.head_forward(s.head_w, x, t, c, s.hc.layers, s.hc.eps),
+                                       pos, neg, 1.3, 10, noise)
+        eng.set_num_steps(10)
+        out = eng.new(1, 64)
+        with torch.cuda.stream(eng.stream):
+            eng.diffusion_sample(1, dev(torch.cat([pos, neg]), eng), dev(noise[:1], eng), 1.3, out)
+        eng.sync()
+        assert rel_err(out, ref) <= 5e-2, rel_err(out, ref)
+    finally:
+        eng.close()

@@ -1,0 +1,862 @@
+// engine.hip -- host side of libvvhip.so: context, parameter registry/repacking,
+// op orchestration (LM step, diffusion sampler, streaming codecs, connectors),
+// hipGraph capture/replay.  Device work lives in gemm.hip / attn.hip / misc.hip.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/vvhip.h"
+#include "vv_common.h"
+
+extern "C" {
+int vv_gemm_launch(VVGemm a, int xs, hipStream_t s);
+int vv_pack_launch(const void* src, int src_is_bf16, void* dst, int N, int K, int kind, int Cin, int Cout, int ksz,
+                   int stride, hipStream_t s);
+int vv_rope_append_launch(int D, const float* qkv, const VVRow* rows, const float* inv_freq, float* q_out, void* kc,
+                          void* vc, int R, int Hq, int Hkv, int64_t cache_stride, int64_t head_stride, hipStream_t s);
+int vv_attn_launch(int D, int xs, const float* q, const VVRow* rows, const void* kc, const void* vc, int R, int Hq,
+                   int Hkv, int64_t cache_stride, int64_t head_stride, int S, float* pm, float* pl, float* po,
+                   float* out, hipStream_t s);
+int vv_embed_launch(const void* table, const int* ids, float* out, int n, int H, hipStream_t s);
+int vv_rmsnorm_rows_launch(const float* x, int ldx, float* y, int ldy, const float* w, int T, int C, float eps, hipStream_t s);
+int vv_dwconv_res_launch(const float* nb, float* x, const float* w, const float* b, const float* gamma, int T, int C, hipStream_t s);
+int vv_shift_rows_launch(const void* tab, int n_entries, int maxC, hipStream_t s);
+int vv_zero_hist_launch(const void* tab, int n_entries, hipStream_t s);
+int vv_cfg_dpm_launch(const float* eps, float* x, float* x0_prev, const float* coef, float cfg, int n, int L, hipStream_t s);
+int vv_affine_launch(const float* x, float* y, float mul, float add, int n, hipStream_t s);
+int vv_add_launch(const float* a, const float* b, float* y, int n, hipStream_t s);
+int vv_tfreq_launch(const float* t, float* out, int n, hipStream_t s);
+int vv_silu_launch(float* x, int n, hipStream_t s);
+int vv_cvt_launch(const void* src, void* dst, int64_t n, int to_bf16, hipStream_t s);
+int vv_dw_transpose_launch(const float* src, float* dst, int C, hipStream_t s);
+}
+
+struct VVShiftH { float* buf; int T, hist, C; };
+
+static thread_local char g_err[512] = "";
+
+namespace {
+
+enum WKind { W_MAT = 0, W_VEC = 1, W_DW = 2, W_TABLE = 3, W_BIAS_REP = 4 };
+
+struct Weight {
+    std::string name;
+    int kind = W_VEC;
+    int64_t nelem = 0;          // source element count
+    void* dev = nullptr;        // final storage
+    // W_MAT packing parameters
+    int N = 0, K = 0, pk = 0, Cin = 0, Cout = 0, ksz = 0, stride = 0;
+    int rep = 1;                // W_BIAS_REP: repeat count
+    bool loaded = false;
+    bool optional = false;
+};
+
+struct Block {
+    int C;
+    float *norm_w, *ffn_norm_w, *gamma, *ffn_gamma, *dw_w, *dw_b, *b1, *b2;
+    void *w1, *w2;
+    float* nb;                  // [6 + Tmax][C] normed buffer with history
+};
+
+struct ConvG {                  // conv / transposed conv as a GEMM over a time-major buffer
+    void* w; float* bias;
+    int K, N, ldx;              // per output row
+    int rows_per_frame;         // output rows per frame
+};
+
+struct Stage {
+    int C, Tpf;                 // channels, time steps per frame
+    int hist;                   // history rows kept in front of xs
+    float* xs;                  // [hist + Tmax][C]
+    std::vector<Block> blocks;
+    ConvG in;                   // produces this stage's rows from the previous buffer
+};
+
+struct CodecNet {
+    bool decoder = false;
+    int Fmax = 1, in_dim = 1, out_dim = 1, in_hist = 6, in_Tpf = 1;
+    std::vector<float*> in_buf;            // per slot: [6 + Tin][in_dim]
+    std::vector<std::vector<Stage>> st;    // per slot
+    ConvG head;
+    float* u = nullptr;                    // FFN hidden scratch (shared)
+    std::vector<std::map<int, void*>> shift_tab;   // per slot: F -> device table
+    std::vector<int> shift_n;
+    std::vector<void*> zero_tab;
+    int maxC = 1;
+};
+
+struct GraphEntry { hipGraphExec_t exec; };
+
+}  // namespace
+
+struct vv_ctx {
+    vv_config c;
+    char err[512];
+    std::vector<Weight> w;
+    std::map<std::string, int> widx;
+    int H, D, Hq, Hkv, I, QKV;
+    // LM params
+    struct Layer { float *ln1, *ln2, *bqkv; void *wqkv, *wo, *wg, *wu, *wd; };
+    std::vector<Layer> layers;
+    float *lm_norm = nullptr, *inv_freq = nullptr;
+    void *embed = nullptr, *lm_head = nullptr;
+    bool lm_head_loaded = false;
+    void* valid_w = nullptr; int n_valid = 0;
+    // LM runtime
+    void *kc = nullptr, *vc = nullptr;
+    int64_t cache_stride = 0, head_stride = 0, layer_stride = 0;
+    VVRow* rows_dev = nullptr; VVRow* rows_pin = nullptr;
+    int* ids_dev = nullptr; int* ids_pin = nullptr;
+    float *h = nullptr, *qkv = nullptr, *qrot = nullptr, *attn = nullptr, *act = nullptr;
+    float *pm = nullptr, *pl = nullptr, *po = nullptr;
+    // head
+    int HF = 0, MODW = 0;
+    struct HLayer { float* norm; void *wg, *wu, *wd; };
+    std::vector<HLayer> hl;
+    void *h_in = nullptr, *h_cond = nullptr, *h_t0 = nullptr, *h_t2 = nullptr, *h_ada = nullptr, *h_out = nullptr;
+    int n_steps = 0;
+    float *temb = nullptr, *coef = nullptr, *tvals = nullptr;
+    float *cproj = nullptr, *mod = nullptr, *zz = nullptr, *x0p = nullptr, *xh = nullptr, *hact = nullptr, *eps = nullptr;
+    float *tmp1 = nullptr, *tmp2 = nullptr;
+    // connectors
+    struct Conn { void *fc1, *fc2; float *b1, *b2, *norm; } ac_conn, sem_conn;
+    float *ct1 = nullptr;
+    // codecs
+    CodecNet dec, aenc, senc;
+    float scaling = 1.f, bias = 0.f;
+    int hop = 3200;
+    // staging
+    void* stage = nullptr; size_t stage_bytes = 0;
+    std::map<std::string, GraphEntry> graphs;
+    int64_t launches = 0;
+};
+
+static int fail(vv_ctx* ctx, const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt);
+    char* dst = ctx ? ctx->err : g_err;
+    vsnprintf(dst, 512, fmt, ap);
+    va_end(ap);
+    if (ctx) snprintf(g_err, 512, "%s", ctx->err);
+    return -1;
+}
+#define HIPCHK(ctx, e) do { hipError_t _e = (e); if (_e != hipSuccess) return fail(ctx, "%s:%d hip error %s", __FILE__, __LINE__, hipGetErrorString(_e)); } while (0)
+#define VVCHK(e) do { int _r = (e); if (_r != 0) return _r < 0 ? fail(ctx, "%s:%d launch failed (%d): %s", __FILE__, __LINE__, _r, hipGetErrorString(hipGetLastError())) : _r; } while (0)
+
+static void* dalloc(vv_ctx* ctx, size_t bytes, bool zero = true) {
+    void* p = nullptr;
+    if (bytes == 0) bytes = 16;
+    if (hipMalloc(&p, bytes) != hipSuccess) { fail(ctx, "hipMalloc(%zu) failed", bytes); return nullptr; }
+    if (zero) hipMemset(p, 0, bytes);
+    return p;
+}
+
+static int add_w(vv_ctx* ctx, const std::string& name, int kind, int64_t nelem, bool optional = false) {
+    Weight w; w.name = name; w.kind = kind; w.nelem = nelem; w.optional = optional;
+    ctx->widx[name] = (int)ctx->w.size();
+    ctx->w.push_back(w);
+    return (int)ctx->w.size() - 1;
+}
+// registers a packed matrix stored inside `base` at n-tile offset `ntile_off` of a [Ntot x K] tile array
+static void add_mat(vv_ctx* ctx, const std::string& name, int N, int K, void* base, int ntile_off,
+                    int pk = 0, int Cin = 0, int Cout = 0, int ksz = 0, int stride = 0, int64_t src_nelem = -1) {
+    int i = add_w(ctx, name, W_MAT, src_nelem < 0 ? (int64_t)N * K : src_nelem);
+    Weight& w = ctx->w[i];
+    w.N = N; w.K = K; w.pk = pk; w.Cin = Cin; w.Cout = Cout; w.ksz = ksz; w.stride = stride;
+    const int k_tiles = (K + 31) / 32;
+    w.dev = (char*)base + (int64_t)ntile_off * k_tiles * 1024;
+}
+static void* alloc_packed(vv_ctx* ctx, int N, int K) { return dalloc(ctx, (size_t)vv_packed_elems(N, K) * 2); }
+static float* add_vec(vv_ctx* ctx, const std::string& name, int64_t n, float* dst = nullptr, int kind = W_VEC, int rep = 1) {
+    int i = add_w(ctx, name, kind, n);
+    if (!dst) dst = (float*)dalloc(ctx, (size_t)n * rep * 4);
+    ctx->w[i].dev = dst; ctx->w[i].rep = rep;
+    return dst;
+}
+
+// ------------------------------------------------------------------ codec nets
+static int build_codec(vv_ctx* ctx, CodecNet& net, const std::string& pfx, bool decoder, int vae_dim, int Fmax, int n_slots) {
+    const vv_config& c = ctx->c;
+    const int ns = c.n_stages;
+    const int nf = c.n_filters;
+    net.decoder = decoder; net.Fmax = Fmax;
+    std::vector<int> depths(ns), ratios(c.n_ratios);
+    if (decoder) { for (int i = 0; i < ns; ++i) depths[i] = c.enc_depths[ns - 1 - i]; for (int i = 0; i < c.n_ratios; ++i) ratios[i] = c.ratios[i]; }
+    else { for (int i = 0; i < ns; ++i) depths[i] = c.enc_depths[i]; for (int i = 0; i < c.n_ratios; ++i) ratios[i] = c.ratios[c.n_ratios - 1 - i]; }
+    int hop = 1; for (int i = 0; i < c.n_ratios; ++i) hop *= c.ratios[i];
+    ctx->hop = hop;
+    // per-stage geometry
+    std::vector<int> C(ns), Tpf(ns);
+    for (int i = 0; i < ns; ++i) {
+        if (decoder) { C[i] = nf << (ns - 1 - i); Tpf[i] = (i == 0) ? 1 : Tpf[i - 1] * ratios[i - 1]; }
+        else { C[i] = nf << i; Tpf[i] = (i == 0) ? hop : Tpf[i - 1] / ratios[i - 1]; }
+    }
+    net.in_dim = decoder ? vae_dim : 1;
+    net.out_dim = decoder ? 1 : vae_dim;
+    net.in_Tpf = decoder ? 1 : hop;
+    net.in_hist = 6;
+    net.maxC = 1;
+    size_t umax = 0;
+    // ---- weights (shared across slots) ----
+    struct StageW { ConvG in; std::vector<Block> blocks; };
+    std::vector<StageW> sw(ns);
+    for (int i = 0; i < ns; ++i) {
+        ConvG& g = sw[i].in;
+        char nm[256];
+        if (i == 0) {
+            const int Cin = net.in_dim;
+            g.K = 7 * Cin; g.N = C[0]; g.ldx = Cin; g.rows_per_frame = Tpf[0];
+            g.w = alloc_packed(ctx, g.N, g.K);
+            snprintf(nm, 256, "%s%s.0.0.conv.conv.", pfx.c_str(), decoder ? "upsample_layers" : "downsample_layers");
+            add_mat(ctx, std::string(nm) + "weight", g.N, g.K, g.w, 0, 1, Cin, g.N, 7, 1);
+            g.bias = add_vec(ctx, std::string(nm) + "bias", g.N);
+        } else if (decoder) {
+            const int s = ratios[i - 1], Cin = C[i - 1], Cout = C[i];
+            g.K = 2 * Cin; g.N = s * Cout; g.ldx = Cin; g.rows_per_frame = Tpf[i - 1];
+            g.w = alloc_packed(ctx, g.N, g.K);
+            snprintf(nm, 256, "%supsample_layers.%d.0.convtr.convtr.", pfx.c_str(), i);
+            add_mat(ctx, std::string(nm) + "weight", g.N, g.K, g.w, 0, 2, Cin, Cout, 2 * s, s, (int64_t)Cin * Cout * 2 * s);
+            g.bias = add_vec(ctx, std::string(nm) + "bias", Cout, nullptr, W_BIAS_REP, s);
+        } else {
+            const int s = ratios[i - 1], Cin = C[i - 1], Cout = C[i];
+            g.K = 2 * s * Cin; g.N = Cout; g.ldx = s * Cin; g.rows_per_frame = Tpf[i];
+            g.w = alloc_packed(ctx, g.N, g.K);
+            snprintf(nm, 256, "%sdownsample_layers.%d.0.conv.conv.", pfx.c_str(), i);
+            add_mat(ctx, std::string(nm) + "weight", g.N, g.K, g.w, 0, 1, Cin, Cout, 2 * s, s);
+            g.bias = add_vec(ctx, std::string(nm) + "bias", Cout);
+        }
+        if (C[i] > net.maxC) net.maxC = C[i];
+        for (int j = 0; j < depths[i]; ++j) {
+            Block b; b.C = C[i]; b.nb = nullptr;
+            snprintf(nm, 256, "%sstages.%d.%d.", pfx.c_str(), i, j);
+            std::string p(nm);
+            b.gamma = add_vec(ctx, p + "gamma", C[i]);
+            b.ffn_gamma = add_vec(ctx, p + "ffn_gamma", C[i]);
+            b.norm_w = add_vec(ctx, p + "norm.weight", C[i]);
+            b.ffn_norm_w = add_vec(ctx, p + "ffn_norm.weight", C[i]);
+            b.dw_w = add_vec(ctx, p + "mixer.conv.conv.conv.weight", (int64_t)C[i] * 7, nullptr, W_DW);
+            b.dw_b = add_vec(ctx, p + "mixer.conv.conv.conv.bias", C[i]);
+            b.w1 = alloc_packed(ctx, 4 * C[i], C[i]);
+            add_mat(ctx, p + "ffn.linear1.weight", 4 * C[i], C[i], b.w1, 0);
+            b.b1 = add_vec(ctx, p + "ffn.linear1.bias", 4 * C[i]);
+            b.w2 = alloc_packed(ctx, C[i], 4 * C[i]);
+            add_mat(ctx, p + "ffn.linear2.weight", C[i], 4 * C[i], b.w2, 0);
+            b.b2 = add_vec(ctx, p + "ffn.linear2.bias", C[i]);
+            sw[i].blocks.push_back(b);
+            size_t ub = (size_t)Tpf[i] * Fmax * 4 * C[i] * 4;
+            if (ub > umax) umax = ub;
+        }
+    }
+    {   // head conv k7
+        ConvG& g = net.head;
+        const int Cin = C[ns - 1];
+        g.K = 7 * Cin; g.N = net.out_dim; g.ldx = Cin; g.rows_per_frame = Tpf[ns - 1];
+        g.w = alloc_packed(ctx, g.N, g.K);
+        add_mat(ctx, pfx + "head.conv.conv.weight", g.N, g.K, g.w, 0, 1, Cin, g.N, 7, 1);
+        g.bias = add_vec(ctx, pfx + "head.conv.conv.bias", g.N);
+    }
+    net.u = (float*)dalloc(ctx, umax);
+    // ---- per-slot buffers + shift tables ----
+    net.in_buf.resize(n_slots); net.st.resize(n_slots); net.shift_tab.resize(n_slots); net.zero_tab.resize(n_slots);
+    net.shift_n.resize(n_slots);
+    for (int sl = 0; sl < n_slots; ++sl) {
+        net.in_buf[sl] = (float*)dalloc(ctx, (size_t)(6 + net.in_Tpf * Fmax) * net.in_dim * 4);
+        net.st[sl].resize(ns);
+        for (int i = 0; i < ns; ++i) {
+            Stage& s = net.st[sl][i];
+            s.C = C[i]; s.Tpf = Tpf[i]; s.in = sw[i].in;
+            if (i == ns - 1) s.hist = 6;
+            else s.hist = decoder ? 1 : ratios[i];
+            s.xs = (float*)dalloc(ctx, (size_t)(s.hist + (size_t)Tpf[i] * Fmax) * C[i] * 4);
+            s.blocks = sw[i].blocks;
+            for (auto& b : s.blocks) b.nb = (float*)dalloc(ctx, (size_t)(6 + (size_t)Tpf[i] * Fmax) * C[i] * 4);
+        }
+        net.zero_tab[sl] = nullptr;
+    }
+    return 0;
+}
+
+static int codec_tables(vv_ctx* ctx, CodecNet& net, int sl, int F, void** tab_out, int* n_out) {
+    auto it = net.shift_tab[sl].find(F);
+    if (it != net.shift_tab[sl].end()) { *tab_out = it->second; *n_out = net.shift_n[sl]; return 0; }
+    std::vector<VVShiftH> t;
+    t.push_back({net.in_buf[sl], net.in_Tpf * F, 6, net.in_dim});
+    for (auto& s : net.st[sl]) {
+        t.push_back({s.xs, s.Tpf * F, s.hist, s.C});
+        for (auto& b : s.blocks) t.push_back({b.nb, s.Tpf * F, 6, s.C});
+    }
+    void* d = dalloc(ctx, t.size() * sizeof(VVShiftH), false);
+    if (!d) return -1;
+    HIPCHK(ctx, hipMemcpy(d, t.data(), t.size() * sizeof(VVShiftH), hipMemcpyHostToDevice));
+    net.shift_tab[sl][F] = d; net.shift_n[sl] = (int)t.size();
+    *tab_out = d; *n_out = (int)t.size();
+    return 0;
+}
+
+static VVGemm mk_gemm(const void* W, const float* X, float* Y, int T, int N, int K, int ldx, int ldy) {
+    VVGemm g; memset(&g, 0, sizeof(g));
+    g.W = (const u32x4*)W; g.X = X; g.Y = Y; g.T = T; g.N = N; g.K = K; g.ldx = ldx; g.ldy = ldy;
+    g.pro = VV_PRO_NONE; g.epi = VV_EPI_STORE; g.ksplit = 0; g.nt = 0; g.eps = 1e-6f;
+    return g;
+}
+#define GEMM(g) do { ctx->launches++; VVCHK(vv_gemm_launch(g, ctx->c.xsplit, st)); } while (0)
+
+// Runs one codec net over F frames for slot `sl`.  The caller has already written the
+// input rows into net.in_buf[sl] + 6*in_dim.
+static int run_codec(vv_ctx* ctx, CodecNet& net, int sl, int F, float* out, hipStream_t st) {
+    const float eps = ctx->c.codec_eps;
+    const bool stream_w = (F == 1);      // T=1 stages stream their weights exactly once
+    auto& stages = net.st[sl];
+    const int ns = (int)stages.size();
+    for (int i = 0; i < ns; ++i) {
+        Stage& s = stages[i];
+        const int T = s.Tpf * F;
+        float* x = s.xs + (size_t)s.hist * s.C;
+        {   // incoming conv
+            const ConvG& cg = s.in;
+            const float* X = (i == 0) ? net.in_buf[sl] : stages[i - 1].xs;
+            const int Trows = cg.rows_per_frame * F;
+            VVGemm g = mk_gemm(cg.w, X, x, Trows, cg.N, cg.K, cg.ldx, cg.N);
+            g.epi = VV_EPI_BIAS; g.bias = cg.bias; g.nt = stream_w && Trows <= 16;
+            GEMM(g);
+        }
+        for (auto& b : s.blocks) {
+            ctx->launches += 2;
+            VVCHK(vv_rmsnorm_rows_launch(x, s.C, b.nb + 6 * (size_t)s.C, s.C, b.norm_w, T, s.C, eps, st));
+            VVCHK(vv_dwconv_res_launch(b.nb, x, b.dw_w, b.dw_b, b.gamma, T, s.C, st));
+            VVGemm g1 = mk_gemm(b.w1, x, net.u, T, 4 * s.C, s.C, s.C, 4 * s.C);
+            g1.pro = VV_PRO_RMS; g1.nw = b.ffn_norm_w; g1.eps = eps; g1.epi = VV_EPI_BIAS_GELU; g1.bias = b.b1;
+            g1.nt = stream_w && T <= 16;
+            GEMM(g1);
+            VVGemm g2 = mk_gemm(b.w2, net.u, x, T, s.C, 4 * s.C, 4 * s.C, s.C);
+            g2.epi = VV_EPI_RESID; g2.bias = b.b2; g2.nscale = b.ffn_gamma; g2.nt = stream_w && T <= 16;
+            GEMM(g2);
+        }
+    }
+    {   // head conv
+        const ConvG& cg = net.head;
+        Stage& s = stages[ns - 1];
+        VVGemm g = mk_gemm(cg.w, s.xs, out, cg.rows_per_frame * F, cg.N, cg.K, cg.ldx, cg.N);
+        g.epi = VV_EPI_BIAS; g.bias = cg.bias;
+        GEMM(g);
+    }
+    void* tab; int nt;
+    if (codec_tables(ctx, net, sl, F, &tab, &nt)) return -1;
+    ctx->launches++;
+    VVCHK(vv_shift_rows_launch(tab, nt, net.maxC, st));
+    return 0;
+}
+
+static int zero_codec(vv_ctx* ctx, CodecNet& net, int sl, hipStream_t st) {
+    void* tab; int nt;
+    if (codec_tables(ctx, net, sl, 1, &tab, &nt)) return -1;
+    ctx->launches++;
+    VVCHK(vv_zero_hist_launch(tab, nt, st));
+    return 0;
+}
+
+// ------------------------------------------------------------------ graphs
+template <class F>
+static int graphed(vv_ctx* ctx, const std::string& key, hipStream_t st, F&& body) {
+    if (!ctx->c.use_graph) return body();
+    auto it = ctx->graphs.find(key);
+    if (it == ctx->graphs.end()) {
+        // warm run first (lazy allocations, shift tables), then capture
+        int r = body();
+        if (r) return r;
+        hipGraph_t graph;
+        HIPCHK(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+        r = body();
+        hipError_t e = hipStreamEndCapture(st, &graph);
+        if (r) return r;
+        HIPCHK(ctx, e);
+        GraphEntry ge;
+        HIPCHK(ctx, hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0));
+        hipGraphDestroy(graph);
+        ctx->graphs[key] = ge;
+        return 0;       // the warm run already produced this call's result
+    }
+    HIPCHK(ctx, hipGraphLaunch(it->second.exec, st));
+    return 0;
+}
+
+// ------------------------------------------------------------------ API
+extern "C" const char* vv_last_error(vv_ctx* ctx) { return ctx ? ctx->err : g_err; }
+
+extern "C" int vv_create(const vv_config* cfg, vv_ctx** out) {
+    vv_ctx* ctx = new vv_ctx();
+    ctx->c = *cfg; ctx->err[0] = 0;
+    vv_config& c = ctx->c;
+    if (c.max_rows < 1 || c.max_rows > 16) { delete ctx; return fail(nullptr, "max_rows must be in [1,16]"); }
+    if (c.lm_head_dim != 64 && c.lm_head_dim != 128) { delete ctx; return fail(nullptr, "head_dim must be 64 or 128"); }
+    if (c.xsplit < 1 || c.xsplit > 3) c.xsplit = 2;
+    if (c.attn_splits < 1) c.attn_splits = 32;
+    if (c.enc_frames < 1) c.enc_frames = 1;
+    c.max_ctx = (c.max_ctx + 127) & ~127;
+    const int H = ctx->H = c.lm_hidden, D = ctx->D = c.lm_head_dim, Hq = ctx->Hq = c.lm_heads, Hkv = ctx->Hkv = c.lm_kv_heads;
+    const int I = ctx->I = c.lm_inter;
+    const int QKV = ctx->QKV = (Hq + 2 * Hkv) * D;
+    const int R = c.max_rows;
+    // ---- LM ----
+    ctx->embed = dalloc(ctx, (size_t)c.lm_vocab * H * 2);
+    { int i = add_w(ctx, "lm.embed_tokens.weight", W_TABLE, (int64_t)c.lm_vocab * H); ctx->w[i].dev = ctx->embed; }
+    { int i = add_w(ctx, "lm_head.weight", W_TABLE, (int64_t)c.lm_vocab * H, true); ctx->w[i].dev = nullptr; }
+    ctx->inv_freq = add_vec(ctx, "lm.rope.inv_freq", D / 2);
+    ctx->lm_norm = add_vec(ctx, "lm.norm.weight", H);
+    ctx->layers.resize(c.lm_layers);
+    for (int l = 0; l < c.lm_layers; ++l) {
+        auto& L = ctx->layers[l];
+        char nm[128]; snprintf(nm, 128, "lm.layers.%d.", l);
+        std::string p(nm);
+        L.ln1 = add_vec(ctx, p + "input_layernorm.weight", H);
+        L.ln2 = add_vec(ctx, p + "post_attention_layernorm.weight", H);
+        L.wqkv = alloc_packed(ctx, QKV, H);
+        L.bqkv = (float*)dalloc(ctx, (size_t)QKV * 4);
+        add_mat(ctx, p + "self_attn.q_proj.weight", Hq * D, H, L.wqkv, 0);
+        add_mat(ctx, p + "self_attn.k_proj.weight", Hkv * D, H, L.wqkv, Hq * D / 16);
+        add_mat(ctx, p + "self_attn.v_proj.weight", Hkv * D, H, L.wqkv, (Hq + Hkv) * D / 16);
+        add_vec(ctx, p + "self_attn.q_proj.bias", Hq * D, L.bqkv);
+        add_vec(ctx, p + "self_attn.k_proj.bias", Hkv * D, L.bqkv + Hq * D);
+        add_vec(ctx, p + "self_attn.v_proj.bias", Hkv * D, L.bqkv + (Hq + Hkv) * D);
+        L.wo = alloc_packed(ctx, H, Hq * D); add_mat(ctx, p + "self_attn.o_proj.weight", H, Hq * D, L.wo, 0);
+        L.wg = alloc_packed(ctx, I, H); add_mat(ctx, p + "mlp.gate_proj.weight", I, H, L.wg, 0);
+        L.wu = alloc_packed(ctx, I, H); add_mat(ctx, p + "mlp.up_proj.weight", I, H, L.wu, 0);
+        L.wd = alloc_packed(ctx, H, I); add_mat(ctx, p + "mlp.down_proj.weight", H, I, L.wd, 0);
+    }
+    const int n_caches = 2 * c.n_slots;
+    ctx->head_stride = (int64_t)c.max_ctx * D;
+    ctx->layer_stride = ctx->head_stride * Hkv;
+    ctx->cache_stride = ctx->layer_stride * c.lm_layers;
+    ctx->kc = dalloc(ctx, (size_t)ctx->cache_stride * n_caches * 2);
+    ctx->vc = dalloc(ctx, (size_t)ctx->cache_stride * n_caches * 2);
+    ctx->rows_dev = (VVRow*)dalloc(ctx, sizeof(VVRow) * 16);
+    hipHostMalloc((void**)&ctx->rows_pin, sizeof(VVRow) * 16);
+    ctx->ids_dev = (int*)dalloc(ctx, sizeof(int) * 64);
+    hipHostMalloc((void**)&ctx->ids_pin, sizeof(int) * 64);
+    ctx->h = (float*)dalloc(ctx, (size_t)R * H * 4);
+    ctx->qkv = (float*)dalloc(ctx, (size_t)R * QKV * 4);
+    ctx->qrot = (float*)dalloc(ctx, (size_t)R * Hq * D * 4);
+    ctx->attn = (float*)dalloc(ctx, (size_t)R * Hq * D * 4);
+    ctx->act = (float*)dalloc(ctx, (size_t)R * I * 4);
+    const size_t np = (size_t)R * Hkv * c.attn_splits * 16;
+    ctx->pm = (float*)dalloc(ctx, np * 4); ctx->pl = (float*)dalloc(ctx, np * 4); ctx->po = (float*)dalloc(ctx, np * D * 4);
+    // ---- diffusion head ----
+    const int L = c.latent_dim, HL = c.head_layers, HF = ctx->HF = c.head_ffn;
+    const int MODW = ctx->MODW = HL * 3 * H + 2 * H;
+    ctx->h_in = alloc_packed(ctx, H, L); add_mat(ctx, "head.noisy_images_proj.weight", H, L, ctx->h_in, 0);
+    ctx->h_cond = alloc_packed(ctx, H, H); add_mat(ctx, "head.cond_proj.weight", H, H, ctx->h_cond, 0);
+    ctx->h_t0 = alloc_packed(ctx, H, 256); add_mat(ctx, "head.t_embedder.mlp.0.weight", H, 256, ctx->h_t0, 0);
+    ctx->h_t2 = alloc_packed(ctx, H, H); add_mat(ctx, "head.t_embedder.mlp.2.weight", H, H, ctx->h_t2, 0);
+    ctx->h_ada = alloc_packed(ctx, MODW, H);
+    ctx->hl.resize(HL);
+    for (int l = 0; l < HL; ++l) {
+        char nm[128]; snprintf(nm, 128, "head.layers.%d.", l);
+        std::string p(nm);
+        ctx->hl[l].norm = add_vec(ctx, p + "norm.weight", H);
+        add_mat(ctx, p + "adaLN_modulation.1.weight", 3 * H, H, ctx->h_ada, l * 3 * H / 16);
+        ctx->hl[l].wg = alloc_packed(ctx, HF, H); add_mat(ctx, p + "ffn.gate_proj.weight", HF, H, ctx->hl[l].wg, 0);
+        ctx->hl[l].wu = alloc_packed(ctx, HF, H); add_mat(ctx, p + "ffn.up_proj.weight", HF, H, ctx->hl[l].wu, 0);
+        ctx->hl[l].wd = alloc_packed(ctx, H, HF); add_mat(ctx, p + "ffn.down_proj.weight", H, HF, ctx->hl[l].wd, 0);
+    }
+    add_mat(ctx, "head.final_layer.adaLN_modulation.1.weight", 2 * H, H, ctx->h_ada, HL * 3 * H / 16);
+    ctx->h_out = alloc_packed(ctx, L, H); add_mat(ctx, "head.final_layer.linear.weight", L, H, ctx->h_out, 0);
+    const int R2 = 16;
+    ctx->cproj = (float*)dalloc(ctx, (size_t)R2 * H * 4);
+    ctx->mod = (float*)dalloc(ctx, (size_t)R2 * MODW * 4);
+    ctx->zz = (float*)dalloc(ctx, (size_t)R2 * L * 4);
+    ctx->x0p = (float*)dalloc(ctx, (size_t)R2 * L * 4);
+    ctx->xh = (float*)dalloc(ctx, (size_t)R2 * H * 4);
+    ctx->hact = (float*)dalloc(ctx, (size_t)R2 * HF * 4);
+    ctx->eps = (float*)dalloc(ctx, (size_t)R2 * L * 4);
+    ctx->tmp1 = (float*)dalloc(ctx, (size_t)64 * H * 4);
+    ctx->tmp2 = (float*)dalloc(ctx, (size_t)64 * 256 * 4);
+    // ---- connectors ----
+    auto mk_conn = [&](vv_ctx::Conn& cn, const std::string& p, int din) {
+        cn.fc1 = alloc_packed(ctx, H, din); add_mat(ctx, p + "fc1.weight", H, din, cn.fc1, 0);
+        cn.b1 = add_vec(ctx, p + "fc1.bias", H);
+        cn.norm = add_vec(ctx, p + "norm.weight", H);
+        cn.fc2 = alloc_packed(ctx, H, H); add_mat(ctx, p + "fc2.weight", H, H, cn.fc2, 0);
+        cn.b2 = add_vec(ctx, p + "fc2.bias", H);
+    };
+    mk_conn(ctx->ac_conn, "ac_conn.", L);
+    if (c.sem_dim > 0) mk_conn(ctx->sem_conn, "sem_conn.", c.sem_dim);
+    ctx->ct1 = (float*)dalloc(ctx, (size_t)256 * H * 4);
+    // ---- codecs ----
+    if (build_codec(ctx, ctx->dec, "dec.", true, L, 1, c.n_slots)) { *out = ctx; return -1; }
+    if (c.sem_dim > 0 && build_codec(ctx, ctx->senc, "senc.", false, c.sem_dim, 1, c.n_slots)) { *out = ctx; return -1; }
+    if (c.has_acoustic_encoder && build_codec(ctx, ctx->aenc, "aenc.", false, L, c.enc_frames, 1)) { *out = ctx; return -1; }
+    if (hipDeviceSynchronize() != hipSuccess || ctx->err[0]) { *out = ctx; return fail(ctx, "vv_create: allocation failed: %s", ctx->err); }
+    *out = ctx;
+    return 0;
+}
+
+extern "C" void vv_destroy(vv_ctx* ctx) {
+    if (!ctx) return;
+    hipDeviceSynchronize();
+    for (auto& g : ctx->graphs) hipGraphExecDestroy(g.second.exec);
+    // device memory is released with the process/context; explicit frees for the big pools
+    hipFree(ctx->kc); hipFree(ctx->vc); hipFree(ctx->embed);
+    if (ctx->lm_head_loaded) hipFree(ctx->lm_head);
+    if (ctx->stage) hipFree(ctx->stage);
+    hipHostFree(ctx->rows_pin); hipHostFree(ctx->ids_pin);
+    delete ctx;
+}
+
+extern "C" int vv_num_weights(vv_ctx* ctx) { return (int)ctx->w.size(); }
+extern "C" int vv_weight_info(vv_ctx* ctx, int idx, char* name, int cap, int64_t* nelem, int* loaded) {
+    if (idx < 0 || idx >= (int)ctx->w.size()) return fail(ctx, "weight index out of range");
+    const Weight& w = ctx->w[idx];
+    snprintf(name, cap, "%s", w.name.c_str());
+    if (nelem) *nelem = w.nelem;
+    if (loaded) *loaded = (w.loaded || w.optional) ? 1 : 0;
+    return 0;
+}
+
+extern "C" int vv_upload(vv_ctx* ctx, const char* name, const void* src, int src_dtype, int64_t nelem) {
+    auto it = ctx->widx.find(name);
+    if (it == ctx->widx.end()) return fail(ctx, "unknown parameter '%s'", name);
+    Weight& w = ctx->w[it->second];
+    if (nelem != w.nelem) return fail(ctx, "parameter '%s': expected %lld elements, got %lld", name, (long long)w.nelem, (long long)nelem);
+    const size_t esz = src_dtype ? 2 : 4;
+    hipPointerAttribute_t attr;
+    bool on_dev = (hipPointerGetAttributes(&attr, src) == hipSuccess) && (attr.type == hipMemoryTypeDevice);
+    (void)hipGetLastError();
+    const void* dsrc = src;
+    if (!on_dev) {
+        const size_t need = (size_t)nelem * esz;
+        if (need > ctx->stage_bytes) {
+            if (ctx->stage) hipFree(ctx->stage);
+            ctx->stage = nullptr; ctx->stage_bytes = 0;
+            HIPCHK(ctx, hipMalloc(&ctx->stage, need));
+            ctx->stage_bytes = need;
+        }
+        HIPCHK(ctx, hipMemcpy(ctx->stage, src, need, hipMemcpyHostToDevice));
+        dsrc = ctx->stage;
+    }
+    hipStream_t st = 0;
+    if (w.kind == W_TABLE) {
+        if (w.name == "lm_head.weight" && !ctx->lm_head_loaded) {
+            ctx->lm_head = dalloc(ctx, (size_t)nelem * 2, false);
+            if (!ctx->lm_head) return -1;
+            ctx->lm_head_loaded = true; w.dev = ctx->lm_head;
+        }
+        if (src_dtype) HIPCHK(ctx, hipMemcpy(w.dev, dsrc, (size_t)nelem * 2, hipMemcpyDeviceToDevice));
+        else VVCHK(vv_cvt_launch(dsrc, w.dev, nelem, 1, st));
+    } else if (w.kind == W_MAT) {
+        VVCHK(vv_pack_launch(dsrc, src_dtype, w.dev, w.N, w.K, w.pk, w.Cin, w.Cout, w.ksz, w.stride, st));
+    } else {
+        // fp32 vectors
+        const float* f32 = (const float*)dsrc;
+        float* tmp = nullptr;
+        if (src_dtype) {
+            tmp = (float*)dalloc(ctx, (size_t)nelem * 4, false);
+            if (!tmp) return -1;
+            VVCHK(vv_cvt_launch(dsrc, tmp, nelem, 0, st));
+            f32 = tmp;
+        }
+        if (w.kind == W_DW) {
+            VVCHK(vv_dw_transpose_launch(f32, (float*)w.dev, (int)(nelem / 7), st));
+        } else if (w.kind == W_BIAS_REP) {
+            for (int r = 0; r < w.rep; ++r)
+                HIPCHK(ctx, hipMemcpyAsync((float*)w.dev + (size_t)r * nelem, f32, (size_t)nelem * 4, hipMemcpyDeviceToDevice, st));
+        } else {
+            HIPCHK(ctx, hipMemcpyAsync(w.dev, f32, (size_t)nelem * 4, hipMemcpyDeviceToDevice, st));
+        }
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        if (tmp) hipFree(tmp);
+    }
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    w.loaded = true;
+    return 0;
+}
+
+extern "C" int vv_set_speech_factors(vv_ctx* ctx, float scaling, float bias) {
+    ctx->scaling = scaling; ctx->bias = bias;
+    for (auto it = ctx->graphs.begin(); it != ctx->graphs.end();) {
+        if (it->first.rfind("dec", 0) == 0) { hipGraphExecDestroy(it->second.exec); it = ctx->graphs.erase(it); } else ++it;
+    }
+    return 0;
+}
+
+extern "C" int vv_set_valid_tokens(vv_ctx* ctx, const int* ids, int n) {
+    if (n < 1 || n > 16) return fail(ctx, "n_valid must be in [1,16]");
+    const int H = ctx->H;
+    const void* table = ctx->lm_head_loaded ? ctx->lm_head : ctx->embed;
+    void* rows = dalloc(ctx, (size_t)n * H * 2, false);
+    if (!rows) return -1;
+    for (int i = 0; i < n; ++i) {
+        if (ids[i] < 0 || ids[i] >= ctx->c.lm_vocab) return fail(ctx, "token id %d out of range", ids[i]);
+        HIPCHK(ctx, hipMemcpy((char*)rows + (size_t)i * H * 2, (const char*)table + (size_t)ids[i] * H * 2, (size_t)H * 2, hipMemcpyDeviceToDevice));
+    }
+    if (!ctx->valid_w) ctx->valid_w = alloc_packed(ctx, 16, H);
+    VVCHK(vv_pack_launch(rows, 1, ctx->valid_w, n, H, 0, 0, 0, 0, 0, 0));
+    HIPCHK(ctx, hipDeviceSynchronize());
+    hipFree(rows);
+    ctx->n_valid = n;
+    return 0;
+}
+
+extern "C" int vv_set_schedule(vv_ctx* ctx, int n_steps, const float* t, const float* coef, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (n_steps < 1 || n_steps > 64) return fail(ctx, "n_steps must be in [1,64]");
+    const int H = ctx->H;
+    if (!ctx->temb) {
+        ctx->temb = (float*)dalloc(ctx, (size_t)64 * H * 4);
+        ctx->coef = (float*)dalloc(ctx, 64 * 5 * 4);
+        ctx->tvals = (float*)dalloc(ctx, 64 * 4);
+    }
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    HIPCHK(ctx, hipMemcpy(ctx->coef, coef, (size_t)n_steps * 5 * 4, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(ctx->tvals, t, (size_t)n_steps * 4, hipMemcpyHostToDevice));
+    // t_emb[i] = W2 . silu(W1 . sinusoid(t_i))   (TimestepEmbedder, modular_vibevoice_diffusion_head.py:66-93)
+    VVCHK(vv_tfreq_launch(ctx->tvals, ctx->tmp2, n_steps, st));
+    for (int i0 = 0; i0 < n_steps; i0 += 16) {
+        const int nn = std::min(16, n_steps - i0);
+        VVGemm g = mk_gemm(ctx->h_t0, ctx->tmp2 + (size_t)i0 * 256, ctx->tmp1 + (size_t)i0 * H, nn, H, 256, 256, H);
+        GEMM(g);
+    }
+    VVCHK(vv_silu_launch(ctx->tmp1, n_steps * H, st));
+    for (int i0 = 0; i0 < n_steps; i0 += 16) {
+        const int nn = std::min(16, n_steps - i0);
+        VVGemm g = mk_gemm(ctx->h_t2, ctx->tmp1 + (size_t)i0 * H, ctx->temb + (size_t)i0 * H, nn, H, H, H, H);
+        GEMM(g);
+    }
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    ctx->n_steps = n_steps;
+    for (auto it = ctx->graphs.begin(); it != ctx->graphs.end();) {
+        if (it->first.rfind("samp", 0) == 0) { hipGraphExecDestroy(it->second.exec); it = ctx->graphs.erase(it); } else ++it;
+    }
+    return 0;
+}
+
+static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float* hidden_out) {
+    const vv_config& c = ctx->c;
+    const int H = ctx->H, D = ctx->D, Hq = ctx->Hq, Hkv = ctx->Hkv, I = ctx->I, QKV = ctx->QKV;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h, x_in, (size_t)R * H * 4, hipMemcpyDeviceToDevice, st));
+    for (int l = 0; l < c.lm_layers; ++l) {
+        auto& L = ctx->layers[l];
+        VVGemm g = mk_gemm(L.wqkv, ctx->h, ctx->qkv, R, QKV, H, H, QKV);
+        g.pro = VV_PRO_RMS; g.nw = L.ln1; g.eps = c.lm_eps; g.epi = VV_EPI_BIAS; g.bias = L.bqkv; g.nt = 1;
+        GEMM(g);
+        ctx->launches += 3;
+        VVCHK(vv_rope_append_launch(D, ctx->qkv, ctx->rows_dev, ctx->inv_freq, ctx->qrot,
+                                    (char*)ctx->kc + (size_t)l * ctx->layer_stride * 2, (char*)ctx->vc + (size_t)l * ctx->layer_stride * 2,
+                                    R, Hq, Hkv, ctx->cache_stride, ctx->head_stride, st));
+        VVCHK(vv_attn_launch(D, c.xsplit, ctx->qrot, ctx->rows_dev, (char*)ctx->kc + (size_t)l * ctx->layer_stride * 2,
+                             (char*)ctx->vc + (size_t)l * ctx->layer_stride * 2, R, Hq, Hkv, ctx->cache_stride,
+                             ctx->head_stride, c.attn_splits, ctx->pm, ctx->pl, ctx->po, ctx->attn, st));
+        VVGemm go = mk_gemm(L.wo, ctx->attn, ctx->h, R, H, Hq * D, Hq * D, H);
+        go.epi = VV_EPI_RESID; go.nt = 1;
+        GEMM(go);
+        VVGemm gm = mk_gemm(L.wg, ctx->h, ctx->act, R, I, H, H, I);
+        gm.W2 = (const u32x4*)L.wu; gm.pro = VV_PRO_RMS; gm.nw = L.ln2; gm.eps = c.lm_eps; gm.epi = VV_EPI_SWIGLU; gm.nt = 1;
+        GEMM(gm);
+        VVGemm gd = mk_gemm(L.wd, ctx->act, ctx->h, R, H, I, I, H);
+        gd.epi = VV_EPI_RESID; gd.nt = 1;
+        GEMM(gd);
+    }
+    ctx->launches++;
+    VVCHK(vv_rmsnorm_rows_launch(ctx->h, H, hidden_out, H, ctx->lm_norm, R, H, c.lm_eps, st));
+    return 0;
+}
+
+extern "C" int vv_lm_forward(vv_ctx* ctx, void* stream, int n_rows, const vv_row* rows, const float* x_in_dev, float* hidden_out_dev) {
+    hipStream_t st = (hipStream_t)stream;
+    if (n_rows < 1 || n_rows > ctx->c.max_rows) return fail(ctx, "n_rows %d out of range [1,%d]", n_rows, ctx->c.max_rows);
+    for (int i = 0; i < n_rows; ++i) {
+        if (rows[i].cache < 0 || rows[i].cache >= 2 * ctx->c.n_slots) return fail(ctx, "row %d: cache id %d out of range", i, rows[i].cache);
+        if (rows[i].pos < 0 || rows[i].pos >= ctx->c.max_ctx) return fail(ctx, "row %d: position %d exceeds max_ctx %d", i, rows[i].pos, ctx->c.max_ctx);
+    }
+    // the pinned staging row table is reused: make sure the previous copy has been consumed
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    for (int i = 0; i < n_rows; ++i) { ctx->rows_pin[i].cache = rows[i].cache; ctx->rows_pin[i].pos = rows[i].pos; }
+    HIPCHK(ctx, hipMemcpyAsync(ctx->rows_dev, ctx->rows_pin, sizeof(VVRow) * n_rows, hipMemcpyHostToDevice, st));
+    ctx->launches = 0;
+    char key[96]; snprintf(key, 96, "lm:%d:%p:%p", n_rows, (const void*)x_in_dev, (void*)hidden_out_dev);
+    return graphed(ctx, key, st, [&]() { return lm_body(ctx, st, n_rows, x_in_dev, hidden_out_dev); });
+}
+
+extern "C" int vv_embed(vv_ctx* ctx, void* stream, int n, const int* ids, float* out_dev) {
+    hipStream_t st = (hipStream_t)stream;
+    if (n < 1 || n > 64) return fail(ctx, "vv_embed: n must be in [1,64]");
+    for (int i = 0; i < n; ++i) if (ids[i] < 0 || ids[i] >= ctx->c.lm_vocab) return fail(ctx, "token id %d out of range", ids[i]);
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    memcpy(ctx->ids_pin, ids, sizeof(int) * n);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->ids_dev, ctx->ids_pin, sizeof(int) * n, hipMemcpyHostToDevice, st));
+    VVCHK(vv_embed_launch(ctx->embed, ctx->ids_dev, out_dev, n, ctx->H, st));
+    return 0;
+}
+
+extern "C" int vv_lm_logits(vv_ctx* ctx, void* stream, int n, const float* hidden_dev, float* logits_out_dev) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!ctx->valid_w) return fail(ctx, "vv_set_valid_tokens has not been called");
+    if (n < 1 || n > 16) return fail(ctx, "vv_lm_logits: n must be in [1,16]");
+    VVGemm g = mk_gemm(ctx->valid_w, hidden_dev, logits_out_dev, n, ctx->n_valid, ctx->H, ctx->H, ctx->n_valid);
+    GEMM(g);
+    return 0;
+}
+
+// one head evaluation on 2n rows; mod/xh/hact/eps are ctx scratch. temb = t-embedding row for this step.
+static int head_eval(vv_ctx* ctx, hipStream_t st, int rows, const float* zrows, const float* temb_row, float* eps_out) {
+    const vv_config& c = ctx->c;
+    const int H = ctx->H, L = c.latent_dim, HL = c.head_layers, HF = ctx->HF, MODW = ctx->MODW;
+    VVGemm ga = mk_gemm(ctx->h_ada, ctx->cproj, ctx->mod, rows, MODW, H, H, MODW);
+    ga.pro = VV_PRO_ADD_SILU; ga.addvec = temb_row; ga.nt = 1;
+    GEMM(ga);
+    VVGemm gi = mk_gemm(ctx->h_in, zrows, ctx->xh, rows, H, L, L, H);
+    GEMM(gi);
+    for (int l = 0; l < HL; ++l) {
+        const float* base = ctx->mod + (size_t)l * 3 * H;
+        VVGemm g1 = mk_gemm(ctx->hl[l].wg, ctx->xh, ctx->hact, rows, HF, H, H, HF);
+        g1.W2 = (const u32x4*)ctx->hl[l].wu; g1.pro = VV_PRO_RMS_MOD; g1.nw = ctx->hl[l].norm; g1.eps = c.head_eps;
+        g1.mod_shift = base; g1.mod_scale = base + H; g1.ld_mod = MODW; g1.epi = VV_EPI_SWIGLU; g1.nt = 1;
+        GEMM(g1);
+        VVGemm g2 = mk_gemm(ctx->hl[l].wd, ctx->hact, ctx->xh, rows, H, HF, HF, H);
+        g2.epi = VV_EPI_GATED_RESID; g2.gate = base + 2 * H; g2.ld_gate = MODW; g2.nt = 1;
+        GEMM(g2);
+    }
+    const float* fb = ctx->mod + (size_t)HL * 3 * H;
+    VVGemm gf = mk_gemm(ctx->h_out, ctx->xh, eps_out, rows, L, H, H, L);
+    gf.pro = VV_PRO_RMS_MOD; gf.nw = nullptr; gf.eps = c.head_eps; gf.mod_shift = fb; gf.mod_scale = fb + H; gf.ld_mod = MODW;
+    GEMM(gf);
+    return 0;
+}
+
+static int sample_body(vv_ctx* ctx, hipStream_t st, int n, const float* cond, const float* noise, float cfg, float* latent_out) {
+    const vv_config& c = ctx->c;
+    const int H = ctx->H, L = c.latent_dim;
+    const int rows = 2 * n;
+    // both CFG halves see the same noisy latent (modeling_vibevoice_inference.py:703-704)
+    HIPCHK(ctx, hipMemcpyAsync(ctx->zz, noise, (size_t)n * L * 4, hipMemcpyDeviceToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->zz + (size_t)n * L, noise, (size_t)n * L * 4, hipMemcpyDeviceToDevice, st));
+    HIPCHK(ctx, hipMemsetAsync(ctx->x0p, 0, (size_t)n * L * 4, st));
+    VVGemm gc = mk_gemm(ctx->h_cond, cond, ctx->cproj, rows, H, H, H, H);
+    gc.nt = 1;
+    GEMM(gc);
+    for (int i = 0; i < ctx->n_steps; ++i) {
+        if (head_eval(ctx, st, rows, ctx->zz, ctx->temb + (size_t)i * H, ctx->eps)) return -1;
+        ctx->launches++;
+        VVCHK(vv_cfg_dpm_launch(ctx->eps, ctx->zz, ctx->x0p, ctx->coef + i * 5, cfg, n, L, st));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->zz + (size_t)n * L, ctx->zz, (size_t)n * L * 4, hipMemcpyDeviceToDevice, st));
+    }
+    HIPCHK(ctx, hipMemcpyAsync(latent_out, ctx->zz, (size_t)n * L * 4, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+extern "C" int vv_diffusion_sample(vv_ctx* ctx, void* stream, int n, const float* cond_dev, const float* noise_dev, float cfg_scale, float* latent_out_dev) {
+    hipStream_t st = (hipStream_t)stream;
+    if (ctx->n_steps < 1) return fail(ctx, "vv_set_schedule has not been called");
+    if (n < 1 || n > 8) return fail(ctx, "vv_diffusion_sample: n must be in [1,8]");
+    ctx->launches = 0;
+    char key[128]; snprintf(key, 128, "samp:%d:%p:%p:%p:%a", n, (const void*)cond_dev, (const void*)noise_dev, (void*)latent_out_dev, cfg_scale);
+    return graphed(ctx, key, st, [&]() { return sample_body(ctx, st, n, cond_dev, noise_dev, cfg_scale, latent_out_dev); });
+}
+
+extern "C" int vv_head_forward(vv_ctx* ctx, void* stream, int n, const float* noisy_dev, const float* t_host, const float* cond_dev, float* out_dev) {
+    hipStream_t st = (hipStream_t)stream;
+    if (n < 1 || n > 16) return fail(ctx, "vv_head_forward: n must be in [1,16]");
+    const int H = ctx->H;
+    for (int i = 1; i < n; ++i) if (t_host[i] != t_host[0]) return fail(ctx, "vv_head_forward: all rows must share one timestep");
+    float* tdev = ctx->tmp2 + 63 * 256;     // scratch
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    HIPCHK(ctx, hipMemcpy(tdev + 128, t_host, 4, hipMemcpyHostToDevice));
+    VVCHK(vv_tfreq_launch(tdev + 128, ctx->tmp2, 1, st));
+    VVGemm g = mk_gemm(ctx->h_t0, ctx->tmp2, ctx->tmp1, 1, H, 256, 256, H); GEMM(g);
+    VVCHK(vv_silu_launch(ctx->tmp1, H, st));
+    VVGemm g2 = mk_gemm(ctx->h_t2, ctx->tmp1, ctx->tmp1 + H, 1, H, H, H, H); GEMM(g2);
+    VVGemm gc = mk_gemm(ctx->h_cond, cond_dev, ctx->cproj, n, H, H, H, H); GEMM(gc);
+    if (head_eval(ctx, st, n, noisy_dev, ctx->tmp1 + H, out_dev)) return -1;
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" int vv_codec_decode(vv_ctx* ctx, void* stream, int slot, int frames, const float* latent_dev, float* audio_out_dev, int apply) {
+    hipStream_t st = (hipStream_t)stream;
+    if (slot < 0 || slot >= ctx->c.n_slots) return fail(ctx, "slot %d out of range", slot);
+    if (frames != 1) return fail(ctx, "vv_codec_decode: streaming decode takes one frame per call");
+    CodecNet& net = ctx->dec;
+    ctx->launches = 0;
+    char key[128]; snprintf(key, 128, "dec:%d:%d:%p:%p:%d", slot, frames, (const void*)latent_dev, (void*)audio_out_dev, apply);
+    return graphed(ctx, key, st, [&]() {
+        const int L = ctx->c.latent_dim;
+        const float mul = apply ? 1.0f / ctx->scaling : 1.0f, add = apply ? -ctx->bias : 0.0f;
+        ctx->launches++;
+        VVCHK(vv_affine_launch(latent_dev, net.in_buf[slot] + 6 * L, mul, add, frames * L, st));
+        return run_codec(ctx, net, slot, frames, audio_out_dev, st);
+    });
+}
+
+extern "C" int vv_semantic_encode(vv_ctx* ctx, void* stream, int slot, int frames, const float* audio_dev, float* sem_out_dev) {
+    hipStream_t st = (hipStream_t)stream;
+    if (ctx->c.sem_dim <= 0) return fail(ctx, "no semantic tokenizer configured");
+    if (slot < 0 || slot >= ctx->c.n_slots) return fail(ctx, "slot %d out of range", slot);
+    if (frames != 1) return fail(ctx, "vv_semantic_encode: streaming encode takes one frame per call");
+    CodecNet& net = ctx->senc;
+    ctx->launches = 0;
+    char key[128]; snprintf(key, 128, "senc:%d:%d:%p:%p", slot, frames, (const void*)audio_dev, (void*)sem_out_dev);
+    return graphed(ctx, key, st, [&]() {
+        HIPCHK(ctx, hipMemcpyAsync(net.in_buf[slot] + 6, audio_dev, (size_t)frames * ctx->hop * 4, hipMemcpyDeviceToDevice, st));
+        return run_codec(ctx, net, slot, frames, sem_out_dev, st);
+    });
+}
+
+extern "C" int vv_acoustic_encode(vv_ctx* ctx, void* stream, int frames, const float* wav_dev, float* mean_out_dev) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!ctx->c.has_acoustic_encoder) return fail(ctx, "no acoustic encoder configured");
+    CodecNet& net = ctx->aenc;
+    if (zero_codec(ctx, net, 0, st)) return -1;
+    const int L = ctx->c.latent_dim;
+    for (int f0 = 0; f0 < frames; f0 += net.Fmax) {
+        const int F = std::min(net.Fmax, frames - f0);
+        HIPCHK(ctx, hipMemcpyAsync(net.in_buf[0] + 6, wav_dev + (size_t)f0 * ctx->hop, (size_t)F * ctx->hop * 4, hipMemcpyDeviceToDevice, st));
+        if (run_codec(ctx, net, 0, F, mean_out_dev + (size_t)f0 * L, st)) return -1;
+    }
+    return 0;
+}
+
+extern "C" int vv_codec_reset(vv_ctx* ctx, void* stream, int slot) {
+    hipStream_t st = (hipStream_t)stream;
+    if (slot < 0 || slot >= ctx->c.n_slots) return fail(ctx, "slot %d out of range", slot);
+    if (zero_codec(ctx, ctx->dec, slot, st)) return -1;
+    if (ctx->c.sem_dim > 0 && zero_codec(ctx, ctx->senc, slot, st)) return -1;
+    return 0;
+}
+
+extern "C" int vv_connect(vv_ctx* ctx, void* stream, int n, const float* latent_dev, const float* sem_dev, float* out_dev) {
+    hipStream_t st = (hipStream_t)stream;
+    const int H = ctx->H, L = ctx->c.latent_dim;
+    for (int i0 = 0; i0 < n; i0 += 16) {
+        const int nn = std::min(16, n - i0);
+        float* out = out_dev + (size_t)i0 * H;
+        VVGemm a1 = mk_gemm(ctx->ac_conn.fc1, latent_dev + (size_t)i0 * L, ctx->ct1, nn, H, L, L, H);
+        a1.epi = VV_EPI_BIAS; a1.bias = ctx->ac_conn.b1; GEMM(a1);
+        VVGemm a2 = mk_gemm(ctx->ac_conn.fc2, ctx->ct1, out, nn, H, H, H, H);
+        a2.pro = VV_PRO_RMS; a2.nw = ctx->ac_conn.norm; a2.eps = 1e-6f; a2.epi = VV_EPI_BIAS; a2.bias = ctx->ac_conn.b2; GEMM(a2);
+        if (sem_dev) {
+            const int S = ctx->c.sem_dim;
+            VVGemm s1 = mk_gemm(ctx->sem_conn.fc1, sem_dev + (size_t)i0 * S, ctx->ct1, nn, H, S, S, H);
+            s1.epi = VV_EPI_BIAS; s1.bias = ctx->sem_conn.b1; GEMM(s1);
+            VVGemm s2 = mk_gemm(ctx->sem_conn.fc2, ctx->ct1, out, nn, H, H, H, H);
+            s2.pro = VV_PRO_RMS; s2.nw = ctx->sem_conn.norm; s2.eps = 1e-6f; s2.epi = VV_EPI_RESID; s2.bias = ctx->sem_conn.b2; GEMM(s2);
+        }
+    }
+    return 0;
+}
+
+extern "C" int64_t vv_packed_bytes(int N, int K) { return vv_packed_elems(N, K) * 2; }
+extern "C" int vv_pack_matrix(void* stream, const float* src_dev, void* dst_dev, int N, int K) {
+    return vv_pack_launch(src_dev, 0, dst_dev, N, K, 0, 0, 0, 0, 0, (hipStream_t)stream);
+}
+extern "C" int vv_gemm_raw(void* stream, const void* w, const void* w2, const float* x, float* y, int T, int N, int K,
+                           int ldx, int ldy, int pro, int epi, const float* nw, float eps, const float* bias,
+                           const float* nscale, int xsplit, int ksplit, int nontemporal) {
+    VVGemm g = mk_gemm(w, x, y, T, N, K, ldx, ldy);
+    g.W2 = (const u32x4*)w2; g.pro = pro; g.epi = epi; g.nw = nw; g.eps = eps; g.bias = bias; g.nscale = nscale;
+    g.ksplit = ksplit; g.nt = nontemporal;
+    return vv_gemm_launch(g, xsplit, (hipStream_t)stream);
+}
+extern "C" int64_t vv_stat(vv_ctx* ctx, int what) { return what == 0 ? ctx->launches : (int64_t)ctx->graphs.size(); }

@@ -1,0 +1,189 @@
+// misc.hip -- the small HBM/L2-bound kernels around the GEMMs: embedding gather,
+// row RMSNorm, causal depthwise conv (+layer-scale residual), streaming-state row
+// shifts, CFG + DPM-Solver++ update, affine/copy helpers.  All are one element (or
+// one float4) per lane, coalesced along the channel axis of time-major buffers.
+#include "vv_common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// out[i][:] = (float) table[ids[i]][:]     grid (n), block 256
+__global__ void vv_embed_kernel(const __bf16* __restrict__ table, const int* __restrict__ ids,
+                                float* __restrict__ out, int H) {
+    const int i = blockIdx.x;
+    const __bf16* src = table + (int64_t)ids[i] * H;
+    for (int k = threadIdx.x; k < H; k += blockDim.x) out[(int64_t)i * H + k] = (float)src[k];
+}
+
+// y[t][:] = x[t][:] * rsqrt(mean(x^2)+eps) * w      one wave per row; grid (ceil(T/4)), block 256
+__global__ void vv_rmsnorm_rows_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
+                                       const float* __restrict__ w, int T, int C, float eps) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (t >= T) return;
+    const float* xr = x + (int64_t)t * ldx;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) { float v = xr[c]; s += v * v; }
+    s = wave_sum(s);
+    const float rs = rsqrtf(s / (float)C + eps);
+    float* yr = y + (int64_t)t * ldy;
+    for (int c = lane; c < C; c += 64) yr[c] = xr[c] * rs * (w ? w[c] : 1.f);
+}
+
+// Causal depthwise conv k=7 over time on the normed buffer nb (6 history rows in front),
+// fused with bias, layer scale and the residual:  x[t][c] += gamma[c]*(sum_j w[j][c]*nb[t+j][c] + b[c])
+__global__ void vv_dwconv_res_kernel(const float* __restrict__ nb, float* __restrict__ x,
+                                     const float* __restrict__ w /*[7][C]*/, const float* __restrict__ b,
+                                     const float* __restrict__ gamma, int T, int C) {
+    const int64_t total = (int64_t)T * C;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int t = (int)(e / C), c = (int)(e - (int64_t)t * C);
+        float acc = b[c];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) acc += w[j * C + c] * nb[(int64_t)(t + j) * C + c];
+        x[e] += gamma[c] * acc;
+    }
+}
+
+// Streaming state carry: for every stateful buffer move rows [T, T+hist) -> [0, hist).
+// One lane owns one column and walks rows in ascending order, so overlapping moves
+// (T < hist) are race-free.                        grid (n_entries, col_chunks), block 256
+struct VVShift { float* buf; int T, hist, C; };
+__global__ void vv_shift_rows_kernel(const VVShift* __restrict__ tab) {
+    const VVShift e = tab[blockIdx.x];
+    for (int c = blockIdx.y * blockDim.x + threadIdx.x; c < e.C; c += gridDim.y * blockDim.x)
+        for (int r = 0; r < e.hist; ++r) e.buf[(int64_t)r * e.C + c] = e.buf[(int64_t)(r + e.T) * e.C + c];
+}
+
+// Zero the history rows of every stateful buffer (<speech_end>: cache.set_to_zero).
+__global__ void vv_zero_hist_kernel(const VVShift* __restrict__ tab) {
+    const VVShift e = tab[blockIdx.x];
+    const int64_t n = (int64_t)e.hist * e.C;
+    for (int64_t i = blockIdx.y * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.y * blockDim.x) e.buf[i] = 0.f;
+}
+
+// Classifier-free guidance + one DPM-Solver++(2M) update on the n x L latent block.
+//   v  = v_u + cfg (v_c - v_u)                  (rows [0,n) cond, [n,2n) uncond of `eps`)
+//   x0 = a x - s v
+//   x' = cs x + c0 x0 + c1 (x0 - x0_prev)       (c1 = 0 on first-order steps)
+// coef = {a, s, cs, c0, c1} for this step.
+__global__ void vv_cfg_dpm_kernel(const float* __restrict__ eps, float* __restrict__ x, float* __restrict__ x0_prev,
+                                  const float* __restrict__ coef, float cfg, int n, int L) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * L) return;
+    const float a = coef[0], s = coef[1], cs = coef[2], c0 = coef[3], c1 = coef[4];
+    const float vc = eps[i], vu = eps[i + n * L];
+    const float v = vu + cfg * (vc - vu);
+    const float xi = x[i];
+    const float x0 = a * xi - s * v;
+    const float xn = cs * xi + c0 * x0 + c1 * (x0 - x0_prev[i]);
+    x0_prev[i] = x0;
+    x[i] = xn;
+}
+
+// y = x * mul + add   (latent un-scaling, copies)
+__global__ void vv_affine_kernel(const float* __restrict__ x, float* __restrict__ y, float mul, float add, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = x[i] * mul + add;
+}
+
+// y[i] = a[i] + b[i]
+__global__ void vv_add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = a[i] + b[i];
+}
+
+// sinusoidal timestep features: out[i][0:128]=cos(t_i f_k), [128:256]=sin(t_i f_k)
+__global__ void vv_tfreq_kernel(const float* __restrict__ t, float* __restrict__ out, int n) {
+    const int i = blockIdx.x, k = threadIdx.x;   // block 128
+    const float f = expf(-logf(10000.f) * (float)k / 128.f);
+    const float arg = t[i] * f;
+    out[i * 256 + k] = cosf(arg);
+    out[i * 256 + 128 + k] = sinf(arg);
+}
+
+__global__ void vv_silu_kernel(float* __restrict__ x, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { float u = x[i]; x[i] = u / (1.f + expf(-u)); }
+}
+
+// fp32 <-> storage conversions used when uploading parameters
+__global__ void vv_cvt_bf16_to_f32_kernel(const __bf16* __restrict__ s, float* __restrict__ d, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = (float)s[i];
+}
+__global__ void vv_cvt_f32_to_bf16_kernel(const float* __restrict__ s, __bf16* __restrict__ d, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = (__bf16)s[i];
+}
+// depthwise weight [C][1][7] -> [7][C]
+__global__ void vv_dw_transpose_kernel(const float* __restrict__ s, float* __restrict__ d, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < C * 7) { const int c = i / 7, j = i - c * 7; d[j * C + c] = s[i]; }
+}
+
+}  // namespace
+
+static inline int okk() { return hipGetLastError() == hipSuccess ? 0 : -2; }
+
+extern "C" {
+
+int vv_embed_launch(const void* table, const int* ids, float* out, int n, int H, hipStream_t s) {
+    hipLaunchKernelGGL(vv_embed_kernel, dim3(n), dim3(256), 0, s, (const __bf16*)table, ids, out, H);
+    return okk();
+}
+int vv_rmsnorm_rows_launch(const float* x, int ldx, float* y, int ldy, const float* w, int T, int C, float eps, hipStream_t s) {
+    hipLaunchKernelGGL(vv_rmsnorm_rows_kernel, dim3((T + 3) / 4), dim3(256), 0, s, x, ldx, y, ldy, w, T, C, eps);
+    return okk();
+}
+int vv_dwconv_res_launch(const float* nb, float* x, const float* w, const float* b, const float* gamma, int T, int C, hipStream_t s) {
+    int64_t total = (int64_t)T * C;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(vv_dwconv_res_kernel, dim3(blocks), dim3(256), 0, s, nb, x, w, b, gamma, T, C);
+    return okk();
+}
+int vv_shift_rows_launch(const void* tab, int n_entries, int maxC, hipStream_t s) {
+    int cy = (maxC + 255) / 256; if (cy < 1) cy = 1; if (cy > 16) cy = 16;
+    hipLaunchKernelGGL(vv_shift_rows_kernel, dim3(n_entries, cy), dim3(256), 0, s, (const VVShift*)tab);
+    return okk();
+}
+int vv_zero_hist_launch(const void* tab, int n_entries, hipStream_t s) {
+    hipLaunchKernelGGL(vv_zero_hist_kernel, dim3(n_entries, 8), dim3(256), 0, s, (const VVShift*)tab);
+    return okk();
+}
+int vv_cfg_dpm_launch(const float* eps, float* x, float* x0_prev, const float* coef, float cfg, int n, int L, hipStream_t s) {
+    hipLaunchKernelGGL(vv_cfg_dpm_kernel, dim3((n * L + 255) / 256), dim3(256), 0, s, eps, x, x0_prev, coef, cfg, n, L);
+    return okk();
+}
+int vv_affine_launch(const float* x, float* y, float mul, float add, int n, hipStream_t s) {
+    hipLaunchKernelGGL(vv_affine_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, y, mul, add, n);
+    return okk();
+}
+int vv_add_launch(const float* a, const float* b, float* y, int n, hipStream_t s) {
+    hipLaunchKernelGGL(vv_add_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, b, y, n);
+    return okk();
+}
+int vv_tfreq_launch(const float* t, float* out, int n, hipStream_t s) {
+    hipLaunchKernelGGL(vv_tfreq_kernel, dim3(n), dim3(128), 0, s, t, out, n);
+    return okk();
+}
+int vv_silu_launch(float* x, int n, hipStream_t s) {
+    hipLaunchKernelGGL(vv_silu_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, n);
+    return okk();
+}
+int vv_cvt_launch(const void* src, void* dst, int64_t n, int to_bf16, hipStream_t s) {
+    int blocks = (int)((n + 255) / 256); if (blocks > 8192) blocks = 8192; if (blocks < 1) blocks = 1;
+    if (to_bf16) hipLaunchKernelGGL(vv_cvt_f32_to_bf16_kernel, dim3(blocks), dim3(256), 0, s, (const float*)src, (__bf16*)dst, n);
+    else hipLaunchKernelGGL(vv_cvt_bf16_to_f32_kernel, dim3(blocks), dim3(256), 0, s, (const __bf16*)src, (float*)dst, n);
+    return okk();
+}
+int vv_dw_transpose_launch(const float* src, float* dst, int C, hipStream_t s) {
+    hipLaunchKernelGGL(vv_dw_transpose_kernel, dim3((C * 7 + 255) / 256), dim3(256), 0, s, src, dst, C);
+    return okk();
+}
+
+}  // extern "C"

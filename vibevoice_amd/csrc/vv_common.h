@@ -1,0 +1,54 @@
+// vv_common.h -- shared device/host declarations for libvvhip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+#define VV_WAVE 64
+
+// ---- packed weight tile ------------------------------------------------------
+// A [N x K] matrix is stored as tiles of 16 rows x 32 k.  One tile = 1 KiB =
+// 64 lanes x 16 B, in exactly the order the lanes of a wave consume it as the
+// A (or B) operand of v_mfma_f32_16x16x32_bf16:
+//   lane l holds W[n0 + (l & 15)][k0 + (l >> 4) * 8 + 0..7]
+// tiles are ordered [n_tile][k_tile]; rows >= N and columns >= K are zero.
+static inline __host__ __device__ int64_t vv_packed_elems(int N, int K) {
+    return (int64_t)((N + 15) / 16) * ((K + 31) / 32) * 512;
+}
+
+// ---- generic skinny GEMM -----------------------------------------------------
+// Y[t][n] (op)= sum_k f(X[t][k]) * W[n][k]
+enum { VV_PRO_NONE = 0, VV_PRO_RMS = 1, VV_PRO_RMS_MOD = 2, VV_PRO_ADD_SILU = 3 };
+enum { VV_EPI_STORE = 0, VV_EPI_BIAS = 1, VV_EPI_BIAS_GELU = 2, VV_EPI_SWIGLU = 3,
+       VV_EPI_RESID = 4, VV_EPI_GATED_RESID = 5 };
+
+struct VVGemm {
+    const u32x4* W;        // packed tiles
+    const u32x4* W2;       // second matrix ("up") for VV_EPI_SWIGLU, else null
+    const float* X;        // [T] rows, K contiguous floats each, row stride ldx
+    float* Y;              // [T][N], row stride ldy
+    const float* nw;       // PRO_RMS*: norm weight [K] (null = no affine)
+    const float* mod_scale;// PRO_RMS_MOD: per-row [T][ld_mod]
+    const float* mod_shift;
+    const float* addvec;   // PRO_ADD_SILU: [K]
+    const float* bias;     // [N] or null
+    const float* nscale;   // EPI_RESID: per-n scale (gamma) or null
+    const float* gate;     // EPI_GATED_RESID: per-row [T][ld_gate]
+    int T, N, K;
+    int ldx, ldy, ld_mod, ld_gate;
+    int pro, epi;
+    int ksplit;            // 1, 2 or 4 waves of the block split K
+    int nt;                // non-temporal weight loads (streamed-once weights)
+    float eps;
+};
+
+// ---- row table for LM steps ---------------------------------------------------
+struct VVRow {
+    int cache;   // KV cache id
+    int pos;     // position of this token == cache length before the append
+};

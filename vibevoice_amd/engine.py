@@ -1,0 +1,292 @@
+"""Thin Python wrapper over the libvvhip.so C ABI (include/vvhip.h).
+
+PyTorch is used here only for device memory (tensors whose data_ptr() is handed
+to the engine) and for the HIP stream; every arithmetic op of the hot path runs
+inside libvvhip.so.  There is no fallback path: constructing an Engine without
+the shared library or without a GPU raises.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import schedule as _schedule
+
+
+@dataclass
+class EngineConfig:
+    # Qwen2 decoder
+    lm_hidden: int
+    lm_layers: int
+    lm_heads: int
+    lm_kv_heads: int
+    lm_inter: int
+    lm_vocab: int
+    lm_head_dim: Optional[int] = None
+    lm_eps: float = 1e-6
+    rope_theta: float = 1e6
+    # diffusion head
+    head_layers: int = 4
+    head_ffn_ratio: float = 3.0
+    latent_dim: int = 64
+    head_eps: float = 1e-5
+    # tokenizers
+    n_filters: int = 32
+    ratios: Sequence[int] = (8, 5, 5, 4, 2, 2)
+    enc_depths: Sequence[int] = (3, 3, 3, 3, 3, 3, 8)
+    sem_dim: int = 128
+    has_acoustic_encoder: bool = True
+    codec_eps: float = 1e-5
+    # runtime
+    n_slots: int = 1
+    max_ctx: int = 4096
+    max_rows: int = 16
+    xsplit: int = 2
+    attn_splits: int = 32
+    enc_frames: int = 4
+    use_graph: bool = True
+
+    def __post_init__(self):
+        if self.lm_head_dim is None:
+            self.lm_head_dim = self.lm_hidden // self.lm_heads
+
+    @property
+    def head_ffn(self):
+        return int(self.lm_hidden * self.head_ffn_ratio)
+
+    @property
+    def hop(self):
+        return int(np.prod(self.ratios))
+
+
+# reference state_dict prefix -> engine parameter prefix
+PREFIX_MAP = (
+    ("model.language_model.", "lm."),
+    ("model.prediction_head.", "head."),
+    ("model.acoustic_tokenizer.decoder.", "dec."),
+    ("model.acoustic_tokenizer.encoder.", "aenc."),
+    ("model.semantic_tokenizer.encoder.", "senc."),
+    ("model.acoustic_connector.", "ac_conn."),
+    ("model.semantic_connector.", "sem_conn."),
+    ("lm_head.", "lm_head."),
+)
+
+
+def map_param_name(ref_key: str) -> Optional[str]:
+    for a, b in PREFIX_MAP:
+        if ref_key.startswith(a):
+            return b + ref_key[len(a):]
+    return None
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class Engine:
+    def __init__(self, cfg: EngineConfig, device: Optional[torch.device] = None):
+        if not torch.cuda.is_available():
+            raise EngineError("vibevoice_amd.Engine needs an AMD GPU (torch.cuda.is_available() is False); "
+                              "there is no CPU fallback")
+        self.lib = _lib.load()
+        self.cfg = cfg
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        torch.cuda.set_device(self.device)
+        c = _lib.VVConfig()
+        for f in ("lm_hidden", "lm_layers", "lm_heads", "lm_kv_heads", "lm_head_dim", "lm_inter", "lm_vocab",
+                  "lm_eps", "head_layers", "latent_dim", "head_eps", "n_filters", "sem_dim", "codec_eps",
+                  "n_slots", "max_ctx", "max_rows", "xsplit", "attn_splits", "enc_frames"):
+            setattr(c, f, getattr(cfg, f))
+        c.head_ffn = cfg.head_ffn
+        c.n_ratios = len(cfg.ratios)
+        for i, r in enumerate(cfg.ratios):
+            c.ratios[i] = int(r)
+        c.n_stages = len(cfg.enc_depths)
+        for i, d in enumerate(cfg.enc_depths):
+            c.enc_depths[i] = int(d)
+        c.has_acoustic_encoder = int(cfg.has_acoustic_encoder)
+        c.use_graph = int(cfg.use_graph)
+        self._ctx = C.c_void_p()
+        # a dedicated non-default stream: hipGraph capture is illegal on the null stream
+        self.stream = torch.cuda.Stream(device=self.device)
+        rc = self.lib.vv_create(C.byref(c), C.byref(self._ctx))
+        if rc != 0:
+            raise EngineError("vv_create failed: " + self._err())
+        self.max_ctx = (cfg.max_ctx + 127) // 128 * 128
+        self._n_steps = None
+        self._loaded = set()
+        # HF Qwen2RotaryEmbedding inv_freq, computed exactly as transformers does
+        d = cfg.lm_head_dim
+        inv_freq = 1.0 / (cfg.rope_theta ** (torch.arange(0, d, 2, dtype=torch.int64).float() / d))
+        self.upload("lm.rope.inv_freq", inv_freq)
+
+    # ------------------------------------------------------------------ plumbing
+    def _err(self):
+        s = self.lib.vv_last_error(self._ctx)
+        return s.decode() if s else "?"
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise EngineError(f"{what} failed: {self._err()}")
+
+    @property
+    def _s(self):
+        return C.c_void_p(self.stream.cuda_stream)
+
+    def close(self):
+        if self._ctx:
+            self.lib.vv_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        self.stream.synchronize()
+
+    def new(self, *shape, dtype=torch.float32):
+        """zero tensor whose fill is ordered on the engine stream"""
+        with torch.cuda.stream(self.stream):
+            return torch.zeros(*shape, dtype=dtype, device=self.device)
+
+    # ------------------------------------------------------------------ parameters
+    def expected_weights(self) -> Dict[str, int]:
+        out = {}
+        buf = C.create_string_buffer(256)
+        n = C.c_int64()
+        ld = C.c_int()
+        for i in range(self.lib.vv_num_weights(self._ctx)):
+            self._chk(self.lib.vv_weight_info(self._ctx, i, buf, 256, C.byref(n), C.byref(ld)), "vv_weight_info")
+            out[buf.value.decode()] = n.value
+        return out
+
+    def missing_weights(self) -> List[str]:
+        miss = []
+        buf = C.create_string_buffer(256)
+        n = C.c_int64()
+        ld = C.c_int()
+        for i in range(self.lib.vv_num_weights(self._ctx)):
+            self.lib.vv_weight_info(self._ctx, i, buf, 256, C.byref(n), C.byref(ld))
+            if not ld.value:
+                miss.append(buf.value.decode())
+        return miss
+
+    def upload(self, name: str, t: torch.Tensor):
+        """t: fp32 or bf16 tensor on any device (host tensors are staged)."""
+        t = t.detach()
+        if t.dtype not in (torch.float32, torch.bfloat16):
+            t = t.to(torch.float32)
+        t = t.contiguous()
+        torch.cuda.synchronize(self.device)
+        rc = self.lib.vv_upload(self._ctx, name.encode(), C.c_void_p(t.data_ptr()),
+                                1 if t.dtype == torch.bfloat16 else 0, t.numel())
+        self._chk(rc, f"vv_upload({name})")
+        self._loaded.add(name)
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], mapped=False, strict=True):
+        """sd keyed by reference names (model.language_model....) unless mapped=True."""
+        exp = self.expected_weights()
+        for k, v in sd.items():
+            name = k if mapped else map_param_name(k)
+            if name is None or name not in exp:
+                continue
+            self.upload(name, v)
+        if strict:
+            miss = self.missing_weights()
+            if miss:
+                raise EngineError(f"{len(miss)} parameters were not provided, e.g. {miss[:5]}")
+
+    def set_speech_factors(self, scaling: float, bias: float):
+        self._chk(self.lib.vv_set_speech_factors(self._ctx, float(scaling), float(bias)), "vv_set_speech_factors")
+
+    def set_valid_tokens(self, ids: Sequence[int]):
+        arr = (C.c_int * len(ids))(*[int(i) for i in ids])
+        self._chk(self.lib.vv_set_valid_tokens(self._ctx, arr, len(ids)), "vv_set_valid_tokens")
+        self.n_valid = len(ids)
+
+    def set_num_steps(self, n_steps: int, t_cast_bf16: bool = False):
+        key = (int(n_steps), bool(t_cast_bf16))
+        if self._n_steps == key:
+            return
+        tv, coef = _schedule.make_table(n_steps, t_cast_bf16)
+        self._chk(self.lib.vv_set_schedule(
+            self._ctx, n_steps, tv.ctypes.data_as(C.POINTER(C.c_float)),
+            np.ascontiguousarray(coef).ctypes.data_as(C.POINTER(C.c_float)), self._s), "vv_set_schedule")
+        self._n_steps = key
+
+    # ------------------------------------------------------------------ ops
+    @staticmethod
+    def _p(t: Optional[torch.Tensor]):
+        return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p()
+
+    def lm_forward(self, rows: Sequence[tuple], x_in: torch.Tensor, hidden_out: torch.Tensor):
+        n = len(rows)
+        arr = (_lib.VVRow * n)()
+        for i, (cache, pos) in enumerate(rows):
+            arr[i].cache, arr[i].pos = int(cache), int(pos)
+        self._chk(self.lib.vv_lm_forward(self._ctx, self._s, n, arr, self._p(x_in), self._p(hidden_out)), "vv_lm_forward")
+
+    def embed(self, ids: Sequence[int], out: torch.Tensor):
+        arr = (C.c_int * len(ids))(*[int(i) for i in ids])
+        self._chk(self.lib.vv_embed(self._ctx, self._s, len(ids), arr, self._p(out)), "vv_embed")
+
+    def lm_logits(self, n: int, hidden: torch.Tensor, logits_out: torch.Tensor):
+        self._chk(self.lib.vv_lm_logits(self._ctx, self._s, n, self._p(hidden), self._p(logits_out)), "vv_lm_logits")
+
+    def diffusion_sample(self, n: int, cond: torch.Tensor, noise: torch.Tensor, cfg_scale: float, latent_out: torch.Tensor):
+        self._chk(self.lib.vv_diffusion_sample(self._ctx, self._s, n, self._p(cond), self._p(noise),
+                                               float(cfg_scale), self._p(latent_out)), "vv_diffusion_sample")
+
+    def head_forward(self, noisy: torch.Tensor, t: float, cond: torch.Tensor, out: torch.Tensor):
+        n = noisy.shape[0]
+        tarr = (C.c_float * n)(*([float(t)] * n))
+        self._chk(self.lib.vv_head_forward(self._ctx, self._s, n, self._p(noisy), tarr, self._p(cond), self._p(out)),
+                  "vv_head_forward")
+
+    def codec_decode(self, slot: int, latent: torch.Tensor, audio_out: torch.Tensor, apply_speech_factors=True):
+        self._chk(self.lib.vv_codec_decode(self._ctx, self._s, slot, 1, self._p(latent), self._p(audio_out),
+                                           int(apply_speech_factors)), "vv_codec_decode")
+
+    def semantic_encode(self, slot: int, audio: torch.Tensor, sem_out: torch.Tensor):
+        self._chk(self.lib.vv_semantic_encode(self._ctx, self._s, slot, 1, self._p(audio), self._p(sem_out)),
+                  "vv_semantic_encode")
+
+    def acoustic_encode(self, frames: int, wav: torch.Tensor, mean_out: torch.Tensor):
+        self._chk(self.lib.vv_acoustic_encode(self._ctx, self._s, frames, self._p(wav), self._p(mean_out)),
+                  "vv_acoustic_encode")
+
+    def codec_reset(self, slot: int):
+        self._chk(self.lib.vv_codec_reset(self._ctx, self._s, slot), "vv_codec_reset")
+
+    def connect(self, n: int, latent: torch.Tensor, sem: Optional[torch.Tensor], out: torch.Tensor):
+        self._chk(self.lib.vv_connect(self._ctx, self._s, n, self._p(latent), self._p(sem), self._p(out)), "vv_connect")
+
+    def stat(self, what=0):
+        return int(self.lib.vv_stat(self._ctx, what))
+
+    # ------------------------------------------------------------------ low level (tests / microbench)
+    def pack_matrix(self, w: torch.Tensor) -> torch.Tensor:
+        N, K = w.shape
+        out = torch.empty(int(self.lib.vv_packed_bytes(N, K)), dtype=torch.uint8, device=self.device)
+        w = w.to(self.device, torch.float32).contiguous()
+        with torch.cuda.stream(self.stream):
+            rc = self.lib.vv_pack_matrix(self._s, self._p(w), self._p(out), N, K)
+        if rc != 0:
+            raise EngineError("vv_pack_matrix failed")
+        self.sync()
+        return out
+
+    def gemm_raw(self, wp, x, y, N, K, T=None, ldx=None, ldy=None, pro=0, epi=0, w2p=None, nw=None, eps=1e-6,
+                 bias=None, nscale=None, xsplit=None, ksplit=0, nontemporal=0):
+        T = x.shape[0] if T is None else T
+        rc = self.lib.vv_gemm_raw(self._s, self._p(wp), self._p(w2p), self._p(x), self._p(y), T, N, K,
+                                  ldx or K, ldy or N, pro, epi, self._p(nw), float(eps), self._p(bias),
+                                  self._p(nscale), xsplit or self.cfg.xsplit, ksplit, nontemporal)
+        if rc != 0:
+            raise EngineError(f"vv_gemm_raw failed ({rc})")
