@@ -1,0 +1,153 @@
+"""End-to-end parity of generate() (HIP engine through the C ABI) against the
+oracle loop on identical inputs, weights, forced/greedy tokens and noise.
+
+Tolerance: xsplit=3 keeps every GEMM at fp32-class accuracy; what accumulates
+through the autoregressive feedback is summation order + the bf16 KV cache
+(mirrored by the oracle's kv_round_bf16).  Stated bounds: token decisions
+identical; per-frame latent rel-L2 <= 5e-3; waveform rel-L2 <= 1e-2 over
+<= 12 frames.
+"""
+import types
+
+import pytest
+import torch
+
+import synth
+from gpu_util import build_small, rel_err
+from oracle import generate as ogen
+
+pytestmark = pytest.mark.gpu
+
+TOK = ogen.TokenIds(speech_start_id=301, speech_end_id=302, speech_diffusion_id=303, eos_token_id=304,
+                    bos_token_id=None, pad_token_id=305)
+
+
+def make_inputs(s, B, with_speech, seed):
+    g = synth.Gen(seed)
+    V = s.lmcfg.vocab
+    lens = [21, 17][:B]
+    L0 = max(lens)
+    ids = torch.full((B, L0), TOK.pad_token_id, dtype=torch.long)
+    mask = torch.zeros((B, L0), dtype=torch.long)
+    sim = torch.zeros((B, L0), dtype=torch.bool)
+    speech_tensors = speech_masks = None
+    n_fr = [2, 3]
+    for b in range(B):
+        n = lens[b]
+        row = torch.from_numpy(g.rng.integers(0, 300, (n,)))
+        row[-1] = TOK.speech_start_id
+        ids[b, L0 - n:] = row
+        mask[b, L0 - n:] = 1
+        if with_speech:
+            # voice prompt placeholders: n_fr[b] <speech_diffusion> positions
+            st = L0 - n + 3
+            ids[b, st:st + n_fr[b]] = TOK.speech_diffusion_id
+            sim[b, st:st + n_fr[b]] = True
+    if with_speech:
+        S = 3 * 3200
+        speech_tensors = g.uniform((B, S), -0.5, 0.5)
+        speech_masks = torch.zeros((B, 3), dtype=torch.bool)
+        for b in range(B):
+            speech_masks[b, :n_fr[b]] = True
+    return ids, mask, sim, speech_tensors, speech_masks
+
+
+def run_both(s, B, forced, with_speech, cfg=1.3, steps=5, seed=11, max_new_tokens=None):
+    from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference
+    ids, mask, sim, st, sm = make_inputs(s, B, with_speech, seed)
+    g = synth.Gen(seed + 1)
+    noise_bank = {}
+
+    def noise_fn(step, n2):
+        if (step, n2) not in noise_bank:
+            noise_bank[(step, n2)] = synth.Gen(seed * 1000 + step).normal((n2, 64), 1.0, mat=False)
+        return noise_bank[(step, n2)]
+    pre = None
+    if with_speech:
+        pre = (g.normal((B,), 1.0, mat=False), g.normal((B, 3, 64), 1.0, mat=False))
+    om = s.oracle_model(kv_round_bf16=True)
+    otr = ogen.Trace()
+    oseq, oaud, omax = ogen.oracle_generate(om, TOK, ids, mask, st, sm, sim if with_speech else None, cfg_scale=cfg,
+                                            num_steps=steps, max_new_tokens=max_new_tokens, noise_fn=noise_fn,
+                                            prefill_noise=pre, forced_tokens=forced, trace=otr)
+    cfgd = {"decoder_config": {"max_position_embeddings": s.lmcfg.max_pos},
+            "diffusion_head_config": {"ddpm_num_inference_steps": steps},
+            "acoustic_tokenizer_config": {"fix_std": 0.5, "std_dist_type": "gaussian"}}
+    m = VibeVoiceForConditionalGenerationInference(cfgd, s.eng, model_dtype=torch.float32)
+    m.set_speech_factors(s.scaling, s.bias)
+    m.set_ddpm_inference_steps(steps)
+    tok = types.SimpleNamespace(speech_start_id=TOK.speech_start_id, speech_end_id=TOK.speech_end_id,
+                                speech_diffusion_id=TOK.speech_diffusion_id, eos_token_id=TOK.eos_token_id,
+                                bos_token_id=None, pad_token_id=TOK.pad_token_id)
+    htr = ogen.Trace()
+    out = m.generate(input_ids=ids, attention_mask=mask, speech_tensors=st, speech_masks=sm,
+                     speech_input_mask=sim if with_speech else None, cfg_scale=cfg, tokenizer=tok,
+                     max_new_tokens=max_new_tokens, generation_config={"do_sample": False},
+                     _forced_tokens=forced, _noise_fn=noise_fn, _prefill_noise=pre, _trace=htr,
+                     show_progress_bar=False)
+    return (oseq, oaud, omax, otr), (out, htr)
+
+
+@pytest.fixture(scope="module")
+def sm():
+    s = build_small(synth.LMCfg(), xsplit=3, n_slots=2, max_ctx=512)
+    yield s
+    s.eng.close()
+
+
+D, E, S, X = TOK.speech_diffusion_id, TOK.speech_end_id, TOK.speech_start_id, TOK.eos_token_id
+
+
+def check(o, h, lat_tol=5e-3, wav_tol=1e-2):
+    (oseq, oaud, omax, otr), (out, htr) = o, h
+    assert torch.equal(out.sequences.cpu(), oseq)
+    assert torch.equal(out.reach_max_step_sample.cpu(), omax)
+    assert len(otr.latents) == len(htr.latents)
+    for a, b in zip(htr.latents, otr.latents):
+        assert rel_err(a, b) <= lat_tol, rel_err(a, b)
+    for a, b in zip(htr.neg_hidden, otr.neg_hidden):
+        assert rel_err(a, b) <= lat_tol, rel_err(a, b)
+    for a, b in zip(out.speech_outputs, oaud):
+        if b is None:
+            assert a is None
+        else:
+            assert a.shape[-1] == b.shape[-1]
+            assert rel_err(a[0], b[0]) <= wav_tol, rel_err(a[0], b[0])
+
+
+def test_generate_forced_single(sm):
+    forced = [[D, D, D, D, E, S, D, D, D, X]]
+    o, h = run_both(sm, 1, forced, with_speech=True)
+    check(o, h)
+    assert h[0].speech_outputs[0].shape[-1] == 7 * 3200
+
+
+def test_generate_forced_batch2_desync(sm):
+    # rows desynchronise: row 1 ends its first segment earlier and finishes earlier
+    forced = [[D, D, D, E, S, D, D, X], [D, D, E, S, D, X]]
+    o, h = run_both(sm, 2, forced, with_speech=True, seed=23)
+    check(o, h)
+
+
+def test_generate_greedy_free_running(sm):
+    # free-running argmax over the 4 valid ids; random weights pick whatever they pick --
+    # both sides must pick the same ids
+    o, h = run_both(sm, 1, None, with_speech=False, seed=31, max_new_tokens=10)
+    check(o, h)
+
+
+def test_generate_max_length_cap(sm):
+    forced = [[D] * 50]
+    o, h = run_both(sm, 1, forced, with_speech=False, seed=41, max_new_tokens=6)
+    check(o, h)
+    assert h[0].sequences.shape[1] == 21 + 6
+
+
+def test_generate_with_graphs():
+    s = build_small(synth.LMCfg(), xsplit=3, n_slots=1, max_ctx=512, use_graph=True)
+    try:
+        forced = [[D, D, D, D, E, S, D, D, D, X]]
+        o, h = run_both(s, 1, forced, with_speech=True)
+        check(o, h)
+    finally:
+        s.eng.close()
