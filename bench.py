@@ -1,0 +1,289 @@
+#!/usr/bin/env python
+"""bench.py -- audio-seconds per wall-second of the VibeVoice hot loop on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--model 1.5b|7b] [--solver-steps N]
+
+One "step" = one iteration of the reference's hot loop emitting <speech_diffusion>
+(modeling_vibevoice_inference.py:432-675): positive + CFG-negative LM decode,
+restricted lm_head, N-step CFG DPM-Solver++ diffusion head, acoustic codec decode
+of the 3200-sample frame, semantic re-encode, connectors, token read-back.
+Workload at N=1 (BASELINE.json configs[1]): VibeVoice-1.5B shapes, 1 speaker,
+prompt sized like demo/text_examples/1p_abs.txt (~220 text tokens + a 75-frame
+voice prompt), bf16 weights, 10 solver steps (the file demo's default,
+demo/inference_from_file.py:365), synthetic seeded weights and forced token
+schedule.  With --gpus N>1 every rank decodes its own utterance
+(weak scaling, no collective inside the step loop); weights are generated on rank 0
+and broadcast over RCCL/xGMI at start-up.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FRAME_SEC = 3200 / 24000.0
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def algorithmic_bytes_per_frame(cfg, n_solver, kv_len_pos, kv_len_neg):
+    """bf16 weights read once per frame, head weights once per solver step
+    (cond_proj once per frame), cond+uncond LM rows share one weight read, lm_head = 5 rows."""
+    from vibevoice_amd.synthetic import param_shapes
+    sh = param_shapes(cfg)
+    H = cfg["decoder_config"]["hidden_size"]
+
+    def count(prefix, pred=lambda k: True):
+        n = 0
+        for k, s in sh.items():
+            if k.startswith(prefix) and pred(k):
+                m = 1
+                for d in s:
+                    m *= d
+                n += m
+        return n
+    p_lm = count("model.language_model.layers.") + count("model.language_model.norm.")
+    p_head = count("model.prediction_head.")
+    p_dec = count("model.acoustic_tokenizer.decoder.")
+    p_sem = count("model.semantic_tokenizer.encoder.")
+    p_conn = count("model.acoustic_connector.") + count("model.semantic_connector.")
+    d = cfg["decoder_config"]
+    kv_tok = 2 * d["num_hidden_layers"] * d["num_key_value_heads"] * (H // d["num_attention_heads"]) * 2
+    b = 2 * p_lm + 2 * (p_head - H * H) * n_solver + 2 * H * H + 2 * p_dec + 2 * p_sem + 2 * p_conn
+    b += 2 * 5 * H + kv_tok * (kv_len_pos + kv_len_neg)
+    return float(b)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=150)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--model", default="1.5b")
+    ap.add_argument("--solver-steps", type=int, default=10)
+    ap.add_argument("--cfg-scale", type=float, default=1.3)
+    ap.add_argument("--xsplit", type=int, default=int(os.environ.get("VVHIP_XSPLIT", "1")))
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=4)
+    ap.add_argument("--text-tokens", type=int, default=220)
+    ap.add_argument("--voice-frames", type=int, default=75)
+    ap.add_argument("--speakers", type=int, default=1)
+    ap.add_argument("--max-ctx", type=int, default=0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from vibevoice_amd import build as vbuild
+    if rank == 0 and vbuild.stale():
+        vbuild.build()
+    if world > 1:
+        dist.barrier()
+    from vibevoice_amd import synthetic
+    from vibevoice_amd.configs import CONFIGS
+    from vibevoice_amd.engine import Engine, map_param_name
+    from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference, engine_config_from_reference
+
+    cfg = CONFIGS[args.model]
+    K, W, NS = args.steps, max(1, args.warmup), args.solver_steps
+    inputs = synthetic.synthetic_inputs(cfg, n_speakers=args.speakers, text_tokens=args.text_tokens,
+                                        voice_frames=args.voice_frames, seed=100 + rank)
+    L0 = inputs["input_ids"].shape[1]
+    total_steps = W + K + 2
+    max_ctx = args.max_ctx or ((L0 + total_steps + 256 + 127) // 128 * 128)
+    ecfg = engine_config_from_reference(cfg, n_slots=1, max_ctx=max_ctx, xsplit=args.xsplit,
+                                        use_graph=not args.no_graph, enc_frames=5)
+    t_load0 = time.time()
+    eng = Engine(ecfg, device)
+    exp = eng.expected_weights()
+    keep_cpu = (rank == 0 and world == 1 and not args.no_cpu_baseline)
+    cpu_sd = {}
+    # rank 0 draws the weights, RCCL broadcasts them over xGMI (one collective per tensor at start-up, none later)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(0)
+    for k, shape in synthetic.param_shapes(cfg).items():
+        if rank == 0:
+            t = synthetic.random_tensor(k, shape, gen, device, torch.bfloat16)
+        else:
+            t = torch.empty(shape, dtype=torch.bfloat16, device=device)
+        if world > 1:
+            dist.broadcast(t, src=0)
+        name = map_param_name(k)
+        if name in exp:
+            eng.upload(name, t)
+        if keep_cpu:
+            cpu_sd[k] = t.to("cpu")
+        del t
+    miss = eng.missing_weights()
+    if miss:
+        raise SystemExit(f"engine parameters not provided: {miss[:5]}")
+    model = VibeVoiceForConditionalGenerationInference(cfg, eng, model_dtype=torch.bfloat16)
+    model.set_speech_factors(0.2, -0.05)
+    model.set_ddpm_inference_steps(NS)
+    load_s = time.time() - t_load0
+
+    forced = [synthetic.forced_schedule(total_steps, turn=150)]
+    g = torch.Generator(device=device)
+    g.manual_seed(1234 + rank)
+    noise_bank = torch.randn(total_steps + 1, 2, cfg["acoustic_vae_dim"], generator=g, device=device)
+    torch.cuda.synchronize()
+
+    marks = {}
+
+    def step_cb(step):
+        if step == W or step == W + K:
+            eng.sync()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+                torch.cuda.synchronize()
+            marks[step] = time.perf_counter()
+        if step == 1:
+            eng.sync()
+            marks["prefill_done"] = time.perf_counter()
+
+    t_gen0 = time.perf_counter()
+    out = model.generate(tokenizer=synthetic.TOKENS, cfg_scale=args.cfg_scale, generation_config={"do_sample": False},
+                         max_new_tokens=total_steps, show_progress_bar=False, _forced_tokens=forced,
+                         _noise_fn=lambda step, n2: noise_bank[step], _step_callback=step_cb, **inputs)
+    eng.sync()
+    t_gen1 = time.perf_counter()
+    wall = marks[W + K] - marks[W]
+    wall_t = torch.tensor([wall], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
+    wall_max = float(wall_t.item())
+    # steps W..W+K-1: count the <speech_diffusion> frames among them (the schedule inserts 2 control tokens per 150)
+    frames = sum(1 for t in forced[0][W:W + K] if t == synthetic.TOKENS.speech_diffusion_id)
+    value = world * frames * FRAME_SEC / wall_max
+    audio_total = out.speech_outputs[0].shape[-1] / 24000.0
+
+    # ---- roofline of the dominant kernel (vv_gemm_kernel): per-launch hipEvents over K_prof live steps ----
+    roof = None
+    if rank == 0:
+        kprof = 8
+        forced_p = [synthetic.forced_schedule(kprof + 3, turn=150)]
+        prof = {}
+
+        def prof_cb(step):
+            if step == 2:
+                eng.sync()
+                eng.profile_begin()
+            if step == 2 + kprof:
+                prof["res"] = eng.profile_end()
+        inp2 = synthetic.synthetic_inputs(cfg, n_speakers=args.speakers, text_tokens=args.text_tokens,
+                                          voice_frames=args.voice_frames, seed=100)
+        model.generate(tokenizer=synthetic.TOKENS, cfg_scale=args.cfg_scale, generation_config={"do_sample": False},
+                       max_new_tokens=kprof + 3, show_progress_bar=False, _forced_tokens=forced_p,
+                       _noise_fn=lambda step, n2: noise_bank[step], _step_callback=prof_cb, **inp2)
+        n_l, ms, by = prof["res"]
+        ach = by / 1e9 / (ms / 1e3) if ms > 0 else 0.0
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                traffic = json.load(f).get(args.model, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            pass
+        formula = algorithmic_bytes_per_frame(cfg, NS, L0 + W + K // 2, 1 + min(150, K) // 2)
+        roof = {"bound": "hbm", "kernel": "vv_gemm_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "launches_per_step": round(n_l / kprof, 1), "avg_launch_us": round(ms * 1e3 / max(1, n_l), 3),
+                "bytes_per_launch": round(by / max(1, n_l), 1),
+                "gemm_bytes_per_step": round(by / kprof, 1), "formula_bytes_per_step": round(formula, 1),
+                "whole_step_GBps": round(formula / 1e9 / (wall_max / K), 1),
+                "whole_step_frac": round(formula / 1e9 / (wall_max / K) / HBM_PEAK_GBS, 4)}
+
+    # ---- CPU baseline: the oracle loop on the host cores, bounded sample ----
+    cpu = None
+    if keep_cpu:
+        try:
+            cpu = cpu_baseline(cfg, cpu_sd, NS, args.cfg_scale, args.cpu_frames)
+        except Exception as ex:   # the baseline is a reported number, never the product path
+            cpu = {"value": None, "error": repr(ex)[:200]}
+    if rank == 0:
+        res = {
+            "metric": "audio-sec/wall-sec", "value": round(value, 3), "unit": "audio-s/wall-s", "n_gpus": world,
+            "steps": K, "warmup": W, "ms_per_step": round(wall_max / K * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"VibeVoice-{args.model.upper()} shapes, {args.speakers} speaker, "
+                                   f"{L0}-token prompt ({args.text_tokens} text + {args.voice_frames}-frame voice), "
+                                   f"{NS} solver steps, cfg {args.cfg_scale}, 1 utterance per GPU, forced token schedule",
+                       "model": f"VibeVoice-{args.model}", "solver_steps": NS, "prompt_tokens": L0,
+                       "xsplit": args.xsplit, "hipgraph": not args.no_graph, "parallelism": f"utterance-dp{world}"},
+            "roofline": roof, "cpu_baseline": cpu,
+            "extra": {"frames_timed": frames, "weights_load_s": round(load_s, 2),
+                      "prefill_plus_first_frame_s": round(marks.get("prefill_done", t_gen0) - t_gen0, 4),
+                      "utterance_audio_s": round(audio_total, 2), "utterance_wall_s": round(t_gen1 - t_gen0, 3),
+                      "utterance_audio_per_wall": round(audio_total / (t_gen1 - t_gen0), 2)},
+        }
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+def cpu_baseline(cfg, cpu_sd, n_solver, cfg_scale, n_frames):
+    """Times oracle/ (the CPU restatement of the reference loop) on this host: `n_frames` decode
+    frames after a short prompt, fp32, all host threads.  kind = "port"."""
+    from oracle import generate as ogen
+    from oracle import lm as olm
+    from vibevoice_amd import synthetic
+    ncpu = os.cpu_count() or 1
+    torch.set_num_threads(ncpu)
+    d = cfg["decoder_config"]
+    H = d["hidden_size"]
+
+    def sub(prefix):
+        return {k[len(prefix):]: v.float() for k, v in cpu_sd.items() if k.startswith(prefix)}
+    lm_w = sub("model.language_model.")
+    lm = olm.Qwen2Oracle(lm_w, d["num_hidden_layers"], d["num_attention_heads"], d["num_key_value_heads"],
+                         H // d["num_attention_heads"], d.get("rope_theta", 1e6), d.get("rms_norm_eps", 1e-6))
+    depths = [int(x) for x in cfg["acoustic_tokenizer_config"]["encoder_depths"].split("-")]
+    m = ogen.OracleModel(
+        lm=lm, lm_head=cpu_sd["lm_head.weight"].float() if "lm_head.weight" in cpu_sd else lm_w["embed_tokens.weight"],
+        head_w=sub("model.prediction_head."), head_layers=cfg["diffusion_head_config"]["head_layers"],
+        ac_w=sub("model.acoustic_tokenizer."), sem_w=sub("model.semantic_tokenizer."),
+        ac_conn=sub("model.acoustic_connector."), sem_conn=sub("model.semantic_connector."),
+        ratios=cfg["acoustic_tokenizer_config"]["encoder_ratios"], enc_depths=depths,
+        dec_depths=list(reversed(depths)), sem_depths=depths, scaling=0.2, bias=-0.05,
+        max_position_embeddings=d["max_position_embeddings"])
+    T = synthetic.TOKENS
+    tok = ogen.TokenIds(T.speech_start_id, T.speech_end_id, T.speech_diffusion_id, T.eos_token_id, None, T.pad_token_id)
+    g = torch.Generator().manual_seed(7)
+    ids = torch.randint(0, 151000, (1, 48), generator=g)
+    ids[0, -1] = T.speech_start_id
+    stamps = []
+
+    def noise_fn(step, n2):
+        stamps.append(time.perf_counter())
+        return torch.randn(n2, 64, generator=g)
+    forced = [[T.speech_diffusion_id] * (n_frames + 1)]
+    with torch.no_grad():
+        ogen.oracle_generate(m, tok, ids, torch.ones_like(ids), cfg_scale=cfg_scale, num_steps=n_solver,
+                             max_new_tokens=n_frames + 1, noise_fn=noise_fn, forced_tokens=forced)
+    per_frame = (stamps[-1] - stamps[0]) / max(1, len(stamps) - 1)
+    return {"value": round(FRAME_SEC / per_frame, 4), "unit": "audio-s/wall-s", "cores": ncpu, "kind": "port",
+            "sample": f"{len(stamps) - 1} decode frames after a 48-token text-only prompt, same model shapes/weights, "
+                      f"fp32, {n_solver} solver steps, oracle loop (CPU restatement of the reference)",
+            "ms_per_step": round(per_frame * 1e3, 2)}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,6 @@
+"""vibevoice_amd -- MI355X-native engine for the VibeVoice generate() hot path.
+
+    from vibevoice_amd import VibeVoiceForConditionalGenerationInference
+"""
+from .engine import Engine, EngineConfig, EngineError  # noqa: F401
+from .modeling import VibeVoiceForConditionalGenerationInference, VibeVoiceGenerationOutput  # noqa: F401

@@ -134,6 +134,11 @@ struct vv_ctx {
     void* stage = nullptr; size_t stage_bytes = 0;
     std::map<std::string, GraphEntry> graphs;
     int64_t launches = 0;
+    // optional per-GEMM-launch hipEvent timing (vv_profile_begin/end)
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;
+    int prof_n = 0;
+    double prof_bytes = 0.0;
 };
 
 static int fail(vv_ctx* ctx, const char* fmt, ...) {
@@ -303,7 +308,27 @@ static VVGemm mk_gemm(const void* W, const float* X, float* Y, int T, int N, int
     g.pro = VV_PRO_NONE; g.epi = VV_EPI_STORE; g.ksplit = 0; g.nt = 0; g.eps = 1e-6f;
     return g;
 }
-#define GEMM(g) do { ctx->launches++; VVCHK(vv_gemm_launch(g, ctx->c.xsplit, st)); } while (0)
+static double gemm_bytes(const VVGemm& g) {
+    // algorithmic bytes of one launch: packed weights once (+ second matrix), activations in, result out (RMW epilogues twice)
+    double w = (double)vv_packed_elems(g.N, g.K) * 2.0 * (g.W2 ? 2.0 : 1.0);
+    double x = (double)g.T * g.K * 4.0;
+    double y = (double)g.T * g.N * 4.0 * ((g.epi == VV_EPI_RESID || g.epi == VV_EPI_GATED_RESID) ? 2.0 : 1.0);
+    return w + x + y;
+}
+static int gemm_prof(vv_ctx* ctx, const VVGemm& g, hipStream_t st) {
+    if ((size_t)(2 * ctx->prof_n + 2) > ctx->prof_ev.size()) {
+        size_t old = ctx->prof_ev.size();
+        ctx->prof_ev.resize(old + 2048);
+        for (size_t i = old; i < ctx->prof_ev.size(); ++i) hipEventCreate(&ctx->prof_ev[i]);
+    }
+    hipEventRecord(ctx->prof_ev[2 * ctx->prof_n], st);
+    int r = vv_gemm_launch(g, ctx->c.xsplit, st);
+    hipEventRecord(ctx->prof_ev[2 * ctx->prof_n + 1], st);
+    ctx->prof_n++;
+    ctx->prof_bytes += gemm_bytes(g);
+    return r;
+}
+#define GEMM(g) do { ctx->launches++; if (ctx->prof_on) VVCHK(gemm_prof(ctx, g, st)); else VVCHK(vv_gemm_launch(g, ctx->c.xsplit, st)); } while (0)
 
 // Runs one codec net over F frames for slot `sl`.  The caller has already written the
 // input rows into net.in_buf[sl] + 6*in_dim.
@@ -362,7 +387,7 @@ static int zero_codec(vv_ctx* ctx, CodecNet& net, int sl, hipStream_t st) {
 // ------------------------------------------------------------------ graphs
 template <class F>
 static int graphed(vv_ctx* ctx, const std::string& key, hipStream_t st, F&& body) {
-    if (!ctx->c.use_graph) return body();
+    if (!ctx->c.use_graph || ctx->prof_on) return body();
     auto it = ctx->graphs.find(key);
     if (it == ctx->graphs.end()) {
         // warm run first (lazy allocations, shift tables), then capture
@@ -858,5 +883,24 @@ extern "C" int vv_gemm_raw(void* stream, const void* w, const void* w2, const fl
     g.W2 = (const u32x4*)w2; g.pro = pro; g.epi = epi; g.nw = nw; g.eps = eps; g.bias = bias; g.nscale = nscale;
     g.ksplit = ksplit; g.nt = nontemporal;
     return vv_gemm_launch(g, xsplit, (hipStream_t)stream);
+}
+extern "C" int vv_profile_begin(vv_ctx* ctx) {
+    HIPCHK(ctx, hipDeviceSynchronize());
+    ctx->prof_on = true; ctx->prof_n = 0; ctx->prof_bytes = 0.0;
+    return 0;
+}
+extern "C" int vv_profile_end(vv_ctx* ctx, int64_t* launches, double* total_ms, double* bytes) {
+    HIPCHK(ctx, hipDeviceSynchronize());
+    double ms = 0.0;
+    for (int i = 0; i < ctx->prof_n; ++i) {
+        float e = 0.f;
+        HIPCHK(ctx, hipEventElapsedTime(&e, ctx->prof_ev[2 * i], ctx->prof_ev[2 * i + 1]));
+        ms += e;
+    }
+    if (launches) *launches = ctx->prof_n;
+    if (total_ms) *total_ms = ms;
+    if (bytes) *bytes = ctx->prof_bytes;
+    ctx->prof_on = false;
+    return 0;
 }
 extern "C" int64_t vv_stat(vv_ctx* ctx, int what) { return what == 0 ? ctx->launches : (int64_t)ctx->graphs.size(); }

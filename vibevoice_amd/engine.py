@@ -267,6 +267,14 @@ class Engine:
     def connect(self, n: int, latent: torch.Tensor, sem: Optional[torch.Tensor], out: torch.Tensor):
         self._chk(self.lib.vv_connect(self._ctx, self._s, n, self._p(latent), self._p(sem), self._p(out)), "vv_connect")
 
+    def profile_begin(self):
+        self._chk(self.lib.vv_profile_begin(self._ctx), "vv_profile_begin")
+
+    def profile_end(self):
+        n, ms, by = C.c_int64(), C.c_double(), C.c_double()
+        self._chk(self.lib.vv_profile_end(self._ctx, C.byref(n), C.byref(ms), C.byref(by)), "vv_profile_end")
+        return n.value, ms.value, by.value
+
     def stat(self, what=0):
         return int(self.lib.vv_stat(self._ctx, what))
 

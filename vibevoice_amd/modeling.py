@@ -231,6 +231,7 @@ class VibeVoiceForConditionalGenerationInference:
         noise_fn = kwargs.pop("_noise_fn", None)                  # test hook: explicit diffusion noise
         prefill_noise = kwargs.pop("_prefill_noise", None)
         trace = kwargs.pop("_trace", None)
+        step_cb = kwargs.pop("_step_callback", None)             # bench hook: called at the top of every step
         input_ids = kwargs["input_ids"] if inputs is None else inputs
         attention_mask = kwargs.get("attention_mask")
         input_ids = input_ids.cpu()
@@ -285,6 +286,8 @@ class VibeVoiceForConditionalGenerationInference:
                 e.codec_reset(b)
             e.embed([start_id], self._start_emb)
             for step in progress:
+                if step_cb is not None:
+                    step_cb(step)
                 if stop_check_fn is not None and stop_check_fn():
                     if audio_streamer is not None:
                         audio_streamer.end()
