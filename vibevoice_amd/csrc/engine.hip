@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -139,6 +140,8 @@ struct vv_ctx {
     std::vector<hipEvent_t> prof_ev;
     int prof_n = 0;
     double prof_bytes = 0.0;
+    struct ProfRec { int T, N, K, pro, epi, dual; double bytes; };
+    std::vector<ProfRec> prof_rec;
 };
 
 static int fail(vv_ctx* ctx, const char* fmt, ...) {
@@ -326,6 +329,7 @@ static int gemm_prof(vv_ctx* ctx, const VVGemm& g, hipStream_t st) {
     hipEventRecord(ctx->prof_ev[2 * ctx->prof_n + 1], st);
     ctx->prof_n++;
     ctx->prof_bytes += gemm_bytes(g);
+    ctx->prof_rec.push_back({g.T, g.N, g.K, g.pro, g.epi, g.W2 ? 1 : 0, gemm_bytes(g)});
     return r;
 }
 #define GEMM(g) do { ctx->launches++; if (ctx->prof_on) VVCHK(gemm_prof(ctx, g, st)); else VVCHK(vv_gemm_launch(g, ctx->c.xsplit, st)); } while (0)
@@ -886,17 +890,22 @@ extern "C" int vv_gemm_raw(void* stream, const void* w, const void* w2, const fl
 }
 extern "C" int vv_profile_begin(vv_ctx* ctx) {
     HIPCHK(ctx, hipDeviceSynchronize());
-    ctx->prof_on = true; ctx->prof_n = 0; ctx->prof_bytes = 0.0;
+    ctx->prof_on = true; ctx->prof_n = 0; ctx->prof_bytes = 0.0; ctx->prof_rec.clear();
     return 0;
 }
 extern "C" int vv_profile_end(vv_ctx* ctx, int64_t* launches, double* total_ms, double* bytes) {
     HIPCHK(ctx, hipDeviceSynchronize());
     double ms = 0.0;
+    const char* csv = getenv("VVHIP_PROF_CSV");
+    FILE* f = csv ? fopen(csv, "w") : nullptr;
+    if (f) fprintf(f, "idx,T,N,K,pro,epi,dual,bytes,us\n");
     for (int i = 0; i < ctx->prof_n; ++i) {
         float e = 0.f;
         HIPCHK(ctx, hipEventElapsedTime(&e, ctx->prof_ev[2 * i], ctx->prof_ev[2 * i + 1]));
         ms += e;
+        if (f) { const auto& r = ctx->prof_rec[i]; fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%.0f,%.3f\n", i, r.T, r.N, r.K, r.pro, r.epi, r.dual, r.bytes, e * 1e3); }
     }
+    if (f) fclose(f);
     if (launches) *launches = ctx->prof_n;
     if (total_ms) *total_ms = ms;
     if (bytes) *bytes = ctx->prof_bytes;
