@@ -8,19 +8,24 @@
 // MI355X mapping
 //  * W is pre-packed at load time into 1 KiB MFMA-fragment tiles (vv_common.h),
 //    so every wave-level weight load is one fully coalesced 1 KiB
-//    global_load_dwordx4 and goes straight to VGPRs (no LDS round trip: the
-//    weights are used once per wave -- HBM-bound, arithmetic intensity ~1).
+//    global_load_dwordx4 (non-temporal for streamed-once weights) straight into
+//    VGPRs -- no LDS round trip for weights: each is used once per wave, the
+//    kernel is HBM-bound (arithmetic intensity ~1 flop/B).  The next batch of
+//    weight tiles is prefetched while the current one feeds the matrix pipe.
 //  * one wave = NT tiles of 16 output features x 16 activation rows, accumulated
 //    with v_mfma_f32_16x16x32_bf16 (A = weight tile, B = activations), fp32 acc.
-//  * activations stay fp32 in HBM/L2; they are converted on the fly into 1..3
-//    bf16 terms (hi [+ mid [+ lo]]) so the product is exact to bf16 / ~fp24 /
-//    fp32 activation precision at 1..3 MFMAs per tile (XS template parameter).
-//    The matrix pipe is <10 % busy either way; HBM is the bound.
-//  * RMSNorm / adaLN-modulate / SiLU prologues and bias / GELU / SwiGLU /
-//    layer-scale-residual / gated-residual epilogues are fused so each
-//    activation vector makes one trip.
-//  * K can be split across the 4 waves of a block (ksplit) and reduced through
-//    LDS in a fixed order -> deterministic, no atomics.
+//  * activations stay fp32 in HBM/L2.  Per batch of U k-steps a wave reads its
+//    rows with coalesced float4 loads, applies the prologue (norm weight, adaLN
+//    modulate, add+SiLU), splits each value into 1..3 bf16 terms (hi [+mid [+lo]],
+//    XS) and parks the terms in a wave-private LDS tile laid out in B-fragment
+//    order; fragments come back with one ds_read_b128 per k-step.  Only the rows
+//    that exist are converted (T=2 at decode), and LDS traffic is on lgkmcnt, so
+//    it never serialises behind the weight stream's vmcnt.
+//  * RMSNorm costs no extra pass: sum(x^2) is accumulated during staging and the
+//    1/rms factor is applied to the accumulator in the epilogue (it is a per-row
+//    scalar); only the adaLN-modulated norm (shift term) needs 1/rms up front.
+//  * K is split across KS of the block's waves (up to 16) and reduced through LDS
+//    in a fixed order -> deterministic, no atomics, enough waves for skinny N.
 #include "vv_common.h"
 
 namespace {
@@ -34,187 +39,283 @@ __device__ __forceinline__ float wave_sum(float v) {
 __device__ __forceinline__ float silu_f(float u) { return u / (1.0f + expf(-u)); }
 __device__ __forceinline__ float gelu_erf_f(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f)); }
 
-template <int XS>
-__device__ __forceinline__ void split_bf16(const float (&v)[8], bf16x8 (&out)[XS]) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        __bf16 h = (__bf16)v[j];
-        out[0][j] = h;
-        if constexpr (XS > 1) {
-            float r = v[j] - (float)h;
-            __bf16 m = (__bf16)r;
-            out[1][j] = m;
-            if constexpr (XS > 2) {
-                float r2 = r - (float)m;
-                out[2][j] = (__bf16)r2;
-            }
-        }
-    }
-}
-
 __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 u) { return __builtin_bit_cast(bf16x8, u); }
 
-template <int NT, int XS, bool DUAL>
-__global__ __launch_bounds__(256) void vv_gemm_kernel(const VVGemm a) {
+// 4 fp32 -> XS packed bf16x4 terms (8 bytes each)
+template <int XS>
+__device__ __forceinline__ void split4(const float (&v)[4], uint2 (&out)[XS]) {
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    bf16x4 h, m, l;
+    float r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        h[j] = (__bf16)v[j];
+        if constexpr (XS > 1) {
+            r[j] = v[j] - (float)h[j];
+            m[j] = (__bf16)r[j];
+            if constexpr (XS > 2) l[j] = (__bf16)(r[j] - (float)m[j]);
+        }
+    }
+    out[0] = __builtin_bit_cast(uint2, h);
+    if constexpr (XS > 1) out[1] = __builtin_bit_cast(uint2, m);
+    if constexpr (XS > 2) out[2] = __builtin_bit_cast(uint2, l);
+}
+
+template <int NT, int XS, bool DUAL, int WPB, int MAXR>
+__global__ __launch_bounds__(WPB * 64) void vv_gemm_kernel(const VVGemm a) {
     constexpr int NM = DUAL ? 2 * NT : NT;
-    constexpr int U = (NM >= 2) ? 4 : 8;          // k-steps per batch: ~8 KiB of weights in flight per wave
+    constexpr bool PREFETCH = (WPB == 8);         // decode variant: second weight buffer; tall variant favours occupancy
+    constexpr bool MODREG = (MAXR <= 4);          // adaLN scale/shift prefetched in registers only for few rows
+    constexpr int U = 8;                          // k-steps per batch = 256 k = one float4 per lane per row
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int KS = a.ksplit;
-    const int NG = 4 / KS;
+    const int NG = WPB / KS;
     const int ng = wave / KS, ks = wave - ng * KS;
     const int n_tiles = (a.N + 15) >> 4;
     const int k_tiles = (a.K + 31) >> 5;
     const int tile0 = ((int)blockIdx.x * NG + ng) * NT;
     const int t0 = (int)blockIdx.y * 16;
-    const int kper = (k_tiles + KS - 1) / KS;
+    const int Tt = min(MAXR, a.T - t0);           // rows of this tile (wave-uniform)
+    int kper = (k_tiles + KS - 1) / KS;
+    kper = (kper + U - 1) / U * U;                // whole batches per wave
     const int kt_begin = ks * kper;
     const int kt_end = min(k_tiles, kt_begin + kper);
-    const int row = t0 + (lane & 15);
-    const bool row_ok = row < a.T;
-    const int kq = (lane >> 4) * 8;
-    const bool active = tile0 < n_tiles;
+    const bool active = tile0 < n_tiles && kt_begin < kt_end;
     const bool vec_ok = ((a.K & 3) == 0) && ((a.ldx & 3) == 0) && ((((uintptr_t)a.X) & 15) == 0);
+    const int Tpad = a.t_pad;                     // LDS row stride (>= Tt), host-chosen
+    // wave-private staging tile: [XS][U][4 q][Tpad] x 16 B
+    unsigned char* stg = smem + (size_t)wave * XS * U * 4 * Tpad * 16;
+    const int kk = lane * 4;                      // this lane's k offset inside a batch
+    const int st_off = (((kk >> 5) * 4 + ((kk & 31) >> 3)) * Tpad) * 16 + (kk & 7) * 2;
+    const int frow = lane & 15, fq = lane >> 4;
 
-    // ---- prologue: per-row 1/rms over the full K (every wave, redundantly: x is L2-resident) ----
-    float rstd = 1.0f;
-    if (a.pro == VV_PRO_RMS || a.pro == VV_PRO_RMS_MOD) {
-        const int nrows = min(16, a.T - t0);
-        for (int r = 0; r < nrows; ++r) {
-            const float* xr = a.X + (int64_t)(t0 + r) * a.ldx;
-            float s = 0.f;
-            if (vec_ok) {
-                for (int k = lane * 4; k < a.K; k += 256) {
-                    float4 v = *reinterpret_cast<const float4*>(xr + k);
-                    s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    // ---- adaLN-modulated norm needs 1/rms before staging: one cheap pass over the tile's rows ----
+    float rstd_rows[MAXR];
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) rstd_rows[r] = 1.0f;
+    if (a.pro == VV_PRO_RMS_MOD) {
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r) {
+            if (r < Tt) {
+                const float* xr = a.X + (int64_t)(t0 + r) * a.ldx;
+                float s = 0.f;
+                if (vec_ok) {
+                    for (int k = lane * 4; k < a.K; k += 256) {
+                        float4 v = *reinterpret_cast<const float4*>(xr + k);
+                        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+                    }
+                } else {
+                    for (int k = lane; k < a.K; k += 64) { float v = xr[k]; s += v * v; }
                 }
-            } else {
-                for (int k = lane; k < a.K; k += 64) { float v = xr[k]; s += v * v; }
+                rstd_rows[r] = rsqrtf(wave_sum(s) / (float)a.K + a.eps);
             }
-            s = wave_sum(s);
-            float rs = rsqrtf(s / (float)a.K + a.eps);
-            if ((lane & 15) == r) rstd = rs;
         }
     }
 
     f32x4 acc[NM];
 #pragma unroll
     for (int i = 0; i < NM; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const float* xrow = a.X + (int64_t)(row_ok ? row : 0) * a.ldx;
+    float ssq[MAXR];
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) ssq[r] = 0.f;
     const u32x4 zero4 = u32x4{0u, 0u, 0u, 0u};
 
-    if (active) {
-        for (int ktb = kt_begin; ktb < kt_end; ktb += U) {
-            u32x4 wv[U][NM];
-            float xv[U][8];
-            // -- issue all weight loads of this batch (coalesced 1 KiB per wave-instruction) --
+    auto load_w = [&](int ktb, u32x4 (&dst)[U][NM]) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int kt = ktb + u;
-                const bool kok = kt < kt_end;
+        for (int u = 0; u < U; ++u) {
+            const int kt = ktb + u;
+            const bool kok = kt < kt_end;
 #pragma unroll
-                for (int i = 0; i < NT; ++i) {
-                    const int tile = tile0 + i;
-                    const bool ok = kok && tile < n_tiles;
-                    const int64_t off = ((int64_t)tile * k_tiles + kt) * 64 + lane;
-                    if (a.nt) {
-                        wv[u][i] = ok ? __builtin_nontemporal_load(a.W + off) : zero4;
-                        if constexpr (DUAL) wv[u][NT + i] = ok ? __builtin_nontemporal_load(a.W2 + off) : zero4;
-                    } else {
-                        wv[u][i] = ok ? a.W[off] : zero4;
-                        if constexpr (DUAL) wv[u][NT + i] = ok ? a.W2[off] : zero4;
-                    }
-                }
-            }
-            // -- activations for this batch (fp32, L2-resident) --
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int k0 = (ktb + u) * 32 + kq;
-                const bool kok = (ktb + u) < kt_end;
-                if (row_ok && kok && vec_ok && k0 + 8 <= a.K) {
-                    float4 lo = *reinterpret_cast<const float4*>(xrow + k0);
-                    float4 hi = *reinterpret_cast<const float4*>(xrow + k0 + 4);
-                    xv[u][0] = lo.x; xv[u][1] = lo.y; xv[u][2] = lo.z; xv[u][3] = lo.w;
-                    xv[u][4] = hi.x; xv[u][5] = hi.y; xv[u][6] = hi.z; xv[u][7] = hi.w;
+            for (int i = 0; i < NT; ++i) {
+                const int tile = tile0 + i;
+                const bool ok = kok && tile < n_tiles;
+                const int64_t off = ((int64_t)tile * k_tiles + kt) * 64 + lane;
+                if (a.nt) {
+                    dst[u][i] = ok ? __builtin_nontemporal_load(a.W + off) : zero4;
+                    if constexpr (DUAL) dst[u][NT + i] = ok ? __builtin_nontemporal_load(a.W2 + off) : zero4;
                 } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        xv[u][j] = (row_ok && kok && (k0 + j) < a.K) ? xrow[k0 + j] : 0.f;
+                    dst[u][i] = ok ? a.W[off] : zero4;
+                    if constexpr (DUAL) dst[u][NT + i] = ok ? a.W2[off] : zero4;
                 }
             }
-            // -- prologue math, bf16 split, MFMA --
+        }
+    };
+
+    // ---- staging, split in two so the loads can be issued ahead of the next weight batch ----
+    struct XRegs { float4 x[MAXR]; float4 sc[MODREG ? MAXR : 1]; float4 sh[MODREG ? MAXR : 1]; float4 nwv, addv; };
+    auto ld4 = [&](const float* p, int k, bool full) -> float4 {
+        float4 v = {0.f, 0.f, 0.f, 0.f};
+        if (full) v = *reinterpret_cast<const float4*>(p + k);
+        else { v.x = p[k]; if (k + 1 < a.K) v.y = p[k + 1]; if (k + 2 < a.K) v.z = p[k + 2]; if (k + 3 < a.K) v.w = p[k + 3]; }
+        return v;
+    };
+    auto stage_load = [&](int ktb, XRegs& R) {
+        const int k = ktb * 32 + kk;
+        const bool kin = k < a.K && (ktb + (kk >> 5)) < kt_end;
+        const bool full = vec_ok && (k + 4 <= a.K);
+        R.nwv = float4{1.f, 1.f, 1.f, 1.f};
+        R.addv = float4{0.f, 0.f, 0.f, 0.f};
+        if (kin && a.nw) R.nwv = ld4(a.nw, k, full);
+        if (kin && a.pro == VV_PRO_ADD_SILU) R.addv = ld4(a.addvec, k, full);
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int k0 = (ktb + u) * 32 + kq;
-                if ((ktb + u) < kt_end) {
-                    if (a.pro != VV_PRO_NONE) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const int k = k0 + j;
-                            const bool ok = row_ok && k < a.K;
-                            float v = xv[u][j];
-                            if (a.pro == VV_PRO_ADD_SILU) {
-                                v = ok ? silu_f(v + a.addvec[k]) : 0.f;
-                            } else {
-                                v = v * rstd;
-                                if (a.nw) v = ok ? v * a.nw[k] : 0.f;
-                                if (a.pro == VV_PRO_RMS_MOD && ok) {
-                                    const int64_t mo = (int64_t)row * a.ld_mod + k;
-                                    v = v * (1.0f + a.mod_scale[mo]) + a.mod_shift[mo];
-                                }
-                            }
-                            xv[u][j] = v;
-                        }
-                    }
-                    bf16x8 xb[XS];
-                    split_bf16<XS>(xv[u], xb);
-#pragma unroll
-                    for (int i = 0; i < NM; ++i) {
-                        const bf16x8 wf = as_bf16x8(wv[u][i]);
-#pragma unroll
-                        for (int p = 0; p < XS; ++p)
-                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xb[p], acc[i], 0, 0, 0);
+        for (int r = 0; r < MAXR; ++r) {
+            R.x[r] = float4{0.f, 0.f, 0.f, 0.f};
+            if (r < Tt && kin) {
+                R.x[r] = ld4(a.X + (int64_t)(t0 + r) * a.ldx, k, full);
+                if constexpr (MODREG) {
+                    if (a.pro == VV_PRO_RMS_MOD) {
+                        const int64_t mo = (int64_t)(t0 + r) * a.ld_mod;
+                        const bool mfull = full && ((a.ld_mod & 3) == 0);
+                        R.sc[r] = ld4(a.mod_scale + mo, k, mfull);
+                        R.sh[r] = ld4(a.mod_shift + mo, k, mfull);
                     }
                 }
+            }
+        }
+    };
+    auto stage_finish = [&](int ktb, const XRegs& R) {
+        const int k = ktb * 32 + kk;
+        const bool kin = k < a.K && (ktb + (kk >> 5)) < kt_end;
+        const bool k1 = kin && k + 1 < a.K, k2 = kin && k + 2 < a.K, k3 = kin && k + 3 < a.K;
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r) {
+            if (r < Tt) {
+                float v[4] = {R.x[r].x, R.x[r].y, R.x[r].z, R.x[r].w};
+                if (a.pro == VV_PRO_RMS) {
+                    ssq[r] += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+                    v[0] *= R.nwv.x; v[1] *= R.nwv.y; v[2] *= R.nwv.z; v[3] *= R.nwv.w;
+                } else if (a.pro == VV_PRO_RMS_MOD) {
+                    const float rs = rstd_rows[r];
+                    float4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (MODREG) { sc = R.sc[r]; sh = R.sh[r]; }
+                    else if (kin) {
+                        const int64_t mo = (int64_t)(t0 + r) * a.ld_mod;
+                        const bool mfull = vec_ok && (k + 4 <= a.K) && ((a.ld_mod & 3) == 0);
+                        sc = ld4(a.mod_scale + mo, k, mfull);
+                        sh = ld4(a.mod_shift + mo, k, mfull);
+                    }
+                    v[0] = kin ? (v[0] * rs * R.nwv.x) * (1.f + sc.x) + sh.x : 0.f;
+                    v[1] = k1 ? (v[1] * rs * R.nwv.y) * (1.f + sc.y) + sh.y : 0.f;
+                    v[2] = k2 ? (v[2] * rs * R.nwv.z) * (1.f + sc.z) + sh.z : 0.f;
+                    v[3] = k3 ? (v[3] * rs * R.nwv.w) * (1.f + sc.w) + sh.w : 0.f;
+                } else if (a.pro == VV_PRO_ADD_SILU) {
+                    v[0] = kin ? silu_f(v[0] + R.addv.x) : 0.f;
+                    v[1] = k1 ? silu_f(v[1] + R.addv.y) : 0.f;
+                    v[2] = k2 ? silu_f(v[2] + R.addv.z) : 0.f;
+                    v[3] = k3 ? silu_f(v[3] + R.addv.w) : 0.f;
+                }
+                uint2 parts[XS];
+                split4<XS>(v, parts);
+#pragma unroll
+                for (int p = 0; p < XS; ++p)
+                    *reinterpret_cast<uint2*>(stg + (size_t)p * U * 4 * Tpad * 16 + st_off + r * 16) = parts[p];
+            }
+        }
+    };
+
+    auto mma_batch = [&](int ktb, const u32x4 (&wb)[U][NM]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (ktb + u < kt_end) {
+                bf16x8 xb[XS];
+#pragma unroll
+                for (int p = 0; p < XS; ++p) {
+                    u32x4 f = zero4;
+                    if (frow < Tt) f = *reinterpret_cast<const u32x4*>(stg + ((size_t)((p * U + u) * 4 + fq) * Tpad + frow) * 16);
+                    xb[p] = as_bf16x8(f);
+                }
+#pragma unroll
+                for (int i = 0; i < NM; ++i) {
+                    const bf16x8 wf = as_bf16x8(wb[u][i]);
+#pragma unroll
+                    for (int p = 0; p < XS; ++p)
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xb[p], acc[i], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    if (active) {
+        XRegs R;
+        u32x4 wcur[U][NM];
+        stage_load(kt_begin, R);
+        load_w(kt_begin, wcur);
+        stage_finish(kt_begin, R);          // waits for the x loads only (issued before the weights)
+        for (int ktb = kt_begin; ktb < kt_end; ktb += U) {
+            const bool more = ktb + U < kt_end;
+            if constexpr (PREFETCH) {
+                u32x4 wnext[U][NM];
+                if (more) { stage_load(ktb + U, R); load_w(ktb + U, wnext); }
+                mma_batch(ktb, wcur);       // LDS is wave-private and in-order: no barrier
+                if (more) {
+                    stage_finish(ktb + U, R);
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+#pragma unroll
+                        for (int i = 0; i < NM; ++i) wcur[u][i] = wnext[u][i];
+                }
+            } else {
+                if (more) stage_load(ktb + U, R);
+                mma_batch(ktb, wcur);
+                if (more) { load_w(ktb + U, wcur); stage_finish(ktb + U, R); }
+            }
+        }
+    }
+
+    // per-row sum of squares of this wave's k-range (PRO_RMS): reduce over lanes
+    float my_ssq = 0.f;
+    if (a.pro == VV_PRO_RMS) {
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r) {
+            if (r < Tt) {
+                const float s = wave_sum(ssq[r]);
+                if (frow == r) my_ssq = s;
             }
         }
     }
 
     // ---- split-K reduction through LDS, fixed order (deterministic) ----
-    __shared__ f32x4 red[4][NM][64];
     if (KS > 1) {
+        __syncthreads();                            // staging tiles are dead; reuse the LDS
+        f32x4* red = reinterpret_cast<f32x4*>(smem);
+        float* redq = reinterpret_cast<float*>(smem + (size_t)WPB * NM * 64 * 16);
 #pragma unroll
-        for (int i = 0; i < NM; ++i) red[wave][i][lane] = acc[i];
+        for (int i = 0; i < NM; ++i) red[(wave * NM + i) * 64 + lane] = acc[i];
+        redq[wave * 64 + lane] = my_ssq;
         __syncthreads();
         if (ks == 0) {
             for (int s = 1; s < KS; ++s) {
 #pragma unroll
-                for (int i = 0; i < NM; ++i) acc[i] += red[wave + s][i][lane];
+                for (int i = 0; i < NM; ++i) acc[i] += red[((wave + s) * NM + i) * 64 + lane];
+                my_ssq += redq[(wave + s) * 64 + lane];
             }
         }
     }
-    if (ks != 0 || !active) return;
+    if (ks != 0 || tile0 >= n_tiles) return;
 
     // ---- epilogue: lane holds D[n = tile*16 + (lane>>4)*4 + r][t = lane&15] ----
-    if (!row_ok) return;
+    const int row = t0 + frow;
+    if (frow >= Tt) return;
+    float rs = 1.0f;
+    if (a.pro == VV_PRO_RMS) rs = rsqrtf(my_ssq / (float)a.K + a.eps);
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-        const int n0 = (tile0 + i) * 16 + (lane >> 4) * 4;
+        const int n0 = (tile0 + i) * 16 + fq * 4;
         if (n0 >= a.N) continue;
-        float v[4] = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
         float* yp = a.Y + (int64_t)row * a.ldy + n0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int n = n0 + r;
             if (n >= a.N) break;
-            float o = v[r];
+            float o = acc[i][r] * rs;
             switch (a.epi) {
                 case VV_EPI_STORE: break;
                 case VV_EPI_BIAS: if (a.bias) o += a.bias[n]; break;
                 case VV_EPI_BIAS_GELU: if (a.bias) o += a.bias[n]; o = gelu_erf_f(o); break;
                 case VV_EPI_SWIGLU:
-                    if constexpr (DUAL) { o = silu_f(o) * acc[NT + i][r]; }
+                    if constexpr (DUAL) { o = silu_f(o) * (acc[NT + i][r] * rs); }
                     break;
                 case VV_EPI_RESID: {
                     if (a.bias) o += a.bias[n];
@@ -272,10 +373,18 @@ __global__ void vv_pack_kernel(const ST* __restrict__ src, __bf16* __restrict__ 
 }  // namespace
 
 // ---- host launchers ------------------------------------------------------------
-template <int NT, int XS, bool DUAL>
-static void launch_t(const VVGemm& a, dim3 grid, hipStream_t s) {
-    hipLaunchKernelGGL((vv_gemm_kernel<NT, XS, DUAL>), grid, dim3(256), 0, s, a);
+template <int NT, int XS, bool DUAL, int WPB, int MAXR>
+static void launch_t(const VVGemm& a, dim3 grid, size_t smem, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_gemm_kernel<NT, XS, DUAL, WPB, MAXR>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((vv_gemm_kernel<NT, XS, DUAL, WPB, MAXR>), grid, dim3(WPB * 64), smem, s, a);
 }
+
+static int pow2_floor(int v) { int p = 1; while (p * 2 <= v) p *= 2; return p; }
 
 // Chooses the decomposition.  `xs` in {1,2,3}.
 extern "C" int vv_gemm_launch(VVGemm a, int xs, hipStream_t s) {
@@ -284,31 +393,46 @@ extern "C" int vv_gemm_launch(VVGemm a, int xs, hipStream_t s) {
     const int t_tiles = (a.T + 15) / 16;
     const bool dual = a.epi == VV_EPI_SWIGLU;
     if (dual && !a.W2) return -1;
-    // K split: enough k-steps per wave to amortise, and enough waves to fill 256 CUs.
+    const int Tt = a.T < 16 ? a.T : 16;
+    // LDS row stride of the staging tile: odd multiples avoid bank conflicts on the 8-byte writes
+    a.t_pad = Tt;
+    // waves per block: 8 for decode-sized row counts (small staging tiles, deep K split), 4 otherwise
+    const int wpb = (Tt <= 4) ? 8 : 4;
+    // two tiles per wave once there are plenty of tiles (halves staging work per weight byte)
+    int nt = 1;
+    if (!dual && (long)n_tiles * t_tiles >= 4096) nt = 2;
+    const long work = ((long)n_tiles + nt - 1) / nt * t_tiles;     // waves if K is not split
     int ks = 1;
     if (a.ksplit > 0) ks = a.ksplit;
     else {
-        const long waves1 = (long)n_tiles * t_tiles;
-        if (k_tiles >= 64 && waves1 < 4096) ks = 4;
-        else if (k_tiles >= 16 && waves1 < 2048) ks = (waves1 < 1024 && k_tiles >= 32) ? 4 : 2;
+        // enough waves to cover 256 CUs x ~8, at least 8 k-steps (one batch) per wave
+        const int want = (int)((2048 + work - 1) / work);
+        ks = pow2_floor(want < 1 ? 1 : want);
+        const int kmax = pow2_floor(k_tiles / 8 < 1 ? 1 : k_tiles / 8);
+        if (ks > kmax) ks = kmax;
     }
+    if (ks > wpb) ks = wpb;
     a.ksplit = ks;
-    const int ng = 4 / ks;
-    // two tiles per wave once there are plenty of tiles (halves the x-fragment work per byte)
-    int nt = 1;
-    if (!dual && (long)n_tiles * t_tiles >= 8192) nt = 2;
+    const int ng = wpb / ks;
     const int per_block = ng * nt;
     dim3 grid((n_tiles + per_block - 1) / per_block, t_tiles);
-#define VV_GO(NT_, DUAL_)                                                         \
+    const int nm = dual ? 2 : nt;
+    size_t stage_b = (size_t)wpb * xs * 8 * 4 * a.t_pad * 16;
+    size_t red_b = (size_t)wpb * nm * 64 * 16 + (size_t)wpb * 64 * 4;
+    size_t smem = stage_b > red_b ? stage_b : red_b;
+#define VV_GO3(NT_, DUAL_, WPB_)                                                  \
     do {                                                                          \
-        if (xs == 1) launch_t<NT_, 1, DUAL_>(a, grid, s);                         \
-        else if (xs == 2) launch_t<NT_, 2, DUAL_>(a, grid, s);                    \
-        else launch_t<NT_, 3, DUAL_>(a, grid, s);                                 \
+        if (xs == 1) launch_t<NT_, 1, DUAL_, WPB_, (WPB_ == 8 ? 4 : 16)>(a, grid, smem, s);             \
+        else if (xs == 2) launch_t<NT_, 2, DUAL_, WPB_, (WPB_ == 8 ? 4 : 16)>(a, grid, smem, s);        \
+        else launch_t<NT_, 3, DUAL_, WPB_, (WPB_ == 8 ? 4 : 16)>(a, grid, smem, s);                     \
     } while (0)
+#define VV_GO(NT_, DUAL_)                                                         \
+    do { if (wpb == 8) VV_GO3(NT_, DUAL_, 8); else VV_GO3(NT_, DUAL_, 4); } while (0)
     if (dual) VV_GO(1, true);
     else if (nt == 2) VV_GO(2, false);
     else VV_GO(1, false);
 #undef VV_GO
+#undef VV_GO3
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -44,6 +44,7 @@ struct VVGemm {
     int pro, epi;
     int ksplit;            // 1, 2 or 4 waves of the block split K
     int nt;                // non-temporal weight loads (streamed-once weights)
+    int t_pad;             // LDS row stride of the staging tile (set by the launcher)
     float eps;
 };
 
