@@ -76,6 +76,9 @@ def main():
     ap.add_argument("--voice-frames", type=int, default=75)
     ap.add_argument("--speakers", type=int, default=1)
     ap.add_argument("--max-ctx", type=int, default=0)
+    ap.add_argument("--kv-start", type=int, default=0,
+                    help="pretend the positive KV cache already holds this many tokens after the prefill "
+                         "(long-context decode measurement; the extra entries are zeros)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -95,7 +98,7 @@ def main():
         vbuild.build()
     if world > 1:
         dist.barrier()
-    from vibevoice_amd import synthetic
+    from vibevoice_amd import parallel, synthetic
     from vibevoice_amd.configs import CONFIGS
     from vibevoice_amd.engine import Engine, map_param_name
     from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference, engine_config_from_reference
@@ -106,7 +109,7 @@ def main():
                                         voice_frames=args.voice_frames, seed=100 + rank)
     L0 = inputs["input_ids"].shape[1]
     total_steps = W + K + 2
-    max_ctx = args.max_ctx or ((L0 + total_steps + 256 + 127) // 128 * 128)
+    max_ctx = args.max_ctx or ((max(L0, args.kv_start) + total_steps + 256 + 127) // 128 * 128)
     ecfg = engine_config_from_reference(cfg, n_slots=1, max_ctx=max_ctx, xsplit=args.xsplit,
                                         use_graph=not args.no_graph, enc_frames=5)
     t_load0 = time.time()
@@ -117,13 +120,8 @@ def main():
     # rank 0 draws the weights, RCCL broadcasts them over xGMI (one collective per tensor at start-up, none later)
     gen = torch.Generator(device=device)
     gen.manual_seed(0)
-    for k, shape in synthetic.param_shapes(cfg).items():
-        if rank == 0:
-            t = synthetic.random_tensor(k, shape, gen, device, torch.bfloat16)
-        else:
-            t = torch.empty(shape, dtype=torch.bfloat16, device=device)
-        if world > 1:
-            dist.broadcast(t, src=0)
+    make = lambda k, shape: synthetic.random_tensor(k, shape, gen, device, torch.bfloat16)
+    for k, t in parallel.broadcast_params(synthetic.param_shapes(cfg).items(), make, device, torch.bfloat16):
         name = map_param_name(k)
         if name in exp:
             eng.upload(name, t)
@@ -161,17 +159,15 @@ def main():
     t_gen0 = time.perf_counter()
     out = model.generate(tokenizer=synthetic.TOKENS, cfg_scale=args.cfg_scale, generation_config={"do_sample": False},
                          max_new_tokens=total_steps, show_progress_bar=False, _forced_tokens=forced,
-                         _noise_fn=lambda step, n2: noise_bank[step], _step_callback=step_cb, **inputs)
+                         _noise_fn=lambda step, n2: noise_bank[step], _step_callback=step_cb,
+                         _kv_start=args.kv_start, **inputs)
     eng.sync()
     t_gen1 = time.perf_counter()
     wall = marks[W + K] - marks[W]
-    wall_t = torch.tensor([wall], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
-    wall_max = float(wall_t.item())
     # steps W..W+K-1: count the <speech_diffusion> frames among them (the schedule inserts 2 control tokens per 150)
     frames = sum(1 for t in forced[0][W:W + K] if t == synthetic.TOKENS.speech_diffusion_id)
-    value = world * frames * FRAME_SEC / wall_max
+    frames_all, wall_max = parallel.aggregate_throughput(frames, wall, device)   # sum over ranks / max over ranks
+    value = frames_all * FRAME_SEC / wall_max
     audio_total = out.speech_outputs[0].shape[-1] / 24000.0
 
     # ---- roofline of the dominant kernel (vv_gemm_kernel): per-launch hipEvents over K_prof live steps ----
@@ -200,7 +196,7 @@ def main():
                 traffic = json.load(f).get(args.model, {}).get("hbm_bytes_per_launch")
         except Exception:
             pass
-        formula = algorithmic_bytes_per_frame(cfg, NS, L0 + W + K // 2, 1 + min(150, K) // 2)
+        formula = algorithmic_bytes_per_frame(cfg, NS, max(L0, args.kv_start) + W + K // 2, 1 + min(150, K) // 2)
         roof = {"bound": "hbm", "kernel": "vv_gemm_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "launches_per_step": round(n_l / kprof, 1), "avg_launch_us": round(ms * 1e3 / max(1, n_l), 3),
@@ -225,7 +221,7 @@ def main():
                                    f"{L0}-token prompt ({args.text_tokens} text + {args.voice_frames}-frame voice), "
                                    f"{NS} solver steps, cfg {args.cfg_scale}, 1 utterance per GPU, forced token schedule",
                        "model": f"VibeVoice-{args.model}", "solver_steps": NS, "prompt_tokens": L0,
-                       "xsplit": args.xsplit, "hipgraph": not args.no_graph, "parallelism": f"utterance-dp{world}"},
+                       "xsplit": args.xsplit, "hipgraph": not args.no_graph, "kv_start": args.kv_start, "parallelism": f"utterance-dp{world}"},
             "roofline": roof, "cpu_baseline": cpu,
             "extra": {"frames_timed": frames, "weights_load_s": round(load_s, 2),
                       "prefill_plus_first_frame_s": round(marks.get("prefill_done", t_gen0) - t_gen0, 4),

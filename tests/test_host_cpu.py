@@ -1,0 +1,164 @@
+"""CPU-only checks: C-ABI surface, host-side schedule/config logic, synthetic shapes,
+and the multi-process (gloo, world_size=2) utterance-sharding logic."""
+import os
+import re
+import socket
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from vibevoice_amd import _lib, build
+    build.build()
+    hdr = open(os.path.join(ROOT, "include", "vvhip.h")).read()
+    declared = set(re.findall(r"\b(vv_[a-z_0-9]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    so = ctypes.CDLL(_lib.LIB_PATH)
+    for s in declared:
+        assert hasattr(so, s), s
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    _lib.load()
+
+
+def test_engine_refuses_to_run_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from vibevoice_amd.engine import Engine, EngineConfig, EngineError
+    with pytest.raises(EngineError):
+        Engine(EngineConfig(lm_hidden=128, lm_layers=1, lm_heads=2, lm_kv_heads=1, lm_inter=256, lm_vocab=100))
+
+
+@pytest.mark.parametrize("n", [5, 10, 20])
+def test_schedule_table_matches_oracle_stepper(n):
+    from oracle import dpm
+    from vibevoice_amd import schedule
+    tv, coef = schedule.make_table(n)
+    s = dpm.Schedule(n)
+    assert np.array_equal(tv, s.timesteps.float().numpy())
+    assert np.isfinite(coef).all()
+    torch.manual_seed(n)
+    x = torch.randn(3, 64)
+    xo = x.clone()
+    st = dpm.DPMState(s)
+    x0p = torch.zeros_like(x)
+    for i in range(n):
+        v = torch.randn(3, 64)
+        xo = st.step(v, xo)
+        a, sg, cs, c0, c1 = [torch.tensor(c) for c in coef[i]]
+        x0 = a * x - sg * v
+        x = cs * x + c0 * x0 + c1 * (x0 - x0p)
+        x0p = x0
+    assert (x - xo).abs().max() < 5e-6
+    tvb, _ = schedule.make_table(10, t_cast_bf16=True)
+    assert tvb[0] == 1000.0        # 999 -> 1000 under the reference's bf16 cast (modeling_vibevoice_inference.py:705)
+
+
+def test_param_shapes_match_survey_counts():
+    from vibevoice_amd.configs import CONFIGS
+    from vibevoice_amd.synthetic import param_shapes
+
+    def count(cfg, prefix):
+        return sum(int(np.prod(s)) for k, s in param_shapes(cfg).items() if k.startswith(prefix))
+    c15, c7 = CONFIGS["1.5b"], CONFIGS["7b"]
+    assert count(c15, "model.language_model.layers.") == 1_310_339_072
+    assert count(c7, "model.language_model.layers.") == 6_525_618_176
+    assert count(c15, "model.prediction_head.") == 123_279_360
+    assert count(c7, "model.prediction_head.") == 669_333_504
+    assert count(c15, "model.acoustic_tokenizer.decoder.") == 343_695_969
+    assert count(c15, "model.acoustic_tokenizer.encoder.") == 343_696_032
+    assert count(c15, "model.semantic_tokenizer.encoder.") == 344_613_600
+    assert "lm_head.weight" in param_shapes(c7) and "lm_head.weight" not in param_shapes(c15)
+
+
+def test_engine_config_from_reference_json():
+    from vibevoice_amd.configs import CONFIGS
+    from vibevoice_amd.modeling import engine_config_from_reference
+    e = engine_config_from_reference(CONFIGS["7b"], n_slots=2)
+    assert (e.lm_hidden, e.lm_heads, e.lm_kv_heads, e.lm_head_dim, e.lm_inter) == (3584, 28, 4, 128, 18944)
+    assert e.head_ffn == 3 * 3584 and e.hop == 3200 and e.max_ctx == 32768 and e.n_slots == 2
+    bad = dict(CONFIGS["7b"])
+    bad["acoustic_tokenizer_config"] = dict(bad["acoustic_tokenizer_config"], mixer_layer="conv")
+    with pytest.raises(ValueError):
+        engine_config_from_reference(bad)
+
+
+def test_param_name_mapping():
+    from vibevoice_amd.engine import map_param_name
+    assert map_param_name("model.language_model.layers.3.mlp.up_proj.weight") == "lm.layers.3.mlp.up_proj.weight"
+    assert map_param_name("model.acoustic_tokenizer.decoder.head.conv.conv.bias") == "dec.head.conv.conv.bias"
+    assert map_param_name("model.semantic_tokenizer.encoder.stages.0.0.gamma") == "senc.stages.0.0.gamma"
+    assert map_param_name("lm_head.weight") == "lm_head.weight"
+    assert map_param_name("model.speech_scaling_factor") is None
+
+
+def test_forced_schedule_and_inputs_layout():
+    from vibevoice_amd import synthetic
+    from vibevoice_amd.configs import CONFIGS
+    T = synthetic.TOKENS
+    f = synthetic.forced_schedule(310, turn=150)
+    assert f[:150] == [T.speech_diffusion_id] * 150 and f[150:152] == [T.speech_end_id, T.speech_start_id]
+    inp = synthetic.synthetic_inputs(CONFIGS["1.5b"], n_speakers=2, text_tokens=50, voice_frames=7)
+    assert inp["input_ids"][0, -1] == T.speech_start_id
+    assert int(inp["speech_input_mask"].sum()) == 14 == int(inp["speech_masks"].sum())
+    assert inp["speech_tensors"].shape == (2, 7 * 3200)
+
+
+def test_shard_utterances_partition():
+    from vibevoice_amd.parallel import shard_utterances
+    costs = [5, 9, 1, 7, 3, 8, 2, 6, 4, 10, 11]
+    for world in (1, 2, 3, 8):
+        sh = shard_utterances(costs, world)
+        assert sorted(i for s in sh for i in s) == list(range(len(costs)))
+        loads = [sum(costs[i] for i in s) for s in sh]
+        assert max(loads) - min(loads) <= max(costs)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _gloo_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from vibevoice_amd import parallel
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    shapes = [("a.weight", (4, 6)), ("b.bias", (5,)), ("c.weight", (3, 2, 2))]
+
+    def make(name, shape):       # only ever called on rank 0
+        assert dist.get_rank() == 0
+        g = torch.Generator().manual_seed(len(name))
+        return torch.randn(shape, generator=g)
+    got = {k: v.clone() for k, v in parallel.broadcast_params(shapes, make, "cpu", torch.float32)}
+    checksum = float(sum(v.double().sum() for v in got.values()))
+    # each rank "decodes" its own shard of utterances: frames proportional to the cost
+    costs = [4, 2, 6, 8]
+    mine = parallel.shard_utterances(costs, world)[rank]
+    units = float(sum(costs[i] for i in mine))
+    total, wall = parallel.aggregate_throughput(units, 1.0 + rank, "cpu")
+    q.put((rank, checksum, mine, total, wall))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_broadcast_and_aggregate_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, c0, m0, t0, w0), (r1, c1, m1, t1, w1) = res
+    assert c0 == c1                       # identical weights on both ranks after the broadcast
+    assert sorted(m0 + m1) == [0, 1, 2, 3] and not set(m0) & set(m1)
+    assert t0 == t1 == 20.0 and w0 == w1 == 2.0    # sum of units, max of walls

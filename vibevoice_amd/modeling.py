@@ -232,6 +232,7 @@ class VibeVoiceForConditionalGenerationInference:
         prefill_noise = kwargs.pop("_prefill_noise", None)
         trace = kwargs.pop("_trace", None)
         step_cb = kwargs.pop("_step_callback", None)             # bench hook: called at the top of every step
+        kv_start = kwargs.pop("_kv_start", 0)                     # bench hook: long-context decode measurement
         input_ids = kwargs["input_ids"] if inputs is None else inputs
         attention_mask = kwargs.get("attention_mask")
         input_ids = input_ids.cpu()
@@ -323,7 +324,7 @@ class VibeVoiceForConditionalGenerationInference:
                         for i0 in range(0, n, 16):
                             k = min(16, n - i0)
                             e.lm_forward([(2 * b, i0 + j) for j in range(k)], emb[i0:i0 + k], hid)
-                        pos_len[b] = n
+                        pos_len[b] = max(n, kv_start)
                         self._hidden[b].copy_(hid[(n - 1) % 16])
                     spec = False
                 else:
