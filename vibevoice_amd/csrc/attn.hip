@@ -104,6 +104,7 @@ __global__ __launch_bounds__(256) void vv_attn_split_kernel(
     chunk = (chunk + 127) & ~127;
     const int start = split * chunk;
     const int end = min(len, start + chunk);
+    if (start >= len) return;                   // whole block: the merge kernel never reads unused splits
 
     const u32x4* kt_base = reinterpret_cast<const u32x4*>(kc + (int64_t)rw.cache * cache_stride + (int64_t)kvh * head_stride);
     const u32x4* vt_base = reinterpret_cast<const u32x4*>(vc + (int64_t)rw.cache * cache_stride + (int64_t)kvh * head_stride);
@@ -218,16 +219,21 @@ __global__ __launch_bounds__(256) void vv_attn_split_kernel(
 // grid (R, Hq), block D threads
 template <int D>
 __global__ void vv_attn_merge_kernel(const float* __restrict__ part_m, const float* __restrict__ part_l,
-                                     const float* __restrict__ part_o, float* __restrict__ out,
-                                     int Hq, int Hkv, int S) {
+                                     const float* __restrict__ part_o, const VVRow* __restrict__ rows,
+                                     float* __restrict__ out, int Hq, int Hkv, int S) {
     const int r = blockIdx.x, h = blockIdx.y, d = threadIdx.x;
     const int G = Hq / Hkv;
     const int kvh = h / G, g = h - kvh * G;
     const int64_t base = ((int64_t)r * Hkv + kvh) * S;
+    // same chunking as the split kernel: only the first `used` splits hold data
+    const int len = rows[r].pos + 1;
+    int chunk = (len + S - 1) / S;
+    chunk = (chunk + 127) & ~127;
+    const int used = (len + chunk - 1) / chunk;
     float M = -INFINITY;
-    for (int s = 0; s < S; ++s) M = fmaxf(M, part_m[(base + s) * 16 + g]);
+    for (int s = 0; s < used; ++s) M = fmaxf(M, part_m[(base + s) * 16 + g]);
     float L = 0.f, acc = 0.f;
-    for (int s = 0; s < S; ++s) {
+    for (int s = 0; s < used; ++s) {
         const float ms = part_m[(base + s) * 16 + g];
         if (ms == -INFINITY) continue;
         const float f = expf(ms - M);
@@ -259,7 +265,7 @@ static void attn_go(const float* q, const VVRow* rows, const void* kc, const voi
                     int64_t cs, int64_t hs, int S, float* pm, float* pl, float* po, float* out, hipStream_t s) {
     hipLaunchKernelGGL((vv_attn_split_kernel<D, XS>), dim3(S, Hkv, R), dim3(256), 0, s, q, rows,
                        (const __bf16*)kc, (const __bf16*)vc, Hq, Hkv, cs, hs, pm, pl, po);
-    hipLaunchKernelGGL((vv_attn_merge_kernel<D>), dim3(R, Hq), dim3(D), 0, s, pm, pl, po, out, Hq, Hkv, S);
+    hipLaunchKernelGGL((vv_attn_merge_kernel<D>), dim3(R, Hq), dim3(D), 0, s, pm, pl, po, rows, out, Hq, Hkv, S);
 }
 
 extern "C" int vv_attn_launch(int D, int xs, const float* q, const VVRow* rows, const void* kc, const void* vc,

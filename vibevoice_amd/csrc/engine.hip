@@ -35,6 +35,11 @@ int vv_tfreq_launch(const float* t, float* out, int n, hipStream_t s);
 int vv_silu_launch(float* x, int n, hipStream_t s);
 int vv_cvt_launch(const void* src, void* dst, int64_t n, int to_bf16, hipStream_t s);
 int vv_dw_transpose_launch(const float* src, float* dst, int C, hipStream_t s);
+int vv_block1d_supported(int C);
+int vv_block1d_launch(int C, int xs, const float* xin, float* xout, float* nst, const float* norm_w,
+                      const float* ffn_norm_w, const float* gamma, const float* ffn_gamma, const float* dw_w,
+                      const float* dw_b, const float* b1, const float* b2, const void* w1, const void* w2, int T,
+                      float eps, hipStream_t s);
 }
 
 struct VVShiftH { float* buf; int T, hist, C; };
@@ -61,7 +66,8 @@ struct Block {
     int C;
     float *norm_w, *ffn_norm_w, *gamma, *ffn_gamma, *dw_w, *dw_b, *b1, *b2;
     void *w1, *w2;
-    float* nb;                  // [6 + Tmax][C] normed buffer with history
+    float* nb;                  // unfused path: [6 + Tmax][C] normed buffer with history
+    float* nst;                 // fused path: [12][C] normed history (rows 0..5) + next state (rows 6..11)
 };
 
 struct ConvG {                  // conv / transposed conv as a GEMM over a time-major buffer
@@ -74,6 +80,9 @@ struct Stage {
     int C, Tpf;                 // channels, time steps per frame
     int hist;                   // history rows kept in front of xs
     float* xs;                  // [hist + Tmax][C]
+    float* xs2;                 // fused stages ping-pong between xs and xs2
+    float* xfinal;              // buffer holding the stage output (and its history rows)
+    bool fused;                 // blocks run as one vv_block1d_kernel each
     std::vector<Block> blocks;
     ConvG in;                   // produces this stage's rows from the previous buffer
 };
@@ -279,9 +288,17 @@ static int build_codec(vv_ctx* ctx, CodecNet& net, const std::string& pfx, bool 
             s.C = C[i]; s.Tpf = Tpf[i]; s.in = sw[i].in;
             if (i == ns - 1) s.hist = 6;
             else s.hist = decoder ? 1 : ratios[i];
-            s.xs = (float*)dalloc(ctx, (size_t)(s.hist + (size_t)Tpf[i] * Fmax) * C[i] * 4);
+            const size_t xbytes = (size_t)(s.hist + (size_t)Tpf[i] * Fmax) * C[i] * 4;
+            s.xs = (float*)dalloc(ctx, xbytes);
             s.blocks = sw[i].blocks;
-            for (auto& b : s.blocks) b.nb = (float*)dalloc(ctx, (size_t)(6 + (size_t)Tpf[i] * Fmax) * C[i] * 4);
+            s.fused = vv_block1d_supported(C[i]) && Tpf[i] >= 8 && !s.blocks.empty() && !getenv("VVHIP_NO_FUSED_BLOCK");
+            s.xs2 = s.fused ? (float*)dalloc(ctx, xbytes) : nullptr;
+            s.xfinal = (s.fused && (s.blocks.size() & 1)) ? s.xs2 : s.xs;
+            for (auto& b : s.blocks) {
+                b.nb = nullptr; b.nst = nullptr;
+                if (s.fused) b.nst = (float*)dalloc(ctx, (size_t)12 * C[i] * 4);
+                else b.nb = (float*)dalloc(ctx, (size_t)(6 + (size_t)Tpf[i] * Fmax) * C[i] * 4);
+            }
         }
         net.zero_tab[sl] = nullptr;
     }
@@ -294,8 +311,11 @@ static int codec_tables(vv_ctx* ctx, CodecNet& net, int sl, int F, void** tab_ou
     std::vector<VVShiftH> t;
     t.push_back({net.in_buf[sl], net.in_Tpf * F, 6, net.in_dim});
     for (auto& s : net.st[sl]) {
-        t.push_back({s.xs, s.Tpf * F, s.hist, s.C});
-        for (auto& b : s.blocks) t.push_back({b.nb, s.Tpf * F, 6, s.C});
+        t.push_back({s.xfinal, s.Tpf * F, s.hist, s.C});
+        for (auto& b : s.blocks) {
+            if (s.fused) t.push_back({b.nst, 6, 6, s.C});
+            else t.push_back({b.nb, s.Tpf * F, 6, s.C});
+        }
     }
     void* d = dalloc(ctx, t.size() * sizeof(VVShiftH), false);
     if (!d) return -1;
@@ -347,11 +367,23 @@ static int run_codec(vv_ctx* ctx, CodecNet& net, int sl, int F, float* out, hipS
         float* x = s.xs + (size_t)s.hist * s.C;
         {   // incoming conv
             const ConvG& cg = s.in;
-            const float* X = (i == 0) ? net.in_buf[sl] : stages[i - 1].xs;
+            const float* X = (i == 0) ? net.in_buf[sl] : stages[i - 1].xfinal;
             const int Trows = cg.rows_per_frame * F;
             VVGemm g = mk_gemm(cg.w, X, x, Trows, cg.N, cg.K, cg.ldx, cg.N);
             g.epi = VV_EPI_BIAS; g.bias = cg.bias; g.nt = stream_w && Trows <= 16;
             GEMM(g);
+        }
+        if (s.fused) {
+            float* cur = s.xs;
+            float* oth = s.xs2;
+            for (auto& b : s.blocks) {
+                ctx->launches++;
+                VVCHK(vv_block1d_launch(s.C, ctx->c.xsplit, cur + (size_t)s.hist * s.C, oth + (size_t)s.hist * s.C, b.nst,
+                                        b.norm_w, b.ffn_norm_w, b.gamma, b.ffn_gamma, b.dw_w, b.dw_b, b.b1, b.b2, b.w1, b.w2,
+                                        T, eps, st));
+                std::swap(cur, oth);
+            }
+            continue;
         }
         for (auto& b : s.blocks) {
             ctx->launches += 2;
@@ -369,7 +401,7 @@ static int run_codec(vv_ctx* ctx, CodecNet& net, int sl, int F, float* out, hipS
     {   // head conv
         const ConvG& cg = net.head;
         Stage& s = stages[ns - 1];
-        VVGemm g = mk_gemm(cg.w, s.xs, out, cg.rows_per_frame * F, cg.N, cg.K, cg.ldx, cg.N);
+        VVGemm g = mk_gemm(cg.w, s.xfinal, out, cg.rows_per_frame * F, cg.N, cg.K, cg.ldx, cg.N);
         g.epi = VV_EPI_BIAS; g.bias = cg.bias;
         GEMM(g);
     }
@@ -770,7 +802,6 @@ static int sample_body(vv_ctx* ctx, hipStream_t st, int n, const float* cond, co
         if (head_eval(ctx, st, rows, ctx->zz, ctx->temb + (size_t)i * H, ctx->eps)) return -1;
         ctx->launches++;
         VVCHK(vv_cfg_dpm_launch(ctx->eps, ctx->zz, ctx->x0p, ctx->coef + i * 5, cfg, n, L, st));
-        HIPCHK(ctx, hipMemcpyAsync(ctx->zz + (size_t)n * L, ctx->zz, (size_t)n * L * 4, hipMemcpyDeviceToDevice, st));
     }
     HIPCHK(ctx, hipMemcpyAsync(latent_out, ctx->zz, (size_t)n * L * 4, hipMemcpyDeviceToDevice, st));
     return 0;

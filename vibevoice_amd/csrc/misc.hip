@@ -84,6 +84,7 @@ __global__ void vv_cfg_dpm_kernel(const float* __restrict__ eps, float* __restri
     const float xn = cs * xi + c0 * x0 + c1 * (x0 - x0_prev[i]);
     x0_prev[i] = x0;
     x[i] = xn;
+    x[i + n * L] = xn;        // both CFG halves see the same latent (modeling_vibevoice_inference.py:703-704)
 }
 
 // y = x * mul + add   (latent un-scaling, copies)
