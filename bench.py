@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--xsplit", type=int, default=int(os.environ.get("VVHIP_XSPLIT", "1")))
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the per-launch hipEvent pass (for rocprof runs)")
     ap.add_argument("--cpu-frames", type=int, default=4)
     ap.add_argument("--text-tokens", type=int, default=220)
     ap.add_argument("--voice-frames", type=int, default=75)
@@ -172,7 +173,7 @@ def main():
 
     # ---- roofline of the dominant kernel (vv_gemm_kernel): per-launch hipEvents over K_prof live steps ----
     roof = None
-    if rank == 0:
+    if rank == 0 and not args.no_roofline:
         kprof = 8
         forced_p = [synthetic.forced_schedule(kprof + 3, turn=150)]
         prof = {}

@@ -61,7 +61,7 @@ __device__ __forceinline__ void split4(const float (&v)[4], uint2 (&out)[XS]) {
     if constexpr (XS > 2) out[2] = __builtin_bit_cast(uint2, l);
 }
 
-template <int NT, int XS, bool DUAL, int WPB, int MAXR>
+template <int NT, int XS, bool DUAL, int WPB, int MAXR, bool VEC>
 __global__ __launch_bounds__(WPB * 64) void vv_gemm_kernel(const VVGemm a) {
     constexpr int NM = DUAL ? 2 * NT : NT;
     constexpr bool PREFETCH = (WPB == 8);         // decode variant: second weight buffer; tall variant favours occupancy
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemm_kernel(const VVGemm a) {
     const int kt_begin = ks * kper;
     const int kt_end = min(k_tiles, kt_begin + kper);
     const bool active = tile0 < n_tiles && kt_begin < kt_end;
-    const bool vec_ok = ((a.K & 3) == 0) && ((a.ldx & 3) == 0) && ((((uintptr_t)a.X) & 15) == 0);
+    constexpr bool vec_ok = VEC;                  // host guarantees K%4==0, ldx%4==0, 16-B aligned X for VEC kernels
     const int Tpad = a.t_pad;                     // LDS row stride (>= Tt), host-chosen
     // wave-private staging tile: [XS][U][4 q][Tpad] x 16 B
     unsigned char* stg = smem + (size_t)wave * XS * U * 4 * Tpad * 16;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemm_kernel(const VVGemm a) {
             if (r < Tt) {
                 const float* xr = a.X + (int64_t)(t0 + r) * a.ldx;
                 float s = 0.f;
-                if (vec_ok) {
+                if constexpr (VEC) {
                     for (int k = lane * 4; k < a.K; k += 256) {
                         float4 v = *reinterpret_cast<const float4*>(xr + k);
                         s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemm_kernel(const VVGemm a) {
                 const int tile = tile0 + i;
                 const bool ok = kok && tile < n_tiles;
                 const int64_t off = ((int64_t)tile * k_tiles + kt) * 64 + lane;
-                if (a.nt) {
+                if constexpr (WPB == 8) {        // decode variant: weights are streamed exactly once
                     dst[u][i] = ok ? __builtin_nontemporal_load(a.W + off) : zero4;
                     if constexpr (DUAL) dst[u][NT + i] = ok ? __builtin_nontemporal_load(a.W2 + off) : zero4;
                 } else {
@@ -147,8 +147,11 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemm_kernel(const VVGemm a) {
     struct XRegs { float4 x[MAXR]; float4 sc[MODREG ? MAXR : 1]; float4 sh[MODREG ? MAXR : 1]; float4 nwv, addv; };
     auto ld4 = [&](const float* p, int k, bool full) -> float4 {
         float4 v = {0.f, 0.f, 0.f, 0.f};
-        if (full) v = *reinterpret_cast<const float4*>(p + k);
-        else { v.x = p[k]; if (k + 1 < a.K) v.y = p[k + 1]; if (k + 2 < a.K) v.z = p[k + 2]; if (k + 3 < a.K) v.w = p[k + 3]; }
+        if constexpr (VEC) { v = *reinterpret_cast<const float4*>(p + k); (void)full; }
+        else {
+            if (full) v = *reinterpret_cast<const float4*>(p + k);
+            else { v.x = p[k]; if (k + 1 < a.K) v.y = p[k + 1]; if (k + 2 < a.K) v.z = p[k + 2]; if (k + 3 < a.K) v.w = p[k + 3]; }
+        }
         return v;
     };
     auto stage_load = [&](int ktb, XRegs& R) {
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemm_kernel(const VVGemm a) {
                 if constexpr (MODREG) {
                     if (a.pro == VV_PRO_RMS_MOD) {
                         const int64_t mo = (int64_t)(t0 + r) * a.ld_mod;
-                        const bool mfull = full && ((a.ld_mod & 3) == 0);
+                        const bool mfull = full;
                         R.sc[r] = ld4(a.mod_scale + mo, k, mfull);
                         R.sh[r] = ld4(a.mod_shift + mo, k, mfull);
                     }
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemm_kernel(const VVGemm a) {
                     if constexpr (MODREG) { sc = R.sc[r]; sh = R.sh[r]; }
                     else if (kin) {
                         const int64_t mo = (int64_t)(t0 + r) * a.ld_mod;
-                        const bool mfull = vec_ok && (k + 4 <= a.K) && ((a.ld_mod & 3) == 0);
+                        const bool mfull = vec_ok && (k + 4 <= a.K);
                         sc = ld4(a.mod_scale + mo, k, mfull);
                         sh = ld4(a.mod_shift + mo, k, mfull);
                     }
@@ -240,26 +243,33 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemm_kernel(const VVGemm a) {
     if (active) {
         XRegs R;
         u32x4 wcur[U][NM];
-        stage_load(kt_begin, R);
-        load_w(kt_begin, wcur);
-        stage_finish(kt_begin, R);          // waits for the x loads only (issued before the weights)
-        for (int ktb = kt_begin; ktb < kt_end; ktb += U) {
-            const bool more = ktb + U < kt_end;
-            if constexpr (PREFETCH) {
-                u32x4 wnext[U][NM];
-                if (more) { stage_load(ktb + U, R); load_w(ktb + U, wnext); }
-                mma_batch(ktb, wcur);       // LDS is wave-private and in-order: no barrier
-                if (more) {
-                    stage_finish(ktb + U, R);
+        if constexpr (PREFETCH) {
+            // software pipeline with one call site per stage: iteration b issues the loads of batch b+1,
+            // runs the MFMAs of batch b, then converts batch b+1 into LDS (x loads were issued before the
+            // weights, so that wait leaves the weight prefetch in flight)
+            const int nb = (kt_end - kt_begin + U - 1) / U;
+            u32x4 wnext[U][NM];
+#pragma unroll 1
+            for (int b = -1; b < nb; ++b) {
+                const int ktn = kt_begin + (b + 1) * U;
+                const bool have_next = b + 1 < nb;
+                if (have_next) { stage_load(ktn, R); load_w(ktn, wnext); }
+                if (b >= 0) mma_batch(kt_begin + b * U, wcur);
+                if (have_next) {
+                    stage_finish(ktn, R);
 #pragma unroll
                     for (int u = 0; u < U; ++u)
 #pragma unroll
                         for (int i = 0; i < NM; ++i) wcur[u][i] = wnext[u][i];
                 }
-            } else {
-                if (more) stage_load(ktb + U, R);
+            }
+        } else {
+#pragma unroll 1
+            for (int ktb = kt_begin; ktb < kt_end; ktb += U) {
+                stage_load(ktb, R);
+                load_w(ktb, wcur);
+                stage_finish(ktb, R);
                 mma_batch(ktb, wcur);
-                if (more) { load_w(ktb + U, wcur); stage_finish(ktb + U, R); }
             }
         }
     }
@@ -305,27 +315,19 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemm_kernel(const VVGemm a) {
         const int n0 = (tile0 + i) * 16 + fq * 4;
         if (n0 >= a.N) continue;
         float* yp = a.Y + (int64_t)row * a.ldy + n0;
-#pragma unroll
+        float o4[4] = {acc[i][0] * rs, acc[i][1] * rs, acc[i][2] * rs, acc[i][3] * rs};
+        float u4[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (DUAL) { u4[0] = acc[NT + i][0] * rs; u4[1] = acc[NT + i][1] * rs; u4[2] = acc[NT + i][2] * rs; u4[3] = acc[NT + i][3] * rs; }
+#pragma unroll 1
         for (int r = 0; r < 4; ++r) {
             const int n = n0 + r;
             if (n >= a.N) break;
-            float o = acc[i][r] * rs;
-            switch (a.epi) {
-                case VV_EPI_STORE: break;
-                case VV_EPI_BIAS: if (a.bias) o += a.bias[n]; break;
-                case VV_EPI_BIAS_GELU: if (a.bias) o += a.bias[n]; o = gelu_erf_f(o); break;
-                case VV_EPI_SWIGLU:
-                    if constexpr (DUAL) { o = silu_f(o) * (acc[NT + i][r] * rs); }
-                    break;
-                case VV_EPI_RESID: {
-                    if (a.bias) o += a.bias[n];
-                    if (a.nscale) o *= a.nscale[n];
-                    o += yp[r];
-                } break;
-                case VV_EPI_GATED_RESID: {
-                    o = yp[r] + a.gate[(int64_t)row * a.ld_gate + n] * o;
-                } break;
-            }
+            float o = o4[r];
+            if (a.bias && a.epi != VV_EPI_STORE) o += a.bias[n];
+            if (a.epi == VV_EPI_BIAS_GELU) o = gelu_erf_f(o);
+            else if (a.epi == VV_EPI_SWIGLU) o = silu_f(o) * u4[r];
+            else if (a.epi == VV_EPI_RESID) { if (a.nscale) o *= a.nscale[n]; o += yp[r]; }
+            else if (a.epi == VV_EPI_GATED_RESID) o = yp[r] + a.gate[(int64_t)row * a.ld_gate + n] * o;
             yp[r] = o;
         }
     }
@@ -373,15 +375,15 @@ __global__ void vv_pack_kernel(const ST* __restrict__ src, __bf16* __restrict__ 
 }  // namespace
 
 // ---- host launchers ------------------------------------------------------------
-template <int NT, int XS, bool DUAL, int WPB, int MAXR>
+template <int NT, int XS, bool DUAL, int WPB, int MAXR, bool VEC>
 static void launch_t(const VVGemm& a, dim3 grid, size_t smem, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_gemm_kernel<NT, XS, DUAL, WPB, MAXR>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_gemm_kernel<NT, XS, DUAL, WPB, MAXR, VEC>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((vv_gemm_kernel<NT, XS, DUAL, WPB, MAXR>), grid, dim3(WPB * 64), smem, s, a);
+    hipLaunchKernelGGL((vv_gemm_kernel<NT, XS, DUAL, WPB, MAXR, VEC>), grid, dim3(WPB * 64), smem, s, a);
 }
 
 static int pow2_floor(int v) { int p = 1; while (p * 2 <= v) p *= 2; return p; }
@@ -394,13 +396,15 @@ extern "C" int vv_gemm_launch(VVGemm a, int xs, hipStream_t s) {
     const bool dual = a.epi == VV_EPI_SWIGLU;
     if (dual && !a.W2) return -1;
     const int Tt = a.T < 16 ? a.T : 16;
+    const bool vec = ((a.K & 3) == 0) && ((a.ldx & 3) == 0) && ((((uintptr_t)a.X) & 15) == 0) &&
+                     (a.pro != VV_PRO_RMS_MOD || (a.ld_mod & 3) == 0);
     // LDS row stride of the staging tile: odd multiples avoid bank conflicts on the 8-byte writes
     a.t_pad = Tt;
     // waves per block: 8 for decode-sized row counts (small staging tiles, deep K split), 4 otherwise
-    const int wpb = (Tt <= 4) ? 8 : 4;
+    const int wpb = (Tt <= 4 && vec) ? 8 : 4;
     // two tiles per wave once there are plenty of tiles (halves staging work per weight byte)
     int nt = 1;
-    if (!dual && (long)n_tiles * t_tiles >= 4096) nt = 2;
+    if (!dual && vec && (long)n_tiles * t_tiles >= 4096) nt = 2;
     const long work = ((long)n_tiles + nt - 1) / nt * t_tiles;     // waves if K is not split
     int ks = 1;
     if (a.ksplit > 0) ks = a.ksplit;
@@ -420,19 +424,25 @@ extern "C" int vv_gemm_launch(VVGemm a, int xs, hipStream_t s) {
     size_t stage_b = (size_t)wpb * xs * 8 * 4 * a.t_pad * 16;
     size_t red_b = (size_t)wpb * nm * 64 * 16 + (size_t)wpb * 64 * 4;
     size_t smem = stage_b > red_b ? stage_b : red_b;
-#define VV_GO3(NT_, DUAL_, WPB_)                                                  \
+#define VV_XS(NT_, DUAL_, WPB_, MAXR_, VEC_)                                      \
     do {                                                                          \
-        if (xs == 1) launch_t<NT_, 1, DUAL_, WPB_, (WPB_ == 8 ? 4 : 16)>(a, grid, smem, s);             \
-        else if (xs == 2) launch_t<NT_, 2, DUAL_, WPB_, (WPB_ == 8 ? 4 : 16)>(a, grid, smem, s);        \
-        else launch_t<NT_, 3, DUAL_, WPB_, (WPB_ == 8 ? 4 : 16)>(a, grid, smem, s);                     \
+        if (xs == 1) launch_t<NT_, 1, DUAL_, WPB_, MAXR_, VEC_>(a, grid, smem, s); \
+        else if (xs == 2) launch_t<NT_, 2, DUAL_, WPB_, MAXR_, VEC_>(a, grid, smem, s); \
+        else launch_t<NT_, 3, DUAL_, WPB_, MAXR_, VEC_>(a, grid, smem, s);        \
     } while (0)
-#define VV_GO(NT_, DUAL_)                                                         \
-    do { if (wpb == 8) VV_GO3(NT_, DUAL_, 8); else VV_GO3(NT_, DUAL_, 4); } while (0)
-    if (dual) VV_GO(1, true);
-    else if (nt == 2) VV_GO(2, false);
-    else VV_GO(1, false);
-#undef VV_GO
-#undef VV_GO3
+    if (!vec) {
+        if (dual) return -3;                       // SwiGLU operands are always aligned on this path
+        VV_XS(1, false, 4, 16, false);             // generic (odd K / unaligned rows): encoder stem, tiny test shapes
+    } else if (wpb == 8) {
+        if (dual) VV_XS(1, true, 8, 4, true);
+        else if (nt == 2) VV_XS(2, false, 8, 4, true);
+        else VV_XS(1, false, 8, 4, true);
+    } else {
+        if (dual) VV_XS(1, true, 4, 16, true);
+        else if (nt == 2) VV_XS(2, false, 4, 16, true);
+        else VV_XS(1, false, 4, 16, true);
+    }
+#undef VV_XS
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

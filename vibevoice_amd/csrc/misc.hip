@@ -20,19 +20,54 @@ __global__ void vv_embed_kernel(const __bf16* __restrict__ table, const int* __r
     for (int k = threadIdx.x; k < H; k += blockDim.x) out[(int64_t)i * H + k] = (float)src[k];
 }
 
-// y[t][:] = x[t][:] * rsqrt(mean(x^2)+eps) * w      one wave per row; grid (ceil(T/4)), block 256
-__global__ void vv_rmsnorm_rows_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
-                                       const float* __restrict__ w, int T, int C, float eps) {
-    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (t >= T) return;
-    const float* xr = x + (int64_t)t * ldx;
+// y[t][:] = x[t][:] * rsqrt(mean(x^2)+eps) * w.  Rows are independent; a row is handled by one wave
+// (rows_per_block = 4) or by the whole 256-thread block (rows_per_block = 1, wide rows) with float4
+// loads kept in registers between the two passes.
+template <int RPB>
+__global__ __launch_bounds__(256) void vv_rmsnorm_rows_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
+                                                              const float* __restrict__ w, int T, int C, float eps) {
+    constexpr int NTH = 256 / RPB;                 // threads cooperating on one row
+    constexpr int MAXV = (RPB == 1) ? 4 : 8;       // float4 per thread kept in registers (C <= NTH*4*MAXV)
+    __shared__ float part[4];
+    const int sub = threadIdx.x / NTH, tl = threadIdx.x % NTH;
+    const int t = blockIdx.x * RPB + sub;
+    const bool live = t < T;
+    const float* xr = x + (int64_t)(live ? t : 0) * ldx;
+    const bool vec = ((C & 3) == 0) && ((ldx & 3) == 0) && ((ldy & 3) == 0) && C <= NTH * 4 * MAXV;
+    float4 v[MAXV];
     float s = 0.f;
-    for (int c = lane; c < C; c += 64) { float v = xr[c]; s += v * v; }
+    if (vec) {
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = (tl + i * NTH) * 4;
+            v[i] = (live && c < C) ? *reinterpret_cast<const float4*>(xr + c) : float4{0.f, 0.f, 0.f, 0.f};
+            s += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+        }
+    } else if (live) {
+        for (int c = tl; c < C; c += NTH) { const float q = xr[c]; s += q * q; }
+    }
     s = wave_sum(s);
+    if (RPB == 1) {
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+        __syncthreads();
+        s = part[0] + part[1] + part[2] + part[3];
+    }
+    if (!live) return;
     const float rs = rsqrtf(s / (float)C + eps);
     float* yr = y + (int64_t)t * ldy;
-    for (int c = lane; c < C; c += 64) yr[c] = xr[c] * rs * (w ? w[c] : 1.f);
+    if (vec) {
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = (tl + i * NTH) * 4;
+            if (c < C) {
+                float4 ww = w ? *reinterpret_cast<const float4*>(w + c) : float4{1.f, 1.f, 1.f, 1.f};
+                float4 o = {v[i].x * rs * ww.x, v[i].y * rs * ww.y, v[i].z * rs * ww.z, v[i].w * rs * ww.w};
+                *reinterpret_cast<float4*>(yr + c) = o;
+            }
+        }
+    } else {
+        for (int c = tl; c < C; c += NTH) yr[c] = xr[c] * rs * (w ? w[c] : 1.f);
+    }
 }
 
 // Causal depthwise conv k=7 over time on the normed buffer nb (6 history rows in front),
@@ -137,7 +172,10 @@ int vv_embed_launch(const void* table, const int* ids, float* out, int n, int H,
     return okk();
 }
 int vv_rmsnorm_rows_launch(const float* x, int ldx, float* y, int ldy, const float* w, int T, int C, float eps, hipStream_t s) {
-    hipLaunchKernelGGL(vv_rmsnorm_rows_kernel, dim3((T + 3) / 4), dim3(256), 0, s, x, ldx, y, ldy, w, T, C, eps);
+    if (C > 1024 || T < 64)
+        hipLaunchKernelGGL((vv_rmsnorm_rows_kernel<1>), dim3(T), dim3(256), 0, s, x, ldx, y, ldy, w, T, C, eps);
+    else
+        hipLaunchKernelGGL((vv_rmsnorm_rows_kernel<4>), dim3((T + 3) / 4), dim3(256), 0, s, x, ldx, y, ldy, w, T, C, eps);
     return okk();
 }
 int vv_dwconv_res_launch(const float* nb, float* x, const float* w, const float* b, const float* gamma, int T, int C, hipStream_t s) {
