@@ -26,6 +26,8 @@ int vv_attn_launch(int D, int xs, const float* q, const VVRow* rows, const void*
 int vv_embed_launch(const void* table, const int* ids, float* out, int n, int H, hipStream_t s);
 int vv_rmsnorm_rows_launch(const float* x, int ldx, float* y, int ldy, const float* w, int T, int C, float eps, hipStream_t s);
 int vv_dwconv_res_launch(const float* nb, float* x, const float* w, const float* b, const float* gamma, int T, int C, hipStream_t s);
+int vv_normdw_launch(float* x, float* nb, const float* nw, const float* w, const float* b, const float* gamma, int T, int C,
+                     float eps, hipStream_t s);
 int vv_shift_rows_launch(const void* tab, int n_entries, int maxC, hipStream_t s);
 int vv_zero_hist_launch(const void* tab, int n_entries, hipStream_t s);
 int vv_cfg_dpm_launch(const float* eps, float* x, float* x0_prev, const float* coef, float cfg, int n, int L, hipStream_t s);
@@ -386,9 +388,14 @@ static int run_codec(vv_ctx* ctx, CodecNet& net, int sl, int F, float* out, hipS
             continue;
         }
         for (auto& b : s.blocks) {
-            ctx->launches += 2;
-            VVCHK(vv_rmsnorm_rows_launch(x, s.C, b.nb + 6 * (size_t)s.C, s.C, b.norm_w, T, s.C, eps, st));
-            VVCHK(vv_dwconv_res_launch(b.nb, x, b.dw_w, b.dw_b, b.gamma, T, s.C, st));
+            if ((size_t)T * s.C <= 65536 && (s.C & 3) == 0) {
+                ctx->launches += 1;
+                VVCHK(vv_normdw_launch(x, b.nb, b.norm_w, b.dw_w, b.dw_b, b.gamma, T, s.C, eps, st));
+            } else {
+                ctx->launches += 2;
+                VVCHK(vv_rmsnorm_rows_launch(x, s.C, b.nb + 6 * (size_t)s.C, s.C, b.norm_w, T, s.C, eps, st));
+                VVCHK(vv_dwconv_res_launch(b.nb, x, b.dw_w, b.dw_b, b.gamma, T, s.C, st));
+            }
             VVGemm g1 = mk_gemm(b.w1, x, net.u, T, 4 * s.C, s.C, s.C, 4 * s.C);
             g1.pro = VV_PRO_RMS; g1.nw = b.ffn_norm_w; g1.eps = eps; g1.epi = VV_EPI_BIAS_GELU; g1.bias = b.b1;
             g1.nt = stream_w && T <= 16;
@@ -762,7 +769,8 @@ extern "C" int vv_lm_logits(vv_ctx* ctx, void* stream, int n, const float* hidde
 }
 
 // one head evaluation on 2n rows; mod/xh/hact/eps are ctx scratch. temb = t-embedding row for this step.
-static int head_eval(vv_ctx* ctx, hipStream_t st, int rows, const float* zrows, const float* temb_row, float* eps_out) {
+static int head_eval(vv_ctx* ctx, hipStream_t st, int rows, const float* zrows, const float* temb_row, float* eps_out,
+                     const float* coef = nullptr, float cfg = 0.f) {
     const vv_config& c = ctx->c;
     const int H = ctx->H, L = c.latent_dim, HL = c.head_layers, HF = ctx->HF, MODW = ctx->MODW;
     VVGemm ga = mk_gemm(ctx->h_ada, ctx->cproj, ctx->mod, rows, MODW, H, H, MODW);
@@ -783,6 +791,9 @@ static int head_eval(vv_ctx* ctx, hipStream_t st, int rows, const float* zrows, 
     const float* fb = ctx->mod + (size_t)HL * 3 * H;
     VVGemm gf = mk_gemm(ctx->h_out, ctx->xh, eps_out, rows, L, H, H, L);
     gf.pro = VV_PRO_RMS_MOD; gf.nw = nullptr; gf.eps = c.head_eps; gf.mod_shift = fb; gf.mod_scale = fb + H; gf.ld_mod = MODW;
+    if (coef) {   // CFG + DPM-Solver++ update fused into the epilogue: the noisy latent is rewritten in place
+        gf.epi = VV_EPI_CFG_DPM; gf.z = ctx->zz; gf.x0p = ctx->x0p; gf.coef = coef; gf.cfg = cfg; gf.n_cfg = rows / 2;
+    }
     GEMM(gf);
     return 0;
 }
@@ -799,9 +810,7 @@ static int sample_body(vv_ctx* ctx, hipStream_t st, int n, const float* cond, co
     gc.nt = 1;
     GEMM(gc);
     for (int i = 0; i < ctx->n_steps; ++i) {
-        if (head_eval(ctx, st, rows, ctx->zz, ctx->temb + (size_t)i * H, ctx->eps)) return -1;
-        ctx->launches++;
-        VVCHK(vv_cfg_dpm_launch(ctx->eps, ctx->zz, ctx->x0p, ctx->coef + i * 5, cfg, n, L, st));
+        if (head_eval(ctx, st, rows, ctx->zz, ctx->temb + (size_t)i * H, ctx->eps, ctx->coef + i * 5, cfg)) return -1;
     }
     HIPCHK(ctx, hipMemcpyAsync(latent_out, ctx->zz, (size_t)n * L * 4, hipMemcpyDeviceToDevice, st));
     return 0;

@@ -318,12 +318,33 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemm_kernel(const VVGemm a) {
         float o4[4] = {acc[i][0] * rs, acc[i][1] * rs, acc[i][2] * rs, acc[i][3] * rs};
         float u4[4] = {0.f, 0.f, 0.f, 0.f};
         if constexpr (DUAL) { u4[0] = acc[NT + i][0] * rs; u4[1] = acc[NT + i][1] * rs; u4[2] = acc[NT + i][2] * rs; u4[3] = acc[NT + i][3] * rs; }
+        if (a.epi == VV_EPI_CFG_DPM) {
+            // lanes frow = j (cond) and frow = j + n (uncond) hold the two guidance branches of latent row j
+            const int nc = a.n_cfg;
+            const float ca = a.coef[0], cs_ = a.coef[1], csx = a.coef[2], c0 = a.coef[3], c1 = a.coef[4];
+#pragma unroll 1
+            for (int r = 0; r < 4; ++r) {
+                const float vu = __shfl(o4[r], lane + nc);
+                const int n = n0 + r;
+                if (frow < nc && n < a.N) {
+                    const float v = vu + a.cfg * (o4[r] - vu);
+                    const int64_t zi = (int64_t)frow * a.N + n;
+                    const float zo = a.z[zi];
+                    const float x0 = ca * zo - cs_ * v;
+                    const float zn = csx * zo + c0 * x0 + c1 * (x0 - a.x0p[zi]);
+                    a.x0p[zi] = x0;
+                    a.z[zi] = zn;
+                    a.z[zi + (int64_t)nc * a.N] = zn;
+                }
+            }
+            continue;
+        }
 #pragma unroll 1
         for (int r = 0; r < 4; ++r) {
             const int n = n0 + r;
             if (n >= a.N) break;
             float o = o4[r];
-            if (a.bias && a.epi != VV_EPI_STORE) o += a.bias[n];
+            if (a.bias && (a.epi == VV_EPI_BIAS || a.epi == VV_EPI_BIAS_GELU || a.epi == VV_EPI_RESID)) o += a.bias[n];
             if (a.epi == VV_EPI_BIAS_GELU) o = gelu_erf_f(o);
             else if (a.epi == VV_EPI_SWIGLU) o = silu_f(o) * u4[r];
             else if (a.epi == VV_EPI_RESID) { if (a.nscale) o *= a.nscale[n]; o += yp[r]; }

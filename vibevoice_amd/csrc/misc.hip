@@ -85,6 +85,40 @@ __global__ void vv_dwconv_res_kernel(const float* __restrict__ nb, float* __rest
     }
 }
 
+// Small-T fused variant of the two kernels above: ONE workgroup normalises all T rows into nb
+// (behind its 6 history rows) and then applies the depthwise conv + residual in place.  Used for
+// the T*C <= 64K stages (C >= 256), where two launches cost more than the arithmetic.
+__global__ __launch_bounds__(1024) void vv_normdw_kernel(float* __restrict__ x, float* __restrict__ nb,
+                                                         const float* __restrict__ nw, const float* __restrict__ w,
+                                                         const float* __restrict__ b, const float* __restrict__ gamma,
+                                                         int T, int C, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int t = wave; t < T; t += 16) {
+        const float* xr = x + (int64_t)t * C;
+        float s = 0.f;
+        for (int c = lane * 4; c < C; c += 256) {
+            const float4 v = *reinterpret_cast<const float4*>(xr + c);
+            s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+        const float rs = rsqrtf(wave_sum(s) / (float)C + eps);
+        float* nr = nb + (int64_t)(6 + t) * C;
+        for (int c = lane * 4; c < C; c += 256) {
+            const float4 v = *reinterpret_cast<const float4*>(xr + c);
+            const float4 ww = *reinterpret_cast<const float4*>(nw + c);
+            *reinterpret_cast<float4*>(nr + c) = float4{v.x * rs * ww.x, v.y * rs * ww.y, v.z * rs * ww.z, v.w * rs * ww.w};
+        }
+    }
+    __syncthreads();
+    const int total = T * C;
+    for (int e = threadIdx.x; e < total; e += 1024) {
+        const int t = e / C, c = e - t * C;
+        float acc = b[c];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) acc += w[j * C + c] * nb[(int64_t)(t + j) * C + c];
+        x[e] += gamma[c] * acc;
+    }
+}
+
 // Streaming state carry: for every stateful buffer move rows [T, T+hist) -> [0, hist).
 // One lane owns one column and walks rows in ascending order, so overlapping moves
 // (T < hist) are race-free.                        grid (n_entries, col_chunks), block 256
@@ -183,6 +217,11 @@ int vv_dwconv_res_launch(const float* nb, float* x, const float* w, const float*
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(vv_dwconv_res_kernel, dim3(blocks), dim3(256), 0, s, nb, x, w, b, gamma, T, C);
+    return okk();
+}
+int vv_normdw_launch(float* x, float* nb, const float* nw, const float* w, const float* b, const float* gamma,
+                     int T, int C, float eps, hipStream_t s) {
+    hipLaunchKernelGGL(vv_normdw_kernel, dim3(1), dim3(1024), 0, s, x, nb, nw, w, b, gamma, T, C, eps);
     return okk();
 }
 int vv_shift_rows_launch(const void* tab, int n_entries, int maxC, hipStream_t s) {

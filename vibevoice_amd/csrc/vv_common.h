@@ -25,7 +25,7 @@ static inline __host__ __device__ int64_t vv_packed_elems(int N, int K) {
 // Y[t][n] (op)= sum_k f(X[t][k]) * W[n][k]
 enum { VV_PRO_NONE = 0, VV_PRO_RMS = 1, VV_PRO_RMS_MOD = 2, VV_PRO_ADD_SILU = 3 };
 enum { VV_EPI_STORE = 0, VV_EPI_BIAS = 1, VV_EPI_BIAS_GELU = 2, VV_EPI_SWIGLU = 3,
-       VV_EPI_RESID = 4, VV_EPI_GATED_RESID = 5 };
+       VV_EPI_RESID = 4, VV_EPI_GATED_RESID = 5, VV_EPI_CFG_DPM = 6 };
 
 struct VVGemm {
     const u32x4* W;        // packed tiles
@@ -45,6 +45,12 @@ struct VVGemm {
     int ksplit;            // 1, 2 or 4 waves of the block split K
     int nt;                // non-temporal weight loads (streamed-once weights)
     int t_pad;             // LDS row stride of the staging tile (set by the launcher)
+    // EPI_CFG_DPM (diffusion-head final layer): rows [0,n) cond, [n,2n) uncond -> CFG + DPM-Solver++ update in place
+    float* z;              // [2n][N] noisy latent (both halves rewritten)
+    float* x0p;            // [n][N] previous x0 prediction
+    const float* coef;     // {a, s, cs, c0, c1}
+    float cfg;
+    int n_cfg;
     float eps;
 };
 
