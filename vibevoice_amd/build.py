@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvvhip.so")
-SOURCES = ["gemm.hip", "attn.hip", "misc.hip", "block1d.hip", "engine.hip"]
+SOURCES = ["gemm.hip", "gemv.hip", "attn.hip", "misc.hip", "block1d.hip", "engine.hip"]
 HEADERS = [os.path.join(CSRC, "vv_common.h"), os.path.join(os.path.dirname(HERE), "include", "vvhip.h")]
 
 
@@ -33,7 +33,8 @@ def build(force=False, verbose=True):
     if not force and not stale():
         return LIB
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-value", "-Wno-unused-result"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
+           "-Wno-unused-value", "-Wno-unused-result"] + os.environ.get("VVHIP_CFLAGS", "").split() + \
+          [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
     if verbose:
         print("[vibevoice_amd] building libvvhip.so:", " ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

@@ -925,7 +925,10 @@ extern "C" int vv_gemm_raw(void* stream, const void* w, const void* w2, const fl
                            const float* nscale, int xsplit, int ksplit, int nontemporal) {
     VVGemm g = mk_gemm(w, x, y, T, N, K, ldx, ldy);
     g.W2 = (const u32x4*)w2; g.pro = pro; g.epi = epi; g.nw = nw; g.eps = eps; g.bias = bias; g.nscale = nscale;
-    g.ksplit = ksplit; g.nt = nontemporal;
+    g.ksplit = ksplit & 0xff; g.nt = 1;
+    g.dbg = (unsigned long long*)(uintptr_t)0;
+    if (nontemporal > 1) g.dbg = reinterpret_cast<unsigned long long*>(const_cast<float*>(nscale));   // timing builds: nscale slot carries the stamp buffer
+    if (g.dbg) g.nscale = nullptr;
     return vv_gemm_launch(g, xsplit, (hipStream_t)stream);
 }
 extern "C" int vv_profile_begin(vv_ctx* ctx) {

@@ -26,7 +26,14 @@
 //    scalar); only the adaLN-modulated norm (shift term) needs 1/rms up front.
 //  * K is split across KS of the block's waves (up to 16) and reduced through LDS
 //    in a fixed order -> deterministic, no atomics, enough waves for skinny N.
+#include <cstdlib>
 #include "vv_common.h"
+
+#ifdef VV_GEMM_TIMING
+#define VV_STAMP(i) do { if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define VV_STAMP(i) do { } while (0)
+#endif
 
 namespace {
 
@@ -68,6 +75,7 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemm_kernel(const VVGemm a) {
     constexpr bool MODREG = (MAXR <= 4);          // adaLN scale/shift prefetched in registers only for few rows
     constexpr int U = 8;                          // k-steps per batch = 256 k = one float4 per lane per row
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    VV_STAMP(0);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int KS = a.ksplit;
@@ -78,8 +86,7 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemm_kernel(const VVGemm a) {
     const int tile0 = ((int)blockIdx.x * NG + ng) * NT;
     const int t0 = (int)blockIdx.y * 16;
     const int Tt = min(MAXR, a.T - t0);           // rows of this tile (wave-uniform)
-    int kper = (k_tiles + KS - 1) / KS;
-    kper = (kper + U - 1) / U * U;                // whole batches per wave
+    const int kper = (k_tiles + KS - 1) / KS;     // k-steps per wave (the last batch may be partial)
     const int kt_begin = ks * kper;
     const int kt_end = min(k_tiles, kt_begin + kper);
     const bool active = tile0 < n_tiles && kt_begin < kt_end;
@@ -254,9 +261,11 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemm_kernel(const VVGemm a) {
                 const int ktn = kt_begin + (b + 1) * U;
                 const bool have_next = b + 1 < nb;
                 if (have_next) { stage_load(ktn, R); load_w(ktn, wnext); }
+                if (b == -1) VV_STAMP(1);
                 if (b >= 0) mma_batch(kt_begin + b * U, wcur);
                 if (have_next) {
                     stage_finish(ktn, R);
+                    if (b == -1) VV_STAMP(2);
 #pragma unroll
                     for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -274,6 +283,7 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemm_kernel(const VVGemm a) {
         }
     }
 
+    VV_STAMP(3);
     // per-row sum of squares of this wave's k-range (PRO_RMS): reduce over lanes
     float my_ssq = 0.f;
     if (a.pro == VV_PRO_RMS) {
@@ -286,6 +296,7 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemm_kernel(const VVGemm a) {
         }
     }
 
+    VV_STAMP(4);
     // ---- split-K reduction through LDS, fixed order (deterministic) ----
     if (KS > 1) {
         __syncthreads();                            // staging tiles are dead; reuse the LDS
@@ -303,6 +314,7 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemm_kernel(const VVGemm a) {
             }
         }
     }
+    VV_STAMP(5);
     if (ks != 0 || tile0 >= n_tiles) return;
 
     // ---- epilogue: lane holds D[n = tile*16 + (lane>>4)*4 + r][t = lane&15] ----
@@ -352,6 +364,7 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemm_kernel(const VVGemm a) {
             yp[r] = o;
         }
     }
+    VV_STAMP(6);
 }
 
 // ---- weight packing ----------------------------------------------------------
@@ -409,8 +422,13 @@ static void launch_t(const VVGemm& a, dim3 grid, size_t smem, hipStream_t s) {
 
 static int pow2_floor(int v) { int p = 1; while (p * 2 <= v) p *= 2; return p; }
 
-// Chooses the decomposition.  `xs` in {1,2,3}.
+extern "C" int vv_gemv_ok(const VVGemm* a);
+extern "C" int vv_gemv_launch(VVGemm a, int xs, hipStream_t s);
+
+// Chooses the kernel and its decomposition.  `xs` in {1,2,3}.
 extern "C" int vv_gemm_launch(VVGemm a, int xs, hipStream_t s) {
+    static const bool no_gemv = getenv("VVHIP_NO_GEMV") != nullptr;
+    if (!no_gemv && a.ksplit <= 0 && vv_gemv_ok(&a)) return vv_gemv_launch(a, xs, s);
     const int n_tiles = (a.N + 15) / 16;
     const int k_tiles = (a.K + 31) / 32;
     const int t_tiles = (a.T + 15) / 16;
@@ -437,6 +455,8 @@ extern "C" int vv_gemm_launch(VVGemm a, int xs, hipStream_t s) {
         if (ks > kmax) ks = kmax;
     }
     if (ks > wpb) ks = wpb;
+    // few tiles: give every tile its own workgroup (more CUs pulling on HBM) rather than packing tiles into one
+    if (a.ksplit <= 0 && wpb == 8 && work < 512) { while (ks < wpb && (k_tiles / (ks * 2)) >= 2) ks *= 2; }
     a.ksplit = ks;
     const int ng = wpb / ks;
     const int per_block = ng * nt;

@@ -1,0 +1,345 @@
+// gemv.hip -- latency-lean decode variant of the weight-streaming GEMM (T <= 4 rows).
+//
+// At decode every dense op of the hot path is a chain of DEPENDENT small launches
+// (~450 per frame), so a launch's fixed cost matters as much as its bandwidth.  An
+// s_memtime trace of the general kernel (gemm.hip) showed ~7000 of ~8500 cycles of a
+// small launch outside the weight stream: 64-bit address arithmetic and guarded-load
+// branches in the prologue, a ds_bpermute reduction chain for RMSNorm's sum(x^2), two
+// barriers around the split-K reduction, and an epilogue that only then starts loading
+// its residual / bias / gate operands.  This kernel keeps the same data path
+//   packed bf16 weight tiles --global_load_dwordx4 nt--> VGPR --MFMA 16x16x32--> fp32 acc
+//   fp32 activations --float4--> prologue --bf16 split--> wave-private LDS B-fragments
+// and restructures everything around it:
+//   * one workgroup = one 16-feature tile (two for SwiGLU), its 8 waves split K evenly;
+//   * 32-bit offsets from uniform bases (no 64-bit multiplies), k-range handled with
+//     clamped loads + one uniform branch per batch instead of a branch per load;
+//   * the epilogue wave issues its residual / bias / gate loads at kernel entry;
+//   * sum(x^2) by DPP row reductions + readlane (no LDS permutes);
+//   * split-K partials go to a dedicated LDS region: a single barrier.
+#include "vv_common.h"
+
+namespace {
+
+__device__ __forceinline__ float silu_f(float u) { return u / (1.0f + __expf(-u)); }
+__device__ __forceinline__ float silu_acc(float u) { return u / (1.0f + expf(-u)); }
+__device__ __forceinline__ float gelu_erf_f(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f)); }
+
+// full-wave sum, result uniform (returned from SGPRs): 4 DPP steps inside each row of 16 + 4 readlanes
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    int x = __builtin_bit_cast(int, v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    x = __builtin_bit_cast(int, v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    x = __builtin_bit_cast(int, v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true));  // row_half_mirror
+    x = __builtin_bit_cast(int, v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true));  // row_mirror
+    x = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
+template <int XS>
+__device__ __forceinline__ void split4(const float (&v)[4], uint2 (&out)[XS]) {
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    bf16x4 h, m, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        h[j] = (__bf16)v[j];
+        if constexpr (XS > 1) {
+            const float r = v[j] - (float)h[j];
+            m[j] = (__bf16)r;
+            if constexpr (XS > 2) l[j] = (__bf16)(r - (float)m[j]);
+        }
+    }
+    out[0] = __builtin_bit_cast(uint2, h);
+    if constexpr (XS > 1) out[1] = __builtin_bit_cast(uint2, m);
+    if constexpr (XS > 2) out[2] = __builtin_bit_cast(uint2, l);
+}
+
+constexpr int WPB = 8;     // waves per workgroup == K split
+constexpr int U = 8;       // k-steps per batch (256 k = one float4 per lane per row)
+constexpr int MR = 4;      // max activation rows
+
+template <int XS, bool DUAL>
+__global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
+    constexpr int NM = DUAL ? 2 : 1;
+    // LDS: [wave][XS][U][4][MR] x 16 B staging tiles, then [wave][NM][64] f32x4 partials, then [wave][MR] ssq
+    __shared__ __attribute__((aligned(16))) unsigned char stg_all[WPB * XS * U * 4 * MR * 16];
+    __shared__ f32x4 red[WPB][NM][64];
+    __shared__ float ssq_sh[WPB][MR];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int T = a.T;
+    const unsigned tile = blockIdx.x;
+    const unsigned k_tiles = (unsigned)(a.K + 31) >> 5;
+    const unsigned kper = (k_tiles + WPB - 1) / WPB;
+    const unsigned kt0 = wave * kper;
+    const unsigned kt1 = min(k_tiles, kt0 + kper);
+    const bool has_k = kt0 < kt1;
+    const int frow = lane & 15, fq = lane >> 4;
+    unsigned char* stg = stg_all + (size_t)wave * (XS * U * 4 * MR * 16);
+    const unsigned kk = lane * 4;
+    const unsigned st_off = (((kk >> 5) * 4 + ((kk & 31) >> 3)) * MR) * 16 + (kk & 7) * 2;
+
+    // ---- epilogue operands: requested now, consumed ~one weight stream later (wave 0 only) ----
+    const int n0 = tile * 16 + fq * 4;
+    const bool epi_lane = (wave == 0) && frow < T && n0 < a.N;
+    const bool full4 = (n0 + 4 <= a.N);
+    float4 pre_y = {0.f, 0.f, 0.f, 0.f}, pre_b = {0.f, 0.f, 0.f, 0.f}, pre_g = {1.f, 1.f, 1.f, 1.f};
+    if (epi_lane) {
+        if (a.bias) {
+            if (full4) pre_b = *reinterpret_cast<const float4*>(a.bias + n0);
+            else { pre_b.x = a.bias[n0]; if (n0 + 1 < a.N) pre_b.y = a.bias[n0 + 1]; if (n0 + 2 < a.N) pre_b.z = a.bias[n0 + 2]; }
+        }
+        if (a.epi == VV_EPI_RESID || a.epi == VV_EPI_GATED_RESID) {
+            const float* yp = a.Y + (unsigned)(frow * a.ldy + n0);
+            if (full4) pre_y = *reinterpret_cast<const float4*>(yp);
+            else { pre_y.x = yp[0]; if (n0 + 1 < a.N) pre_y.y = yp[1]; if (n0 + 2 < a.N) pre_y.z = yp[2]; }
+            const float* gp = (a.epi == VV_EPI_GATED_RESID) ? a.gate + (unsigned)(frow * a.ld_gate + n0) : (a.nscale ? a.nscale + n0 : nullptr);
+            if (gp) {
+                if (full4) pre_g = *reinterpret_cast<const float4*>(gp);
+                else { pre_g.x = gp[0]; if (n0 + 1 < a.N) pre_g.y = gp[1]; if (n0 + 2 < a.N) pre_g.z = gp[2]; }
+            }
+        }
+    }
+
+    // ---- adaLN-modulated norm: 1/rms of the whole row is needed before staging ----
+    float rstd[MR] = {1.f, 1.f, 1.f, 1.f};
+    if (a.pro == VV_PRO_RMS_MOD) {
+#pragma unroll
+        for (int r = 0; r < MR; ++r) {
+            float s = 0.f;
+            if (r < T) {
+                const float* xr = a.X + (unsigned)(r * a.ldx);
+                for (unsigned k = kt0 * 32 + kk; k < min(kt1 * 32, (unsigned)a.K); k += 256) {
+                    const float4 v = *reinterpret_cast<const float4*>(xr + k);
+                    s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+                }
+                s = wave_sum_dpp(s);
+            }
+            if (lane == 0) ssq_sh[wave][r] = s;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < MR; ++r) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < WPB; ++w) s += ssq_sh[w][r];
+            rstd[r] = rsqrtf(s / (float)a.K + a.eps);
+        }
+        __syncthreads();          // ssq_sh is reused by the epilogue path of PRO_RMS only, but keep phases apart
+    }
+
+    f32x4 acc[NM];
+#pragma unroll
+    for (int i = 0; i < NM; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float ssq[MR] = {0.f, 0.f, 0.f, 0.f};
+
+    const u32x4* wbase = a.W + (size_t)tile * k_tiles * 64 + lane;
+    const u32x4* wbase2 = DUAL ? a.W2 + (size_t)tile * k_tiles * 64 + lane : nullptr;
+
+    struct XR { float4 x[MR]; float4 sc[MR]; float4 sh[MR]; float4 nwv, addv; };
+    auto x_load = [&](unsigned ktb, XR& R) {
+        unsigned k = ktb * 32 + kk;
+        const bool kin = k < min(kt1 * 32, (unsigned)a.K);
+        if (!kin) k = 0;                                   // clamped: always a legal address, masked later
+        R.nwv = a.nw ? *reinterpret_cast<const float4*>(a.nw + k) : float4{1.f, 1.f, 1.f, 1.f};
+        if (a.pro == VV_PRO_ADD_SILU) R.addv = *reinterpret_cast<const float4*>(a.addvec + k);
+#pragma unroll
+        for (int r = 0; r < MR; ++r) {
+            if (r < T) {
+                R.x[r] = *reinterpret_cast<const float4*>(a.X + (unsigned)(r * a.ldx) + k);
+                if (a.pro == VV_PRO_RMS_MOD) {
+                    R.sc[r] = *reinterpret_cast<const float4*>(a.mod_scale + (unsigned)(r * a.ld_mod) + k);
+                    R.sh[r] = *reinterpret_cast<const float4*>(a.mod_shift + (unsigned)(r * a.ld_mod) + k);
+                }
+            }
+        }
+    };
+    auto x_stage = [&](unsigned ktb, const XR& R) {
+        const unsigned k = ktb * 32 + kk;
+        const float msk = (k < min(kt1 * 32, (unsigned)a.K)) ? 1.f : 0.f;
+#pragma unroll
+        for (int r = 0; r < MR; ++r) {
+            if (r < T) {
+                float v[4] = {R.x[r].x * msk, R.x[r].y * msk, R.x[r].z * msk, R.x[r].w * msk};
+                if (a.pro == VV_PRO_RMS) {
+                    ssq[r] += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+                    v[0] *= R.nwv.x; v[1] *= R.nwv.y; v[2] *= R.nwv.z; v[3] *= R.nwv.w;
+                } else if (a.pro == VV_PRO_RMS_MOD) {
+                    const float rs = rstd[r];
+                    v[0] = ((v[0] * rs * R.nwv.x) * (1.f + R.sc[r].x) + R.sh[r].x) * msk;
+                    v[1] = ((v[1] * rs * R.nwv.y) * (1.f + R.sc[r].y) + R.sh[r].y) * msk;
+                    v[2] = ((v[2] * rs * R.nwv.z) * (1.f + R.sc[r].z) + R.sh[r].z) * msk;
+                    v[3] = ((v[3] * rs * R.nwv.w) * (1.f + R.sc[r].w) + R.sh[r].w) * msk;
+                } else if (a.pro == VV_PRO_ADD_SILU) {
+                    v[0] = silu_acc(v[0] + R.addv.x) * msk; v[1] = silu_acc(v[1] + R.addv.y) * msk;
+                    v[2] = silu_acc(v[2] + R.addv.z) * msk; v[3] = silu_acc(v[3] + R.addv.w) * msk;
+                }
+                uint2 parts[XS];
+                split4<XS>(v, parts);
+#pragma unroll
+                for (int p = 0; p < XS; ++p)
+                    *reinterpret_cast<uint2*>(stg + p * (U * 4 * MR * 16) + st_off + r * 16) = parts[p];
+            }
+        }
+    };
+    auto w_load = [&](unsigned ktb, u32x4 (&dst)[U][NM]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned kt = min(ktb + u, kt1 - 1);      // clamped: tail k-steps re-read the last tile, MFMA skipped
+            dst[u][0] = __builtin_nontemporal_load(wbase + kt * 64);
+            if constexpr (DUAL) dst[u][1] = __builtin_nontemporal_load(wbase2 + kt * 64);
+        }
+    };
+    auto mma = [&](unsigned ktb, const u32x4 (&wb)[U][NM]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (ktb + u < kt1) {
+#pragma unroll
+                for (int p = 0; p < XS; ++p) {
+                    u32x4 f = u32x4{0u, 0u, 0u, 0u};
+                    if (frow < MR) f = *reinterpret_cast<const u32x4*>(stg + (size_t)((p * U + u) * 4 + fq) * (MR * 16) + frow * 16);
+                    const bf16x8 xb = __builtin_bit_cast(bf16x8, f);
+#pragma unroll
+                    for (int i = 0; i < NM; ++i)
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wb[u][i]), xb, acc[i], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    if (has_k) {
+        XR R;
+        u32x4 wcur[U][NM], wnext[U][NM];
+        const int nb = (int)((kt1 - kt0 + U - 1) / U);
+#pragma unroll 1
+        for (int b = -1; b < nb; ++b) {
+            const unsigned ktn = kt0 + (unsigned)(b + 1) * U;
+            const bool have_next = b + 1 < nb;
+            if (have_next) { x_load(ktn, R); w_load(ktn, wnext); }
+            if (b >= 0) mma(kt0 + (unsigned)b * U, wcur);
+            if (have_next) {
+                x_stage(ktn, R);
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int i = 0; i < NM; ++i) wcur[u][i] = wnext[u][i];
+            }
+        }
+    }
+    // rows beyond T were never staged: their fragment slots hold stale LDS -> D columns >= T are garbage, never stored.
+
+    // ---- split-K partials -> LDS, one barrier, wave 0 finishes ----
+#pragma unroll
+    for (int i = 0; i < NM; ++i) red[wave][i][lane] = acc[i];
+    if (a.pro == VV_PRO_RMS) {
+#pragma unroll
+        for (int r = 0; r < MR; ++r) {
+            const float s = (r < T) ? wave_sum_dpp(ssq[r]) : 0.f;
+            if (lane == 0) ssq_sh[wave][r] = s;
+        }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 1; w < WPB; ++w)
+#pragma unroll
+        for (int i = 0; i < NM; ++i) acc[i] += red[w][i][lane];
+    if (!epi_lane) return;
+    float rs = 1.0f;
+    if (a.pro == VV_PRO_RMS) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < WPB; ++w) s += ssq_sh[w][frow & (MR - 1)];
+        rs = rsqrtf(s / (float)a.K + a.eps);
+    }
+    float o[4] = {acc[0][0] * rs, acc[0][1] * rs, acc[0][2] * rs, acc[0][3] * rs};
+    const float pb[4] = {pre_b.x, pre_b.y, pre_b.z, pre_b.w};
+    const float py[4] = {pre_y.x, pre_y.y, pre_y.z, pre_y.w};
+    const float pg[4] = {pre_g.x, pre_g.y, pre_g.z, pre_g.w};
+    switch (a.epi) {
+        case VV_EPI_BIAS:
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] += pb[r];
+            break;
+        case VV_EPI_BIAS_GELU:
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = gelu_erf_f(o[r] + pb[r]);
+            break;
+        case VV_EPI_SWIGLU:
+            if constexpr (DUAL) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = silu_acc(o[r]) * (acc[1][r] * rs);
+            }
+            break;
+        case VV_EPI_RESID:
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = py[r] + pg[r] * (o[r] + pb[r]);
+            break;
+        case VV_EPI_GATED_RESID:
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = py[r] + pg[r] * o[r];
+            break;
+        default: break;
+    }
+    if (a.epi == VV_EPI_CFG_DPM) {
+        const int nc = a.n_cfg;
+        const float ca = a.coef[0], cs_ = a.coef[1], csx = a.coef[2], c0 = a.coef[3], c1 = a.coef[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float vu = __shfl(o[r], lane + nc);
+            const int n = n0 + r;
+            if (frow < nc && n < a.N) {
+                const float v = vu + a.cfg * (o[r] - vu);
+                const unsigned zi = (unsigned)(frow * a.N + n);
+                const float zo = a.z[zi];
+                const float x0 = ca * zo - cs_ * v;
+                const float zn = csx * zo + c0 * x0 + c1 * (x0 - a.x0p[zi]);
+                a.x0p[zi] = x0;
+                a.z[zi] = zn;
+                a.z[zi + (unsigned)(nc * a.N)] = zn;
+            }
+        }
+        return;
+    }
+    float* yp = a.Y + (unsigned)(frow * a.ldy + n0);
+    if (full4 && ((a.ldy & 3) == 0)) *reinterpret_cast<float4*>(yp) = float4{o[0], o[1], o[2], o[3]};
+    else { yp[0] = o[0]; if (n0 + 1 < a.N) yp[1] = o[1]; if (n0 + 2 < a.N) yp[2] = o[2]; if (n0 + 3 < a.N) yp[3] = o[3]; }
+}
+
+}  // namespace
+
+// Eligibility: decode rows, aligned operands, 32-bit offsets.
+extern "C" int vv_gemv_ok(const VVGemm* a) {
+    if (a->T < 1 || a->T > 4) return 0;
+    if ((a->K & 3) || (a->ldx & 3) || (((uintptr_t)a->X) & 15)) return 0;
+    if (a->pro == VV_PRO_RMS_MOD && (a->ld_mod & 3)) return 0;
+    if (a->nw && (((uintptr_t)a->nw) & 15)) return 0;
+    if (a->K < 32) return 0;
+    if ((int64_t)a->T * a->ldy >= (1LL << 30) || (int64_t)a->T * a->ldx >= (1LL << 30)) return 0;
+    if ((a->ldy & 3) && (a->epi == VV_EPI_RESID || a->epi == VV_EPI_GATED_RESID)) return 0;
+    if ((((uintptr_t)a->Y) & 15) || (a->bias && (((uintptr_t)a->bias) & 15))) return 0;
+    return 1;
+}
+
+extern "C" int vv_gemv_launch(VVGemm a, int xs, hipStream_t s) {
+    const int n_tiles = (a.N + 15) / 16;
+    const bool dual = a.epi == VV_EPI_SWIGLU;
+    if (dual && !a.W2) return -1;
+    dim3 grid(n_tiles), block(WPB * 64);
+#define VV_G(XS_)                                                                        \
+    do {                                                                                 \
+        if (dual) hipLaunchKernelGGL((vv_gemv_kernel<XS_, true>), grid, block, 0, s, a); \
+        else hipLaunchKernelGGL((vv_gemv_kernel<XS_, false>), grid, block, 0, s, a);     \
+    } while (0)
+    if (xs == 1) VV_G(1);
+    else if (xs == 2) VV_G(2);
+    else VV_G(3);
+#undef VV_G
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}

@@ -51,6 +51,7 @@ struct VVGemm {
     const float* coef;     // {a, s, cs, c0, c1}
     float cfg;
     int n_cfg;
+    unsigned long long* dbg;   // optional phase timestamps (VV_GEMM_TIMING builds only)
     float eps;
 };
 
