@@ -45,6 +45,10 @@ typedef struct vv_config {
     int attn_splits;   /* flash-decoding splits along the sequence */
     int enc_frames;    /* frames per chunk of the voice-prompt encoder (>=1) */
     int use_graph;     /* replay captured hipGraphs for repeated shapes */
+    /* Streaming-0.5B split LM (modeling_vibevoice_streaming.py:108-164): the last `tts_layers` of the
+     * lm_layers stack form the TTS LM (own final norm), the first lm_layers-tts_layers the text LM
+     * (final norm = Identity); adds tts_input_types + the binary EOS classifier.  0 = ordinary model. */
+    int tts_layers;
 } vv_config;
 
 int vv_create(const vv_config* cfg, vv_ctx** out);
@@ -81,6 +85,20 @@ typedef struct vv_row { int cache; int pos; } vv_row;
  * over the weights.  hidden_out = last_hidden_state (after the final RMSNorm). */
 int vv_lm_forward(vv_ctx* ctx, void* stream, int n_rows, const vv_row* rows,
                   const float* x_in_dev, float* hidden_out_dev);
+/* Same over the layer range [layer_begin, layer_end) only; final_norm selects whether lm.norm is applied.
+ * Streaming-0.5B: forward_lm = layers [0, n_lm) without norm (modeling_vibevoice_streaming_inference.py:181-241),
+ * forward_tts_lm = layers [n_lm, n_lm+n_tts) with norm (:243-318). */
+int vv_lm_forward_range(vv_ctx* ctx, void* stream, int n_rows, const vv_row* rows, const float* x_in_dev,
+                        float* hidden_out_dev, int layer_begin, int layer_end, int final_norm);
+/* Import n_pos cached positions of one layer into cache `cache` from HF layout k/v [kv_heads][n_pos][head_dim]
+ * (keys already rotated, as DynamicCache stores them); src_dtype 0 fp32, 1 bf16.  Used for the voice presets
+ * (demo/voices/streaming_model/*.pt -> all_prefilled_outputs). */
+int vv_kv_import(vv_ctx* ctx, void* stream, int cache, int layer, int n_pos, const void* k_dev, const void* v_dev,
+                 int src_dtype);
+/* y[t][:] = x[t][:] + tts_input_types[type]  (forward_tts_lm, :293) */
+int vv_add_type_embedding(vv_ctx* ctx, void* stream, int n, const float* x_dev, int type, float* out_dev);
+/* tts_eos_classifier: fc2(relu(fc1(h))) -> out_dev[n] logits (BinaryClassifier, modeling_vibevoice_streaming.py:42-53) */
+int vv_eos_logit(vv_ctx* ctx, void* stream, int n, const float* hidden_dev, float* out_dev);
 /* embed_tokens lookup (modeling_vibevoice_inference.py:218,569); ids on host */
 int vv_embed(vv_ctx* ctx, void* stream, int n, const int* ids, float* out_dev);
 /* logits restricted to the valid ids: replaces lm_head + constraint mask (:241-242,488-490).

@@ -16,7 +16,7 @@ class VVConfig(C.Structure):
         ("n_stages", C.c_int), ("enc_depths", C.c_int * 8), ("sem_dim", C.c_int),
         ("has_acoustic_encoder", C.c_int), ("codec_eps", C.c_float),
         ("n_slots", C.c_int), ("max_ctx", C.c_int), ("max_rows", C.c_int), ("xsplit", C.c_int),
-        ("attn_splits", C.c_int), ("enc_frames", C.c_int), ("use_graph", C.c_int),
+        ("attn_splits", C.c_int), ("enc_frames", C.c_int), ("use_graph", C.c_int), ("tts_layers", C.c_int),
     ]
 
 
@@ -36,6 +36,10 @@ _SIGS = {
     "vv_set_valid_tokens": (C.c_int, [_P, C.POINTER(C.c_int), C.c_int]),
     "vv_set_schedule": (C.c_int, [_P, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), _P]),
     "vv_lm_forward": (C.c_int, [_P, _P, C.c_int, C.POINTER(VVRow), _P, _P]),
+    "vv_lm_forward_range": (C.c_int, [_P, _P, C.c_int, C.POINTER(VVRow), _P, _P, C.c_int, C.c_int, C.c_int]),
+    "vv_kv_import": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int]),
+    "vv_add_type_embedding": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P]),
+    "vv_eos_logit": (C.c_int, [_P, _P, C.c_int, _P, _P]),
     "vv_embed": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int), _P]),
     "vv_lm_logits": (C.c_int, [_P, _P, C.c_int, _P, _P]),
     "vv_diffusion_sample": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_float, _P]),

@@ -35,6 +35,9 @@ int vv_affine_launch(const float* x, float* y, float mul, float add, int n, hipS
 int vv_add_launch(const float* a, const float* b, float* y, int n, hipStream_t s);
 int vv_tfreq_launch(const float* t, float* out, int n, hipStream_t s);
 int vv_silu_launch(float* x, int n, hipStream_t s);
+int vv_add_rows_launch(const float* x, const float* v, float* y, int n, int C, hipStream_t s);
+int vv_relu_launch(float* x, int n, hipStream_t s);
+int vv_kv_import_launch(const void* k, const void* v, int src_bf16, void* kc, void* vc, int L, int Hkv, int D, int64_t head_stride, hipStream_t s);
 int vv_cvt_launch(const void* src, void* dst, int64_t n, int to_bf16, hipStream_t s);
 int vv_dw_transpose_launch(const float* src, float* dst, int C, hipStream_t s);
 int vv_block1d_supported(int C);
@@ -116,6 +119,7 @@ struct vv_ctx {
     struct Layer { float *ln1, *ln2, *bqkv; void *wqkv, *wo, *wg, *wu, *wd; };
     std::vector<Layer> layers;
     float *lm_norm = nullptr, *inv_freq = nullptr;
+    float *tts_types = nullptr, *eos_b1 = nullptr, *eos_b2 = nullptr; void *eos_w1 = nullptr, *eos_w2 = nullptr;
     void *embed = nullptr, *lm_head = nullptr;
     bool lm_head_loaded = false;
     void* valid_w = nullptr; int n_valid = 0;
@@ -475,6 +479,14 @@ extern "C" int vv_create(const vv_config* cfg, vv_ctx** out) {
     { int i = add_w(ctx, "lm_head.weight", W_TABLE, (int64_t)c.lm_vocab * H, true); ctx->w[i].dev = nullptr; }
     ctx->inv_freq = add_vec(ctx, "lm.rope.inv_freq", D / 2);
     ctx->lm_norm = add_vec(ctx, "lm.norm.weight", H);
+    if (c.tts_layers > 0) {
+        if (c.tts_layers >= c.lm_layers) { delete ctx; return fail(nullptr, "tts_layers must be < lm_layers"); }
+        ctx->tts_types = add_vec(ctx, "tts_input_types.weight", 2 * (int64_t)H);
+        ctx->eos_w1 = alloc_packed(ctx, H, H); add_mat(ctx, "eos.fc1.weight", H, H, ctx->eos_w1, 0);
+        ctx->eos_b1 = add_vec(ctx, "eos.fc1.bias", H);
+        ctx->eos_w2 = alloc_packed(ctx, 1, H); add_mat(ctx, "eos.fc2.weight", 1, H, ctx->eos_w2, 0);
+        ctx->eos_b2 = add_vec(ctx, "eos.fc2.bias", 1);
+    }
     ctx->layers.resize(c.lm_layers);
     for (int l = 0; l < c.lm_layers; ++l) {
         auto& L = ctx->layers[l];
@@ -701,11 +713,11 @@ extern "C" int vv_set_schedule(vv_ctx* ctx, int n_steps, const float* t, const f
     return 0;
 }
 
-static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float* hidden_out) {
+static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float* hidden_out, int l0, int l1, int final_norm) {
     const vv_config& c = ctx->c;
     const int H = ctx->H, D = ctx->D, Hq = ctx->Hq, Hkv = ctx->Hkv, I = ctx->I, QKV = ctx->QKV;
     HIPCHK(ctx, hipMemcpyAsync(ctx->h, x_in, (size_t)R * H * 4, hipMemcpyDeviceToDevice, st));
-    for (int l = 0; l < c.lm_layers; ++l) {
+    for (int l = l0; l < l1; ++l) {
         auto& L = ctx->layers[l];
         VVGemm g = mk_gemm(L.wqkv, ctx->h, ctx->qkv, R, QKV, H, H, QKV);
         g.pro = VV_PRO_RMS; g.nw = L.ln1; g.eps = c.lm_eps; g.epi = VV_EPI_BIAS; g.bias = L.bqkv; g.nt = 1;
@@ -728,12 +740,20 @@ static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float*
         GEMM(gd);
     }
     ctx->launches++;
-    VVCHK(vv_rmsnorm_rows_launch(ctx->h, H, hidden_out, H, ctx->lm_norm, R, H, c.lm_eps, st));
+    if (final_norm) VVCHK(vv_rmsnorm_rows_launch(ctx->h, H, hidden_out, H, ctx->lm_norm, R, H, c.lm_eps, st));
+    else HIPCHK(ctx, hipMemcpyAsync(hidden_out, ctx->h, (size_t)R * H * 4, hipMemcpyDeviceToDevice, st));
     return 0;
 }
 
+extern "C" int vv_lm_forward_range(vv_ctx* ctx, void* stream, int n_rows, const vv_row* rows, const float* x_in_dev,
+                                   float* hidden_out_dev, int l0, int l1, int final_norm);
 extern "C" int vv_lm_forward(vv_ctx* ctx, void* stream, int n_rows, const vv_row* rows, const float* x_in_dev, float* hidden_out_dev) {
+    return vv_lm_forward_range(ctx, stream, n_rows, rows, x_in_dev, hidden_out_dev, 0, ctx->c.lm_layers, 1);
+}
+extern "C" int vv_lm_forward_range(vv_ctx* ctx, void* stream, int n_rows, const vv_row* rows, const float* x_in_dev,
+                                   float* hidden_out_dev, int l0, int l1, int final_norm) {
     hipStream_t st = (hipStream_t)stream;
+    if (l0 < 0 || l1 > ctx->c.lm_layers || l0 >= l1) return fail(ctx, "layer range [%d,%d) invalid", l0, l1);
     if (n_rows < 1 || n_rows > ctx->c.max_rows) return fail(ctx, "n_rows %d out of range [1,%d]", n_rows, ctx->c.max_rows);
     for (int i = 0; i < n_rows; ++i) {
         if (rows[i].cache < 0 || rows[i].cache >= 2 * ctx->c.n_slots) return fail(ctx, "row %d: cache id %d out of range", i, rows[i].cache);
@@ -744,8 +764,40 @@ extern "C" int vv_lm_forward(vv_ctx* ctx, void* stream, int n_rows, const vv_row
     for (int i = 0; i < n_rows; ++i) { ctx->rows_pin[i].cache = rows[i].cache; ctx->rows_pin[i].pos = rows[i].pos; }
     HIPCHK(ctx, hipMemcpyAsync(ctx->rows_dev, ctx->rows_pin, sizeof(VVRow) * n_rows, hipMemcpyHostToDevice, st));
     ctx->launches = 0;
-    char key[96]; snprintf(key, 96, "lm:%d:%p:%p", n_rows, (const void*)x_in_dev, (void*)hidden_out_dev);
-    return graphed(ctx, key, st, [&]() { return lm_body(ctx, st, n_rows, x_in_dev, hidden_out_dev); });
+    char key[128]; snprintf(key, 128, "lm:%d:%p:%p:%d:%d:%d", n_rows, (const void*)x_in_dev, (void*)hidden_out_dev, l0, l1, final_norm);
+    return graphed(ctx, key, st, [&]() { return lm_body(ctx, st, n_rows, x_in_dev, hidden_out_dev, l0, l1, final_norm); });
+}
+
+extern "C" int vv_kv_import(vv_ctx* ctx, void* stream, int cache, int layer, int n_pos, const void* k_dev, const void* v_dev, int src_dtype) {
+    hipStream_t st = (hipStream_t)stream;
+    if (cache < 0 || cache >= 2 * ctx->c.n_slots) return fail(ctx, "cache id %d out of range", cache);
+    if (layer < 0 || layer >= ctx->c.lm_layers) return fail(ctx, "layer %d out of range", layer);
+    if (n_pos < 0 || n_pos > ctx->c.max_ctx) return fail(ctx, "n_pos %d exceeds max_ctx", n_pos);
+    if (n_pos == 0) return 0;
+    const size_t off = ((size_t)cache * ctx->cache_stride + (size_t)layer * ctx->layer_stride) * 2;
+    VVCHK(vv_kv_import_launch(k_dev, v_dev, src_dtype, (char*)ctx->kc + off, (char*)ctx->vc + off, n_pos, ctx->Hkv, ctx->D, ctx->head_stride, st));
+    return 0;
+}
+
+extern "C" int vv_add_type_embedding(vv_ctx* ctx, void* stream, int n, const float* x_dev, int type, float* out_dev) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!ctx->tts_types) return fail(ctx, "engine was not configured with tts_layers");
+    if (type < 0 || type > 1) return fail(ctx, "type must be 0 (speech) or 1 (text)");
+    VVCHK(vv_add_rows_launch(x_dev, ctx->tts_types + (size_t)type * ctx->H, out_dev, n, ctx->H, st));
+    return 0;
+}
+
+extern "C" int vv_eos_logit(vv_ctx* ctx, void* stream, int n, const float* hidden_dev, float* out_dev) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!ctx->eos_w1) return fail(ctx, "engine was not configured with tts_layers");
+    if (n < 1 || n > 16) return fail(ctx, "vv_eos_logit: n must be in [1,16]");
+    const int H = ctx->H;
+    VVGemm g1 = mk_gemm(ctx->eos_w1, hidden_dev, ctx->ct1, n, H, H, H, H);
+    g1.epi = VV_EPI_BIAS; g1.bias = ctx->eos_b1; GEMM(g1);
+    VVCHK(vv_relu_launch(ctx->ct1, n * H, st));
+    VVGemm g2 = mk_gemm(ctx->eos_w2, ctx->ct1, out_dev, n, 1, H, H, 1);
+    g2.epi = VV_EPI_BIAS; g2.bias = ctx->eos_b2; GEMM(g2);
+    return 0;
 }
 
 extern "C" int vv_embed(vv_ctx* ctx, void* stream, int n, const int* ids, float* out_dev) {

@@ -177,6 +177,36 @@ __global__ void vv_tfreq_kernel(const float* __restrict__ t, float* __restrict__
     out[i * 256 + 128 + k] = sinf(arg);
 }
 
+// y[t][c] = x[t][c] + v[c]
+__global__ void vv_add_rows_kernel(const float* __restrict__ x, const float* __restrict__ v, float* __restrict__ y, int n, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n * C) y[i] = x[i] + v[i % C];
+}
+__global__ void vv_relu_kernel(float* __restrict__ x, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = fmaxf(x[i], 0.f);
+}
+// HF KV layout [kvh][L][D] -> tiled cache layout (attn.hip header).  grid (L, kvh), block D threads
+template <typename ST>
+__global__ void vv_kv_import_kernel(const ST* __restrict__ k, const ST* __restrict__ v, __bf16* __restrict__ kc,
+                                    __bf16* __restrict__ vc, int L, int D, int64_t head_stride) {
+    const int pos = blockIdx.x, h = blockIdx.y, d = threadIdx.x;
+    const int64_t si = ((int64_t)h * L + pos) * D + d;
+    __bf16* kb = kc + (int64_t)h * head_stride;
+    __bf16* vb = vc + (int64_t)h * head_stride;
+    {
+        const int64_t tile = (int64_t)(pos >> 4) * (D / 32) + (d >> 5);
+        const int ln = (pos & 15) + 16 * ((d & 31) >> 3);
+        kb[(tile * 64 + ln) * 8 + (d & 7)] = (__bf16)(float)k[si];
+    }
+    {
+        const int p = pos & 31, half = p >> 4, pp = p & 15, q4 = pp >> 2, rr = pp & 3;
+        const int64_t tile = (int64_t)(pos >> 5) * (D / 16) + (d >> 4);
+        const int ln = (d & 15) + 16 * q4;
+        vb[(tile * 64 + ln) * 8 + half * 4 + rr] = (__bf16)(float)v[si];
+    }
+}
+
 __global__ void vv_silu_kernel(float* __restrict__ x, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { float u = x[i]; x[i] = u / (1.f + expf(-u)); }
@@ -247,6 +277,20 @@ int vv_add_launch(const float* a, const float* b, float* y, int n, hipStream_t s
 }
 int vv_tfreq_launch(const float* t, float* out, int n, hipStream_t s) {
     hipLaunchKernelGGL(vv_tfreq_kernel, dim3(n), dim3(128), 0, s, t, out, n);
+    return okk();
+}
+int vv_add_rows_launch(const float* x, const float* v, float* y, int n, int C, hipStream_t s) {
+    hipLaunchKernelGGL(vv_add_rows_kernel, dim3((n * C + 255) / 256), dim3(256), 0, s, x, v, y, n, C);
+    return okk();
+}
+int vv_relu_launch(float* x, int n, hipStream_t s) {
+    hipLaunchKernelGGL(vv_relu_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, n);
+    return okk();
+}
+int vv_kv_import_launch(const void* k, const void* v, int src_bf16, void* kc, void* vc, int L, int Hkv, int D,
+                        int64_t head_stride, hipStream_t s) {
+    if (src_bf16) hipLaunchKernelGGL((vv_kv_import_kernel<__bf16>), dim3(L, Hkv), dim3(D), 0, s, (const __bf16*)k, (const __bf16*)v, (__bf16*)kc, (__bf16*)vc, L, D, head_stride);
+    else hipLaunchKernelGGL((vv_kv_import_kernel<float>), dim3(L, Hkv), dim3(D), 0, s, (const float*)k, (const float*)v, (__bf16*)kc, (__bf16*)vc, L, D, head_stride);
     return okk();
 }
 int vv_silu_launch(float* x, int n, hipStream_t s) {

@@ -48,6 +48,7 @@ class EngineConfig:
     attn_splits: int = 32
     enc_frames: int = 4
     use_graph: bool = True
+    tts_layers: int = 0          # Streaming-0.5B: the last tts_layers of lm_layers form the TTS LM
 
     def __post_init__(self):
         if self.lm_head_dim is None:
@@ -109,6 +110,7 @@ class Engine:
             c.enc_depths[i] = int(d)
         c.has_acoustic_encoder = int(cfg.has_acoustic_encoder)
         c.use_graph = int(cfg.use_graph)
+        c.tts_layers = int(cfg.tts_layers)
         self._ctx = C.c_void_p()
         # a dedicated non-default stream: hipGraph capture is illegal on the null stream
         self.stream = torch.cuda.Stream(device=self.device)
@@ -231,6 +233,32 @@ class Engine:
         for i, (cache, pos) in enumerate(rows):
             arr[i].cache, arr[i].pos = int(cache), int(pos)
         self._chk(self.lib.vv_lm_forward(self._ctx, self._s, n, arr, self._p(x_in), self._p(hidden_out)), "vv_lm_forward")
+
+    def lm_forward_range(self, rows: Sequence[tuple], x_in: torch.Tensor, hidden_out: torch.Tensor, l0: int, l1: int,
+                         final_norm: bool):
+        n = len(rows)
+        arr = (_lib.VVRow * n)()
+        for i, (cache, pos) in enumerate(rows):
+            arr[i].cache, arr[i].pos = int(cache), int(pos)
+        self._chk(self.lib.vv_lm_forward_range(self._ctx, self._s, n, arr, self._p(x_in), self._p(hidden_out),
+                                               int(l0), int(l1), int(final_norm)), "vv_lm_forward_range")
+
+    def kv_import(self, cache: int, layer: int, k: torch.Tensor, v: torch.Tensor):
+        """k, v: [kv_heads, n_pos, head_dim] (keys already rotated), fp32 or bf16, on the engine device."""
+        assert k.shape == v.shape and k.dim() == 3
+        k = k.contiguous()
+        v = v.contiguous()
+        if k.dtype not in (torch.float32, torch.bfloat16):
+            k, v = k.float(), v.float()
+        self._chk(self.lib.vv_kv_import(self._ctx, self._s, cache, layer, k.shape[1], self._p(k), self._p(v),
+                                        1 if k.dtype == torch.bfloat16 else 0), "vv_kv_import")
+
+    def add_type_embedding(self, n: int, x: torch.Tensor, type_id: int, out: torch.Tensor):
+        self._chk(self.lib.vv_add_type_embedding(self._ctx, self._s, n, self._p(x), int(type_id), self._p(out)),
+                  "vv_add_type_embedding")
+
+    def eos_logit(self, n: int, hidden: torch.Tensor, out: torch.Tensor):
+        self._chk(self.lib.vv_eos_logit(self._ctx, self._s, n, self._p(hidden), self._p(out)), "vv_eos_logit")
 
     def embed(self, ids: Sequence[int], out: torch.Tensor):
         arr = (C.c_int * len(ids))(*[int(i) for i in ids])

@@ -1,0 +1,227 @@
+"""Host-side mirror of `VibeVoiceStreamingForConditionalGenerationInference.generate`
+(vibevoice/modular/modeling_vibevoice_streaming_inference.py:412-725) on the HIP engine.
+
+Text is fed in windows of 5 tokens through the text LM (lower layers, no final norm) and the
+TTS LM (upper layers); after each window 6 speech frames are produced: CFG diffusion sample
+-> acoustic decode -> connector -> TTS-LM step on the positive and the negative branch (ONE
+weight pass for both rows) -> binary EOS head.  The four prefilled branches of a voice preset
+(`all_prefilled_outputs`) are imported into the engine's KV caches with `vv_kv_import`.
+"""
+from typing import Callable, Optional
+
+import torch
+
+from .engine import Engine, EngineConfig
+from .modeling import VibeVoiceGenerationOutput, engine_config_from_reference
+
+TTS_TEXT_WINDOW_SIZE = 5
+TTS_SPEECH_WINDOW_SIZE = 6
+
+LM_CACHE, TTS_CACHE, NEG_TTS_CACHE = 0, 1, 2
+
+
+def map_streaming_param_name(key: str, n_lm: int):
+    """reference state_dict key -> engine parameter name (None = not used on this path)."""
+    import re
+    m = re.match(r"model\.language_model\.layers\.(\d+)\.(.*)", key)
+    if m:
+        return f"lm.layers.{int(m.group(1))}.{m.group(2)}"
+    m = re.match(r"model\.tts_language_model\.layers\.(\d+)\.(.*)", key)
+    if m:
+        return f"lm.layers.{n_lm + int(m.group(1))}.{m.group(2)}"
+    table = {
+        "model.language_model.embed_tokens.weight": "lm.embed_tokens.weight",
+        "model.tts_language_model.norm.weight": "lm.norm.weight",
+        "model.tts_input_types.weight": "tts_input_types.weight",
+    }
+    if key in table:
+        return table[key]
+    for a, b in (("tts_eos_classifier.", "eos."), ("model.prediction_head.", "head."),
+                 ("model.acoustic_tokenizer.decoder.", "dec."), ("model.acoustic_connector.", "ac_conn.")):
+        if key.startswith(a):
+            return b + key[len(a):]
+    return None
+
+
+def _kv_layers(past):
+    """[(k, v)] per layer from an HF DynamicCache (4.x `.key_cache`, 5.x `.layers`) or a plain list."""
+    if hasattr(past, "key_cache"):
+        return list(zip(past.key_cache, past.value_cache))
+    if hasattr(past, "layers"):
+        return [(l.keys, l.values) for l in past.layers]
+    return list(past)
+
+
+class VibeVoiceStreamingForConditionalGenerationInference:
+    def __init__(self, config: dict, engine: Engine, model_dtype=torch.bfloat16):
+        self.config_dict = config
+        self.engine = engine
+        self.dtype = model_dtype
+        self.device = engine.device
+        self.n_tts = engine.cfg.tts_layers
+        self.n_lm = engine.cfg.lm_layers - self.n_tts
+        self.ddpm_inference_steps = config["diffusion_head_config"].get("ddpm_num_inference_steps", 20)
+        self.max_position_embeddings = config["decoder_config"].get("max_position_embeddings", 8192)
+        self.speech_scaling_factor = float("nan")
+        self.speech_bias_factor = float("nan")
+        e = engine
+        H = e.cfg.lm_hidden
+        self._x = e.new(8, H)
+        self._h = e.new(8, H)
+        self._hid = e.new(8, H)
+        self._cond = e.new(2, H)
+        self._noise = e.new(1, e.cfg.latent_dim)
+        self._latent = e.new(1, e.cfg.latent_dim)
+        self._audio = e.new(1, e.cfg.hop)
+        self._emb = e.new(1, H)
+        self._eos = e.new(1)
+
+    @classmethod
+    def from_state_dict(cls, config: dict, state_dict, model_dtype=torch.bfloat16, device=None, **runtime):
+        n_tts = config["tts_backbone_num_hidden_layers"]
+        runtime.setdefault("n_slots", 2)
+        ecfg = engine_config_from_reference(dict(config, semantic_tokenizer_config=None), tts_layers=n_tts,
+                                            has_acoustic_encoder=False, **runtime)
+        eng = Engine(ecfg, device)
+        n_lm = ecfg.lm_layers - n_tts
+        exp = eng.expected_weights()
+        scaling = bias = None
+        items = state_dict.items() if hasattr(state_dict, "items") else state_dict
+        for k, v in items:
+            if k == "model.speech_scaling_factor":
+                scaling = float(v)
+            elif k == "model.speech_bias_factor":
+                bias = float(v)
+            else:
+                name = map_streaming_param_name(k, n_lm)
+                if name is not None and name in exp:
+                    eng.upload(name, v)
+        miss = eng.missing_weights()
+        if miss:
+            raise RuntimeError(f"checkpoint is missing {len(miss)} parameters, e.g. {miss[:4]}")
+        m = cls(config, eng, model_dtype)
+        if scaling is not None and bias is not None:
+            m.set_speech_factors(scaling, bias)
+        return m
+
+    def set_speech_factors(self, scaling, bias):
+        self.speech_scaling_factor, self.speech_bias_factor = float(scaling), float(bias)
+        self.engine.set_speech_factors(scaling, bias)
+
+    def eval(self):
+        return self
+
+    def set_ddpm_inference_steps(self, num_steps=None):
+        self.ddpm_inference_steps = num_steps or self.config_dict["diffusion_head_config"].get("ddpm_num_inference_steps", 20)
+
+    def _import_branch(self, out, cache, l0):
+        n = 0
+        for j, (k, v) in enumerate(_kv_layers(out.past_key_values)):
+            k = k.to(self.device)
+            v = v.to(self.device)
+            self.engine.kv_import(cache, l0 + j, k[0], v[0])
+            n = k.shape[2]
+        return n
+
+    @torch.no_grad()
+    def generate(self, inputs=None, generation_config=None, audio_streamer=None, tts_text_ids=None,
+                 return_speech=True, cfg_scale=1.0, stop_check_fn: Optional[Callable[[], bool]] = None, **kwargs):
+        e = self.engine
+        all_pre = kwargs.pop("all_prefilled_outputs")
+        noise_fn = kwargs.pop("_noise_fn", None)
+        trace = kwargs.pop("_trace", None)
+        marks = kwargs.pop("_marks", None)            # bench hook: first-audio timestamp
+        verbose = kwargs.get("verbose", False)
+        tts_text_ids = tts_text_ids.reshape(-1).cpu()
+        H = e.cfg.lm_hidden
+        e.set_num_steps(self.ddpm_inference_steps, t_cast_bf16=(self.dtype == torch.bfloat16))
+        with torch.cuda.stream(e.stream):
+            e.codec_reset(0)
+            lm_len = self._import_branch(all_pre["lm"], LM_CACHE, 0)
+            tts_len = self._import_branch(all_pre["tts_lm"], TTS_CACHE, self.n_lm)
+            neg_len = self._import_branch(all_pre["neg_tts_lm"], NEG_TTS_CACHE, self.n_lm)
+            self._cond[0].copy_(all_pre["tts_lm"].last_hidden_state[0, -1].to(self.device, torch.float32))
+            self._cond[1].copy_(all_pre["neg_tts_lm"].last_hidden_state[0, -1].to(self.device, torch.float32))
+            if kwargs.get("max_new_tokens", None) is None:
+                max_length = self.max_position_embeddings
+            else:
+                max_length = tts_len + kwargs["max_new_tokens"]
+            max_length = min(max_length, e.max_ctx)
+            n_tok = tts_len
+            finished = False
+            reach_max = False
+            chunks = []
+            w = 0
+            frame = 0
+            seq_tail = []
+            while True:
+                if stop_check_fn is not None and stop_check_fn():
+                    if audio_streamer is not None:
+                        audio_streamer.end()
+                    break
+                if finished:
+                    break
+                cur = tts_text_ids[w * TTS_TEXT_WINDOW_SIZE:(w + 1) * TTS_TEXT_WINDOW_SIZE].tolist()
+                w += 1
+                if cur:
+                    n_tok += len(cur)
+                    if n_tok > max_length:
+                        reach_max = True
+                        break
+                    k = len(cur)
+                    seq_tail.extend(cur)
+                    e.embed(cur, self._x)
+                    e.lm_forward_range([(LM_CACHE, lm_len + j) for j in range(k)], self._x, self._h, 0, self.n_lm, False)
+                    lm_len += k
+                    e.add_type_embedding(k, self._h, 1, self._x)
+                    e.lm_forward_range([(TTS_CACHE, tts_len + j) for j in range(k)], self._x, self._hid,
+                                       self.n_lm, self.n_lm + self.n_tts, True)
+                    tts_len += k
+                    self._cond[0].copy_(self._hid[k - 1])
+                for i in range(TTS_SPEECH_WINDOW_SIZE):
+                    nz = noise_fn(frame, 2) if noise_fn is not None else torch.randn(2, e.cfg.latent_dim)
+                    self._noise[0].copy_(nz[0].to(torch.float32))
+                    e.diffusion_sample(1, self._cond, self._noise, cfg_scale, self._latent)
+                    e.codec_decode(0, self._latent, self._audio[0])
+                    chunk = self._audio.clone()
+                    if marks is not None and "first_audio" not in marks:
+                        e.sync()
+                        import time as _t
+                        marks["first_audio"] = _t.perf_counter()
+                    if not finished:
+                        chunks.append(chunk)
+                    if audio_streamer is not None:
+                        audio_streamer.put(chunk[:, None, :].to(self.dtype), torch.tensor([0]))
+                    e.connect(1, self._latent, None, self._emb)
+                    frame += 1
+                    n_tok += 1
+                    seq_tail.append(1)
+                    if n_tok > max_length:
+                        break
+                    # positive and negative TTS-LM rows consume the same embedding: one weight pass
+                    e.add_type_embedding(1, self._emb, 0, self._x)
+                    self._x[1].copy_(self._x[0])
+                    e.lm_forward_range([(TTS_CACHE, tts_len), (NEG_TTS_CACHE, neg_len)], self._x, self._hid,
+                                       self.n_lm, self.n_lm + self.n_tts, True)
+                    tts_len += 1
+                    neg_len += 1
+                    self._cond.copy_(self._hid[:2])
+                    e.eos_logit(1, self._hid, self._eos)
+                    logit = float(self._eos.cpu()[0])
+                    if trace is not None:
+                        trace.append({"latent": self._latent.cpu().clone(), "tts_last": self._hid[0].cpu().clone(), "eos": logit})
+                    if torch.sigmoid(torch.tensor(logit)).item() > 0.5:
+                        finished = True
+                        if audio_streamer is not None:
+                            audio_streamer.end(torch.tensor([0]))
+                if n_tok > max_length:
+                    if not finished:
+                        reach_max = True
+                    break
+            if audio_streamer is not None:
+                audio_streamer.end()
+            audio = torch.cat(chunks, dim=-1).to(self.dtype) if chunks else None
+        e.sync()
+        return VibeVoiceGenerationOutput(sequences=torch.tensor([seq_tail], dtype=torch.long),
+                                         speech_outputs=[audio] if return_speech else None,
+                                         reach_max_step_sample=torch.tensor([reach_max]))
