@@ -105,6 +105,8 @@ def main():
     from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference, engine_config_from_reference
 
     cfg = CONFIGS[args.model]
+    if "streaming" in args.model:
+        return bench_streaming(args, cfg, rank, world, device)
     K, W, NS = args.steps, max(1, args.warmup), args.solver_steps
     inputs = synthetic.synthetic_inputs(cfg, n_speakers=args.speakers, text_tokens=args.text_tokens,
                                         voice_frames=args.voice_frames, seed=100 + rank)
@@ -234,6 +236,70 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     eng.close()
+
+
+def bench_streaming(args, cfg, rank, world, device):
+    """BASELINE.json configs[4]: Streaming-0.5B, hipGraph-captured decode+diffusion step, p50 first-audio latency.
+    Synthetic weights and an Emma-shaped synthetic preset (lm 74 / tts_lm 251 cached positions)."""
+    import statistics
+    import types
+    from vibevoice_amd import synthetic
+    from vibevoice_amd.modeling_streaming import VibeVoiceStreamingForConditionalGenerationInference
+    NS = args.solver_steps if args.solver_steps != 10 else 5          # the streaming demo default is 5
+    gen = torch.Generator(device=device)
+    gen.manual_seed(0)
+    sd = ((k, synthetic.random_tensor(k, shp, gen, device, torch.bfloat16))
+          for k, shp in synthetic.streaming_param_shapes(cfg).items())
+    model = VibeVoiceStreamingForConditionalGenerationInference.from_state_dict(
+        cfg, sd, torch.bfloat16, device, xsplit=args.xsplit, use_graph=not args.no_graph, max_ctx=2048, n_slots=2)
+    model.set_speech_factors(0.2, -0.05)
+    model.set_ddpm_inference_steps(NS)
+    model.engine.upload("eos.fc2.bias", torch.tensor([-30.0]))       # random weights: keep the EOS head from firing
+    d = cfg["decoder_config"]
+    H, kvh, hd = d["hidden_size"], d["num_key_value_heads"], d["hidden_size"] // d["num_attention_heads"]
+    n_tts = cfg["tts_backbone_num_hidden_layers"]
+    n_lm = d["num_hidden_layers"] - n_tts
+
+    def branch(n_layers, L):
+        kv = [(torch.randn(1, kvh, L, hd, device=device, dtype=torch.bfloat16) * 0.5,
+               torch.randn(1, kvh, L, hd, device=device, dtype=torch.bfloat16) * 0.5) for _ in range(n_layers)]
+        return types.SimpleNamespace(past_key_values=kv, last_hidden_state=torch.randn(1, L, H, device=device))
+    preset = {"lm": branch(n_lm, 74), "tts_lm": branch(n_tts, 251), "neg_lm": None, "neg_tts_lm": branch(n_tts, 1)}
+    T = synthetic.TOKENS
+    tok = types.SimpleNamespace(convert_tokens_to_ids=lambda s: T.pad_token_id)
+    g = torch.Generator().manual_seed(3)
+    lat = []
+    for trial in range(3 + 30):
+        text = torch.randint(0, 151000, (1, 5), generator=g)
+        marks = {}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model.generate(tts_text_ids=text, all_prefilled_outputs=preset, cfg_scale=1.5, tokenizer=tok,
+                       max_new_tokens=5 + 6, _marks=marks)
+        if trial >= 3:
+            lat.append((marks["first_audio"] - t0) * 1e3)
+    # steady state: K frames
+    K = args.steps
+    n_text = ((K + 5) // 6) * 5
+    text = torch.randint(0, 151000, (1, n_text), generator=g)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = model.generate(tts_text_ids=text, all_prefilled_outputs=preset, cfg_scale=1.5, tokenizer=tok,
+                         max_new_tokens=n_text + (n_text // 5) * 6)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    audio_s = out.speech_outputs[0].shape[-1] / 24000.0
+    res = {"metric": "audio-sec/wall-sec", "value": round(audio_s / wall, 3), "unit": "audio-s/wall-s", "n_gpus": 1,
+           "steps": int(audio_s / FRAME_SEC + 0.5), "warmup": 33, "ms_per_step": round(wall / (audio_s / FRAME_SEC) * 1e3, 4),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": f"VibeVoice-Streaming-0.5B shapes, Emma-shaped synthetic preset (lm 74 / tts 251), {NS} solver steps, "
+                                  "whole generate() incl. preset import, text windows of 5 / speech windows of 6",
+                      "model": "VibeVoice-Streaming-0.5B", "solver_steps": NS, "hipgraph": not args.no_graph},
+           "roofline": None, "cpu_baseline": None,
+           "extra": {"p50_first_audio_ms": round(statistics.median(lat), 3), "p90_first_audio_ms": round(sorted(lat)[int(0.9 * len(lat))], 3),
+                     "trials": len(lat), "finished_by_eos_or_cap": True}}
+    print(json.dumps(res), flush=True)
+    model.engine.close()
 
 
 def cpu_baseline(cfg, cpu_sd, n_solver, cfg_scale, n_frames):

@@ -43,3 +43,11 @@ CONFIGS = {
     "1.5b": _mk(1536, 8960, 12, 2, 65536, 151936, True),
     "7b": _mk(3584, 18944, 28, 4, 32768, 152064, False),
 }
+
+# VibeVoice-Streaming-0.5B: hidden/heads/kv/head_dim from the shipped voice presets (lm KV
+# [1,2,74,64] x 4 layers, tts_lm [1,2,251,64] x 20), intermediate/vocab from the public Qwen2.5-0.5B config
+# (the reference ships no JSON for it); 8K context (README.md:53).
+_s = _mk(896, 4864, 14, 2, 8192, 151936, True, layers=24)
+_s["tts_backbone_num_hidden_layers"] = 20
+_s["semantic_tokenizer_config"] = None
+CONFIGS["0.5b-streaming"] = _s

@@ -122,6 +122,36 @@ def param_shapes(cfg) -> "OrderedDict[str, tuple]":
     return sh
 
 
+def streaming_param_shapes(cfg) -> "OrderedDict[str, tuple]":
+    """Key names/shapes of VibeVoiceStreamingForConditionalGenerationInference's hot-path parameters
+    (modeling_vibevoice_streaming.py:108-164, modeling_vibevoice_streaming_inference.py:84-100)."""
+    base = param_shapes(dict(cfg, semantic_tokenizer_config=None))
+    n_tts = cfg["tts_backbone_num_hidden_layers"]
+    n_lm = cfg["decoder_config"]["num_hidden_layers"] - n_tts
+    H = cfg["decoder_config"]["hidden_size"]
+    sh = OrderedDict()
+    for k, v in base.items():
+        if k.startswith("model.language_model.layers."):
+            i = int(k.split(".")[3])
+            rest = ".".join(k.split(".")[4:])
+            if i < n_lm:
+                sh[k] = v
+            else:
+                sh[f"model.tts_language_model.layers.{i - n_lm}.{rest}"] = v
+        elif k == "model.language_model.norm.weight":
+            sh["model.tts_language_model.norm.weight"] = v
+        elif k.startswith("model.acoustic_tokenizer.encoder.") or k.startswith("model.semantic_") or k == "lm_head.weight":
+            continue
+        else:
+            sh[k] = v
+    sh["model.tts_input_types.weight"] = (2, H)
+    sh["tts_eos_classifier.fc1.weight"] = (H, H)
+    sh["tts_eos_classifier.fc1.bias"] = (H,)
+    sh["tts_eos_classifier.fc2.weight"] = (1, H)
+    sh["tts_eos_classifier.fc2.bias"] = (1,)
+    return sh
+
+
 def random_tensor(key, shape, gen, device, dtype):
     """One seeded tensor.  Matrices ~ N(0, 1/sqrt(fan_in)) (keeps activations O(1) through
     28 layers and the codec), norm weights ~ 1, biases small, layer scales 0.5."""
