@@ -191,7 +191,7 @@ def main():
         model.generate(tokenizer=synthetic.TOKENS, cfg_scale=args.cfg_scale, generation_config={"do_sample": False},
                        max_new_tokens=kprof + 3, show_progress_bar=False, _forced_tokens=forced_p,
                        _noise_fn=lambda step, n2: noise_bank[step], _step_callback=prof_cb, **inp2)
-        n_l, ms, by = prof["res"]
+        (n_l, ms, by), (n_o, ms_o, by_o) = prof["res"]       # [decode GEMV kernel], [general GEMM kernel]
         ach = by / 1e9 / (ms / 1e3) if ms > 0 else 0.0
         traffic = None
         try:
@@ -200,11 +200,14 @@ def main():
         except Exception:
             pass
         formula = algorithmic_bytes_per_frame(cfg, NS, max(L0, args.kv_start) + W + K // 2, 1 + min(150, K) // 2)
-        roof = {"bound": "hbm", "kernel": "vv_gemm_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+        roof = {"bound": "hbm", "kernel": "vv_gemv_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "launches_per_step": round(n_l / kprof, 1), "avg_launch_us": round(ms * 1e3 / max(1, n_l), 3),
                 "bytes_per_launch": round(by / max(1, n_l), 1),
-                "gemm_bytes_per_step": round(by / kprof, 1), "formula_bytes_per_step": round(formula, 1),
+                "gemv_bytes_per_step": round(by / kprof, 1),
+                "other_gemm": {"kernel": "vv_gemm_kernel", "launches_per_step": round(n_o / kprof, 1),
+                               "bytes_per_step": round(by_o / kprof, 1), "GBps": round(by_o / 1e9 / (ms_o / 1e3), 1) if ms_o > 0 else None},
+                "formula_bytes_per_step": round(formula, 1),
                 "whole_step_GBps": round(formula / 1e9 / (wall_max / K), 1),
                 "whole_step_frac": round(formula / 1e9 / (wall_max / K) / HBM_PEAK_GBS, 4)}
 

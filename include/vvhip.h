@@ -139,9 +139,10 @@ int vv_gemm_raw(void* stream, const void* w_packed_dev, const void* w2_packed_de
                 float* y_dev, int T, int N, int K, int ldx, int ldy, int pro, int epi,
                 const float* nw_dev, float eps, const float* bias_dev, const float* nscale_dev,
                 int xsplit, int ksplit, int nontemporal);
-/* hipEvent timing of every vv_gemm_kernel launch issued between begin and end (graphs are
- * bypassed meanwhile): number of launches, summed kernel time, summed algorithmic bytes
- * (packed weights once + activations in + result out).  Used by bench.py's roofline. */
+/* hipEvent timing of every GEMM launch issued between begin and end (graphs are bypassed meanwhile):
+ * number of launches, summed kernel time, summed algorithmic bytes (packed weights once + activations
+ * in + result out).  Each output is a 2-element array: [0] the decode kernel vv_gemv_kernel (T <= 4),
+ * [1] the general vv_gemm_kernel.  Used by bench.py's roofline. */
 int vv_profile_begin(vv_ctx* ctx);
 int vv_profile_end(vv_ctx* ctx, int64_t* launches, double* total_ms, double* bytes);
 /* number of kernel launches issued by the last engine call (graph nodes when replayed) */

@@ -299,9 +299,9 @@ class Engine:
         self._chk(self.lib.vv_profile_begin(self._ctx), "vv_profile_begin")
 
     def profile_end(self):
-        n, ms, by = C.c_int64(), C.c_double(), C.c_double()
-        self._chk(self.lib.vv_profile_end(self._ctx, C.byref(n), C.byref(ms), C.byref(by)), "vv_profile_end")
-        return n.value, ms.value, by.value
+        n, ms, by = (C.c_int64 * 2)(), (C.c_double * 2)(), (C.c_double * 2)()
+        self._chk(self.lib.vv_profile_end(self._ctx, n, ms, by), "vv_profile_end")
+        return (n[0], ms[0], by[0]), (n[1], ms[1], by[1])
 
     def stat(self, what=0):
         return int(self.lib.vv_stat(self._ctx, what))
