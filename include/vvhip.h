@@ -141,7 +141,7 @@ int vv_gemm_raw(void* stream, const void* w_packed_dev, const void* w2_packed_de
                 int xsplit, int ksplit, int nontemporal);
 /* hipEvent timing of every GEMM launch issued between begin and end (graphs are bypassed meanwhile):
  * number of launches, summed kernel time, summed algorithmic bytes (packed weights once + activations
- * in + result out).  Each output is a 2-element array: [0] the decode kernel vv_gemv_kernel (T <= 4),
+ * in + result out).  Each output is a 2-element array: [0] the decode kernel vv_gemv_kernel with T <= 4,
  * [1] the general vv_gemm_kernel.  Used by bench.py's roofline. */
 int vv_profile_begin(vv_ctx* ctx);
 int vv_profile_end(vv_ctx* ctx, int64_t* launches, double* total_ms, double* bytes);
