@@ -92,7 +92,7 @@ int vv_lm_forward_range(vv_ctx* ctx, void* stream, int n_rows, const vv_row* row
                         float* hidden_out_dev, int layer_begin, int layer_end, int final_norm);
 /* Import n_pos cached positions of one layer into cache `cache` from HF layout k/v [kv_heads][n_pos][head_dim]
  * (keys already rotated, as DynamicCache stores them); src_dtype 0 fp32, 1 bf16.  Used for the voice presets
- * (demo/voices/streaming_model/*.pt -> all_prefilled_outputs). */
+ * (demo/voices/streaming_model/ presets -> all_prefilled_outputs). */
 int vv_kv_import(vv_ctx* ctx, void* stream, int cache, int layer, int n_pos, const void* k_dev, const void* v_dev,
                  int src_dtype);
 /* y[t][:] = x[t][:] + tts_input_types[type]  (forward_tts_lm, :293) */
