@@ -7,7 +7,7 @@ import torch, synth
 from gpu_util import build_small
 s = build_small(synth.LMCfg(), xsplit=1)
 eng = s.eng
-names = ["entry->loads issued", "loads issued->x staged", "x staged->loop done", "loop done->ssq", "ssq->reduced", "reduced->end"]
+names = ["entry->loads issued", "loads issued->x staged", "x staged->loop done", "loop done->partials written", "barrier", "reduce+epilogue"]
 for (N, K, pro, epi) in [(64, 1536, 0, 0), (1536, 1536, 0, 4), (2048, 1536, 1, 1), (1536, 8960, 0, 4), (4608, 3584, 1, 1)]:
     w = torch.randint(0, 255, (int(eng.lib.vv_packed_bytes(N, K)),), dtype=torch.uint8, device=eng.device); w[1::2] &= 0x3F
     x = torch.randn(2, K, device=eng.device); y = torch.zeros(2, N, device=eng.device)

@@ -993,12 +993,28 @@ extern "C" int vv_profile_end(vv_ctx* ctx, int64_t* launches, double* total_ms, 
     HIPCHK(ctx, hipDeviceSynchronize());
     double ms = 0.0;
     int64_t n_other = 0; double ms_other = 0.0, by_other = 0.0;
+    // calibrate the fixed cost of an event pair with nothing in between and subtract it from every sample
+    double ev_over = 0.0;
+    {
+        hipEvent_t a[2];
+        hipEventCreate(&a[0]); hipEventCreate(&a[1]);
+        const int reps = 64;
+        for (int i = 0; i < reps; ++i) {
+            hipEventRecord(a[0], 0); hipEventRecord(a[1], 0);
+            hipEventSynchronize(a[1]);
+            float e = 0.f; hipEventElapsedTime(&e, a[0], a[1]);
+            ev_over += e;
+        }
+        ev_over /= reps;
+        hipEventDestroy(a[0]); hipEventDestroy(a[1]);
+    }
     const char* csv = getenv("VVHIP_PROF_CSV");
     FILE* f = csv ? fopen(csv, "w") : nullptr;
     if (f) fprintf(f, "idx,T,N,K,pro,epi,dual,bytes,us\n");
     for (int i = 0; i < ctx->prof_n; ++i) {
         float e = 0.f;
         HIPCHK(ctx, hipEventElapsedTime(&e, ctx->prof_ev[2 * i], ctx->prof_ev[2 * i + 1]));
+        e = (float)std::max(0.0, (double)e - ev_over);
         if (ctx->prof_rec[i].gemv) ms += e;
         else { n_other++; ms_other += e; by_other += ctx->prof_rec[i].bytes; }
         if (f) { const auto& r = ctx->prof_rec[i]; fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%.0f,%.3f\n", i, r.T, r.N, r.K, r.pro, r.epi, r.dual, r.bytes, e * 1e3); }

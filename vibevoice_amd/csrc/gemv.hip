@@ -18,6 +18,12 @@
 //   * split-K partials go to a dedicated LDS region: a single barrier.
 #include "vv_common.h"
 
+#ifdef VV_GEMM_TIMING
+#define VV_STAMP(i) do { if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define VV_STAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 __device__ __forceinline__ float silu_f(float u) { return u / (1.0f + __expf(-u)); }
@@ -71,6 +77,13 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
     __shared__ __attribute__((aligned(16))) unsigned char stg_all[WPB * XS * U * 4 * MR * 16];
     __shared__ f32x4 red[WPB][NM][64];
     __shared__ float ssq_sh[WPB][MR];
+    // Pull every kernel argument into SGPRs with ONE batch of s_loads: left alone the compiler fetches
+    // them lazily behind branches, i.e. 3-4 dependent ~600-cycle round trips on a launch's critical path.
+    asm volatile("" ::"s"(a.W), "s"(a.W2), "s"(a.X), "s"(a.Y), "s"(a.nw), "s"(a.mod_scale), "s"(a.mod_shift),
+                 "s"(a.addvec), "s"(a.bias), "s"(a.nscale), "s"(a.gate));
+    asm volatile("" ::"s"(a.T), "s"(a.N), "s"(a.K), "s"(a.ldx), "s"(a.ldy), "s"(a.ld_mod), "s"(a.ld_gate), "s"(a.pro),
+                 "s"(a.epi), "s"(a.eps), "s"(a.z), "s"(a.x0p), "s"(a.coef), "s"(a.cfg), "s"(a.n_cfg));
+    VV_STAMP(0);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int T = a.T;
@@ -85,25 +98,52 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
     const unsigned kk = lane * 4;
     const unsigned st_off = (((kk >> 5) * 4 + ((kk & 31) >> 3)) * MR) * 16 + (kk & 7) * 2;
 
+    const u32x4* wbase = a.W + (size_t)tile * k_tiles * 64 + lane;
+    const u32x4* wbase2 = DUAL ? a.W2 + (size_t)tile * k_tiles * 64 + lane : nullptr;
+
+    struct XR { float4 x[MR]; float4 sc[MR]; float4 sh[MR]; float4 nwv, addv; };
+    auto x_load = [&](unsigned ktb, XR& R) {
+        unsigned k = ktb * 32 + kk;
+        const bool kin = k < min(kt1 * 32, (unsigned)a.K);
+        if (!kin) k = 0;                                   // clamped: always a legal address, masked later
+        R.nwv = a.nw ? *reinterpret_cast<const float4*>(a.nw + k) : float4{1.f, 1.f, 1.f, 1.f};
+        if (a.pro == VV_PRO_ADD_SILU) R.addv = *reinterpret_cast<const float4*>(a.addvec + k);
+#pragma unroll
+        for (int r = 0; r < MR; ++r) {
+            if (r < T) {
+                R.x[r] = *reinterpret_cast<const float4*>(a.X + (unsigned)(r * a.ldx) + k);
+                if (a.pro == VV_PRO_RMS_MOD) {
+                    R.sc[r] = *reinterpret_cast<const float4*>(a.mod_scale + (unsigned)(r * a.ld_mod) + k);
+                    R.sh[r] = *reinterpret_cast<const float4*>(a.mod_shift + (unsigned)(r * a.ld_mod) + k);
+                }
+            }
+        }
+    };
+    auto w_load = [&](unsigned ktb, u32x4 (&dst)[U][NM]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned kt = min(ktb + u, kt1 - 1);      // clamped: tail k-steps re-read the last tile, MFMA skipped
+            dst[u][0] = __builtin_nontemporal_load(wbase + kt * 64);
+            if constexpr (DUAL) dst[u][1] = __builtin_nontemporal_load(wbase2 + kt * 64);
+        }
+    };
+    // ---- first activation batch and first weight batch go out before anything else ----
+    XR R;
+    u32x4 wA[U][NM], wB[U][NM];
+    if (has_k) { x_load(kt0, R); w_load(kt0, wA); }      // x first: its wait must not drag the weight stream along
+    __builtin_amdgcn_sched_barrier(0);
+    VV_STAMP(1);
+
     // ---- epilogue operands: requested now, consumed ~one weight stream later (wave 0 only) ----
     const int n0 = tile * 16 + fq * 4;
     const bool epi_lane = (wave == 0) && frow < T && n0 < a.N;
-    const bool full4 = (n0 + 4 <= a.N);
     float4 pre_y = {0.f, 0.f, 0.f, 0.f}, pre_b = {0.f, 0.f, 0.f, 0.f}, pre_g = {1.f, 1.f, 1.f, 1.f};
-    if (epi_lane) {
-        if (a.bias) {
-            if (full4) pre_b = *reinterpret_cast<const float4*>(a.bias + n0);
-            else { pre_b.x = a.bias[n0]; if (n0 + 1 < a.N) pre_b.y = a.bias[n0 + 1]; if (n0 + 2 < a.N) pre_b.z = a.bias[n0 + 2]; }
-        }
+    if (epi_lane) {            // N % 4 == 0 and 16-B aligned operands are launch preconditions (vv_gemv_ok)
+        if (a.bias) pre_b = *reinterpret_cast<const float4*>(a.bias + n0);
         if (a.epi == VV_EPI_RESID || a.epi == VV_EPI_GATED_RESID) {
-            const float* yp = a.Y + (unsigned)(frow * a.ldy + n0);
-            if (full4) pre_y = *reinterpret_cast<const float4*>(yp);
-            else { pre_y.x = yp[0]; if (n0 + 1 < a.N) pre_y.y = yp[1]; if (n0 + 2 < a.N) pre_y.z = yp[2]; }
-            const float* gp = (a.epi == VV_EPI_GATED_RESID) ? a.gate + (unsigned)(frow * a.ld_gate + n0) : (a.nscale ? a.nscale + n0 : nullptr);
-            if (gp) {
-                if (full4) pre_g = *reinterpret_cast<const float4*>(gp);
-                else { pre_g.x = gp[0]; if (n0 + 1 < a.N) pre_g.y = gp[1]; if (n0 + 2 < a.N) pre_g.z = gp[2]; }
-            }
+            pre_y = *reinterpret_cast<const float4*>(a.Y + (unsigned)(frow * a.ldy + n0));
+            if (a.epi == VV_EPI_GATED_RESID) pre_g = *reinterpret_cast<const float4*>(a.gate + (unsigned)(frow * a.ld_gate + n0));
+            else if (a.nscale) pre_g = *reinterpret_cast<const float4*>(a.nscale + n0);
         }
     }
 
@@ -139,27 +179,6 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
     for (int i = 0; i < NM; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     float ssq[MR] = {0.f, 0.f, 0.f, 0.f};
 
-    const u32x4* wbase = a.W + (size_t)tile * k_tiles * 64 + lane;
-    const u32x4* wbase2 = DUAL ? a.W2 + (size_t)tile * k_tiles * 64 + lane : nullptr;
-
-    struct XR { float4 x[MR]; float4 sc[MR]; float4 sh[MR]; float4 nwv, addv; };
-    auto x_load = [&](unsigned ktb, XR& R) {
-        unsigned k = ktb * 32 + kk;
-        const bool kin = k < min(kt1 * 32, (unsigned)a.K);
-        if (!kin) k = 0;                                   // clamped: always a legal address, masked later
-        R.nwv = a.nw ? *reinterpret_cast<const float4*>(a.nw + k) : float4{1.f, 1.f, 1.f, 1.f};
-        if (a.pro == VV_PRO_ADD_SILU) R.addv = *reinterpret_cast<const float4*>(a.addvec + k);
-#pragma unroll
-        for (int r = 0; r < MR; ++r) {
-            if (r < T) {
-                R.x[r] = *reinterpret_cast<const float4*>(a.X + (unsigned)(r * a.ldx) + k);
-                if (a.pro == VV_PRO_RMS_MOD) {
-                    R.sc[r] = *reinterpret_cast<const float4*>(a.mod_scale + (unsigned)(r * a.ld_mod) + k);
-                    R.sh[r] = *reinterpret_cast<const float4*>(a.mod_shift + (unsigned)(r * a.ld_mod) + k);
-                }
-            }
-        }
-    };
     auto x_stage = [&](unsigned ktb, const XR& R) {
         const unsigned k = ktb * 32 + kk;
         const float msk = (k < min(kt1 * 32, (unsigned)a.K)) ? 1.f : 0.f;
@@ -188,14 +207,6 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
             }
         }
     };
-    auto w_load = [&](unsigned ktb, u32x4 (&dst)[U][NM]) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const unsigned kt = min(ktb + u, kt1 - 1);      // clamped: tail k-steps re-read the last tile, MFMA skipped
-            dst[u][0] = __builtin_nontemporal_load(wbase + kt * 64);
-            if constexpr (DUAL) dst[u][1] = __builtin_nontemporal_load(wbase2 + kt * 64);
-        }
-    };
     auto mma = [&](unsigned ktb, const u32x4 (&wb)[U][NM]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -214,26 +225,24 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
     };
 
     if (has_k) {
-        XR R;
-        u32x4 wcur[U][NM], wnext[U][NM];
-        const int nb = (int)((kt1 - kt0 + U - 1) / U);
+        x_stage(kt0, R);
+        VV_STAMP(2);
+        // two batches per trip, ping-ponging the weight buffers: no register copies, so the prefetched batch
+        // stays in flight across the MFMAs of the current one
 #pragma unroll 1
-        for (int b = -1; b < nb; ++b) {
-            const unsigned ktn = kt0 + (unsigned)(b + 1) * U;
-            const bool have_next = b + 1 < nb;
-            if (have_next) { x_load(ktn, R); w_load(ktn, wnext); }
-            if (b >= 0) mma(kt0 + (unsigned)b * U, wcur);
-            if (have_next) {
-                x_stage(ktn, R);
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-#pragma unroll
-                    for (int i = 0; i < NM; ++i) wcur[u][i] = wnext[u][i];
-            }
+        for (unsigned ktb = kt0; ktb < kt1; ktb += 2 * U) {
+            const bool n1 = ktb + U < kt1, n2 = ktb + 2 * U < kt1;
+            if (n1) { x_load(ktb + U, R); w_load(ktb + U, wB); }
+            mma(ktb, wA);
+            if (n1) x_stage(ktb + U, R);
+            if (n2) { x_load(ktb + 2 * U, R); w_load(ktb + 2 * U, wA); }
+            if (n1) mma(ktb + U, wB);
+            if (n2) x_stage(ktb + 2 * U, R);
         }
     }
     // rows beyond T were never staged: their fragment slots hold stale LDS -> D columns >= T are garbage, never stored.
 
+    VV_STAMP(3);
     // ---- split-K partials -> LDS, one barrier, wave 0 finishes ----
 #pragma unroll
     for (int i = 0; i < NM; ++i) red[wave][i][lane] = acc[i];
@@ -244,7 +253,9 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
             if (lane == 0) ssq_sh[wave][r] = s;
         }
     }
+    VV_STAMP(4);
     __syncthreads();
+    VV_STAMP(5);
     if (wave != 0) return;
 #pragma unroll
     for (int w = 1; w < WPB; ++w)
@@ -308,8 +319,8 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
         return;
     }
     float* yp = a.Y + (unsigned)(frow * a.ldy + n0);
-    if (full4 && ((a.ldy & 3) == 0)) *reinterpret_cast<float4*>(yp) = float4{o[0], o[1], o[2], o[3]};
-    else { yp[0] = o[0]; if (n0 + 1 < a.N) yp[1] = o[1]; if (n0 + 2 < a.N) yp[2] = o[2]; if (n0 + 3 < a.N) yp[3] = o[3]; }
+    *reinterpret_cast<float4*>(yp) = float4{o[0], o[1], o[2], o[3]};
+    VV_STAMP(6);
 }
 
 }  // namespace
@@ -322,8 +333,12 @@ extern "C" int vv_gemv_ok(const VVGemm* a) {
     if (a->nw && (((uintptr_t)a->nw) & 15)) return 0;
     if (a->K < 32) return 0;
     if ((int64_t)a->T * a->ldy >= (1LL << 30) || (int64_t)a->T * a->ldx >= (1LL << 30)) return 0;
-    if ((a->ldy & 3) && (a->epi == VV_EPI_RESID || a->epi == VV_EPI_GATED_RESID)) return 0;
+    if ((a->N & 3) || (a->ldy & 3)) return 0;
     if ((((uintptr_t)a->Y) & 15) || (a->bias && (((uintptr_t)a->bias) & 15))) return 0;
+    if (a->nscale && (((uintptr_t)a->nscale) & 15)) return 0;
+    if (a->epi == VV_EPI_GATED_RESID && ((a->ld_gate & 3) || (((uintptr_t)a->gate) & 15))) return 0;
+    if (a->pro == VV_PRO_RMS_MOD && ((((uintptr_t)a->mod_scale) & 15) || (((uintptr_t)a->mod_shift) & 15))) return 0;
+    if (a->pro == VV_PRO_ADD_SILU && (((uintptr_t)a->addvec) & 15)) return 0;
     return 1;
 }
 
