@@ -90,14 +90,15 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)   # torchrun, even with one rank
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from vibevoice_amd import build as vbuild
     if rank == 0 and vbuild.stale():
         vbuild.build()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     from vibevoice_amd import parallel, synthetic
     from vibevoice_amd.configs import CONFIGS
@@ -151,7 +152,7 @@ def main():
         if step == W or step == W + K:
             eng.sync()
             torch.cuda.synchronize()
-            if world > 1:
+            if use_dist:
                 dist.barrier()
                 torch.cuda.synchronize()
             marks[step] = time.perf_counter()
@@ -235,7 +236,7 @@ def main():
                       "utterance_audio_per_wall": round(audio_total / (t_gen1 - t_gen0), 2)},
         }
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()

@@ -43,7 +43,7 @@ def broadcast_params(shapes: Iterable[Tuple[str, tuple]], make: Callable[[str, t
             t = make(name, shape).to(device=device, dtype=dtype).contiguous()
         else:
             t = torch.empty(shape, dtype=dtype, device=device)
-        if world > 1:
+        if dist.is_available() and dist.is_initialized():     # also with a single rank: exercises the RCCL path
             dist.broadcast(t, src=src)
         yield name, t
 
@@ -52,7 +52,7 @@ def aggregate_throughput(units_local: float, wall_local: float, device) -> Tuple
     """Whole-job (sum of units over ranks) / (max wall over ranks)."""
     rank, world = world_info()
     t = torch.tensor([units_local, wall_local], dtype=torch.float64, device=device)
-    if world > 1:
+    if dist.is_available() and dist.is_initialized():
         s = t.clone()
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         m = t.clone()
