@@ -23,6 +23,9 @@ int vv_rope_append_launch(int D, const float* qkv, const VVRow* rows, const floa
 int vv_attn_launch(int D, int xs, const float* q, const VVRow* rows, const void* kc, const void* vc, int R, int Hq,
                    int Hkv, int64_t cache_stride, int64_t head_stride, int S, float* pm, float* pl, float* po,
                    float* out, hipStream_t s);
+int vv_attn_fused_launch(int D, int xs, const float* qkv, const VVRow* rows, void* kc, void* vc, int R, int Hq, int Hkv,
+                         int64_t cache_stride, int64_t head_stride, int S, float* pm, float* pl, float* po,
+                         const float* inv_freq, hipStream_t s);
 int vv_embed_launch(const void* table, const int* ids, float* out, int n, int H, hipStream_t s);
 int vv_rmsnorm_rows_launch(const float* x, int ldx, float* y, int ldy, const float* w, int T, int C, float eps, hipStream_t s);
 int vv_dwconv_res_launch(const float* nb, float* x, const float* w, const float* b, const float* gamma, int T, int C, hipStream_t s);
@@ -138,6 +141,7 @@ struct vv_ctx {
     void *h_in = nullptr, *h_cond = nullptr, *h_t0 = nullptr, *h_t2 = nullptr, *h_ada = nullptr, *h_out = nullptr;
     int n_steps = 0;
     float *temb = nullptr, *coef = nullptr, *tvals = nullptr;
+    float* mod_all = nullptr; size_t mod_all_bytes = 0;
     float *cproj = nullptr, *mod = nullptr, *zz = nullptr, *x0p = nullptr, *xh = nullptr, *hact = nullptr, *eps = nullptr;
     float *tmp1 = nullptr, *tmp2 = nullptr;
     // connectors
@@ -708,13 +712,21 @@ extern "C" int vv_set_schedule(vv_ctx* ctx, int n_steps, const float* t, const f
     }
     HIPCHK(ctx, hipStreamSynchronize(st));
     ctx->n_steps = n_steps;
+    {   // room for the batched adaLN modulations of up to 8 sampled utterances (16 rows) per step
+        const size_t need = (size_t)n_steps * 16 * ctx->MODW * 4;
+        if (need > ctx->mod_all_bytes) {
+            if (ctx->mod_all) hipFree(ctx->mod_all);
+            ctx->mod_all = (float*)dalloc(ctx, need, false);
+            ctx->mod_all_bytes = ctx->mod_all ? need : 0;
+        }
+    }
     for (auto it = ctx->graphs.begin(); it != ctx->graphs.end();) {
         if (it->first.rfind("samp", 0) == 0) { hipGraphExecDestroy(it->second.exec); it = ctx->graphs.erase(it); } else ++it;
     }
     return 0;
 }
 
-static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float* hidden_out, int l0, int l1, int final_norm) {
+static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float* hidden_out, int l0, int l1, int final_norm, bool fused_attn) {
     const vv_config& c = ctx->c;
     const int H = ctx->H, D = ctx->D, Hq = ctx->Hq, Hkv = ctx->Hkv, I = ctx->I, QKV = ctx->QKV;
     HIPCHK(ctx, hipMemcpyAsync(ctx->h, x_in, (size_t)R * H * 4, hipMemcpyDeviceToDevice, st));
@@ -723,15 +735,25 @@ static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float*
         VVGemm g = mk_gemm(L.wqkv, ctx->h, ctx->qkv, R, QKV, H, H, QKV);
         g.pro = VV_PRO_RMS; g.nw = L.ln1; g.eps = c.lm_eps; g.epi = VV_EPI_BIAS; g.bias = L.bqkv; g.nt = 1;
         GEMM(g);
-        ctx->launches += 3;
-        VVCHK(vv_rope_append_launch(D, ctx->qkv, ctx->rows_dev, ctx->inv_freq, ctx->qrot,
-                                    (char*)ctx->kc + (size_t)l * ctx->layer_stride * 2, (char*)ctx->vc + (size_t)l * ctx->layer_stride * 2,
-                                    R, Hq, Hkv, ctx->cache_stride, ctx->head_stride, st));
-        VVCHK(vv_attn_launch(D, c.xsplit, ctx->qrot, ctx->rows_dev, (char*)ctx->kc + (size_t)l * ctx->layer_stride * 2,
-                             (char*)ctx->vc + (size_t)l * ctx->layer_stride * 2, R, Hq, Hkv, ctx->cache_stride,
-                             ctx->head_stride, c.attn_splits, ctx->pm, ctx->pl, ctx->po, ctx->attn, st));
         VVGemm go = mk_gemm(L.wo, ctx->attn, ctx->h, R, H, Hq * D, Hq * D, H);
         go.epi = VV_EPI_RESID; go.nt = 1;
+        if (fused_attn) {
+            // decode: RoPE + KV append + split attention in one launch; o_proj's prologue merges the partials
+            ctx->launches += 1;
+            VVCHK(vv_attn_fused_launch(D, c.xsplit, ctx->qkv, ctx->rows_dev, (char*)ctx->kc + (size_t)l * ctx->layer_stride * 2,
+                                       (char*)ctx->vc + (size_t)l * ctx->layer_stride * 2, R, Hq, Hkv, ctx->cache_stride,
+                                       ctx->head_stride, c.attn_splits, ctx->pm, ctx->pl, ctx->po, ctx->inv_freq, st));
+            go.pro = VV_PRO_ATTN_MERGE; go.att_m = ctx->pm; go.att_l = ctx->pl; go.att_o = ctx->po; go.att_rows = ctx->rows_dev;
+            go.att_S = c.attn_splits; go.att_Hq = Hq; go.att_Hkv = Hkv; go.att_D = D;
+        } else {
+            ctx->launches += 3;
+            VVCHK(vv_rope_append_launch(D, ctx->qkv, ctx->rows_dev, ctx->inv_freq, ctx->qrot,
+                                        (char*)ctx->kc + (size_t)l * ctx->layer_stride * 2, (char*)ctx->vc + (size_t)l * ctx->layer_stride * 2,
+                                        R, Hq, Hkv, ctx->cache_stride, ctx->head_stride, st));
+            VVCHK(vv_attn_launch(D, c.xsplit, ctx->qrot, ctx->rows_dev, (char*)ctx->kc + (size_t)l * ctx->layer_stride * 2,
+                                 (char*)ctx->vc + (size_t)l * ctx->layer_stride * 2, R, Hq, Hkv, ctx->cache_stride,
+                                 ctx->head_stride, c.attn_splits, ctx->pm, ctx->pl, ctx->po, ctx->attn, st));
+        }
         GEMM(go);
         VVGemm gm = mk_gemm(L.wg, ctx->h, ctx->act, R, I, H, H, I);
         gm.W2 = (const u32x4*)L.wu; gm.pro = VV_PRO_RMS; gm.nw = L.ln2; gm.eps = c.lm_eps; gm.epi = VV_EPI_SWIGLU; gm.nt = 1;
@@ -765,8 +787,14 @@ extern "C" int vv_lm_forward_range(vv_ctx* ctx, void* stream, int n_rows, const 
     for (int i = 0; i < n_rows; ++i) { ctx->rows_pin[i].cache = rows[i].cache; ctx->rows_pin[i].pos = rows[i].pos; }
     HIPCHK(ctx, hipMemcpyAsync(ctx->rows_dev, ctx->rows_pin, sizeof(VVRow) * n_rows, hipMemcpyHostToDevice, st));
     ctx->launches = 0;
-    char key[128]; snprintf(key, 128, "lm:%d:%p:%p:%d:%d:%d", n_rows, (const void*)x_in_dev, (void*)hidden_out_dev, l0, l1, final_norm);
-    return graphed(ctx, key, st, [&]() { return lm_body(ctx, st, n_rows, x_in_dev, hidden_out_dev, l0, l1, final_norm); });
+    // fused attention needs every row to own its cache (a chunk of prefill rows shares one) and the decode GEMV (<= 4 rows)
+    // (measured slower than the three small launches on MI355X -- the merge and the RoPE land on the critical path of
+    //  bigger kernels -- so it is opt-in: VVHIP_FUSED_ATTN=1)
+    bool fused = n_rows <= 4 && getenv("VVHIP_FUSED_ATTN") && !getenv("VVHIP_NO_GEMV");
+    for (int i = 0; i < n_rows && fused; ++i)
+        for (int j = 0; j < i; ++j) if (rows[i].cache == rows[j].cache) fused = false;
+    char key[128]; snprintf(key, 128, "lm:%d:%p:%p:%d:%d:%d:%d", n_rows, (const void*)x_in_dev, (void*)hidden_out_dev, l0, l1, final_norm, (int)fused);
+    return graphed(ctx, key, st, [&]() { return lm_body(ctx, st, n_rows, x_in_dev, hidden_out_dev, l0, l1, final_norm, fused); });
 }
 
 extern "C" int vv_kv_import(vv_ctx* ctx, void* stream, int cache, int layer, int n_pos, const void* k_dev, const void* v_dev, int src_dtype) {
@@ -823,16 +851,19 @@ extern "C" int vv_lm_logits(vv_ctx* ctx, void* stream, int n, const float* hidde
 
 // one head evaluation on 2n rows; mod/xh/hact/eps are ctx scratch. temb = t-embedding row for this step.
 static int head_eval(vv_ctx* ctx, hipStream_t st, int rows, const float* zrows, const float* temb_row, float* eps_out,
-                     const float* coef = nullptr, float cfg = 0.f) {
+                     const float* coef = nullptr, float cfg = 0.f, const float* mod_ready = nullptr) {
     const vv_config& c = ctx->c;
     const int H = ctx->H, L = c.latent_dim, HL = c.head_layers, HF = ctx->HF, MODW = ctx->MODW;
-    VVGemm ga = mk_gemm(ctx->h_ada, ctx->cproj, ctx->mod, rows, MODW, H, H, MODW);
-    ga.pro = VV_PRO_ADD_SILU; ga.addvec = temb_row; ga.nt = 1;
-    GEMM(ga);
+    const float* mod = mod_ready ? mod_ready : ctx->mod;
+    if (!mod_ready) {
+        VVGemm ga = mk_gemm(ctx->h_ada, ctx->cproj, ctx->mod, rows, MODW, H, H, MODW);
+        ga.pro = VV_PRO_ADD_SILU; ga.addvec = temb_row; ga.nt = 1;
+        GEMM(ga);
+    }
     VVGemm gi = mk_gemm(ctx->h_in, zrows, ctx->xh, rows, H, L, L, H);
     GEMM(gi);
     for (int l = 0; l < HL; ++l) {
-        const float* base = ctx->mod + (size_t)l * 3 * H;
+        const float* base = mod + (size_t)l * 3 * H;
         VVGemm g1 = mk_gemm(ctx->hl[l].wg, ctx->xh, ctx->hact, rows, HF, H, H, HF);
         g1.W2 = (const u32x4*)ctx->hl[l].wu; g1.pro = VV_PRO_RMS_MOD; g1.nw = ctx->hl[l].norm; g1.eps = c.head_eps;
         g1.mod_shift = base; g1.mod_scale = base + H; g1.ld_mod = MODW; g1.epi = VV_EPI_SWIGLU; g1.nt = 1;
@@ -841,7 +872,7 @@ static int head_eval(vv_ctx* ctx, hipStream_t st, int rows, const float* zrows, 
         g2.epi = VV_EPI_GATED_RESID; g2.gate = base + 2 * H; g2.ld_gate = MODW; g2.nt = 1;
         GEMM(g2);
     }
-    const float* fb = ctx->mod + (size_t)HL * 3 * H;
+    const float* fb = mod + (size_t)HL * 3 * H;
     VVGemm gf = mk_gemm(ctx->h_out, ctx->xh, eps_out, rows, L, H, H, L);
     gf.pro = VV_PRO_RMS_MOD; gf.nw = nullptr; gf.eps = c.head_eps; gf.mod_shift = fb; gf.mod_scale = fb + H; gf.ld_mod = MODW;
     if (coef) {   // CFG + DPM-Solver++ update fused into the epilogue: the noisy latent is rewritten in place
@@ -862,8 +893,24 @@ static int sample_body(vv_ctx* ctx, hipStream_t st, int n, const float* cond, co
     VVGemm gc = mk_gemm(ctx->h_cond, cond, ctx->cproj, rows, H, H, H, H);
     gc.nt = 1;
     GEMM(gc);
+    // adaLN modulations depend on (cond, t) only, not on the evolving latent: evaluate them for ALL solver steps
+    // up front, <=16 rows per GEMM, so the (3*layers+2)*H x H modulation matrix is streamed ceil(2nN/16) times per
+    // frame instead of N times (the reference recomputes it inside every head call)
+    const int MODW = ctx->MODW;
+    const bool batch_ada = ctx->mod_all != nullptr && !getenv("VVHIP_NO_ADA_BATCH");
+    if (batch_ada) {
+        const int total = rows * ctx->n_steps;
+        const int per = (16 / rows) * rows;                 // whole steps per launch
+        for (int t0 = 0; t0 < total; t0 += per) {
+            const int T = std::min(per, total - t0);
+            VVGemm ga = mk_gemm(ctx->h_ada, ctx->cproj, ctx->mod_all + (size_t)t0 * MODW, T, MODW, H, H, MODW);
+            ga.pro = VV_PRO_ADD_SILU; ga.addvec = ctx->temb + (size_t)(t0 / rows) * H; ga.x_row_mod = rows; ga.add_rows_per_vec = rows;
+            GEMM(ga);
+        }
+    }
     for (int i = 0; i < ctx->n_steps; ++i) {
-        if (head_eval(ctx, st, rows, ctx->zz, ctx->temb + (size_t)i * H, ctx->eps, ctx->coef + i * 5, cfg)) return -1;
+        const float* mod_i = batch_ada ? ctx->mod_all + (size_t)i * rows * MODW : nullptr;
+        if (head_eval(ctx, st, rows, ctx->zz, ctx->temb + (size_t)i * H, ctx->eps, ctx->coef + i * 5, cfg, mod_i)) return -1;
     }
     HIPCHK(ctx, hipMemcpyAsync(latent_out, ctx->zz, (size_t)n * L * 4, hipMemcpyDeviceToDevice, st));
     return 0;

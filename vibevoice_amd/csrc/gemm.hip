@@ -168,12 +168,13 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemm_kernel(const VVGemm a) {
         R.nwv = float4{1.f, 1.f, 1.f, 1.f};
         R.addv = float4{0.f, 0.f, 0.f, 0.f};
         if (kin && a.nw) R.nwv = ld4(a.nw, k, full);
-        if (kin && a.pro == VV_PRO_ADD_SILU) R.addv = ld4(a.addvec, k, full);
+        if (kin && a.pro == VV_PRO_ADD_SILU && a.add_rows_per_vec <= 0) R.addv = ld4(a.addvec, k, full);
 #pragma unroll
         for (int r = 0; r < MAXR; ++r) {
             R.x[r] = float4{0.f, 0.f, 0.f, 0.f};
             if (r < Tt && kin) {
-                R.x[r] = ld4(a.X + (int64_t)(t0 + r) * a.ldx, k, full);
+                const int xr_idx = a.x_row_mod > 0 ? (t0 + r) % a.x_row_mod : (t0 + r);
+                R.x[r] = ld4(a.X + (int64_t)xr_idx * a.ldx, k, full);
                 if constexpr (MODREG) {
                     if (a.pro == VV_PRO_RMS_MOD) {
                         const int64_t mo = (int64_t)(t0 + r) * a.ld_mod;
@@ -211,10 +212,18 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemm_kernel(const VVGemm a) {
                     v[2] = k2 ? (v[2] * rs * R.nwv.z) * (1.f + sc.z) + sh.z : 0.f;
                     v[3] = k3 ? (v[3] * rs * R.nwv.w) * (1.f + sc.w) + sh.w : 0.f;
                 } else if (a.pro == VV_PRO_ADD_SILU) {
-                    v[0] = kin ? silu_f(v[0] + R.addv.x) : 0.f;
-                    v[1] = k1 ? silu_f(v[1] + R.addv.y) : 0.f;
-                    v[2] = k2 ? silu_f(v[2] + R.addv.z) : 0.f;
-                    v[3] = k3 ? silu_f(v[3] + R.addv.w) : 0.f;
+                    float4 av = R.addv;
+                    if (a.add_rows_per_vec > 0 && kin) {
+                        const int64_t ao = (int64_t)((t0 + r) / a.add_rows_per_vec) * a.K + k;
+                        av.x = a.addvec[ao];
+                        av.y = k1 ? a.addvec[ao + 1] : 0.f;
+                        av.z = k2 ? a.addvec[ao + 2] : 0.f;
+                        av.w = k3 ? a.addvec[ao + 3] : 0.f;
+                    }
+                    v[0] = kin ? silu_f(v[0] + av.x) : 0.f;
+                    v[1] = k1 ? silu_f(v[1] + av.y) : 0.f;
+                    v[2] = k2 ? silu_f(v[2] + av.z) : 0.f;
+                    v[3] = k3 ? silu_f(v[3] + av.w) : 0.f;
                 }
                 uint2 parts[XS];
                 split4<XS>(v, parts);
