@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libvvhip.so")
+LIB_PATH = os.environ.get("VVHIP_LIB", os.path.join(HERE, "libvvhip.so"))   # override only for A/B benchmarking of builds
 
 
 class VVConfig(C.Structure):

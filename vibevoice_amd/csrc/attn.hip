@@ -84,16 +84,11 @@ __global__ __launch_bounds__(64) void vv_rope_append_kernel(
     }
 }
 
-// FUSED = decode rows with distinct caches: `q` is the raw qkv row block [R][(Hq+2Hkv)*D]; RoPE, the
-// 1/sqrt(D) scale and the KV append of the new token happen here.  The new token's own K/V never take the
-// round trip through the cache: the block that owns the last split folds it in from registers/LDS (values
-// rounded to bf16 exactly as the cache stores them) and also writes it to the cache for later steps.
-template <int D, int XS, bool FUSED>
+template <int D, int XS>
 __global__ __launch_bounds__(256) void vv_attn_split_kernel(
-    const float* __restrict__ q, const VVRow* __restrict__ rows, __bf16* __restrict__ kc,
-    __bf16* __restrict__ vc, int Hq, int Hkv, int64_t cache_stride, int64_t head_stride,
-    float* __restrict__ part_m, float* __restrict__ part_l, float* __restrict__ part_o,
-    const float* __restrict__ inv_freq) {
+    const float* __restrict__ q, const VVRow* __restrict__ rows, const __bf16* __restrict__ kc,
+    const __bf16* __restrict__ vc, int Hq, int Hkv, int64_t cache_stride, int64_t head_stride,
+    float* __restrict__ part_m, float* __restrict__ part_l, float* __restrict__ part_o) {
     constexpr int KT = D / 32;     // k-steps of the QK^T contraction
     constexpr int DT = D / 16;     // 16-dim output tiles of P.V
     const int S = gridDim.x;
@@ -108,76 +103,21 @@ __global__ __launch_bounds__(256) void vv_attn_split_kernel(
     int chunk = (len + S - 1) / S;
     chunk = (chunk + 127) & ~127;
     const int start = split * chunk;
-    const int end_all = min(len, start + chunk);
-    if (start >= len) return;                   // whole block: the merge never reads unused splits
-    const bool owns_new = FUSED && (end_all == len);          // this block folds in (and stores) the new token
-    const int end = owns_new ? len - 1 : end_all;              // cached positions this block reads
-    constexpr int HALF = D / 2;
-    __shared__ float cs[2][HALF];
-    __shared__ float knew[D], vnew[D];
-    const int QKVW = (Hq + 2 * Hkv) * D;
-    if constexpr (FUSED) {
-        const int tid = threadIdx.x;
-        if (tid < HALF) {
-            const float ang = (float)rw.pos * inv_freq[tid];
-            cs[0][tid] = cosf(ang);
-            cs[1][tid] = sinf(ang);
-        }
-        __syncthreads();
-        if (owns_new && tid < D) {
-            const float* kp = q + (int64_t)r * QKVW + (int64_t)(Hq + kvh) * D;
-            const float* vp = q + (int64_t)r * QKVW + (int64_t)(Hq + Hkv + kvh) * D;
-            const int i = tid < HALF ? tid : tid - HALF;
-            const float x1 = kp[i], x2 = kp[i + HALF];
-            const float kr = tid < HALF ? x1 * cs[0][i] - x2 * cs[1][i] : x2 * cs[0][i] + x1 * cs[1][i];
-            const __bf16 kb16 = (__bf16)kr, vb16 = (__bf16)vp[tid];
-            knew[tid] = (float)kb16;
-            vnew[tid] = (float)vb16;
-            const int pos = rw.pos, d = tid;
-            __bf16* kb = kc + (int64_t)rw.cache * cache_stride + (int64_t)kvh * head_stride;
-            __bf16* vb = vc + (int64_t)rw.cache * cache_stride + (int64_t)kvh * head_stride;
-            kb[(((int64_t)(pos >> 4) * (D / 32) + (d >> 5)) * 64 + (pos & 15) + 16 * ((d & 31) >> 3)) * 8 + (d & 7)] = kb16;
-            const int p = pos & 31, hf = p >> 4, pp = p & 15;
-            vb[(((int64_t)(pos >> 5) * (D / 16) + (d >> 4)) * 64 + (d & 15) + 16 * (pp >> 2)) * 8 + hf * 4 + (pp & 3)] = vb16;
-        }
-        __syncthreads();
-    }
+    const int end = min(len, start + chunk);
+    if (start >= len) return;                   // whole block: the merge kernel never reads unused splits
 
     const u32x4* kt_base = reinterpret_cast<const u32x4*>(kc + (int64_t)rw.cache * cache_stride + (int64_t)kvh * head_stride);
     const u32x4* vt_base = reinterpret_cast<const u32x4*>(vc + (int64_t)rw.cache * cache_stride + (int64_t)kvh * head_stride);
 
     // q as B operand: lane holds q[g][kt*32 + qg*8 + j]
     bf16x8 qf[KT][XS];
-    float snew = 0.f;                            // this lane's share of q . k_new (FUSED, owner block only)
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
         float v[8];
-        if constexpr (FUSED) {
-            const float qs = 1.0f / sqrtf((float)D);
-            const float* qp = q + (int64_t)r * QKVW + (int64_t)(kvh * G + g) * D;
-            const int d0 = kt * 32 + qg * 8;
+        const float* qp = q + ((int64_t)r * Hq + kvh * G + g) * D + kt * 32 + qg * 8;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int d = d0 + j;
-                const int i = d < HALF ? d : d - HALF;
-                float o = 0.f;
-                if (g < G) {
-                    const float x1 = qp[i], x2 = qp[i + HALF];
-                    o = (d < HALF ? x1 * cs[0][i] - x2 * cs[1][i] : x2 * cs[0][i] + x1 * cs[1][i]) * qs;
-                }
-                v[j] = o;
-                if (owns_new) snew += o * knew[d];
-            }
-        } else {
-            const float* qp = q + ((int64_t)r * Hq + kvh * G + g) * D + kt * 32 + qg * 8;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (g < G) ? qp[j] : 0.f;
-        }
+        for (int j = 0; j < 8; ++j) v[j] = (g < G) ? qp[j] : 0.f;
         split8<XS>(v, qf[kt]);
-    }
-    if constexpr (FUSED) {
-        snew += __shfl_xor(snew, 16);
-        snew += __shfl_xor(snew, 32);
     }
 
     float m = -INFINITY, lsum = 0.f;
@@ -265,18 +205,6 @@ __global__ __launch_bounds__(256) void vv_attn_split_kernel(
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) O[dt] += so[w][dt][lane] * f;
     }
-    if (owns_new) {
-        const float Mn = fmaxf(M, snew);
-        const float al = (M == -INFINITY) ? 0.f : expf(M - Mn);
-        const float pn = expf(snew - Mn);
-        L = L * al + pn;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) O[dt][rr] = O[dt][rr] * al + pn * vnew[dt * 16 + qg * 4 + rr];
-        }
-        M = Mn;
-    }
     const int64_t pidx = ((int64_t)r * Hkv + kvh) * S + split;
     if (lane < 16) { part_m[pidx * 16 + lane] = M; part_l[pidx * 16 + lane] = L; }
     if (g < G) {
@@ -335,16 +263,9 @@ extern "C" int vv_rope_append_launch(int D, const float* qkv, const VVRow* rows,
 template <int D, int XS>
 static void attn_go(const float* q, const VVRow* rows, const void* kc, const void* vc, int R, int Hq, int Hkv,
                     int64_t cs, int64_t hs, int S, float* pm, float* pl, float* po, float* out, hipStream_t s) {
-    hipLaunchKernelGGL((vv_attn_split_kernel<D, XS, false>), dim3(S, Hkv, R), dim3(256), 0, s, q, rows,
-                       (__bf16*)const_cast<void*>(kc), (__bf16*)const_cast<void*>(vc), Hq, Hkv, cs, hs, pm, pl, po,
-                       (const float*)nullptr);
+    hipLaunchKernelGGL((vv_attn_split_kernel<D, XS>), dim3(S, Hkv, R), dim3(256), 0, s, q, rows,
+                       (const __bf16*)kc, (const __bf16*)vc, Hq, Hkv, cs, hs, pm, pl, po);
     hipLaunchKernelGGL((vv_attn_merge_kernel<D>), dim3(R, Hq), dim3(D), 0, s, pm, pl, po, rows, out, Hq, Hkv, S);
-}
-template <int D, int XS>
-static void attn_fused_go(const float* qkv, const VVRow* rows, void* kc, void* vc, int R, int Hq, int Hkv, int64_t cs,
-                          int64_t hs, int S, float* pm, float* pl, float* po, const float* inv_freq, hipStream_t s) {
-    hipLaunchKernelGGL((vv_attn_split_kernel<D, XS, true>), dim3(S, Hkv, R), dim3(256), 0, s, qkv, rows, (__bf16*)kc,
-                       (__bf16*)vc, Hq, Hkv, cs, hs, pm, pl, po, inv_freq);
 }
 
 extern "C" int vv_attn_launch(int D, int xs, const float* q, const VVRow* rows, const void* kc, const void* vc,
@@ -361,24 +282,5 @@ extern "C" int vv_attn_launch(int D, int xs, const float* q, const VVRow* rows, 
     else if (D == 64) VV_A(64);
     else return -1;
 #undef VV_A
-    return hipGetLastError() == hipSuccess ? 0 : -2;
-}
-
-// Decode rows with distinct caches: RoPE + KV append + split attention in ONE launch; the partials are merged
-// by the consumer (o_proj GEMV prologue VV_PRO_ATTN_MERGE), so no merge launch either.
-extern "C" int vv_attn_fused_launch(int D, int xs, const float* qkv, const VVRow* rows, void* kc, void* vc, int R,
-                                    int Hq, int Hkv, int64_t cache_stride, int64_t head_stride, int S, float* pm,
-                                    float* pl, float* po, const float* inv_freq, hipStream_t s) {
-    if (Hq % Hkv != 0 || Hq / Hkv > 16) return -1;
-#define VV_F(D_)                                                                                                    \
-    do {                                                                                                            \
-        if (xs == 1) attn_fused_go<D_, 1>(qkv, rows, kc, vc, R, Hq, Hkv, cache_stride, head_stride, S, pm, pl, po, inv_freq, s); \
-        else if (xs == 2) attn_fused_go<D_, 2>(qkv, rows, kc, vc, R, Hq, Hkv, cache_stride, head_stride, S, pm, pl, po, inv_freq, s); \
-        else attn_fused_go<D_, 3>(qkv, rows, kc, vc, R, Hq, Hkv, cache_stride, head_stride, S, pm, pl, po, inv_freq, s); \
-    } while (0)
-    if (D == 128) VV_F(128);
-    else if (D == 64) VV_F(64);
-    else return -1;
-#undef VV_F
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -23,9 +23,6 @@ int vv_rope_append_launch(int D, const float* qkv, const VVRow* rows, const floa
 int vv_attn_launch(int D, int xs, const float* q, const VVRow* rows, const void* kc, const void* vc, int R, int Hq,
                    int Hkv, int64_t cache_stride, int64_t head_stride, int S, float* pm, float* pl, float* po,
                    float* out, hipStream_t s);
-int vv_attn_fused_launch(int D, int xs, const float* qkv, const VVRow* rows, void* kc, void* vc, int R, int Hq, int Hkv,
-                         int64_t cache_stride, int64_t head_stride, int S, float* pm, float* pl, float* po,
-                         const float* inv_freq, hipStream_t s);
 int vv_embed_launch(const void* table, const int* ids, float* out, int n, int H, hipStream_t s);
 int vv_rmsnorm_rows_launch(const float* x, int ldx, float* y, int ldy, const float* w, int T, int C, float eps, hipStream_t s);
 int vv_dwconv_res_launch(const float* nb, float* x, const float* w, const float* b, const float* gamma, int T, int C, hipStream_t s);
@@ -726,7 +723,7 @@ extern "C" int vv_set_schedule(vv_ctx* ctx, int n_steps, const float* t, const f
     return 0;
 }
 
-static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float* hidden_out, int l0, int l1, int final_norm, bool fused_attn) {
+static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float* hidden_out, int l0, int l1, int final_norm) {
     const vv_config& c = ctx->c;
     const int H = ctx->H, D = ctx->D, Hq = ctx->Hq, Hkv = ctx->Hkv, I = ctx->I, QKV = ctx->QKV;
     HIPCHK(ctx, hipMemcpyAsync(ctx->h, x_in, (size_t)R * H * 4, hipMemcpyDeviceToDevice, st));
@@ -735,25 +732,18 @@ static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float*
         VVGemm g = mk_gemm(L.wqkv, ctx->h, ctx->qkv, R, QKV, H, H, QKV);
         g.pro = VV_PRO_RMS; g.nw = L.ln1; g.eps = c.lm_eps; g.epi = VV_EPI_BIAS; g.bias = L.bqkv; g.nt = 1;
         GEMM(g);
+        ctx->launches += 3;
+        VVCHK(vv_rope_append_launch(D, ctx->qkv, ctx->rows_dev, ctx->inv_freq, ctx->qrot,
+                                    (char*)ctx->kc + (size_t)l * ctx->layer_stride * 2, (char*)ctx->vc + (size_t)l * ctx->layer_stride * 2,
+                                    R, Hq, Hkv, ctx->cache_stride, ctx->head_stride, st));
+        VVCHK(vv_attn_launch(D, c.xsplit, ctx->qrot, ctx->rows_dev, (char*)ctx->kc + (size_t)l * ctx->layer_stride * 2,
+                             (char*)ctx->vc + (size_t)l * ctx->layer_stride * 2, R, Hq, Hkv, ctx->cache_stride,
+                             ctx->head_stride, c.attn_splits, ctx->pm, ctx->pl, ctx->po, ctx->attn, st));
+        // (a single-launch variant -- RoPE + KV append inside the split kernel, merge inside o_proj's prologue --
+        //  was built and measured 4-5 % SLOWER end to end: graph-replayed boundaries cost ~1.6 us, while the extra
+        //  work landed on the critical path of bigger kernels.  See DESIGN.md "negative results".)
         VVGemm go = mk_gemm(L.wo, ctx->attn, ctx->h, R, H, Hq * D, Hq * D, H);
         go.epi = VV_EPI_RESID; go.nt = 1;
-        if (fused_attn) {
-            // decode: RoPE + KV append + split attention in one launch; o_proj's prologue merges the partials
-            ctx->launches += 1;
-            VVCHK(vv_attn_fused_launch(D, c.xsplit, ctx->qkv, ctx->rows_dev, (char*)ctx->kc + (size_t)l * ctx->layer_stride * 2,
-                                       (char*)ctx->vc + (size_t)l * ctx->layer_stride * 2, R, Hq, Hkv, ctx->cache_stride,
-                                       ctx->head_stride, c.attn_splits, ctx->pm, ctx->pl, ctx->po, ctx->inv_freq, st));
-            go.pro = VV_PRO_ATTN_MERGE; go.att_m = ctx->pm; go.att_l = ctx->pl; go.att_o = ctx->po; go.att_rows = ctx->rows_dev;
-            go.att_S = c.attn_splits; go.att_Hq = Hq; go.att_Hkv = Hkv; go.att_D = D;
-        } else {
-            ctx->launches += 3;
-            VVCHK(vv_rope_append_launch(D, ctx->qkv, ctx->rows_dev, ctx->inv_freq, ctx->qrot,
-                                        (char*)ctx->kc + (size_t)l * ctx->layer_stride * 2, (char*)ctx->vc + (size_t)l * ctx->layer_stride * 2,
-                                        R, Hq, Hkv, ctx->cache_stride, ctx->head_stride, st));
-            VVCHK(vv_attn_launch(D, c.xsplit, ctx->qrot, ctx->rows_dev, (char*)ctx->kc + (size_t)l * ctx->layer_stride * 2,
-                                 (char*)ctx->vc + (size_t)l * ctx->layer_stride * 2, R, Hq, Hkv, ctx->cache_stride,
-                                 ctx->head_stride, c.attn_splits, ctx->pm, ctx->pl, ctx->po, ctx->attn, st));
-        }
         GEMM(go);
         VVGemm gm = mk_gemm(L.wg, ctx->h, ctx->act, R, I, H, H, I);
         gm.W2 = (const u32x4*)L.wu; gm.pro = VV_PRO_RMS; gm.nw = L.ln2; gm.eps = c.lm_eps; gm.epi = VV_EPI_SWIGLU; gm.nt = 1;
@@ -787,14 +777,8 @@ extern "C" int vv_lm_forward_range(vv_ctx* ctx, void* stream, int n_rows, const 
     for (int i = 0; i < n_rows; ++i) { ctx->rows_pin[i].cache = rows[i].cache; ctx->rows_pin[i].pos = rows[i].pos; }
     HIPCHK(ctx, hipMemcpyAsync(ctx->rows_dev, ctx->rows_pin, sizeof(VVRow) * n_rows, hipMemcpyHostToDevice, st));
     ctx->launches = 0;
-    // fused attention needs every row to own its cache (a chunk of prefill rows shares one) and the decode GEMV (<= 4 rows)
-    // (measured slower than the three small launches on MI355X -- the merge and the RoPE land on the critical path of
-    //  bigger kernels -- so it is opt-in: VVHIP_FUSED_ATTN=1)
-    bool fused = n_rows <= 4 && getenv("VVHIP_FUSED_ATTN") && !getenv("VVHIP_NO_GEMV");
-    for (int i = 0; i < n_rows && fused; ++i)
-        for (int j = 0; j < i; ++j) if (rows[i].cache == rows[j].cache) fused = false;
-    char key[128]; snprintf(key, 128, "lm:%d:%p:%p:%d:%d:%d:%d", n_rows, (const void*)x_in_dev, (void*)hidden_out_dev, l0, l1, final_norm, (int)fused);
-    return graphed(ctx, key, st, [&]() { return lm_body(ctx, st, n_rows, x_in_dev, hidden_out_dev, l0, l1, final_norm, fused); });
+    char key[128]; snprintf(key, 128, "lm:%d:%p:%p:%d:%d:%d", n_rows, (const void*)x_in_dev, (void*)hidden_out_dev, l0, l1, final_norm);
+    return graphed(ctx, key, st, [&]() { return lm_body(ctx, st, n_rows, x_in_dev, hidden_out_dev, l0, l1, final_norm); });
 }
 
 extern "C" int vv_kv_import(vv_ctx* ctx, void* stream, int cache, int layer, int n_pos, const void* k_dev, const void* v_dev, int src_dtype) {

@@ -81,7 +81,6 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
     // them lazily behind branches, i.e. 3-4 dependent ~600-cycle round trips on a launch's critical path.
     asm volatile("" ::"s"(a.W), "s"(a.W2), "s"(a.X), "s"(a.Y), "s"(a.nw), "s"(a.mod_scale), "s"(a.mod_shift),
                  "s"(a.addvec), "s"(a.bias), "s"(a.nscale), "s"(a.gate));
-    asm volatile("" ::"s"(a.att_m), "s"(a.att_l), "s"(a.att_o), "s"(a.att_rows), "s"(a.att_S), "s"(a.att_Hq), "s"(a.att_Hkv), "s"(a.att_D));
     asm volatile("" ::"s"(a.T), "s"(a.N), "s"(a.K), "s"(a.ldx), "s"(a.ldy), "s"(a.ld_mod), "s"(a.ld_gate), "s"(a.pro),
                  "s"(a.epi), "s"(a.eps), "s"(a.z), "s"(a.x0p), "s"(a.coef), "s"(a.cfg), "s"(a.n_cfg));
     VV_STAMP(0);
@@ -112,30 +111,6 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
 #pragma unroll
         for (int r = 0; r < MR; ++r) {
             if (r < T) {
-                if (a.pro == VV_PRO_ATTN_MERGE) {
-                    // merge the flash-decoding partials of (row r, head k / D): same chunking as the split kernel
-                    const int D = a.att_D, S = a.att_S, G = a.att_Hq / a.att_Hkv;
-                    const int h = (int)k / D, d = (int)k - h * D;
-                    const int kvh = h / G, g = h - kvh * G;
-                    const int len = a.att_rows[r].pos + 1;
-                    int chunk = (len + S - 1) / S;
-                    chunk = (chunk + 127) & ~127;
-                    const int used = (len + chunk - 1) / chunk;
-                    const unsigned base = (unsigned)((r * a.att_Hkv + kvh) * S);
-                    float M = -INFINITY;
-                    for (int sidx = 0; sidx < used; ++sidx) M = fmaxf(M, a.att_m[(base + sidx) * 16 + g]);
-                    float L = 0.f;
-                    float4 o = {0.f, 0.f, 0.f, 0.f};
-                    for (int sidx = 0; sidx < used; ++sidx) {
-                        const float f = expf(a.att_m[(base + sidx) * 16 + g] - M);
-                        L += a.att_l[(base + sidx) * 16 + g] * f;
-                        const float4 p = *reinterpret_cast<const float4*>(a.att_o + (size_t)((base + sidx) * 16 + g) * D + d);
-                        o.x += p.x * f; o.y += p.y * f; o.z += p.z * f; o.w += p.w * f;
-                    }
-                    const float inv = 1.0f / L;
-                    R.x[r] = float4{o.x * inv, o.y * inv, o.z * inv, o.w * inv};
-                    continue;
-                }
                 R.x[r] = *reinterpret_cast<const float4*>(a.X + (unsigned)(r * a.ldx) + k);
                 if (a.pro == VV_PRO_RMS_MOD) {
                     R.sc[r] = *reinterpret_cast<const float4*>(a.mod_scale + (unsigned)(r * a.ld_mod) + k);
@@ -354,8 +329,7 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
 extern "C" int vv_gemv_ok(const VVGemm* a) {
     if (a->T < 1 || a->T > 4) return 0;
     if (a->x_row_mod > 0 || a->add_rows_per_vec > 0) return 0;
-    if (a->pro == VV_PRO_ATTN_MERGE) { if ((a->K & 3) || (a->att_D & 3)) return 0; }
-    else if ((a->K & 3) || (a->ldx & 3) || (((uintptr_t)a->X) & 15)) return 0;
+    if ((a->K & 3) || (a->ldx & 3) || (((uintptr_t)a->X) & 15)) return 0;
     if (a->pro == VV_PRO_RMS_MOD && (a->ld_mod & 3)) return 0;
     if (a->nw && (((uintptr_t)a->nw) & 15)) return 0;
     if (a->K < 32) return 0;

@@ -29,7 +29,7 @@ struct VVRow {
 
 // ---- generic skinny GEMM -----------------------------------------------------
 // Y[t][n] (op)= sum_k f(X[t][k]) * W[n][k]
-enum { VV_PRO_NONE = 0, VV_PRO_RMS = 1, VV_PRO_RMS_MOD = 2, VV_PRO_ADD_SILU = 3, VV_PRO_ATTN_MERGE = 4 };
+enum { VV_PRO_NONE = 0, VV_PRO_RMS = 1, VV_PRO_RMS_MOD = 2, VV_PRO_ADD_SILU = 3 };
 enum { VV_EPI_STORE = 0, VV_EPI_BIAS = 1, VV_EPI_BIAS_GELU = 2, VV_EPI_SWIGLU = 3,
        VV_EPI_RESID = 4, VV_EPI_GATED_RESID = 5, VV_EPI_CFG_DPM = 6 };
 
@@ -58,11 +58,6 @@ struct VVGemm {
     float cfg;
     int n_cfg;
     unsigned long long* dbg;   // optional phase timestamps (VV_GEMM_TIMING builds only)
-    // PRO_ATTN_MERGE (o_proj at decode): X is not read; the activation row is the merge of the flash-decoding
-    // partials written by vv_attn_split_kernel<FUSED> (attn.hip)
-    const float *att_m, *att_l, *att_o;
-    const struct VVRow* att_rows;
-    int att_S, att_Hq, att_Hkv, att_D;
     // row t reads activation row (t % x_row_mod) and, for PRO_ADD_SILU, the add-vector (t / add_rows_per_vec)
     // (0 = off).  Used to batch the diffusion head's adaLN GEMM over all solver steps of a frame.
     int x_row_mod, add_rows_per_vec;
