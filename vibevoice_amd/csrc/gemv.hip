@@ -70,8 +70,11 @@ constexpr int WPB = 8;     // waves per workgroup == K split
 constexpr int U = 8;       // k-steps per batch (256 k = one float4 per lane per row)
 constexpr int MR = 4;      // max activation rows
 
-template <int XS, bool DUAL>
+// PRO / EPI are compile-time: a launch executes only the code of its own prologue/epilogue (the runtime-
+// switched version spent a third of a small launch fetching and skipping code it never needed).
+template <int XS, int PRO, int EPI>
 __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
+    constexpr bool DUAL = (EPI == VV_EPI_SWIGLU);
     constexpr int NM = DUAL ? 2 : 1;
     // LDS: [wave][XS][U][4][MR] x 16 B staging tiles, then [wave][NM][64] f32x4 partials, then [wave][MR] ssq
     __shared__ __attribute__((aligned(16))) unsigned char stg_all[WPB * XS * U * 4 * MR * 16];
@@ -81,8 +84,8 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
     // them lazily behind branches, i.e. 3-4 dependent ~600-cycle round trips on a launch's critical path.
     asm volatile("" ::"s"(a.W), "s"(a.W2), "s"(a.X), "s"(a.Y), "s"(a.nw), "s"(a.mod_scale), "s"(a.mod_shift),
                  "s"(a.addvec), "s"(a.bias), "s"(a.nscale), "s"(a.gate));
-    asm volatile("" ::"s"(a.T), "s"(a.N), "s"(a.K), "s"(a.ldx), "s"(a.ldy), "s"(a.ld_mod), "s"(a.ld_gate), "s"(a.pro),
-                 "s"(a.epi), "s"(a.eps), "s"(a.z), "s"(a.x0p), "s"(a.coef), "s"(a.cfg), "s"(a.n_cfg));
+    asm volatile("" ::"s"(a.T), "s"(a.N), "s"(a.K), "s"(a.ldx), "s"(a.ldy), "s"(a.ld_mod), "s"(a.ld_gate),
+                 "s"(a.eps), "s"(a.z), "s"(a.x0p), "s"(a.coef), "s"(a.cfg), "s"(a.n_cfg));
     VV_STAMP(0);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -107,12 +110,12 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
         const bool kin = k < min(kt1 * 32, (unsigned)a.K);
         if (!kin) k = 0;                                   // clamped: always a legal address, masked later
         R.nwv = a.nw ? *reinterpret_cast<const float4*>(a.nw + k) : float4{1.f, 1.f, 1.f, 1.f};
-        if (a.pro == VV_PRO_ADD_SILU) R.addv = *reinterpret_cast<const float4*>(a.addvec + k);
+        if constexpr (PRO == VV_PRO_ADD_SILU) R.addv = *reinterpret_cast<const float4*>(a.addvec + k);
 #pragma unroll
         for (int r = 0; r < MR; ++r) {
             if (r < T) {
                 R.x[r] = *reinterpret_cast<const float4*>(a.X + (unsigned)(r * a.ldx) + k);
-                if (a.pro == VV_PRO_RMS_MOD) {
+                if constexpr (PRO == VV_PRO_RMS_MOD) {
                     R.sc[r] = *reinterpret_cast<const float4*>(a.mod_scale + (unsigned)(r * a.ld_mod) + k);
                     R.sh[r] = *reinterpret_cast<const float4*>(a.mod_shift + (unsigned)(r * a.ld_mod) + k);
                 }
@@ -139,17 +142,19 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
     const bool epi_lane = (wave == 0) && frow < T && n0 < a.N;
     float4 pre_y = {0.f, 0.f, 0.f, 0.f}, pre_b = {0.f, 0.f, 0.f, 0.f}, pre_g = {1.f, 1.f, 1.f, 1.f};
     if (epi_lane) {            // N % 4 == 0 and 16-B aligned operands are launch preconditions (vv_gemv_ok)
-        if (a.bias) pre_b = *reinterpret_cast<const float4*>(a.bias + n0);
-        if (a.epi == VV_EPI_RESID || a.epi == VV_EPI_GATED_RESID) {
+        if constexpr (EPI == VV_EPI_BIAS || EPI == VV_EPI_BIAS_GELU || EPI == VV_EPI_RESID) {
+            if (a.bias) pre_b = *reinterpret_cast<const float4*>(a.bias + n0);
+        }
+        if constexpr (EPI == VV_EPI_RESID || EPI == VV_EPI_GATED_RESID) {
             pre_y = *reinterpret_cast<const float4*>(a.Y + (unsigned)(frow * a.ldy + n0));
-            if (a.epi == VV_EPI_GATED_RESID) pre_g = *reinterpret_cast<const float4*>(a.gate + (unsigned)(frow * a.ld_gate + n0));
+            if constexpr (EPI == VV_EPI_GATED_RESID) pre_g = *reinterpret_cast<const float4*>(a.gate + (unsigned)(frow * a.ld_gate + n0));
             else if (a.nscale) pre_g = *reinterpret_cast<const float4*>(a.nscale + n0);
         }
     }
 
     // ---- adaLN-modulated norm: 1/rms of the whole row is needed before staging ----
     float rstd[MR] = {1.f, 1.f, 1.f, 1.f};
-    if (a.pro == VV_PRO_RMS_MOD) {
+    if constexpr (PRO == VV_PRO_RMS_MOD) {
 #pragma unroll
         for (int r = 0; r < MR; ++r) {
             float s = 0.f;
@@ -186,16 +191,16 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
         for (int r = 0; r < MR; ++r) {
             if (r < T) {
                 float v[4] = {R.x[r].x * msk, R.x[r].y * msk, R.x[r].z * msk, R.x[r].w * msk};
-                if (a.pro == VV_PRO_RMS) {
+                if constexpr (PRO == VV_PRO_RMS) {
                     ssq[r] += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
                     v[0] *= R.nwv.x; v[1] *= R.nwv.y; v[2] *= R.nwv.z; v[3] *= R.nwv.w;
-                } else if (a.pro == VV_PRO_RMS_MOD) {
+                } else if constexpr (PRO == VV_PRO_RMS_MOD) {
                     const float rs = rstd[r];
                     v[0] = ((v[0] * rs * R.nwv.x) * (1.f + R.sc[r].x) + R.sh[r].x) * msk;
                     v[1] = ((v[1] * rs * R.nwv.y) * (1.f + R.sc[r].y) + R.sh[r].y) * msk;
                     v[2] = ((v[2] * rs * R.nwv.z) * (1.f + R.sc[r].z) + R.sh[r].z) * msk;
                     v[3] = ((v[3] * rs * R.nwv.w) * (1.f + R.sc[r].w) + R.sh[r].w) * msk;
-                } else if (a.pro == VV_PRO_ADD_SILU) {
+                } else if constexpr (PRO == VV_PRO_ADD_SILU) {
                     v[0] = silu_acc(v[0] + R.addv.x) * msk; v[1] = silu_acc(v[1] + R.addv.y) * msk;
                     v[2] = silu_acc(v[2] + R.addv.z) * msk; v[3] = silu_acc(v[3] + R.addv.w) * msk;
                 }
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
     // ---- split-K partials -> LDS, one barrier, wave 0 finishes ----
 #pragma unroll
     for (int i = 0; i < NM; ++i) red[wave][i][lane] = acc[i];
-    if (a.pro == VV_PRO_RMS) {
+    if constexpr (PRO == VV_PRO_RMS) {
 #pragma unroll
         for (int r = 0; r < MR; ++r) {
             const float s = (r < T) ? wave_sum_dpp(ssq[r]) : 0.f;
@@ -263,7 +268,7 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
         for (int i = 0; i < NM; ++i) acc[i] += red[w][i][lane];
     if (!epi_lane) return;
     float rs = 1.0f;
-    if (a.pro == VV_PRO_RMS) {
+    if constexpr (PRO == VV_PRO_RMS) {
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < WPB; ++w) s += ssq_sh[w][frow & (MR - 1)];
@@ -273,32 +278,23 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
     const float pb[4] = {pre_b.x, pre_b.y, pre_b.z, pre_b.w};
     const float py[4] = {pre_y.x, pre_y.y, pre_y.z, pre_y.w};
     const float pg[4] = {pre_g.x, pre_g.y, pre_g.z, pre_g.w};
-    switch (a.epi) {
-        case VV_EPI_BIAS:
+    if constexpr (EPI == VV_EPI_BIAS) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] += pb[r];
-            break;
-        case VV_EPI_BIAS_GELU:
+        for (int r = 0; r < 4; ++r) o[r] += pb[r];
+    } else if constexpr (EPI == VV_EPI_BIAS_GELU) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = gelu_erf_f(o[r] + pb[r]);
-            break;
-        case VV_EPI_SWIGLU:
-            if constexpr (DUAL) {
+        for (int r = 0; r < 4; ++r) o[r] = gelu_erf_f(o[r] + pb[r]);
+    } else if constexpr (EPI == VV_EPI_SWIGLU) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = silu_acc(o[r]) * (acc[1][r] * rs);
-            }
-            break;
-        case VV_EPI_RESID:
+        for (int r = 0; r < 4; ++r) o[r] = silu_acc(o[r]) * (acc[NM - 1][r] * rs);
+    } else if constexpr (EPI == VV_EPI_RESID) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = py[r] + pg[r] * (o[r] + pb[r]);
-            break;
-        case VV_EPI_GATED_RESID:
+        for (int r = 0; r < 4; ++r) o[r] = py[r] + pg[r] * (o[r] + pb[r]);
+    } else if constexpr (EPI == VV_EPI_GATED_RESID) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = py[r] + pg[r] * o[r];
-            break;
-        default: break;
+        for (int r = 0; r < 4; ++r) o[r] = py[r] + pg[r] * o[r];
     }
-    if (a.epi == VV_EPI_CFG_DPM) {
+    if constexpr (EPI == VV_EPI_CFG_DPM) {
         const int nc = a.n_cfg;
         const float ca = a.coef[0], cs_ = a.coef[1], csx = a.coef[2], c0 = a.coef[3], c1 = a.coef[4];
 #pragma unroll
@@ -325,9 +321,11 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
 
 }  // namespace
 
-// Eligibility: decode rows, aligned operands, 32-bit offsets.
+static bool gemv_combo_ok(int pro, int epi);
+// Eligibility: decode rows, aligned operands, 32-bit offsets, a specialised (prologue, epilogue) pair.
 extern "C" int vv_gemv_ok(const VVGemm* a) {
     if (a->T < 1 || a->T > 4) return 0;
+    if (!gemv_combo_ok(a->pro, a->epi)) return 0;
     if (a->x_row_mod > 0 || a->add_rows_per_vec > 0) return 0;
     if ((a->K & 3) || (a->ldx & 3) || (((uintptr_t)a->X) & 15)) return 0;
     if (a->pro == VV_PRO_RMS_MOD && (a->ld_mod & 3)) return 0;
@@ -343,19 +341,33 @@ extern "C" int vv_gemv_ok(const VVGemm* a) {
     return 1;
 }
 
+// The (prologue, epilogue) pairs the engine actually issues at decode; anything else runs on the general kernel.
+#define VV_GEMV_COMBOS(X)                                                                      \
+    X(VV_PRO_NONE, VV_EPI_STORE) X(VV_PRO_NONE, VV_EPI_BIAS) X(VV_PRO_NONE, VV_EPI_RESID)      \
+    X(VV_PRO_NONE, VV_EPI_GATED_RESID) X(VV_PRO_RMS, VV_EPI_BIAS) X(VV_PRO_RMS, VV_EPI_BIAS_GELU) \
+    X(VV_PRO_RMS, VV_EPI_SWIGLU) X(VV_PRO_RMS, VV_EPI_RESID) X(VV_PRO_RMS, VV_EPI_STORE)       \
+    X(VV_PRO_RMS_MOD, VV_EPI_SWIGLU) X(VV_PRO_RMS_MOD, VV_EPI_CFG_DPM) X(VV_PRO_RMS_MOD, VV_EPI_STORE) \
+    X(VV_PRO_ADD_SILU, VV_EPI_STORE)
+
+static bool gemv_combo_ok(int pro, int epi) {
+#define X(P, E) if (pro == P && epi == E) return true;
+    VV_GEMV_COMBOS(X)
+#undef X
+    return false;
+}
+
 extern "C" int vv_gemv_launch(VVGemm a, int xs, hipStream_t s) {
     const int n_tiles = (a.N + 15) / 16;
-    const bool dual = a.epi == VV_EPI_SWIGLU;
-    if (dual && !a.W2) return -1;
+    if (a.epi == VV_EPI_SWIGLU && !a.W2) return -1;
     dim3 grid(n_tiles), block(WPB * 64);
-#define VV_G(XS_)                                                                        \
-    do {                                                                                 \
-        if (dual) hipLaunchKernelGGL((vv_gemv_kernel<XS_, true>), grid, block, 0, s, a); \
-        else hipLaunchKernelGGL((vv_gemv_kernel<XS_, false>), grid, block, 0, s, a);     \
-    } while (0)
-    if (xs == 1) VV_G(1);
-    else if (xs == 2) VV_G(2);
-    else VV_G(3);
-#undef VV_G
-    return hipGetLastError() == hipSuccess ? 0 : -2;
+#define X(P, E)                                                                                         \
+    if (a.pro == P && a.epi == E) {                                                                     \
+        if (xs == 1) hipLaunchKernelGGL((vv_gemv_kernel<1, P, E>), grid, block, 0, s, a);               \
+        else if (xs == 2) hipLaunchKernelGGL((vv_gemv_kernel<2, P, E>), grid, block, 0, s, a);          \
+        else hipLaunchKernelGGL((vv_gemv_kernel<3, P, E>), grid, block, 0, s, a);                       \
+        return hipGetLastError() == hipSuccess ? 0 : -2;                                                \
+    }
+    VV_GEMV_COMBOS(X)
+#undef X
+    return -3;
 }
