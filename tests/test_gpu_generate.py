@@ -151,3 +151,56 @@ def test_generate_with_graphs():
         check(o, h)
     finally:
         s.eng.close()
+
+
+class FakeStreamer:
+    """Records the AudioStreamer calls generate() must make (streamer.py:42-76)."""
+
+    def __init__(self, batch):
+        self.finished_flags = [False] * batch
+        self.puts, self.ends = [], []
+
+    def put(self, chunk, idx):
+        self.puts.append((tuple(chunk.shape), idx.tolist()))
+
+    def end(self, idx=None):
+        self.ends.append(None if idx is None else idx.tolist())
+
+
+def test_streamer_contract_and_stop_check(sm):
+    from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference
+    s = sm
+    ids, mask, sim, st, smk = make_inputs(s, 2, False, 51)
+    cfgd = {"decoder_config": {"max_position_embeddings": s.lmcfg.max_pos},
+            "diffusion_head_config": {"ddpm_num_inference_steps": 5},
+            "acoustic_tokenizer_config": {"fix_std": 0.5, "std_dist_type": "gaussian"}}
+    m = VibeVoiceForConditionalGenerationInference(cfgd, s.eng, model_dtype=torch.float32)
+    m.set_speech_factors(s.scaling, s.bias)
+    m.set_ddpm_inference_steps(5)
+    tok = types.SimpleNamespace(speech_start_id=S, speech_end_id=E, speech_diffusion_id=D, eos_token_id=X,
+                                bos_token_id=None, pad_token_id=TOK.pad_token_id)
+    fs = FakeStreamer(2)
+    forced = [[D, D, X], [D, X]]
+    out = m.generate(input_ids=ids, attention_mask=mask, cfg_scale=1.3, tokenizer=tok, audio_streamer=fs,
+                     _forced_tokens=forced, show_progress_bar=False)
+    # one put per step with the rows that diffused, [n,1,3200] chunks; end(idx) at EOS; a final end()
+    assert fs.puts == [((2, 1, 3200), [0, 1]), ((1, 1, 3200), [0])]
+    assert fs.ends == [[1], [0], None]
+    assert out.speech_outputs[0].shape[-1] == 2 * 3200 and out.speech_outputs[1].shape[-1] == 3200
+    # external stop: generation ends before the first step and the streamer is closed
+    fs2 = FakeStreamer(2)
+    out2 = m.generate(input_ids=ids, attention_mask=mask, cfg_scale=1.3, tokenizer=tok, audio_streamer=fs2,
+                      stop_check_fn=lambda: True, _forced_tokens=forced, show_progress_bar=False)
+    assert fs2.puts == [] and fs2.ends[0] is None
+    assert out2.sequences.shape[1] == ids.shape[1] and out2.speech_outputs == [None, None]
+    # a consumer that closed its stream stops generation at the next step
+    fs3 = FakeStreamer(2)
+    fs3.finished_flags[0] = True
+    out3 = m.generate(input_ids=ids, attention_mask=mask, cfg_scale=1.3, tokenizer=tok, audio_streamer=fs3,
+                      _forced_tokens=forced, show_progress_bar=False)
+    assert fs3.puts == []
+    with pytest.raises(NotImplementedError):
+        m.generate(input_ids=ids, attention_mask=mask, tokenizer=tok, refresh_negative=False)
+    with pytest.raises(ValueError):
+        big = torch.cat([ids, ids, ids], 0)
+        m.generate(input_ids=big, attention_mask=torch.ones_like(big), tokenizer=tok)

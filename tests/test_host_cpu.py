@@ -162,3 +162,47 @@ def test_two_rank_broadcast_and_aggregate_gloo():
     assert c0 == c1                       # identical weights on both ranks after the broadcast
     assert sorted(m0 + m1) == [0, 1, 2, 3] and not set(m0) & set(m1)
     assert t0 == t1 == 20.0 and w0 == w1 == 2.0    # sum of units, max of walls
+
+
+def test_streaming_param_mapping_and_shapes():
+    from vibevoice_amd.configs import CONFIGS
+    from vibevoice_amd.modeling_streaming import map_streaming_param_name
+    from vibevoice_amd.synthetic import streaming_param_shapes
+    cfg = CONFIGS["0.5b-streaming"]
+    sh = streaming_param_shapes(cfg)
+    n_tts = cfg["tts_backbone_num_hidden_layers"]
+    n_lm = cfg["decoder_config"]["num_hidden_layers"] - n_tts
+    assert (n_lm, n_tts) == (4, 20)
+    assert sum(int(np.prod(v)) for k, v in sh.items() if "language_model.layers" in k) == 357_897_216
+    names = {map_streaming_param_name(k, n_lm) for k in sh}
+    assert "lm.layers.23.mlp.down_proj.weight" in names and "lm.layers.3.self_attn.q_proj.bias" in names
+    assert {"lm.norm.weight", "tts_input_types.weight", "eos.fc1.weight", "eos.fc2.bias", "dec.head.conv.conv.weight"} <= names
+    assert map_streaming_param_name("model.semantic_connector.fc1.weight", n_lm) is None
+
+
+def test_streaming_oracle_windows_cpu():
+    """The streaming oracle loop on a tiny CPU model: 7 text tokens -> windows of 5 and 2, six frames after each,
+    then speech-only windows until the length cap."""
+    import synth
+    from oracle import generate_streaming as ogs
+    from oracle import lm as olm
+    cfg = synth.LMCfg(hidden=128, layers=2, heads=2, kv_heads=1, inter=256, vocab=320)
+    w = synth.lm_weights(cfg)
+    lm_w = {k: v for k, v in w.items() if k.startswith("embed") or k.startswith("layers.0.")}
+    tts_w = {"norm.weight": w["norm.weight"], "embed_tokens.weight": w["embed_tokens.weight"]}
+    tts_w.update({"layers.0." + k[len("layers.1."):]: v for k, v in w.items() if k.startswith("layers.1.")})
+    mk = lambda ww: olm.Qwen2Oracle(ww, 1, cfg.heads, cfg.kv_heads, cfg.head_dim, cfg.theta, cfg.eps)
+    hc, cc = synth.HeadCfg(hidden=128, layers=1), synth.CodecCfg()
+    g = synth.Gen(1)
+    eos = {"fc1.weight": g.linear(128, 128), "fc1.bias": g.vec(128), "fc2.weight": g.linear(1, 128), "fc2.bias": g.vec(1, 0.1, -30.0)}
+    m = ogs.StreamingOracleModel(lm=mk(lm_w), tts_lm=mk(tts_w), tts_types=g.normal((2, 128), 0.5, mat=False), eos=eos,
+                                 head_w=synth.head_weights(hc), head_layers=1, ac_w=synth.decoder_weights(cc, 3),
+                                 ac_conn=synth.connector_weights(64, 128, 4), ratios=cc.ratios, dec_depths=cc.dec_depths,
+                                 scaling=0.2, bias=-0.05)
+    pre = ogs.make_preset(m, torch.arange(9), 300)
+    calls = []
+    noise = lambda f, n2: (calls.append(f), torch.zeros(n2, 64))[1]
+    n_tok, audio, reach, fin = ogs.oracle_generate_streaming(m, pre, torch.arange(7), 1.5, 3, noise, max_length=9 + 7 + 14)
+    assert reach and not fin
+    assert calls == list(range(len(calls))) and len(calls) == 15         # 6 + 6 + 3: the cap hits inside the third speech window
+    assert audio.shape[-1] == 15 * 3200
