@@ -357,7 +357,7 @@ static int gemm_prof(vv_ctx* ctx, const VVGemm& g, hipStream_t st) {
     hipEventRecord(ctx->prof_ev[2 * ctx->prof_n + 1], st);
     ctx->prof_n++;
     ctx->prof_bytes += gemm_bytes(g);
-    ctx->prof_rec.push_back({g.T, g.N, g.K, g.pro, g.epi, g.W2 ? 1 : 0, gemm_bytes(g), vv_gemv_ok(&g)});
+    ctx->prof_rec.push_back({g.T, g.N, g.K, g.pro, g.epi, g.W2 ? 1 : 0, gemm_bytes(g), vv_gemv_ok(&g) && (g.T <= 4 || ctx->c.xsplit <= 2)});
     return r;
 }
 #define GEMM(g) do { ctx->launches++; if (ctx->prof_on) VVCHK(gemm_prof(ctx, g, st)); else VVCHK(vv_gemm_launch(g, ctx->c.xsplit, st)); } while (0)

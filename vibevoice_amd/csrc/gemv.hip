@@ -68,11 +68,12 @@ __device__ __forceinline__ void split4(const float (&v)[4], uint2 (&out)[XS]) {
 
 constexpr int WPB = 8;     // waves per workgroup == K split
 constexpr int U = 8;       // k-steps per batch (256 k = one float4 per lane per row)
-constexpr int MR = 4;      // max activation rows
 
 // PRO / EPI are compile-time: a launch executes only the code of its own prologue/epilogue (the runtime-
 // switched version spent a third of a small launch fetching and skipping code it never needed).
-template <int XS, int PRO, int EPI>
+// MR = activation rows a launch can carry: 4 for decode steps, 16 for prefill chunks / batched adaLN / the T = 8 codec
+// stage (same weight stream, 4x the staging work and LDS).
+template <int XS, int PRO, int EPI, int MR>
 __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
     constexpr bool DUAL = (EPI == VV_EPI_SWIGLU);
     constexpr int NM = DUAL ? 2 : 1;
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
     // them lazily behind branches, i.e. 3-4 dependent ~600-cycle round trips on a launch's critical path.
     asm volatile("" ::"s"(a.W), "s"(a.W2), "s"(a.X), "s"(a.Y), "s"(a.nw), "s"(a.mod_scale), "s"(a.mod_shift),
                  "s"(a.addvec), "s"(a.bias), "s"(a.nscale), "s"(a.gate));
-    asm volatile("" ::"s"(a.T), "s"(a.N), "s"(a.K), "s"(a.ldx), "s"(a.ldy), "s"(a.ld_mod), "s"(a.ld_gate),
+    asm volatile("" ::"s"(a.T), "s"(a.N), "s"(a.K), "s"(a.ldx), "s"(a.ldy), "s"(a.ld_mod), "s"(a.ld_gate), "s"(a.x_row_mod), "s"(a.add_rows_per_vec),
                  "s"(a.eps), "s"(a.z), "s"(a.x0p), "s"(a.coef), "s"(a.cfg), "s"(a.n_cfg));
     VV_STAMP(0);
     const int lane = threadIdx.x & 63;
@@ -104,17 +105,23 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
     const u32x4* wbase = a.W + (size_t)tile * k_tiles * 64 + lane;
     const u32x4* wbase2 = DUAL ? a.W2 + (size_t)tile * k_tiles * 64 + lane : nullptr;
 
-    struct XR { float4 x[MR]; float4 sc[MR]; float4 sh[MR]; float4 nwv, addv; };
+    constexpr int MODR = (PRO == VV_PRO_RMS_MOD) ? MR : 1;
+    constexpr int ADDR = (PRO == VV_PRO_ADD_SILU) ? MR : 1;
+    struct XR { float4 x[MR]; float4 sc[MODR]; float4 sh[MODR]; float4 addv[ADDR]; float4 nwv; };
     auto x_load = [&](unsigned ktb, XR& R) {
         unsigned k = ktb * 32 + kk;
         const bool kin = k < min(kt1 * 32, (unsigned)a.K);
         if (!kin) k = 0;                                   // clamped: always a legal address, masked later
         R.nwv = a.nw ? *reinterpret_cast<const float4*>(a.nw + k) : float4{1.f, 1.f, 1.f, 1.f};
-        if constexpr (PRO == VV_PRO_ADD_SILU) R.addv = *reinterpret_cast<const float4*>(a.addvec + k);
 #pragma unroll
         for (int r = 0; r < MR; ++r) {
             if (r < T) {
-                R.x[r] = *reinterpret_cast<const float4*>(a.X + (unsigned)(r * a.ldx) + k);
+                const int xr_idx = a.x_row_mod > 0 ? r % a.x_row_mod : r;
+                R.x[r] = *reinterpret_cast<const float4*>(a.X + (unsigned)(xr_idx * a.ldx) + k);
+                if constexpr (PRO == VV_PRO_ADD_SILU) {
+                    const int av = a.add_rows_per_vec > 0 ? r / a.add_rows_per_vec : 0;
+                    R.addv[r] = *reinterpret_cast<const float4*>(a.addvec + (unsigned)(av * a.K) + k);
+                }
                 if constexpr (PRO == VV_PRO_RMS_MOD) {
                     R.sc[r] = *reinterpret_cast<const float4*>(a.mod_scale + (unsigned)(r * a.ld_mod) + k);
                     R.sh[r] = *reinterpret_cast<const float4*>(a.mod_shift + (unsigned)(r * a.ld_mod) + k);
@@ -153,7 +160,9 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
     }
 
     // ---- adaLN-modulated norm: 1/rms of the whole row is needed before staging ----
-    float rstd[MR] = {1.f, 1.f, 1.f, 1.f};
+    float rstd[MR];
+#pragma unroll
+    for (int r = 0; r < MR; ++r) rstd[r] = 1.f;
     if constexpr (PRO == VV_PRO_RMS_MOD) {
 #pragma unroll
         for (int r = 0; r < MR; ++r) {
@@ -182,7 +191,9 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
     f32x4 acc[NM];
 #pragma unroll
     for (int i = 0; i < NM; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float ssq[MR] = {0.f, 0.f, 0.f, 0.f};
+    float ssq[MR];
+#pragma unroll
+    for (int r = 0; r < MR; ++r) ssq[r] = 0.f;
 
     auto x_stage = [&](unsigned ktb, const XR& R) {
         const unsigned k = ktb * 32 + kk;
@@ -201,8 +212,8 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
                     v[2] = ((v[2] * rs * R.nwv.z) * (1.f + R.sc[r].z) + R.sh[r].z) * msk;
                     v[3] = ((v[3] * rs * R.nwv.w) * (1.f + R.sc[r].w) + R.sh[r].w) * msk;
                 } else if constexpr (PRO == VV_PRO_ADD_SILU) {
-                    v[0] = silu_acc(v[0] + R.addv.x) * msk; v[1] = silu_acc(v[1] + R.addv.y) * msk;
-                    v[2] = silu_acc(v[2] + R.addv.z) * msk; v[3] = silu_acc(v[3] + R.addv.w) * msk;
+                    v[0] = silu_acc(v[0] + R.addv[r].x) * msk; v[1] = silu_acc(v[1] + R.addv[r].y) * msk;
+                    v[2] = silu_acc(v[2] + R.addv[r].z) * msk; v[3] = silu_acc(v[3] + R.addv[r].w) * msk;
                 }
                 uint2 parts[XS];
                 split4<XS>(v, parts);
@@ -234,6 +245,15 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
         VV_STAMP(2);
         // two batches per trip, ping-ponging the weight buffers: no register copies, so the prefetched batch
         // stays in flight across the MFMAs of the current one
+        if constexpr (DUAL && MR == 16) {
+            // 16 rows x two weight streams: a second weight buffer would spill; run single-buffered (prefill only)
+#pragma unroll 1
+            for (unsigned ktb = kt0; ktb < kt1; ktb += U) {
+                const bool n1 = ktb + U < kt1;
+                mma(ktb, wA);
+                if (n1) { x_load(ktb + U, R); w_load(ktb + U, wA); x_stage(ktb + U, R); }
+            }
+        } else
 #pragma unroll 1
         for (unsigned ktb = kt0; ktb < kt1; ktb += 2 * U) {
             const bool n1 = ktb + U < kt1, n2 = ktb + 2 * U < kt1;
@@ -271,7 +291,7 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
     if constexpr (PRO == VV_PRO_RMS) {
         float s = 0.f;
 #pragma unroll
-        for (int w = 0; w < WPB; ++w) s += ssq_sh[w][frow & (MR - 1)];
+        for (int w = 0; w < WPB; ++w) s += ssq_sh[w][frow];
         rs = rsqrtf(s / (float)a.K + a.eps);
     }
     float o[4] = {acc[0][0] * rs, acc[0][1] * rs, acc[0][2] * rs, acc[0][3] * rs};
@@ -321,12 +341,12 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
 
 }  // namespace
 
-static bool gemv_combo_ok(int pro, int epi);
+static bool gemv_combo_ok(int pro, int epi, bool wide);
 // Eligibility: decode rows, aligned operands, 32-bit offsets, a specialised (prologue, epilogue) pair.
 extern "C" int vv_gemv_ok(const VVGemm* a) {
-    if (a->T < 1 || a->T > 4) return 0;
-    if (!gemv_combo_ok(a->pro, a->epi)) return 0;
-    if (a->x_row_mod > 0 || a->add_rows_per_vec > 0) return 0;
+    if (a->T < 1 || a->T > 16) return 0;
+    if (!gemv_combo_ok(a->pro, a->epi, a->T > 4)) return 0;
+    if ((a->x_row_mod > 0 || a->add_rows_per_vec > 0) && a->pro != VV_PRO_ADD_SILU) return 0;
     if ((a->K & 3) || (a->ldx & 3) || (((uintptr_t)a->X) & 15)) return 0;
     if (a->pro == VV_PRO_RMS_MOD && (a->ld_mod & 3)) return 0;
     if (a->nw && (((uintptr_t)a->nw) & 15)) return 0;
@@ -341,17 +361,22 @@ extern "C" int vv_gemv_ok(const VVGemm* a) {
     return 1;
 }
 
-// The (prologue, epilogue) pairs the engine actually issues at decode; anything else runs on the general kernel.
+// The (prologue, epilogue) pairs the engine actually issues; anything else runs on the general kernel.
 #define VV_GEMV_COMBOS(X)                                                                      \
     X(VV_PRO_NONE, VV_EPI_STORE) X(VV_PRO_NONE, VV_EPI_BIAS) X(VV_PRO_NONE, VV_EPI_RESID)      \
     X(VV_PRO_NONE, VV_EPI_GATED_RESID) X(VV_PRO_RMS, VV_EPI_BIAS) X(VV_PRO_RMS, VV_EPI_BIAS_GELU) \
     X(VV_PRO_RMS, VV_EPI_SWIGLU) X(VV_PRO_RMS, VV_EPI_RESID) X(VV_PRO_RMS, VV_EPI_STORE)       \
     X(VV_PRO_RMS_MOD, VV_EPI_SWIGLU) X(VV_PRO_RMS_MOD, VV_EPI_CFG_DPM) X(VV_PRO_RMS_MOD, VV_EPI_STORE) \
     X(VV_PRO_ADD_SILU, VV_EPI_STORE)
+// pairs that also exist in the 16-row form (prefill chunks, batched adaLN, T = 8 codec stage, connectors)
+#define VV_GEMV_WIDE(X)                                                                        \
+    X(VV_PRO_NONE, VV_EPI_STORE) X(VV_PRO_NONE, VV_EPI_BIAS) X(VV_PRO_NONE, VV_EPI_RESID)      \
+    X(VV_PRO_RMS, VV_EPI_BIAS) X(VV_PRO_RMS, VV_EPI_BIAS_GELU) X(VV_PRO_RMS, VV_EPI_SWIGLU)    \
+    X(VV_PRO_ADD_SILU, VV_EPI_STORE)
 
-static bool gemv_combo_ok(int pro, int epi) {
+static bool gemv_combo_ok(int pro, int epi, bool wide) {
 #define X(P, E) if (pro == P && epi == E) return true;
-    VV_GEMV_COMBOS(X)
+    if (wide) { VV_GEMV_WIDE(X) } else { VV_GEMV_COMBOS(X) }
 #undef X
     return false;
 }
@@ -360,11 +385,23 @@ extern "C" int vv_gemv_launch(VVGemm a, int xs, hipStream_t s) {
     const int n_tiles = (a.N + 15) / 16;
     if (a.epi == VV_EPI_SWIGLU && !a.W2) return -1;
     dim3 grid(n_tiles), block(WPB * 64);
+    if (a.T > 4) {
+        if (xs > 2) return -3;       // 16-row staging tiles of the exact mode exceed the LDS: general kernel
 #define X(P, E)                                                                                         \
     if (a.pro == P && a.epi == E) {                                                                     \
-        if (xs == 1) hipLaunchKernelGGL((vv_gemv_kernel<1, P, E>), grid, block, 0, s, a);               \
-        else if (xs == 2) hipLaunchKernelGGL((vv_gemv_kernel<2, P, E>), grid, block, 0, s, a);          \
-        else hipLaunchKernelGGL((vv_gemv_kernel<3, P, E>), grid, block, 0, s, a);                       \
+        if (xs == 1) hipLaunchKernelGGL((vv_gemv_kernel<1, P, E, 16>), grid, block, 0, s, a);           \
+        else hipLaunchKernelGGL((vv_gemv_kernel<2, P, E, 16>), grid, block, 0, s, a);                   \
+        return hipGetLastError() == hipSuccess ? 0 : -2;                                                \
+    }
+        VV_GEMV_WIDE(X)
+#undef X
+        return -3;
+    }
+#define X(P, E)                                                                                         \
+    if (a.pro == P && a.epi == E) {                                                                     \
+        if (xs == 1) hipLaunchKernelGGL((vv_gemv_kernel<1, P, E, 4>), grid, block, 0, s, a);            \
+        else if (xs == 2) hipLaunchKernelGGL((vv_gemv_kernel<2, P, E, 4>), grid, block, 0, s, a);       \
+        else hipLaunchKernelGGL((vv_gemv_kernel<3, P, E, 4>), grid, block, 0, s, a);                    \
         return hipGetLastError() == hipSuccess ? 0 : -2;                                                \
     }
     VV_GEMV_COMBOS(X)
