@@ -174,6 +174,11 @@ def main():
     value = frames_all * FRAME_SEC / wall_max
     audio_total = out.speech_outputs[0].shape[-1] / 24000.0
 
+    if os.environ.get("VVHIP_TIMELINE") and rank == 0:      # timing builds only: tools/step_timeline.py
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import step_timeline
+        step_timeline.dump(eng, os.environ["VVHIP_TIMELINE"])
+
     # ---- roofline of the dominant kernel (vv_gemm_kernel): per-launch hipEvents over K_prof live steps ----
     roof = None
     if rank == 0 and not args.no_roofline:

@@ -159,6 +159,12 @@ struct vv_ctx {
     double prof_bytes = 0.0;
     struct ProfRec { int T, N, K, pro, epi, dual; double bytes; int gemv; };
     std::vector<ProfRec> prof_rec;
+#ifdef VV_GEMM_TIMING
+    // timing builds only (tools/step_timeline.py): every GEMM launch gets a stamp slice for its workgroups' entry/exit clocks
+    unsigned long long* tl_base = nullptr; int tl_idx = 0;
+    struct TlRec { int T, N, K, pro, epi; };
+    std::vector<TlRec> tl_rec;
+#endif
 };
 
 static int fail(vv_ctx* ctx, const char* fmt, ...) {
@@ -360,7 +366,31 @@ static int gemm_prof(vv_ctx* ctx, const VVGemm& g, hipStream_t st) {
     ctx->prof_rec.push_back({g.T, g.N, g.K, g.pro, g.epi, g.W2 ? 1 : 0, gemm_bytes(g), vv_gemv_ok(&g) && (g.T <= 4 || ctx->c.xsplit <= 2)});
     return r;
 }
+#ifdef VV_GEMM_TIMING
+constexpr int TL_MAX = 2048, TL_STRIDE = 16 + 2 * 1536;
+static int gemm_tl(vv_ctx* ctx, VVGemm g, hipStream_t st) {
+    if (!ctx->tl_base && getenv("VVHIP_TIMELINE")) {
+        if (hipMalloc(&ctx->tl_base, (size_t)TL_MAX * TL_STRIDE * 8) != hipSuccess) return -9;
+        hipMemset(ctx->tl_base, 0, (size_t)TL_MAX * TL_STRIDE * 8);
+    }
+    if (ctx->tl_base && ctx->tl_idx < TL_MAX && (g.N + 15) / 16 <= 1536 && g.T <= 4 && vv_gemv_ok(&g)) {
+        g.dbg = ctx->tl_base + (size_t)ctx->tl_idx * TL_STRIDE;
+        ctx->tl_rec.push_back({g.T, g.N, g.K, g.pro, g.epi});
+        ctx->tl_idx++;
+    }
+    return vv_gemm_launch(g, ctx->c.xsplit, st);
+}
+extern "C" int vv_timeline_dump(vv_ctx* ctx, unsigned long long* out_host, int* meta_host, int max_launches) {
+    hipDeviceSynchronize();
+    const int n = std::min(max_launches, ctx->tl_idx);
+    if (n > 0) hipMemcpy(out_host, ctx->tl_base, (size_t)n * TL_STRIDE * 8, hipMemcpyDeviceToHost);
+    for (int i = 0; i < n; ++i) { const auto& r = ctx->tl_rec[i]; int* m = meta_host + 5 * i; m[0] = r.T; m[1] = r.N; m[2] = r.K; m[3] = r.pro; m[4] = r.epi; }
+    return n;
+}
+#define GEMM(g) do { ctx->launches++; VVCHK(gemm_tl(ctx, g, st)); } while (0)
+#else
 #define GEMM(g) do { ctx->launches++; if (ctx->prof_on) VVCHK(gemm_prof(ctx, g, st)); else VVCHK(vv_gemm_launch(g, ctx->c.xsplit, st)); } while (0)
+#endif
 
 // Runs one codec net over F frames for slot `sl`.  The caller has already written the
 // input rows into net.in_buf[sl] + 6*in_dim.

@@ -20,7 +20,10 @@
 
 #ifdef VV_GEMM_TIMING
 #define VV_STAMP(i) do { if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+// per-workgroup wall-clock (100 MHz, chip-wide) entry/exit stamps: the launch's occupancy timeline (tools/gemv_timeline.py)
+#define VV_BSTAMP(i) do { if (a.dbg && threadIdx.x == 0) a.dbg[16 + 2 * blockIdx.x + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
+#define VV_BSTAMP(i) do { } while (0)
 #define VV_STAMP(i) do { } while (0)
 #endif
 
@@ -66,14 +69,16 @@ __device__ __forceinline__ void split4(const float (&v)[4], uint2 (&out)[XS]) {
     if constexpr (XS > 2) out[2] = __builtin_bit_cast(uint2, l);
 }
 
-constexpr int WPB = 8;     // waves per workgroup == K split
 constexpr int U = 8;       // k-steps per batch (256 k = one float4 per lane per row)
 
 // PRO / EPI are compile-time: a launch executes only the code of its own prologue/epilogue (the runtime-
 // switched version spent a third of a small launch fetching and skipping code it never needed).
 // MR = activation rows a launch can carry: 4 for decode steps, 16 for prefill chunks / batched adaLN / the T = 8 codec
 // stage (same weight stream, 4x the staging work and LDS).
-template <int XS, int PRO, int EPI, int MR>
+// WPB = waves per workgroup = K split inside the workgroup.  The launcher picks it so that EVERY workgroup of the launch
+// is resident at once (a second dispatch round costs a full load-latency chain): 4 for wide outputs (> 256 tiles),
+// 16 for few tiles x long K (the streaming rate of a CU is set by its waves' loads in flight), 8 otherwise.
+template <int XS, int PRO, int EPI, int MR, int WPB>
 __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
     constexpr bool DUAL = (EPI == VV_EPI_SWIGLU);
     constexpr int NM = DUAL ? 2 : 1;
@@ -88,6 +93,7 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
     asm volatile("" ::"s"(a.T), "s"(a.N), "s"(a.K), "s"(a.ldx), "s"(a.ldy), "s"(a.ld_mod), "s"(a.ld_gate), "s"(a.x_row_mod), "s"(a.add_rows_per_vec),
                  "s"(a.eps), "s"(a.z), "s"(a.x0p), "s"(a.coef), "s"(a.cfg), "s"(a.n_cfg));
     VV_STAMP(0);
+    VV_BSTAMP(0);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int T = a.T;
@@ -245,13 +251,15 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
         VV_STAMP(2);
         // two batches per trip, ping-ponging the weight buffers: no register copies, so the prefetched batch
         // stays in flight across the MFMAs of the current one
-        if constexpr (DUAL && MR == 16) {
-            // 16 rows x two weight streams: a second weight buffer would spill; run single-buffered (prefill only)
+        if constexpr (DUAL) {
+            // two weight streams: a second weight buffer costs 64 VGPRs and halves the resident workgroups per CU
+            // (1 instead of 2); run single-buffered and let the other resident waves cover the load latency
 #pragma unroll 1
             for (unsigned ktb = kt0; ktb < kt1; ktb += U) {
                 const bool n1 = ktb + U < kt1;
+                if (n1) x_load(ktb + U, R);
                 mma(ktb, wA);
-                if (n1) { x_load(ktb + U, R); w_load(ktb + U, wA); x_stage(ktb + U, R); }
+                if (n1) { w_load(ktb + U, wA); x_stage(ktb + U, R); }
             }
         } else
 #pragma unroll 1
@@ -337,6 +345,7 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
     float* yp = a.Y + (unsigned)(frow * a.ldy + n0);
     *reinterpret_cast<float4*>(yp) = float4{o[0], o[1], o[2], o[3]};
     VV_STAMP(6);
+    VV_BSTAMP(1);
 }
 
 }  // namespace
@@ -381,30 +390,45 @@ static bool gemv_combo_ok(int pro, int epi, bool wide) {
     return false;
 }
 
+// pairs with a 4-wave form (wide outputs) and a 16-wave form (few tiles, long K); bench mode (xs == 1) only
+#define VV_GEMV_W4(X)                                                                          \
+    X(VV_PRO_RMS, VV_EPI_SWIGLU) X(VV_PRO_RMS_MOD, VV_EPI_SWIGLU) X(VV_PRO_RMS, VV_EPI_BIAS_GELU) \
+    X(VV_PRO_RMS, VV_EPI_BIAS) X(VV_PRO_NONE, VV_EPI_STORE) X(VV_PRO_NONE, VV_EPI_BIAS) X(VV_PRO_ADD_SILU, VV_EPI_STORE)
+#define VV_GEMV_W16(X)                                                                         \
+    X(VV_PRO_NONE, VV_EPI_RESID) X(VV_PRO_NONE, VV_EPI_GATED_RESID) X(VV_PRO_NONE, VV_EPI_BIAS) X(VV_PRO_NONE, VV_EPI_STORE)
+
 extern "C" int vv_gemv_launch(VVGemm a, int xs, hipStream_t s) {
-    const int n_tiles = (a.N + 15) / 16;
+    const int n_tiles = (a.N + 15) / 16, k_tiles = (a.K + 31) / 32;
     if (a.epi == VV_EPI_SWIGLU && !a.W2) return -1;
-    dim3 grid(n_tiles), block(WPB * 64);
+    dim3 grid(n_tiles);
+#define VV_GO(XS_, P, E, MR_, WP_)                                                                      \
+    do { hipLaunchKernelGGL((vv_gemv_kernel<XS_, P, E, MR_, WP_>), grid, dim3(WP_ * 64), 0, s, a);       \
+         return hipGetLastError() == hipSuccess ? 0 : -2; } while (0)
     if (a.T > 4) {
         if (xs > 2) return -3;       // 16-row staging tiles of the exact mode exceed the LDS: general kernel
-#define X(P, E)                                                                                         \
-    if (a.pro == P && a.epi == E) {                                                                     \
-        if (xs == 1) hipLaunchKernelGGL((vv_gemv_kernel<1, P, E, 16>), grid, block, 0, s, a);           \
-        else hipLaunchKernelGGL((vv_gemv_kernel<2, P, E, 16>), grid, block, 0, s, a);                   \
-        return hipGetLastError() == hipSuccess ? 0 : -2;                                                \
-    }
+#define X(P, E) if (a.pro == P && a.epi == E) { if (xs == 1) VV_GO(1, P, E, 16, 8); else VV_GO(2, P, E, 16, 8); }
         VV_GEMV_WIDE(X)
 #undef X
         return -3;
     }
+    static const bool wpb8_only = getenv("VVHIP_GEMV_WPB8") != nullptr;      // A/B switch
+    if (xs == 1 && !wpb8_only) {
+        if (n_tiles > 256) {
+#define X(P, E) if (a.pro == P && a.epi == E) VV_GO(1, P, E, 4, 4);
+            VV_GEMV_W4(X)
+#undef X
+        } else if (n_tiles <= 128 && k_tiles >= 96) {
+#define X(P, E) if (a.pro == P && a.epi == E) VV_GO(1, P, E, 4, 16);
+            VV_GEMV_W16(X)
+#undef X
+        }
+    }
 #define X(P, E)                                                                                         \
     if (a.pro == P && a.epi == E) {                                                                     \
-        if (xs == 1) hipLaunchKernelGGL((vv_gemv_kernel<1, P, E, 4>), grid, block, 0, s, a);            \
-        else if (xs == 2) hipLaunchKernelGGL((vv_gemv_kernel<2, P, E, 4>), grid, block, 0, s, a);       \
-        else hipLaunchKernelGGL((vv_gemv_kernel<3, P, E, 4>), grid, block, 0, s, a);                    \
-        return hipGetLastError() == hipSuccess ? 0 : -2;                                                \
+        if (xs == 1) VV_GO(1, P, E, 4, 8); else if (xs == 2) VV_GO(2, P, E, 4, 8); else VV_GO(3, P, E, 4, 8); \
     }
     VV_GEMV_COMBOS(X)
 #undef X
+#undef VV_GO
     return -3;
 }
