@@ -10,7 +10,7 @@ import sys
 
 import numpy as np
 
-TL_MAX, TL_STRIDE = 2048, 16 + 2 * 1536
+TL_MAX, TL_STRIDE = 4096, 16 + 2 * 3200
 
 
 def dump(eng, path):

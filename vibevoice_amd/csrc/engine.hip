@@ -35,6 +35,7 @@ int vv_affine_launch(const float* x, float* y, float mul, float add, int n, hipS
 int vv_add_launch(const float* a, const float* b, float* y, int n, hipStream_t s);
 int vv_tfreq_launch(const float* t, float* out, int n, hipStream_t s);
 int vv_silu_launch(float* x, int n, hipStream_t s);
+int vv_ada_in_launch(const float* cproj, const float* temb, float* out, int rows, int n_steps, int H, hipStream_t s);
 int vv_add_rows_launch(const float* x, const float* v, float* y, int n, int C, hipStream_t s);
 int vv_relu_launch(float* x, int n, hipStream_t s);
 int vv_kv_import_launch(const void* k, const void* v, int src_bf16, void* kc, void* vc, int L, int Hkv, int D, int64_t head_stride, hipStream_t s);
@@ -139,6 +140,7 @@ struct vv_ctx {
     int n_steps = 0;
     float *temb = nullptr, *coef = nullptr, *tvals = nullptr;
     float* mod_all = nullptr; size_t mod_all_bytes = 0;
+    float* ada_in = nullptr;
     float *cproj = nullptr, *mod = nullptr, *zz = nullptr, *x0p = nullptr, *xh = nullptr, *hact = nullptr, *eps = nullptr;
     float *tmp1 = nullptr, *tmp2 = nullptr;
     // connectors
@@ -367,13 +369,13 @@ static int gemm_prof(vv_ctx* ctx, const VVGemm& g, hipStream_t st) {
     return r;
 }
 #ifdef VV_GEMM_TIMING
-constexpr int TL_MAX = 2048, TL_STRIDE = 16 + 2 * 1536;
+constexpr int TL_MAX = 4096, TL_STRIDE = 16 + 2 * 3200;
 static int gemm_tl(vv_ctx* ctx, VVGemm g, hipStream_t st) {
     if (!ctx->tl_base && getenv("VVHIP_TIMELINE")) {
         if (hipMalloc(&ctx->tl_base, (size_t)TL_MAX * TL_STRIDE * 8) != hipSuccess) return -9;
         hipMemset(ctx->tl_base, 0, (size_t)TL_MAX * TL_STRIDE * 8);
     }
-    if (ctx->tl_base && ctx->tl_idx < TL_MAX && (g.N + 15) / 16 <= 1536 && g.T <= 4 && vv_gemv_ok(&g)) {
+    if (ctx->tl_base && ctx->tl_idx < TL_MAX && (g.N + 15) / 16 <= 3200 && g.T <= 16 && vv_gemv_ok(&g)) {
         g.dbg = ctx->tl_base + (size_t)ctx->tl_idx * TL_STRIDE;
         ctx->tl_rec.push_back({g.T, g.N, g.K, g.pro, g.epi});
         ctx->tl_idx++;
@@ -743,8 +745,10 @@ extern "C" int vv_set_schedule(vv_ctx* ctx, int n_steps, const float* t, const f
         const size_t need = (size_t)n_steps * 16 * ctx->MODW * 4;
         if (need > ctx->mod_all_bytes) {
             if (ctx->mod_all) hipFree(ctx->mod_all);
+            if (ctx->ada_in) hipFree(ctx->ada_in);
             ctx->mod_all = (float*)dalloc(ctx, need, false);
-            ctx->mod_all_bytes = ctx->mod_all ? need : 0;
+            ctx->ada_in = (float*)dalloc(ctx, (size_t)n_steps * 16 * ctx->H * 4, false);
+            ctx->mod_all_bytes = (ctx->mod_all && ctx->ada_in) ? need : 0;
         }
     }
     for (auto it = ctx->graphs.begin(); it != ctx->graphs.end();) {
@@ -911,14 +915,16 @@ static int sample_body(vv_ctx* ctx, hipStream_t st, int n, const float* cond, co
     // up front, <=16 rows per GEMM, so the (3*layers+2)*H x H modulation matrix is streamed ceil(2nN/16) times per
     // frame instead of N times (the reference recomputes it inside every head call)
     const int MODW = ctx->MODW;
-    const bool batch_ada = ctx->mod_all != nullptr && !getenv("VVHIP_NO_ADA_BATCH");
+    const bool batch_ada = ctx->mod_all_bytes != 0 && !getenv("VVHIP_NO_ADA_BATCH");
     if (batch_ada) {
+        // SiLU(cond + t) for all (step, row) pairs in one small launch: the GEMM workgroups (one per 16 output features,
+        // > 1000 of them) then stage plain rows instead of each re-evaluating 16 x H SiLUs
         const int total = rows * ctx->n_steps;
-        const int per = (16 / rows) * rows;                 // whole steps per launch
-        for (int t0 = 0; t0 < total; t0 += per) {
-            const int T = std::min(per, total - t0);
-            VVGemm ga = mk_gemm(ctx->h_ada, ctx->cproj, ctx->mod_all + (size_t)t0 * MODW, T, MODW, H, H, MODW);
-            ga.pro = VV_PRO_ADD_SILU; ga.addvec = ctx->temb + (size_t)(t0 / rows) * H; ga.x_row_mod = rows; ga.add_rows_per_vec = rows;
+        VVCHK(vv_ada_in_launch(ctx->cproj, ctx->temb, ctx->ada_in, rows, ctx->n_steps, H, st));
+        ctx->launches++;
+        for (int t0 = 0; t0 < total; t0 += 16) {
+            const int T = std::min(16, total - t0);
+            VVGemm ga = mk_gemm(ctx->h_ada, ctx->ada_in + (size_t)t0 * H, ctx->mod_all + (size_t)t0 * MODW, T, MODW, H, H, MODW);
             GEMM(ga);
         }
     }

@@ -406,6 +406,7 @@ extern "C" int vv_gemv_launch(VVGemm a, int xs, hipStream_t s) {
          return hipGetLastError() == hipSuccess ? 0 : -2; } while (0)
     if (a.T > 4) {
         if (xs > 2) return -3;       // 16-row staging tiles of the exact mode exceed the LDS: general kernel
+        if (xs == 1 && n_tiles > 256 && a.pro == VV_PRO_NONE && a.epi == VV_EPI_STORE) VV_GO(1, VV_PRO_NONE, VV_EPI_STORE, 16, 4);   // batched adaLN
 #define X(P, E) if (a.pro == P && a.epi == E) { if (xs == 1) VV_GO(1, P, E, 16, 8); else VV_GO(2, P, E, 16, 8); }
         VV_GEMV_WIDE(X)
 #undef X

@@ -207,6 +207,25 @@ __global__ void vv_kv_import_kernel(const ST* __restrict__ k, const ST* __restri
     }
 }
 
+// adaLN input rows for every solver step at once: out[i*rows + r] = SiLU(cond_proj[r] + t_emb[i])  (float4 lanes)
+__global__ void vv_ada_in_kernel(const float* __restrict__ cproj, const float* __restrict__ temb, float* __restrict__ out,
+                                 int rows, int n_steps, int H) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;          // float4 index
+    const int H4 = H >> 2;
+    if (q >= rows * n_steps * H4) return;
+    const int t = q / H4, k4 = q - t * H4;
+    const int i = t / rows, r = t - i * rows;
+    const float4 c = reinterpret_cast<const float4*>(cproj)[r * H4 + k4];
+    const float4 e = reinterpret_cast<const float4*>(temb)[i * H4 + k4];
+    float4 o;
+    float u;
+    u = c.x + e.x; o.x = u / (1.0f + expf(-u));
+    u = c.y + e.y; o.y = u / (1.0f + expf(-u));
+    u = c.z + e.z; o.z = u / (1.0f + expf(-u));
+    u = c.w + e.w; o.w = u / (1.0f + expf(-u));
+    reinterpret_cast<float4*>(out)[q] = o;
+}
+
 __global__ void vv_silu_kernel(float* __restrict__ x, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { float u = x[i]; x[i] = u / (1.f + expf(-u)); }
@@ -292,6 +311,12 @@ int vv_kv_import_launch(const void* k, const void* v, int src_bf16, void* kc, vo
     if (src_bf16) hipLaunchKernelGGL((vv_kv_import_kernel<__bf16>), dim3(L, Hkv), dim3(D), 0, s, (const __bf16*)k, (const __bf16*)v, (__bf16*)kc, (__bf16*)vc, L, D, head_stride);
     else hipLaunchKernelGGL((vv_kv_import_kernel<float>), dim3(L, Hkv), dim3(D), 0, s, (const float*)k, (const float*)v, (__bf16*)kc, (__bf16*)vc, L, D, head_stride);
     return okk();
+}
+int vv_ada_in_launch(const float* cproj, const float* temb, float* out, int rows, int n_steps, int H, hipStream_t s) {
+    if (H & 3) return -1;
+    const int n4 = rows * n_steps * (H >> 2);
+    hipLaunchKernelGGL(vv_ada_in_kernel, dim3((n4 + 255) / 256), dim3(256), 0, s, cproj, temb, out, rows, n_steps, H);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 int vv_silu_launch(float* x, int n, hipStream_t s) {
     hipLaunchKernelGGL(vv_silu_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, n);
