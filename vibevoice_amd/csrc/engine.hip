@@ -130,6 +130,10 @@ struct vv_ctx {
     int64_t cache_stride = 0, head_stride = 0, layer_stride = 0;
     VVRow* rows_dev = nullptr; VVRow* rows_pin = nullptr;
     int* ids_dev = nullptr; int* ids_pin = nullptr;
+    // pinned staging is a ring (slot reuse waits on that slot's own copy event, long since complete): a step's
+    // launches can be enqueued while the previous step is still running, no host-side stream sync
+    static constexpr int RING = 32;
+    hipEvent_t ring_ev[RING] = {}; bool ring_used[RING] = {}; int ring_i = 0;
     float *h = nullptr, *qkv = nullptr, *qrot = nullptr, *attn = nullptr, *act = nullptr;
     float *pm = nullptr, *pl = nullptr, *po = nullptr;
     // head
@@ -179,6 +183,14 @@ static int fail(vv_ctx* ctx, const char* fmt, ...) {
 }
 #define HIPCHK(ctx, e) do { hipError_t _e = (e); if (_e != hipSuccess) return fail(ctx, "%s:%d hip error %s", __FILE__, __LINE__, hipGetErrorString(_e)); } while (0)
 #define VVCHK(e) do { int _r = (e); if (_r != 0) return _r < 0 ? fail(ctx, "%s:%d launch failed (%d): %s", __FILE__, __LINE__, _r, hipGetErrorString(hipGetLastError())) : _r; } while (0)
+
+static int ring_acquire(vv_ctx* ctx) {
+    const int slot = ctx->ring_i;
+    ctx->ring_i = (ctx->ring_i + 1) % vv_ctx::RING;
+    if (ctx->ring_used[slot]) hipEventSynchronize(ctx->ring_ev[slot]);
+    ctx->ring_used[slot] = true;
+    return slot;
+}
 
 static void* dalloc(vv_ctx* ctx, size_t bytes, bool zero = true) {
     void* p = nullptr;
@@ -375,7 +387,7 @@ static int gemm_tl(vv_ctx* ctx, VVGemm g, hipStream_t st) {
         if (hipMalloc(&ctx->tl_base, (size_t)TL_MAX * TL_STRIDE * 8) != hipSuccess) return -9;
         hipMemset(ctx->tl_base, 0, (size_t)TL_MAX * TL_STRIDE * 8);
     }
-    if (ctx->tl_base && ctx->tl_idx < TL_MAX && (g.N + 15) / 16 <= 3200 && g.T <= 16 && vv_gemv_ok(&g)) {
+    if (ctx->tl_base && ctx->tl_idx < TL_MAX && (g.N + 15) / 16 <= 3200 && (g.T <= 4 || g.N > 16384) && vv_gemv_ok(&g)) {
         g.dbg = ctx->tl_base + (size_t)ctx->tl_idx * TL_STRIDE;
         ctx->tl_rec.push_back({g.T, g.N, g.K, g.pro, g.epi});
         ctx->tl_idx++;
@@ -548,9 +560,10 @@ extern "C" int vv_create(const vv_config* cfg, vv_ctx** out) {
     ctx->kc = dalloc(ctx, (size_t)ctx->cache_stride * n_caches * 2);
     ctx->vc = dalloc(ctx, (size_t)ctx->cache_stride * n_caches * 2);
     ctx->rows_dev = (VVRow*)dalloc(ctx, sizeof(VVRow) * 16);
-    hipHostMalloc((void**)&ctx->rows_pin, sizeof(VVRow) * 16);
+    hipHostMalloc((void**)&ctx->rows_pin, sizeof(VVRow) * 16 * vv_ctx::RING);
+    for (int i = 0; i < vv_ctx::RING; ++i) hipEventCreateWithFlags(&ctx->ring_ev[i], hipEventDisableTiming);
     ctx->ids_dev = (int*)dalloc(ctx, sizeof(int) * 64);
-    hipHostMalloc((void**)&ctx->ids_pin, sizeof(int) * 64);
+    hipHostMalloc((void**)&ctx->ids_pin, sizeof(int) * 64 * vv_ctx::RING);
     ctx->h = (float*)dalloc(ctx, (size_t)R * H * 4);
     ctx->qkv = (float*)dalloc(ctx, (size_t)R * QKV * 4);
     ctx->qrot = (float*)dalloc(ctx, (size_t)R * Hq * D * 4);
@@ -617,6 +630,7 @@ extern "C" void vv_destroy(vv_ctx* ctx) {
     if (ctx->lm_head_loaded) hipFree(ctx->lm_head);
     if (ctx->stage) hipFree(ctx->stage);
     hipHostFree(ctx->rows_pin); hipHostFree(ctx->ids_pin);
+    for (int i = 0; i < vv_ctx::RING; ++i) if (ctx->ring_ev[i]) hipEventDestroy(ctx->ring_ev[i]);
     delete ctx;
 }
 
@@ -806,10 +820,11 @@ extern "C" int vv_lm_forward_range(vv_ctx* ctx, void* stream, int n_rows, const 
         if (rows[i].cache < 0 || rows[i].cache >= 2 * ctx->c.n_slots) return fail(ctx, "row %d: cache id %d out of range", i, rows[i].cache);
         if (rows[i].pos < 0 || rows[i].pos >= ctx->c.max_ctx) return fail(ctx, "row %d: position %d exceeds max_ctx %d", i, rows[i].pos, ctx->c.max_ctx);
     }
-    // the pinned staging row table is reused: make sure the previous copy has been consumed
-    HIPCHK(ctx, hipStreamSynchronize(st));
-    for (int i = 0; i < n_rows; ++i) { ctx->rows_pin[i].cache = rows[i].cache; ctx->rows_pin[i].pos = rows[i].pos; }
-    HIPCHK(ctx, hipMemcpyAsync(ctx->rows_dev, ctx->rows_pin, sizeof(VVRow) * n_rows, hipMemcpyHostToDevice, st));
+    const int slot = ring_acquire(ctx);
+    VVRow* pin = ctx->rows_pin + (size_t)slot * 16;
+    for (int i = 0; i < n_rows; ++i) { pin[i].cache = rows[i].cache; pin[i].pos = rows[i].pos; }
+    HIPCHK(ctx, hipMemcpyAsync(ctx->rows_dev, pin, sizeof(VVRow) * n_rows, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipEventRecord(ctx->ring_ev[slot], st));
     ctx->launches = 0;
     char key[128]; snprintf(key, 128, "lm:%d:%p:%p:%d:%d:%d", n_rows, (const void*)x_in_dev, (void*)hidden_out_dev, l0, l1, final_norm);
     return graphed(ctx, key, st, [&]() { return lm_body(ctx, st, n_rows, x_in_dev, hidden_out_dev, l0, l1, final_norm); });
@@ -851,9 +866,11 @@ extern "C" int vv_embed(vv_ctx* ctx, void* stream, int n, const int* ids, float*
     hipStream_t st = (hipStream_t)stream;
     if (n < 1 || n > 64) return fail(ctx, "vv_embed: n must be in [1,64]");
     for (int i = 0; i < n; ++i) if (ids[i] < 0 || ids[i] >= ctx->c.lm_vocab) return fail(ctx, "token id %d out of range", ids[i]);
-    HIPCHK(ctx, hipStreamSynchronize(st));
-    memcpy(ctx->ids_pin, ids, sizeof(int) * n);
-    HIPCHK(ctx, hipMemcpyAsync(ctx->ids_dev, ctx->ids_pin, sizeof(int) * n, hipMemcpyHostToDevice, st));
+    const int slot = ring_acquire(ctx);
+    int* pin = ctx->ids_pin + (size_t)slot * 64;
+    memcpy(pin, ids, sizeof(int) * n);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->ids_dev, pin, sizeof(int) * n, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipEventRecord(ctx->ring_ev[slot], st));
     VVCHK(vv_embed_launch(ctx->embed, ctx->ids_dev, out_dev, n, ctx->H, st));
     return 0;
 }

@@ -111,6 +111,12 @@ class VibeVoiceForConditionalGenerationInference:
         self._emb_out = e.new(8, H)
         self._start_emb = e.new(1, H)
         self._neg_hidden = e.new(8, H)
+        # pinned host staging: the logits come back without a blocking copy, noise goes out without one
+        self._logits_pin = torch.empty(R, 16, dtype=torch.float32).pin_memory()
+        self._noise_pin = [torch.empty(8, engine.cfg.latent_dim, dtype=torch.float32).pin_memory() for _ in range(4)]
+        self._noise_i = 0
+        self._lg_event = torch.cuda.Event()
+        self.speculate_sampling = os.environ.get("VVHIP_NO_SPEC") is None
         self.last_stats = {}
 
     # ------------------------------------------------------------------ construction
@@ -176,6 +182,16 @@ class VibeVoiceForConditionalGenerationInference:
     def _embed_ids(self, ids: List[int], out: torch.Tensor):
         for i0 in range(0, len(ids), 64):
             self.engine.embed(ids[i0:i0 + 64], out[i0:])
+
+    def _stage_noise(self, nz, n):
+        """noise rows -> device without blocking the host (pageable H2D copies are synchronous with the stream)"""
+        if nz.is_cuda:
+            self._noise[:n].copy_(nz[:n].to(torch.float32))
+            return
+        pin = self._noise_pin[self._noise_i]
+        self._noise_i = (self._noise_i + 1) % len(self._noise_pin)
+        pin[:n].copy_(nz[:n])
+        self._noise[:n].copy_(pin[:n], non_blocking=True)
 
     def _process_speech_inputs(self, speech_tensors, speech_masks, prefill_noise=None):
         """_process_speech_inputs (:149-163): encode voice prompts, sample, scale, connect."""
@@ -337,7 +353,27 @@ class VibeVoiceForConditionalGenerationInference:
                     for b in act:
                         pos_len[b] += 1
                 e.lm_logits(nA, self._hidden, self._logits)
-                logits = self._logits[:nA, :nv].float().cpu()          # syncs the stream
+                self._logits_pin.copy_(self._logits, non_blocking=True)      # whole (contiguous) buffer: a true async D2H
+                self._lg_event.record(e.stream)
+                # ---- speculative sampling: a row that has just emitted <speech_diffusion>/<speech_start> almost always
+                # emits <speech_diffusion> next.  The sampler (stateless: cond + noise -> latent) is enqueued behind the LM
+                # pass BEFORE the host waits for the logits, so the token decision below overlaps GPU work instead of
+                # leaving the GPU idle; if the guess is wrong the latent is discarded and the RNG state restored.
+                spec_sample, rng_state = False, None
+                if (spec and self.speculate_sampling and step > 0
+                        and not (do_sample and noise_fn is None and forced_tokens is None)   # keep the reference's RNG draw order
+                        and all(int(seq[b, -1]) in (diff_id, start_id) for b in act)):
+                    if noise_fn is not None:
+                        nz = noise_fn(step, 2 * nA)
+                    else:
+                        rng_state = torch.get_rng_state()
+                        nz = torch.randn(2 * nA, e.cfg.latent_dim)
+                    self._stage_noise(nz, nA)
+                    # all active rows diffusing, in order: cond rows == [hidden[:nA]; hidden[nA:2nA]]
+                    e.diffusion_sample(nA, self._hidden, self._noise, cfg_scale, self._latent)
+                    spec_sample = True
+                self._lg_event.synchronize()
+                logits = self._logits_pin[:nA, :nv].clone()
                 if trace is not None:
                     trace.pos_hidden.append(self._hidden[:nA].cpu())
                 # ---------------- token selection (:488-501) ----------------
@@ -388,7 +424,16 @@ class VibeVoiceForConditionalGenerationInference:
                     self._embed_ids([int(nxt[b]) for b in plain], tmp)
                     for i, b in enumerate(plain):
                         nxt_x[live.index(b)].copy_(tmp[i])
-                if diff:
+                if spec_sample and diff != act:
+                    spec_sample = False                                  # wrong guess: drop the latent, undo the draw
+                    if rng_state is not None:
+                        torch.set_rng_state(rng_state)
+                cond_used = self._hidden if spec_sample else self._cond
+                if diff and spec_sample:
+                    n = len(diff)
+                    for b in diff:
+                        neg_len[b] += 1
+                elif diff:
                     n = len(diff)
                     # ---- negative condition ----
                     for j, b in enumerate(diff):
@@ -408,8 +453,9 @@ class VibeVoiceForConditionalGenerationInference:
                         nz = noise_fn(step, 2 * n)
                     else:
                         nz = torch.randn(2 * n, e.cfg.latent_dim)      # CPU global RNG, as the reference (:701)
-                    self._noise[:n].copy_(nz[:n].to(torch.float32), non_blocking=False)
+                    self._stage_noise(nz, n)
                     e.diffusion_sample(n, self._cond, self._noise, cfg_scale, self._latent)
+                if diff:
                     # ---- codec decode, semantic encode, connectors (:636-672) ----
                     for j, b in enumerate(diff):
                         e.codec_decode(b, self._latent[j:j + 1], self._audio[j])
@@ -424,7 +470,7 @@ class VibeVoiceForConditionalGenerationInference:
                         audio_streamer.put(chunk[:, None, :].to(self.dtype), torch.tensor(diff))
                     n_frames += n
                     if trace is not None:
-                        trace.neg_hidden.append(self._cond[n:2 * n].cpu())
+                        trace.neg_hidden.append(cond_used[n:2 * n].cpu())
                         trace.latents.append(self._latent[:n].cpu())
                         trace.semantic.append(self._sem[:n].cpu())
                 if live:
