@@ -65,6 +65,44 @@ def test_gemm_transpose_detecting(sm):
     assert max_err(y, x) < 1e-6
 
 
+@pytest.mark.parametrize("T", [8, 40, 203])
+@pytest.mark.parametrize("pro,epi", [(1, 1), (1, 2), (0, 4), (1, 3), (0, 0), (0, 1)])
+@pytest.mark.parametrize("xs,tol", [(2, 2e-4), (1, 2e-2)])
+def test_gemm_fused_tall(sm, T, pro, epi, xs, tol):
+    """16-row GEMV form walking row tiles (grid.y): tokenizer stages / prefill chunks in bench and bf16-split modes"""
+    eng = sm.eng
+    N, K = 1040, 160          # 65 tiles x 13 row tiles > 512 workgroups at T = 203: also exercises the 4-wave form
+    g = synth.Gen(177 + pro * 10 + epi + T)
+    w = g.normal((N, K), 1.0 / np.sqrt(K))
+    w2 = g.normal((N, K), 1.0 / np.sqrt(K))
+    x = g.normal((T, K), 1.0, mat=False)
+    nw = g.vec(K, 0.1, 1.0)
+    bias = g.vec(N, 0.3)
+    nscale = g.uniform((N,), 0.5, 1.5)
+    y0 = g.normal((T, N), 1.0, mat=False)
+    xin = x
+    if pro == 1:
+        xin = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-5) * nw
+    acc = xin @ w.t()
+    if epi == 1:
+        ref = acc + bias
+    elif epi == 2:
+        ref = torch.nn.functional.gelu(acc + bias)
+    elif epi == 3:
+        ref = torch.nn.functional.silu(acc) * (xin @ w2.t())
+    elif epi == 4:
+        ref = y0 + nscale * (acc + bias)
+    else:
+        ref = acc
+    y = dev(y0.clone(), eng)
+    with torch.cuda.stream(eng.stream):
+        eng.gemm_raw(eng.pack_matrix(w), dev(x, eng), y, N, K, pro=pro, epi=epi,
+                     w2p=eng.pack_matrix(w2) if epi == 3 else None, nw=dev(nw, eng), eps=1e-5,
+                     bias=dev(bias, eng), nscale=dev(nscale, eng), xsplit=xs)
+    eng.sync()
+    assert rel_err(y, ref) <= tol, rel_err(y, ref)
+
+
 @pytest.mark.parametrize("pro,epi", [(1, 1), (1, 2), (0, 4), (1, 3), (0, 0)])
 def test_gemm_fused(sm, pro, epi):
     eng = sm.eng

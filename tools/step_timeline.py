@@ -30,24 +30,24 @@ def main(path):
     rows = []
     for i in range(len(meta)):
         T, N, K, pro, epi = meta[i]
-        nt = (N + 15) // 16
-        d = st[i, 16:16 + 2 * nt].reshape(nt, 2)
-        if d[:, 0].min() == 0:
+        d = st[i, 16:].reshape(-1, 2)
+        d = d[d[:, 0] > 0]                                # workgroups that stamped (the general kernel has 2-D grids)
+        if len(d) == 0:
             continue
         d[:, 1] = np.maximum(d[:, 1], d[:, 0])       # the CFG+DPM epilogue returns before its exit stamp
-        rows.append((d[:, 0].min(), d[:, 1].max(), d[:, 0].max(), np.median(d[:, 1] - d[:, 0]), i, T, N, K, pro, epi))
+        rows.append((d[:, 0].min(), d[:, 1].max(), d[:, 0].max(), np.median(d[:, 1] - d[:, 0]), len(d), T, N, K, pro, epi))
     rows.sort()
     tmax = rows[-1][1]
     rows = [r for r in rows if r[0] > tmax - 450000]      # last ~4.5 ms (100 MHz clock)
     t0 = rows[0][0]
     prev_end = None
     tot_span = tot_gap = 0.0
-    print(" t_start  span   gap_prev  last_blk_start  blk_life_p50   T     N     K pro epi   MB    TB/s(span)")
+    print(" t_start  span   gap_prev  last_blk_start  blk_life_p50  blks    T     N     K pro epi(+100: general kernel)   MB    TB/s(span)")
     for (a, b, c, life, i, T, N, K, pro, epi) in rows:
         span = (b - a) * 0.01
         gap = (a - prev_end) * 0.01 if prev_end is not None else 0.0
         mb = N * K * 2 * (2 if epi == 3 else 1) / 1e6
-        print(f"{(a-t0)*0.01:8.2f} {span:6.2f} {gap:8.2f} {(c-a)*0.01:10.2f} {life*0.01:12.2f}   {T:3d} {N:5d} {K:5d} {pro:3d} {epi:3d} {mb:6.1f} {mb/span:8.2f}")
+        print(f"{(a-t0)*0.01:8.2f} {span:6.2f} {gap:8.2f} {(c-a)*0.01:10.2f} {life*0.01:12.2f} {i:5d}  {T:4d} {N:5d} {K:5d} {pro:3d} {epi:3d} {mb:6.1f} {mb/span:8.2f}")
         tot_span += span
         tot_gap += max(gap, 0.0)
         prev_end = b

@@ -59,65 +59,140 @@ __global__ __launch_bounds__(256) void vv_block1d_kernel(const VVBlock a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int t0 = blockIdx.x * TT;
+    // The packed weights do not depend on x: every fragment this wave will feed to the MFMA pipe is requested NOW
+    // (FFN1: NT1/4 tiles x KT1, FFN2: NT2/4 tiles x KT2 -- at most 32 + 32 fragments for C = 128), so the L2 round
+    // trips overlap the norm / conv phases instead of forming a chain of dependent loads inside the GEMM loops.
+    constexpr int M1 = (NT1 + 3) / 4, M2 = (NT2 + 3) / 4;
+    u32x4 w1r[M1][KT1], w2r[M2][KT2];
+#pragma unroll
+    for (int i = 0; i < M1; ++i) {
+        const int nt = wave + 4 * i;
+#pragma unroll
+        for (int kt = 0; kt < KT1; ++kt)
+            w1r[i][kt] = (nt < NT1) ? a.w1[((int64_t)nt * KT1 + kt) * 64 + lane] : u32x4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int i = 0; i < M2; ++i) {
+        const int nt = wave + 4 * i;
+#pragma unroll
+        for (int kt = 0; kt < KT2; ++kt)
+            w2r[i][kt] = (nt < NT2) ? a.w2[((int64_t)nt * KT2 + kt) * 64 + lane] : u32x4{0u, 0u, 0u, 0u};
+    }
 
-    // ---- A: RMSNorm of rows t0-6 .. t0+15 (history rows come from the streaming state) ----
-    for (int rr = wave; rr < TT + HALO; rr += 4) {
+    // per-channel parameters, requested up front as well (C divides 256: a thread's conv channel is fixed)
+    constexpr int CL = (C + 63) / 64;
+    float nw_r[CL], fnw_r[CL];
+#pragma unroll
+    for (int i = 0; i < CL; ++i) {
+        const int c = lane + i * 64;
+        nw_r[i] = (c < C) ? a.norm_w[c] : 0.f;
+        fnw_r[i] = (c < C) ? a.ffn_norm_w[c] : 0.f;
+    }
+    const int cc = tid % C;
+    float dw_r[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) dw_r[j] = a.dw_w[j * C + cc];
+    const float dwb_r = a.dw_b[cc], gam_r = a.gamma[cc];
+    const int frow = lane & 15, fq = lane >> 4;
+    float4 b1_r[M1], b2_r[M2], fg_r[M2];
+#pragma unroll
+    for (int i = 0; i < M1; ++i) {
+        const int nt = wave + 4 * i;
+        b1_r[i] = (nt < NT1) ? *reinterpret_cast<const float4*>(a.b1 + nt * 16 + fq * 4) : float4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < M2; ++i) {
+        const int nt = wave + 4 * i;
+        b2_r[i] = (nt < NT2) ? *reinterpret_cast<const float4*>(a.b2 + nt * 16 + fq * 4) : float4{0.f, 0.f, 0.f, 0.f};
+        fg_r[i] = (nt < NT2) ? *reinterpret_cast<const float4*>(a.ffn_gamma + nt * 16 + fq * 4) : float4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    // ---- A: RMSNorm of rows t0-6 .. t0+15 (history rows come from the streaming state); all row loads first ----
+    constexpr int RW = (TT + HALO + 3) / 4;
+    float xv[RW][CL];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+        const int rr = wave + 4 * i;
+        const int t = t0 - HALO + rr;
+#pragma unroll
+        for (int q = 0; q < CL; ++q) {
+            const int c = lane + q * 64;
+            float v = 0.f;
+            if (rr < TT + HALO && c < C) {
+                if (t < 0) v = a.nst[(HALO + t) * C + c];
+                else if (t < a.T) v = a.xin[(int64_t)t * C + c];
+            }
+            xv[i][q] = v;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+        const int rr = wave + 4 * i;
+        if (rr >= TT + HALO) break;
         const int t = t0 - HALO + rr;
         if (t < 0) {
-            for (int c = lane; c < C; c += 64) nrm[rr * C + c] = a.nst[(HALO + t) * C + c];
+#pragma unroll
+            for (int q = 0; q < CL; ++q) { const int c = lane + q * 64; if (c < C) nrm[rr * C + c] = xv[i][q]; }
         } else if (t < a.T) {
-            float v[(C + 63) / 64];
             float s = 0.f;
 #pragma unroll
-            for (int i = 0; i < (C + 63) / 64; ++i) {
-                const int c = lane + i * 64;
-                v[i] = (c < C) ? a.xin[(int64_t)t * C + c] : 0.f;
-                s += v[i] * v[i];
-            }
+            for (int q = 0; q < CL; ++q) s += xv[i][q] * xv[i][q];
             const float r = rsqrtf(wsum(s) / (float)C + a.eps);
 #pragma unroll
-            for (int i = 0; i < (C + 63) / 64; ++i) {
-                const int c = lane + i * 64;
+            for (int q = 0; q < CL; ++q) {
+                const int c = lane + q * 64;
                 if (c < C) {
-                    const float n = v[i] * r * a.norm_w[c];
+                    const float n = xv[i][q] * r * nw_r[q];
                     nrm[rr * C + c] = n;
-                    if (rr >= HALO) xs[(rr - HALO) * C + c] = v[i];
+                    if (rr >= HALO) xs[(rr - HALO) * C + c] = xv[i][q];
                     if (t >= a.T - HALO) a.nst[(HALO + t - (a.T - HALO)) * C + c] = n;     // next frame's history
                 }
             }
         } else {
-            for (int c = lane; c < C; c += 64) { nrm[rr * C + c] = 0.f; if (rr >= HALO) xs[(rr - HALO) * C + c] = 0.f; }
+#pragma unroll
+            for (int q = 0; q < CL; ++q) {
+                const int c = lane + q * 64;
+                if (c < C) { nrm[rr * C + c] = 0.f; if (rr >= HALO) xs[(rr - HALO) * C + c] = 0.f; }
+            }
         }
     }
     __syncthreads();
     // ---- B: causal depthwise conv k=7 + bias, layer scale, residual -> x1 (in xs) ----
     for (int e = tid; e < TT * C; e += 256) {
-        const int r = e / C, c = e - r * C;
-        float acc = a.dw_b[c];
+        const int r = e / C;                           // channel of e is cc
+        float acc = dwb_r;
 #pragma unroll
-        for (int j = 0; j < 7; ++j) acc += a.dw_w[j * C + c] * nrm[(r + j) * C + c];
-        xs[e] += a.gamma[c] * acc;
+        for (int j = 0; j < 7; ++j) acc += dw_r[j] * nrm[(r + j) * C + cc];
+        xs[e] += gam_r * acc;
     }
     __syncthreads();
     // ---- C: second RMSNorm -> bf16 B fragments of n2 ----
     for (int r = wave; r < TT; r += 4) {
         float s = 0.f;
-        for (int c = lane; c < C; c += 64) { const float v = xs[r * C + c]; s += v * v; }
+        float xr[CL];
+#pragma unroll
+        for (int q = 0; q < CL; ++q) { const int c = lane + q * 64; xr[q] = (c < C) ? xs[r * C + c] : 0.f; s += xr[q] * xr[q]; }
         const float rr = rsqrtf(wsum(s) / (float)C + a.eps);
-        for (int c = lane; c < C; c += 64) {
-            const float n = xs[r * C + c] * rr * a.ffn_norm_w[c];
-            const int off = (((c >> 5) * 64 + r + 16 * ((c & 31) >> 3)) * 8 + (c & 7)) * 2;
-            split_store<XS>(f1, (size_t)KT1 * 1024, off, n);
+#pragma unroll
+        for (int q = 0; q < CL; ++q) {
+            const int c = lane + q * 64;
+            if (c < C) {
+                const float n = xr[q] * rr * fnw_r[q];
+                const int off = (((c >> 5) * 64 + r + 16 * ((c & 31) >> 3)) * 8 + (c & 7)) * 2;
+                split_store<XS>(f1, (size_t)KT1 * 1024, off, n);
+            }
         }
     }
     __syncthreads();
-    const int frow = lane & 15, fq = lane >> 4;
     // ---- D: FFN1 + bias + exact GELU -> bf16 B fragments of u ----
-    for (int nt = wave; nt < NT1; nt += 4) {
+#pragma unroll
+    for (int i1 = 0; i1 < M1; ++i1) {
+        const int nt = wave + 4 * i1;
+        if (nt >= NT1) break;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kt = 0; kt < KT1; ++kt) {
-            const bf16x8 wf = __builtin_bit_cast(bf16x8, a.w1[((int64_t)nt * KT1 + kt) * 64 + lane]);
+            const bf16x8 wf = __builtin_bit_cast(bf16x8, w1r[i1][kt]);
 #pragma unroll
             for (int p = 0; p < XS; ++p) {
                 const bf16x8 xb = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(f1 + ((size_t)(p * KT1 + kt) * 64 + lane) * 16));
@@ -126,19 +201,23 @@ __global__ __launch_bounds__(256) void vv_block1d_kernel(const VVBlock a) {
         }
         const int n0 = nt * 16 + fq * 4;           // lane holds u[t=frow][n0..n0+3]
         float u[4];
+        const float bb[4] = {b1_r[i1].x, b1_r[i1].y, b1_r[i1].z, b1_r[i1].w};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) u[r] = gelu_erf(acc[r] + a.b1[n0 + r]);
+        for (int r = 0; r < 4; ++r) u[r] = gelu_erf(acc[r] + bb[r]);
         const int off = (((n0 >> 5) * 64 + frow + 16 * ((n0 & 31) >> 3)) * 8 + (n0 & 7)) * 2;
 #pragma unroll
         for (int r = 0; r < 4; ++r) split_store<XS>(f2, (size_t)KT2 * 1024, off + r * 2, u[r]);
     }
     __syncthreads();
     // ---- E: FFN2 + bias, layer scale, residual -> out ----
-    for (int nt = wave; nt < NT2; nt += 4) {
+#pragma unroll
+    for (int i2 = 0; i2 < M2; ++i2) {
+        const int nt = wave + 4 * i2;
+        if (nt >= NT2) break;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
+#pragma unroll
         for (int kt = 0; kt < KT2; ++kt) {
-            const bf16x8 wf = __builtin_bit_cast(bf16x8, a.w2[((int64_t)nt * KT2 + kt) * 64 + lane]);
+            const bf16x8 wf = __builtin_bit_cast(bf16x8, w2r[i2][kt]);
 #pragma unroll
             for (int p = 0; p < XS; ++p) {
                 const bf16x8 ub = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(f2 + ((size_t)(p * KT2 + kt) * 64 + lane) * 16));
@@ -149,10 +228,10 @@ __global__ __launch_bounds__(256) void vv_block1d_kernel(const VVBlock a) {
         const int t = t0 + frow;
         if (t < a.T) {
             float4 o;
-            o.x = xs[frow * C + c0 + 0] + a.ffn_gamma[c0 + 0] * (acc[0] + a.b2[c0 + 0]);
-            o.y = xs[frow * C + c0 + 1] + a.ffn_gamma[c0 + 1] * (acc[1] + a.b2[c0 + 1]);
-            o.z = xs[frow * C + c0 + 2] + a.ffn_gamma[c0 + 2] * (acc[2] + a.b2[c0 + 2]);
-            o.w = xs[frow * C + c0 + 3] + a.ffn_gamma[c0 + 3] * (acc[3] + a.b2[c0 + 3]);
+            o.x = xs[frow * C + c0 + 0] + fg_r[i2].x * (acc[0] + b2_r[i2].x);
+            o.y = xs[frow * C + c0 + 1] + fg_r[i2].y * (acc[1] + b2_r[i2].y);
+            o.z = xs[frow * C + c0 + 2] + fg_r[i2].z * (acc[2] + b2_r[i2].z);
+            o.w = xs[frow * C + c0 + 3] + fg_r[i2].w * (acc[3] + b2_r[i2].w);
             *reinterpret_cast<float4*>(a.xout + (int64_t)t * C + c0) = o;
         }
     }

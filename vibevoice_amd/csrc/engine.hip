@@ -387,9 +387,11 @@ static int gemm_tl(vv_ctx* ctx, VVGemm g, hipStream_t st) {
         if (hipMalloc(&ctx->tl_base, (size_t)TL_MAX * TL_STRIDE * 8) != hipSuccess) return -9;
         hipMemset(ctx->tl_base, 0, (size_t)TL_MAX * TL_STRIDE * 8);
     }
-    if (ctx->tl_base && ctx->tl_idx < TL_MAX && (g.N + 15) / 16 <= 3200 && (g.T <= 4 || g.N > 16384) && vv_gemv_ok(&g)) {
+    const bool gv = vv_gemv_ok(&g) && (g.T <= 4 || ctx->c.xsplit <= 2);
+    const bool want = gv ? ((g.T <= 4 || g.T != 16 || g.N > 16384) && (g.N + 15) / 16 <= 3200) : (g.T > 16);
+    if (ctx->tl_base && ctx->tl_idx < TL_MAX && want) {
         g.dbg = ctx->tl_base + (size_t)ctx->tl_idx * TL_STRIDE;
-        ctx->tl_rec.push_back({g.T, g.N, g.K, g.pro, g.epi});
+        ctx->tl_rec.push_back({g.T, g.N, g.K, g.pro, gv ? g.epi : g.epi + 100});
         ctx->tl_idx++;
     }
     return vv_gemm_launch(g, ctx->c.xsplit, st);

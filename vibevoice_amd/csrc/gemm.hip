@@ -31,8 +31,10 @@
 
 #ifdef VV_GEMM_TIMING
 #define VV_STAMP(i) do { if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define VV_BSTAMP(i) do { if (a.dbg && threadIdx.x == 0 && blockIdx.y * gridDim.x + blockIdx.x < 3200) a.dbg[16 + 2 * (blockIdx.y * gridDim.x + blockIdx.x) + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define VV_STAMP(i) do { } while (0)
+#define VV_BSTAMP(i) do { } while (0)
 #endif
 
 namespace {
@@ -75,7 +77,13 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemm_kernel(const VVGemm a) {
     constexpr bool MODREG = (MAXR <= 4);          // adaLN scale/shift prefetched in registers only for few rows
     constexpr int U = 8;                          // k-steps per batch = 256 k = one float4 per lane per row
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // one batch of s_loads for every kernel argument (fetched lazily they cost 3-4 dependent round trips per launch)
+    asm volatile("" ::"s"(a.W), "s"(a.W2), "s"(a.X), "s"(a.Y), "s"(a.nw), "s"(a.mod_scale), "s"(a.mod_shift),
+                 "s"(a.addvec), "s"(a.bias), "s"(a.nscale), "s"(a.gate));
+    asm volatile("" ::"s"(a.T), "s"(a.N), "s"(a.K), "s"(a.ldx), "s"(a.ldy), "s"(a.ld_mod), "s"(a.ld_gate), "s"(a.x_row_mod), "s"(a.add_rows_per_vec),
+                 "s"(a.eps), "s"(a.pro), "s"(a.epi), "s"(a.ksplit), "s"(a.t_pad));
     VV_STAMP(0);
+    VV_BSTAMP(0);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int KS = a.ksplit;
@@ -118,6 +126,25 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemm_kernel(const VVGemm a) {
                 }
                 rstd_rows[r] = rsqrtf(wave_sum(s) / (float)a.K + a.eps);
             }
+        }
+    }
+
+    // ---- epilogue operands (bias / residual / gate rows), requested before the weight stream when everything is
+    //      16-byte aligned: one overlapped round trip instead of a chain of dependent scalar loads after the MFMAs ----
+    const bool vec_epi = VEC && a.epi != VV_EPI_CFG_DPM && !((a.N | a.ldy) & 3) &&
+                         !((reinterpret_cast<uintptr_t>(a.Y) | reinterpret_cast<uintptr_t>(a.bias) | reinterpret_cast<uintptr_t>(a.nscale)) & 15) &&
+                         (a.epi != VV_EPI_GATED_RESID || (!(a.ld_gate & 3) && !(reinterpret_cast<uintptr_t>(a.gate) & 15)));
+    float4 pre_b[NT], pre_y[NT], pre_g[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        pre_b[i] = float4{0.f, 0.f, 0.f, 0.f}; pre_y[i] = float4{0.f, 0.f, 0.f, 0.f}; pre_g[i] = float4{1.f, 1.f, 1.f, 1.f};
+        const int n0 = (tile0 + i) * 16 + fq * 4;
+        if (vec_epi && ks == 0 && frow < Tt && n0 < a.N) {
+            const int64_t yo = (int64_t)(t0 + frow) * a.ldy + n0;
+            if (a.bias && (a.epi == VV_EPI_BIAS || a.epi == VV_EPI_BIAS_GELU || a.epi == VV_EPI_RESID)) pre_b[i] = *reinterpret_cast<const float4*>(a.bias + n0);
+            if (a.epi == VV_EPI_RESID || a.epi == VV_EPI_GATED_RESID) pre_y[i] = *reinterpret_cast<const float4*>(a.Y + yo);
+            if (a.epi == VV_EPI_GATED_RESID) pre_g[i] = *reinterpret_cast<const float4*>(a.gate + (int64_t)(t0 + frow) * a.ld_gate + n0);
+            else if (a.epi == VV_EPI_RESID && a.nscale) pre_g[i] = *reinterpret_cast<const float4*>(a.nscale + n0);
         }
     }
 
@@ -360,6 +387,23 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemm_kernel(const VVGemm a) {
             }
             continue;
         }
+        if (vec_epi) {
+            const float pb[4] = {pre_b[i].x, pre_b[i].y, pre_b[i].z, pre_b[i].w};
+            const float py[4] = {pre_y[i].x, pre_y[i].y, pre_y[i].z, pre_y[i].w};
+            const float pg[4] = {pre_g[i].x, pre_g[i].y, pre_g[i].z, pre_g[i].w};
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                o[r] = o4[r];
+                if (a.epi == VV_EPI_BIAS) o[r] += pb[r];
+                else if (a.epi == VV_EPI_BIAS_GELU) o[r] = gelu_erf_f(o[r] + pb[r]);
+                else if (a.epi == VV_EPI_SWIGLU) o[r] = silu_f(o[r]) * u4[r];
+                else if (a.epi == VV_EPI_RESID) o[r] = (o[r] + pb[r]) * pg[r] + py[r];
+                else if (a.epi == VV_EPI_GATED_RESID) o[r] = py[r] + pg[r] * o[r];
+            }
+            *reinterpret_cast<float4*>(yp) = float4{o[0], o[1], o[2], o[3]};
+            continue;
+        }
 #pragma unroll 1
         for (int r = 0; r < 4; ++r) {
             const int n = n0 + r;
@@ -374,6 +418,7 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemm_kernel(const VVGemm a) {
         }
     }
     VV_STAMP(6);
+    VV_BSTAMP(1);
 }
 
 // ---- weight packing ----------------------------------------------------------

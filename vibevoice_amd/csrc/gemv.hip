@@ -21,7 +21,7 @@
 #ifdef VV_GEMM_TIMING
 #define VV_STAMP(i) do { if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
 // per-workgroup wall-clock (100 MHz, chip-wide) entry/exit stamps: the launch's occupancy timeline (tools/gemv_timeline.py)
-#define VV_BSTAMP(i) do { if (a.dbg && threadIdx.x == 0) a.dbg[16 + 2 * blockIdx.x + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define VV_BSTAMP(i) do { if (a.dbg && threadIdx.x == 0 && blockIdx.y * gridDim.x + blockIdx.x < 3200) a.dbg[16 + 2 * (blockIdx.y * gridDim.x + blockIdx.x) + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define VV_BSTAMP(i) do { } while (0)
 #define VV_STAMP(i) do { } while (0)
@@ -96,7 +96,9 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
     VV_BSTAMP(0);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int T = a.T;
+    // 16-row form: grid.y walks 16-row tiles of a tall activation (tokenizer stages, prefill chunks)
+    const int t_base = (MR == 16) ? (int)blockIdx.y * 16 : 0;
+    const int T = min(MR, a.T - t_base);
     const unsigned tile = blockIdx.x;
     const unsigned k_tiles = (unsigned)(a.K + 31) >> 5;
     const unsigned kper = (k_tiles + WPB - 1) / WPB;
@@ -122,15 +124,16 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
 #pragma unroll
         for (int r = 0; r < MR; ++r) {
             if (r < T) {
-                const int xr_idx = a.x_row_mod > 0 ? r % a.x_row_mod : r;
+                const int rg = t_base + r;
+                const int xr_idx = a.x_row_mod > 0 ? rg % a.x_row_mod : rg;
                 R.x[r] = *reinterpret_cast<const float4*>(a.X + (unsigned)(xr_idx * a.ldx) + k);
                 if constexpr (PRO == VV_PRO_ADD_SILU) {
-                    const int av = a.add_rows_per_vec > 0 ? r / a.add_rows_per_vec : 0;
+                    const int av = a.add_rows_per_vec > 0 ? rg / a.add_rows_per_vec : 0;
                     R.addv[r] = *reinterpret_cast<const float4*>(a.addvec + (unsigned)(av * a.K) + k);
                 }
                 if constexpr (PRO == VV_PRO_RMS_MOD) {
-                    R.sc[r] = *reinterpret_cast<const float4*>(a.mod_scale + (unsigned)(r * a.ld_mod) + k);
-                    R.sh[r] = *reinterpret_cast<const float4*>(a.mod_shift + (unsigned)(r * a.ld_mod) + k);
+                    R.sc[r] = *reinterpret_cast<const float4*>(a.mod_scale + (unsigned)(rg * a.ld_mod) + k);
+                    R.sh[r] = *reinterpret_cast<const float4*>(a.mod_shift + (unsigned)(rg * a.ld_mod) + k);
                 }
             }
         }
@@ -159,8 +162,8 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
             if (a.bias) pre_b = *reinterpret_cast<const float4*>(a.bias + n0);
         }
         if constexpr (EPI == VV_EPI_RESID || EPI == VV_EPI_GATED_RESID) {
-            pre_y = *reinterpret_cast<const float4*>(a.Y + (unsigned)(frow * a.ldy + n0));
-            if constexpr (EPI == VV_EPI_GATED_RESID) pre_g = *reinterpret_cast<const float4*>(a.gate + (unsigned)(frow * a.ld_gate + n0));
+            pre_y = *reinterpret_cast<const float4*>(a.Y + (unsigned)((t_base + frow) * a.ldy + n0));
+            if constexpr (EPI == VV_EPI_GATED_RESID) pre_g = *reinterpret_cast<const float4*>(a.gate + (unsigned)((t_base + frow) * a.ld_gate + n0));
             else if (a.nscale) pre_g = *reinterpret_cast<const float4*>(a.nscale + n0);
         }
     }
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
         for (int r = 0; r < MR; ++r) {
             float s = 0.f;
             if (r < T) {
-                const float* xr = a.X + (unsigned)(r * a.ldx);
+                const float* xr = a.X + (unsigned)((t_base + r) * a.ldx);
                 for (unsigned k = kt0 * 32 + kk; k < min(kt1 * 32, (unsigned)a.K); k += 256) {
                     const float4 v = *reinterpret_cast<const float4*>(xr + k);
                     s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
         }
         return;
     }
-    float* yp = a.Y + (unsigned)(frow * a.ldy + n0);
+    float* yp = a.Y + (unsigned)((t_base + frow) * a.ldy + n0);
     *reinterpret_cast<float4*>(yp) = float4{o[0], o[1], o[2], o[3]};
     VV_STAMP(6);
     VV_BSTAMP(1);
@@ -353,7 +356,7 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
 static bool gemv_combo_ok(int pro, int epi, bool wide);
 // Eligibility: decode rows, aligned operands, 32-bit offsets, a specialised (prologue, epilogue) pair.
 extern "C" int vv_gemv_ok(const VVGemm* a) {
-    if (a->T < 1 || a->T > 16) return 0;
+    if (a->T < 1) return 0;
     if (!gemv_combo_ok(a->pro, a->epi, a->T > 4)) return 0;
     if ((a->x_row_mod > 0 || a->add_rows_per_vec > 0) && a->pro != VV_PRO_ADD_SILU) return 0;
     if ((a->K & 3) || (a->ldx & 3) || (((uintptr_t)a->X) & 15)) return 0;
@@ -390,6 +393,9 @@ static bool gemv_combo_ok(int pro, int epi, bool wide) {
     return false;
 }
 
+// 16-row pairs that also have a 4-wave form (tall tokenizer stages, batched adaLN)
+#define VV_GEMV_WIDE4(X)                                                                       \
+    X(VV_PRO_NONE, VV_EPI_STORE) X(VV_PRO_NONE, VV_EPI_BIAS) X(VV_PRO_NONE, VV_EPI_RESID) X(VV_PRO_RMS, VV_EPI_BIAS_GELU)
 // pairs with a 4-wave form (wide outputs) and a 16-wave form (few tiles, long K); bench mode (xs == 1) only
 #define VV_GEMV_W4(X)                                                                          \
     X(VV_PRO_RMS, VV_EPI_SWIGLU) X(VV_PRO_RMS_MOD, VV_EPI_SWIGLU) X(VV_PRO_RMS, VV_EPI_BIAS_GELU) \
@@ -406,7 +412,12 @@ extern "C" int vv_gemv_launch(VVGemm a, int xs, hipStream_t s) {
          return hipGetLastError() == hipSuccess ? 0 : -2; } while (0)
     if (a.T > 4) {
         if (xs > 2) return -3;       // 16-row staging tiles of the exact mode exceed the LDS: general kernel
-        if (xs == 1 && n_tiles > 256 && a.pro == VV_PRO_NONE && a.epi == VV_EPI_STORE) VV_GO(1, VV_PRO_NONE, VV_EPI_STORE, 16, 4);   // batched adaLN
+        grid.y = (a.T + 15) / 16;
+        if (xs == 1 && (int64_t)n_tiles * grid.y > 512) {       // more workgroups than 2 per CU: the 4-wave form keeps them all resident
+#define X(P, E) if (a.pro == P && a.epi == E) VV_GO(1, P, E, 16, 4);
+            VV_GEMV_WIDE4(X)
+#undef X
+        }
 #define X(P, E) if (a.pro == P && a.epi == E) { if (xs == 1) VV_GO(1, P, E, 16, 8); else VV_GO(2, P, E, 16, 8); }
         VV_GEMV_WIDE(X)
 #undef X
