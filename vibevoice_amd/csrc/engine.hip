@@ -135,6 +135,8 @@ struct vv_ctx {
     static constexpr int RING = 32;
     hipEvent_t ring_ev[RING] = {}; bool ring_used[RING] = {}; int ring_i = 0;
     float *h = nullptr, *qkv = nullptr, *qrot = nullptr, *attn = nullptr, *act = nullptr;
+    float *h_parts = nullptr, *xh_parts = nullptr;     // K-split partial tensors of the residual streams (2 x [rows][H] each)
+    bool ksplit_ok = true;
     float *pm = nullptr, *pl = nullptr, *po = nullptr;
     // head
     int HF = 0, MODW = 0;
@@ -359,6 +361,16 @@ static VVGemm mk_gemm(const void* W, const float* X, float* Y, int T, int N, int
     g.pro = VV_PRO_NONE; g.epi = VV_EPI_STORE; g.ksplit = 0; g.nt = 0; g.eps = 1e-6f;
     return g;
 }
+// Few output tiles x long K (the down projections of small models): split K over 2-3 workgroup columns so every CU
+// streams; the partial tensors are added back by the consumers (VVGemm::xa / ya).  Returns the number of EXTRA parts.
+static int ksplit_parts(const vv_ctx* ctx, VVGemm& g, float* parts, int part_stride) {
+    const int n_tiles = (g.N + 15) / 16, k_tiles = (g.K + 31) / 32;
+    if (!ctx->ksplit_ok || g.T > 4 || n_tiles > 128 || k_tiles < 96) return 0;
+    const int ks = 3;
+    g.kgrid = ks; g.yparts = parts; g.part_stride = part_stride;
+    if (!vv_gemv_ok(&g)) { g.kgrid = 0; g.yparts = nullptr; g.part_stride = 0; return 0; }
+    return ks - 1;
+}
 static double gemm_bytes(const VVGemm& g) {
     // algorithmic bytes of one launch: packed weights once (+ second matrix), activations in, result out (RMW epilogues twice)
     double w = (double)vv_packed_elems(g.N, g.K) * 2.0 * (g.W2 ? 2.0 : 1.0);
@@ -567,6 +579,8 @@ extern "C" int vv_create(const vv_config* cfg, vv_ctx** out) {
     ctx->ids_dev = (int*)dalloc(ctx, sizeof(int) * 64);
     hipHostMalloc((void**)&ctx->ids_pin, sizeof(int) * 64 * vv_ctx::RING);
     ctx->h = (float*)dalloc(ctx, (size_t)R * H * 4);
+    ctx->h_parts = (float*)dalloc(ctx, (size_t)2 * R * H * 4);
+    ctx->ksplit_ok = !getenv("VVHIP_NO_GEMV") && !getenv("VVHIP_NO_KSPLIT");
     ctx->qkv = (float*)dalloc(ctx, (size_t)R * QKV * 4);
     ctx->qrot = (float*)dalloc(ctx, (size_t)R * Hq * D * 4);
     ctx->attn = (float*)dalloc(ctx, (size_t)R * Hq * D * 4);
@@ -599,6 +613,7 @@ extern "C" int vv_create(const vv_config* cfg, vv_ctx** out) {
     ctx->zz = (float*)dalloc(ctx, (size_t)R2 * L * 4);
     ctx->x0p = (float*)dalloc(ctx, (size_t)R2 * L * 4);
     ctx->xh = (float*)dalloc(ctx, (size_t)R2 * H * 4);
+    ctx->xh_parts = (float*)dalloc(ctx, (size_t)4 * R2 * H * 4);      // two generations: a layer reads one while writing the other
     ctx->hact = (float*)dalloc(ctx, (size_t)R2 * HF * 4);
     ctx->eps = (float*)dalloc(ctx, (size_t)R2 * L * 4);
     ctx->tmp1 = (float*)dalloc(ctx, (size_t)64 * H * 4);
@@ -777,10 +792,13 @@ static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float*
     const vv_config& c = ctx->c;
     const int H = ctx->H, D = ctx->D, Hq = ctx->Hq, Hkv = ctx->Hkv, I = ctx->I, QKV = ctx->QKV;
     HIPCHK(ctx, hipMemcpyAsync(ctx->h, x_in, (size_t)R * H * 4, hipMemcpyDeviceToDevice, st));
+    int hp = 0;                                    // extra parts the residual stream h currently consists of
+    const int hps = ctx->c.max_rows * H;
     for (int l = l0; l < l1; ++l) {
         auto& L = ctx->layers[l];
         VVGemm g = mk_gemm(L.wqkv, ctx->h, ctx->qkv, R, QKV, H, H, QKV);
         g.pro = VV_PRO_RMS; g.nw = L.ln1; g.eps = c.lm_eps; g.epi = VV_EPI_BIAS; g.bias = L.bqkv; g.nt = 1;
+        g.xa = ctx->h_parts; g.n_xa = hp; g.part_stride = hps;
         GEMM(g);
         ctx->launches += 3;
         VVCHK(vv_rope_append_launch(D, ctx->qkv, ctx->rows_dev, ctx->inv_freq, ctx->qrot,
@@ -794,12 +812,15 @@ static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float*
         //  work landed on the critical path of bigger kernels.  See DESIGN.md "negative results".)
         VVGemm go = mk_gemm(L.wo, ctx->attn, ctx->h, R, H, Hq * D, Hq * D, H);
         go.epi = VV_EPI_RESID; go.nt = 1;
+        go.ya = ctx->h_parts; go.n_ya = hp; go.part_stride = hps;     // o_proj folds the parts back: h is whole again
         GEMM(go);
+        hp = 0;
         VVGemm gm = mk_gemm(L.wg, ctx->h, ctx->act, R, I, H, H, I);
         gm.W2 = (const u32x4*)L.wu; gm.pro = VV_PRO_RMS; gm.nw = L.ln2; gm.eps = c.lm_eps; gm.epi = VV_EPI_SWIGLU; gm.nt = 1;
         GEMM(gm);
         VVGemm gd = mk_gemm(L.wd, ctx->act, ctx->h, R, H, I, I, H);
         gd.epi = VV_EPI_RESID; gd.nt = 1;
+        if (l + 1 < l1) hp = ksplit_parts(ctx, gd, ctx->h_parts, hps);     // the last layer leaves h whole for the final norm
         GEMM(gd);
     }
     ctx->launches++;
@@ -899,19 +920,27 @@ static int head_eval(vv_ctx* ctx, hipStream_t st, int rows, const float* zrows, 
     }
     VVGemm gi = mk_gemm(ctx->h_in, zrows, ctx->xh, rows, H, L, L, H);
     GEMM(gi);
+    int xp = 0;                                    // extra parts xh currently consists of
+    const int xps = 16 * H;
     for (int l = 0; l < HL; ++l) {
         const float* base = mod + (size_t)l * 3 * H;
         VVGemm g1 = mk_gemm(ctx->hl[l].wg, ctx->xh, ctx->hact, rows, HF, H, H, HF);
         g1.W2 = (const u32x4*)ctx->hl[l].wu; g1.pro = VV_PRO_RMS_MOD; g1.nw = ctx->hl[l].norm; g1.eps = c.head_eps;
         g1.mod_shift = base; g1.mod_scale = base + H; g1.ld_mod = MODW; g1.epi = VV_EPI_SWIGLU; g1.nt = 1;
+        float* cur = ctx->xh_parts + (size_t)(l & 1) * 2 * xps;          // parts written by layer l-1
+        float* nxt = ctx->xh_parts + (size_t)((l + 1) & 1) * 2 * xps;    // parts layer l writes
+        g1.xa = cur; g1.n_xa = xp; g1.part_stride = xps;
         GEMM(g1);
         VVGemm g2 = mk_gemm(ctx->hl[l].wd, ctx->hact, ctx->xh, rows, H, HF, HF, H);
         g2.epi = VV_EPI_GATED_RESID; g2.gate = base + 2 * H; g2.ld_gate = MODW; g2.nt = 1;
+        g2.ya = cur; g2.n_ya = xp; g2.part_stride = xps;
+        xp = ksplit_parts(ctx, g2, nxt, xps);
         GEMM(g2);
     }
     const float* fb = mod + (size_t)HL * 3 * H;
     VVGemm gf = mk_gemm(ctx->h_out, ctx->xh, eps_out, rows, L, H, H, L);
     gf.pro = VV_PRO_RMS_MOD; gf.nw = nullptr; gf.eps = c.head_eps; gf.mod_shift = fb; gf.mod_scale = fb + H; gf.ld_mod = MODW;
+    gf.xa = ctx->xh_parts + (size_t)(HL & 1) * 2 * xps; gf.n_xa = xp; gf.part_stride = xps;
     if (coef) {   // CFG + DPM-Solver++ update fused into the epilogue: the noisy latent is rewritten in place
         gf.epi = VV_EPI_CFG_DPM; gf.z = ctx->zz; gf.x0p = ctx->x0p; gf.coef = coef; gf.cfg = cfg; gf.n_cfg = rows / 2;
     }

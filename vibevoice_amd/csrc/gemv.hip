@@ -78,7 +78,9 @@ constexpr int U = 8;       // k-steps per batch (256 k = one float4 per lane per
 // WPB = waves per workgroup = K split inside the workgroup.  The launcher picks it so that EVERY workgroup of the launch
 // is resident at once (a second dispatch round costs a full load-latency chain): 4 for wide outputs (> 256 tiles),
 // 16 for few tiles x long K (the streaming rate of a CU is set by its waves' loads in flight), 8 otherwise.
-template <int XS, int PRO, int EPI, int MR, int WPB>
+// PARTS: the activation (prologue side) or residual (epilogue side) tensor arrives as base + 2 part tensors (the producer
+// split K over 3 workgroup columns): the three loads are issued together and summed in a fixed order.
+template <int XS, int PRO, int EPI, int MR, int WPB, int PARTS = 0>      // PARTS: 0 none, 1 activation side, 2 residual side
 __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
     constexpr bool DUAL = (EPI == VV_EPI_SWIGLU);
     constexpr int NM = DUAL ? 2 : 1;
@@ -92,6 +94,7 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
                  "s"(a.addvec), "s"(a.bias), "s"(a.nscale), "s"(a.gate));
     asm volatile("" ::"s"(a.T), "s"(a.N), "s"(a.K), "s"(a.ldx), "s"(a.ldy), "s"(a.ld_mod), "s"(a.ld_gate), "s"(a.x_row_mod), "s"(a.add_rows_per_vec),
                  "s"(a.eps), "s"(a.z), "s"(a.x0p), "s"(a.coef), "s"(a.cfg), "s"(a.n_cfg));
+    asm volatile("" ::"s"(a.yparts), "s"(a.xa), "s"(a.ya), "s"(a.n_xa), "s"(a.n_ya), "s"(a.part_stride));
     VV_STAMP(0);
     VV_BSTAMP(0);
     const int lane = threadIdx.x & 63;
@@ -101,9 +104,14 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
     const int T = min(MR, a.T - t_base);
     const unsigned tile = blockIdx.x;
     const unsigned k_tiles = (unsigned)(a.K + 31) >> 5;
-    const unsigned kper = (k_tiles + WPB - 1) / WPB;
-    const unsigned kt0 = wave * kper;
-    const unsigned kt1 = min(k_tiles, kt0 + kper);
+    // K range of this workgroup (grid.y splits K for few-tile x long-K shapes so that all CUs stream), then of this wave
+    const unsigned KSB = (MR == 4) ? gridDim.y : 1u;
+    const unsigned ksb = (MR == 4) ? blockIdx.y : 0u;
+    const unsigned kchunk = (k_tiles + KSB - 1) / KSB;
+    const unsigned kb0 = min(k_tiles, ksb * kchunk), kb1 = min(k_tiles, kb0 + kchunk);
+    const unsigned kper = (kb1 - kb0 + WPB - 1) / WPB;
+    const unsigned kt0 = kb0 + wave * kper;
+    const unsigned kt1 = min(kb1, kt0 + kper);
     const bool has_k = kt0 < kt1;
     const int frow = lane & 15, fq = lane >> 4;
     unsigned char* stg = stg_all + (size_t)wave * (XS * U * 4 * MR * 16);
@@ -115,7 +123,8 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
 
     constexpr int MODR = (PRO == VV_PRO_RMS_MOD) ? MR : 1;
     constexpr int ADDR = (PRO == VV_PRO_ADD_SILU) ? MR : 1;
-    struct XR { float4 x[MR]; float4 sc[MODR]; float4 sh[MODR]; float4 addv[ADDR]; float4 nwv; };
+    constexpr int PR = (PARTS == 1) ? MR : 1;
+    struct XR { float4 x[MR]; float4 p0[PR]; float4 p1[PR]; float4 sc[MODR]; float4 sh[MODR]; float4 addv[ADDR]; float4 nwv; };
     auto x_load = [&](unsigned ktb, XR& R) {
         unsigned k = ktb * 32 + kk;
         const bool kin = k < min(kt1 * 32, (unsigned)a.K);
@@ -127,6 +136,10 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
                 const int rg = t_base + r;
                 const int xr_idx = a.x_row_mod > 0 ? rg % a.x_row_mod : rg;
                 R.x[r] = *reinterpret_cast<const float4*>(a.X + (unsigned)(xr_idx * a.ldx) + k);
+                if constexpr (PARTS == 1) {
+                    R.p0[r] = *reinterpret_cast<const float4*>(a.xa + (unsigned)(xr_idx * a.ldx) + k);
+                    R.p1[r] = *reinterpret_cast<const float4*>(a.xa + (unsigned)(a.part_stride + xr_idx * a.ldx) + k);
+                }
                 if constexpr (PRO == VV_PRO_ADD_SILU) {
                     const int av = a.add_rows_per_vec > 0 ? rg / a.add_rows_per_vec : 0;
                     R.addv[r] = *reinterpret_cast<const float4*>(a.addvec + (unsigned)(av * a.K) + k);
@@ -157,12 +170,18 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
     const int n0 = tile * 16 + fq * 4;
     const bool epi_lane = (wave == 0) && frow < T && n0 < a.N;
     float4 pre_y = {0.f, 0.f, 0.f, 0.f}, pre_b = {0.f, 0.f, 0.f, 0.f}, pre_g = {1.f, 1.f, 1.f, 1.f};
+    float4 pre_y0 = {0.f, 0.f, 0.f, 0.f}, pre_y1 = {0.f, 0.f, 0.f, 0.f};
     if (epi_lane) {            // N % 4 == 0 and 16-B aligned operands are launch preconditions (vv_gemv_ok)
         if constexpr (EPI == VV_EPI_BIAS || EPI == VV_EPI_BIAS_GELU || EPI == VV_EPI_RESID) {
             if (a.bias) pre_b = *reinterpret_cast<const float4*>(a.bias + n0);
         }
         if constexpr (EPI == VV_EPI_RESID || EPI == VV_EPI_GATED_RESID) {
             pre_y = *reinterpret_cast<const float4*>(a.Y + (unsigned)((t_base + frow) * a.ldy + n0));
+            if constexpr (PARTS == 2) {
+                const float* yp0 = a.ya + (unsigned)((t_base + frow) * a.ldy + n0);
+                pre_y0 = *reinterpret_cast<const float4*>(yp0);
+                pre_y1 = *reinterpret_cast<const float4*>(yp0 + a.part_stride);
+            }
             if constexpr (EPI == VV_EPI_GATED_RESID) pre_g = *reinterpret_cast<const float4*>(a.gate + (unsigned)((t_base + frow) * a.ld_gate + n0));
             else if (a.nscale) pre_g = *reinterpret_cast<const float4*>(a.nscale + n0);
         }
@@ -179,7 +198,13 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
             if (r < T) {
                 const float* xr = a.X + (unsigned)((t_base + r) * a.ldx);
                 for (unsigned k = kt0 * 32 + kk; k < min(kt1 * 32, (unsigned)a.K); k += 256) {
-                    const float4 v = *reinterpret_cast<const float4*>(xr + k);
+                    float4 v = *reinterpret_cast<const float4*>(xr + k);
+                    if constexpr (PARTS == 1) {
+                        const float* xp = a.xa + (unsigned)((t_base + r) * a.ldx);
+                        const float4 p0 = *reinterpret_cast<const float4*>(xp + k);
+                        const float4 p1 = *reinterpret_cast<const float4*>(xp + a.part_stride + k);
+                        v.x = (v.x + p0.x) + p1.x; v.y = (v.y + p0.y) + p1.y; v.z = (v.z + p0.z) + p1.z; v.w = (v.w + p0.w) + p1.w;
+                    }
                     s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
                 }
                 s = wave_sum_dpp(s);
@@ -210,7 +235,12 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
 #pragma unroll
         for (int r = 0; r < MR; ++r) {
             if (r < T) {
-                float v[4] = {R.x[r].x * msk, R.x[r].y * msk, R.x[r].z * msk, R.x[r].w * msk};
+                float v[4] = {R.x[r].x, R.x[r].y, R.x[r].z, R.x[r].w};
+                if constexpr (PARTS == 1) {
+                    v[0] = (v[0] + R.p0[r].x) + R.p1[r].x; v[1] = (v[1] + R.p0[r].y) + R.p1[r].y;
+                    v[2] = (v[2] + R.p0[r].z) + R.p1[r].z; v[3] = (v[3] + R.p0[r].w) + R.p1[r].w;
+                }
+                v[0] *= msk; v[1] *= msk; v[2] *= msk; v[3] *= msk;
                 if constexpr (PRO == VV_PRO_RMS) {
                     ssq[r] += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
                     v[0] *= R.nwv.x; v[1] *= R.nwv.y; v[2] *= R.nwv.z; v[3] *= R.nwv.w;
@@ -307,7 +337,7 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
     }
     float o[4] = {acc[0][0] * rs, acc[0][1] * rs, acc[0][2] * rs, acc[0][3] * rs};
     const float pb[4] = {pre_b.x, pre_b.y, pre_b.z, pre_b.w};
-    const float py[4] = {pre_y.x, pre_y.y, pre_y.z, pre_y.w};
+    const float py[4] = {(pre_y.x + pre_y0.x) + pre_y1.x, (pre_y.y + pre_y0.y) + pre_y1.y, (pre_y.z + pre_y0.z) + pre_y1.z, (pre_y.w + pre_y0.w) + pre_y1.w};
     const float pg[4] = {pre_g.x, pre_g.y, pre_g.z, pre_g.w};
     if constexpr (EPI == VV_EPI_BIAS) {
 #pragma unroll
@@ -320,10 +350,10 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
         for (int r = 0; r < 4; ++r) o[r] = silu_acc(o[r]) * (acc[NM - 1][r] * rs);
     } else if constexpr (EPI == VV_EPI_RESID) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = py[r] + pg[r] * (o[r] + pb[r]);
+        for (int r = 0; r < 4; ++r) o[r] = (ksb == 0) ? py[r] + pg[r] * (o[r] + pb[r]) : pg[r] * o[r];
     } else if constexpr (EPI == VV_EPI_GATED_RESID) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = py[r] + pg[r] * o[r];
+        for (int r = 0; r < 4; ++r) o[r] = (ksb == 0) ? py[r] + pg[r] * o[r] : pg[r] * o[r];
     }
     if constexpr (EPI == VV_EPI_CFG_DPM) {
         const int nc = a.n_cfg;
@@ -345,7 +375,7 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
         }
         return;
     }
-    float* yp = a.Y + (unsigned)((t_base + frow) * a.ldy + n0);
+    float* yp = (ksb == 0 ? a.Y : a.yparts + (unsigned)((ksb - 1) * a.part_stride)) + (unsigned)((t_base + frow) * a.ldy + n0);
     *reinterpret_cast<float4*>(yp) = float4{o[0], o[1], o[2], o[3]};
     VV_STAMP(6);
     VV_BSTAMP(1);
@@ -354,6 +384,7 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
 }  // namespace
 
 static bool gemv_combo_ok(int pro, int epi, bool wide);
+static bool gemv_parts_ok(int pro, int epi, bool xside);
 // Eligibility: decode rows, aligned operands, 32-bit offsets, a specialised (prologue, epilogue) pair.
 extern "C" int vv_gemv_ok(const VVGemm* a) {
     if (a->T < 1) return 0;
@@ -370,6 +401,11 @@ extern "C" int vv_gemv_ok(const VVGemm* a) {
     if (a->epi == VV_EPI_GATED_RESID && ((a->ld_gate & 3) || (((uintptr_t)a->gate) & 15))) return 0;
     if (a->pro == VV_PRO_RMS_MOD && ((((uintptr_t)a->mod_scale) & 15) || (((uintptr_t)a->mod_shift) & 15))) return 0;
     if (a->pro == VV_PRO_ADD_SILU && (((uintptr_t)a->addvec) & 15)) return 0;
+    if (a->kgrid > 1 && (a->T > 4 || a->kgrid != 3 || a->pro != VV_PRO_NONE || !a->yparts || (a->part_stride & 3) ||
+                         (a->epi != VV_EPI_RESID && a->epi != VV_EPI_GATED_RESID) || (((uintptr_t)a->yparts) & 15))) return 0;
+    if ((a->n_xa > 0 && (!a->xa || (((uintptr_t)a->xa) & 15))) || (a->n_ya > 0 && (!a->ya || (((uintptr_t)a->ya) & 15)))) return 0;
+    if ((a->n_xa != 0 && a->n_xa != 2) || (a->n_ya != 0 && a->n_ya != 2) || (a->n_xa && a->n_ya)) return 0;
+    if ((a->n_xa || a->n_ya) && ((a->part_stride & 3) || a->T > 4 || !gemv_parts_ok(a->pro, a->epi, a->n_xa > 0))) return 0;
     return 1;
 }
 
@@ -403,6 +439,17 @@ static bool gemv_combo_ok(int pro, int epi, bool wide) {
 #define VV_GEMV_W16(X)                                                                         \
     X(VV_PRO_NONE, VV_EPI_RESID) X(VV_PRO_NONE, VV_EPI_GATED_RESID) X(VV_PRO_NONE, VV_EPI_BIAS) X(VV_PRO_NONE, VV_EPI_STORE)
 
+// pairs that can consume a K-split tensor: on the activation side (x) or on the residual side (y)
+#define VV_GEMV_PARTS_X(X) X(VV_PRO_RMS, VV_EPI_BIAS) X(VV_PRO_RMS_MOD, VV_EPI_SWIGLU) X(VV_PRO_RMS_MOD, VV_EPI_CFG_DPM) X(VV_PRO_RMS_MOD, VV_EPI_STORE)
+#define VV_GEMV_PARTS_Y(X) X(VV_PRO_NONE, VV_EPI_RESID) X(VV_PRO_NONE, VV_EPI_GATED_RESID)
+#define VV_GEMV_PARTS(X) VV_GEMV_PARTS_X(X) VV_GEMV_PARTS_Y(X)
+static bool gemv_parts_ok(int pro, int epi, bool xside) {
+#define X(P, E) if (pro == P && epi == E) return true;
+    if (xside) { VV_GEMV_PARTS_X(X) } else { VV_GEMV_PARTS_Y(X) }
+#undef X
+    return false;
+}
+
 extern "C" int vv_gemv_launch(VVGemm a, int xs, hipStream_t s) {
     const int n_tiles = (a.N + 15) / 16, k_tiles = (a.K + 31) / 32;
     if (a.epi == VV_EPI_SWIGLU && !a.W2) return -1;
@@ -423,8 +470,30 @@ extern "C" int vv_gemv_launch(VVGemm a, int xs, hipStream_t s) {
 #undef X
         return -3;
     }
+    if (a.n_xa > 0 || a.n_ya > 0) {           // consumers of a K-split tensor (decode rows only)
+        if (a.kgrid > 1) grid.y = a.kgrid;
+#define VV_GOP(XS_, P, E, WP_, S_)                                                                      \
+    do { hipLaunchKernelGGL((vv_gemv_kernel<XS_, P, E, 4, WP_, S_>), grid, dim3(WP_ * 64), 0, s, a);     \
+         return hipGetLastError() == hipSuccess ? 0 : -2; } while (0)
+#define X(P, E)                                                                                         \
+    if (a.pro == P && a.epi == E) {                                                                     \
+        if (xs == 1 && n_tiles > 256 && E == VV_EPI_SWIGLU) VV_GOP(1, P, E, 4, 1);                       \
+        if (xs == 1) VV_GOP(1, P, E, 8, 1); else if (xs == 2) VV_GOP(2, P, E, 8, 1); else VV_GOP(3, P, E, 8, 1); \
+    }
+        if (a.n_xa > 0) { VV_GEMV_PARTS_X(X) }
+#undef X
+#define X(P, E)                                                                                         \
+    if (a.pro == P && a.epi == E) {                                                                     \
+        if (xs == 1) VV_GOP(1, P, E, 8, 2); else if (xs == 2) VV_GOP(2, P, E, 8, 2); else VV_GOP(3, P, E, 8, 2); \
+    }
+        if (a.n_ya > 0) { VV_GEMV_PARTS_Y(X) }
+#undef X
+#undef VV_GOP
+        return -3;
+    }
     static const bool wpb8_only = getenv("VVHIP_GEMV_WPB8") != nullptr;      // A/B switch
-    if (xs == 1 && !wpb8_only) {
+    if (a.kgrid > 1) grid.y = a.kgrid;
+    if (xs == 1 && !wpb8_only && a.kgrid <= 1) {
         if (n_tiles > 256) {
 #define X(P, E) if (a.pro == P && a.epi == E) VV_GO(1, P, E, 4, 4);
             VV_GEMV_W4(X)

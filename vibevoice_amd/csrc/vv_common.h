@@ -62,5 +62,14 @@ struct VVGemm {
     // (0 = off).  Used to batch the diffusion head's adaLN GEMM over all solver steps of a frame.
     int x_row_mod, add_rows_per_vec;
     float eps;
+    // K split across workgroups (decode GEMV only, PRO_NONE + residual epilogues): workgroup column ks > 0 stores its
+    // scaled partial to yparts + (ks-1)*part_stride instead of Y; consumers of that tensor add the parts back in a
+    // fixed order (deterministic): xa/n_xa on the activation side, ya/n_ya on the residual side, same row strides.
+    int kgrid;             // 0/1 = off
+    float* yparts;
+    const float* xa;       // n_xa part tensors laid out like X, part_stride floats apart
+    const float* ya;       // n_ya part tensors laid out like Y
+    int n_xa, n_ya;
+    int part_stride;
 };
 
