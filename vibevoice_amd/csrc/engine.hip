@@ -25,7 +25,10 @@ int vv_attn_launch(int D, int xs, const float* q, const VVRow* rows, const void*
                    float* out, hipStream_t s);
 int vv_embed_launch(const void* table, const int* ids, float* out, int n, int H, hipStream_t s);
 int vv_rmsnorm_rows_launch(const float* x, int ldx, float* y, int ldy, const float* w, int T, int C, float eps, hipStream_t s);
-int vv_dwconv_res_launch(const float* nb, float* x, const float* w, const float* b, const float* gamma, int T, int C, hipStream_t s);
+int vv_dwconv_res_launch(const float* nb, const float* x, float* xo, const float* w, const float* b, const float* gamma, int T, int C, hipStream_t s);
+int vv_normdw_sliced_ok(int T, int C);
+int vv_normdw_sliced_launch(const float* xin, float* xout, float* nb, const float* nw, const float* w, const float* b,
+                            const float* gamma, int T, int C, float eps, hipStream_t s);
 int vv_normdw_launch(float* x, float* nb, const float* nw, const float* w, const float* b, const float* gamma, int T, int C,
                      float eps, hipStream_t s);
 int vv_shift_rows_launch(const void* tab, int n_entries, int maxC, hipStream_t s);
@@ -90,6 +93,7 @@ struct Stage {
     float* xs2;                 // fused stages ping-pong between xs and xs2
     float* xfinal;              // buffer holding the stage output (and its history rows)
     bool fused;                 // blocks run as one vv_block1d_kernel each
+    bool pp;                    // unfused T <= 8 stage: channel-sliced norm+conv, blocks ping-pong between xs and xs2
     std::vector<Block> blocks;
     ConvG in;                   // produces this stage's rows from the previous buffer
 };
@@ -322,8 +326,9 @@ static int build_codec(vv_ctx* ctx, CodecNet& net, const std::string& pfx, bool 
             s.xs = (float*)dalloc(ctx, xbytes);
             s.blocks = sw[i].blocks;
             s.fused = vv_block1d_supported(C[i]) && Tpf[i] >= 8 && !s.blocks.empty() && !getenv("VVHIP_NO_FUSED_BLOCK");
-            s.xs2 = s.fused ? (float*)dalloc(ctx, xbytes) : nullptr;
-            s.xfinal = (s.fused && (s.blocks.size() & 1)) ? s.xs2 : s.xs;
+            s.pp = !s.fused && !s.blocks.empty() && vv_normdw_sliced_ok(Tpf[i], C[i]) && !getenv("VVHIP_NO_SLICED_NORMDW");
+            s.xs2 = (s.fused || s.pp) ? (float*)dalloc(ctx, xbytes) : nullptr;
+            s.xfinal = ((s.fused || s.pp) && (s.blocks.size() & 1)) ? s.xs2 : s.xs;
             for (auto& b : s.blocks) {
                 b.nb = nullptr; b.nst = nullptr;
                 if (s.fused) b.nst = (float*)dalloc(ctx, (size_t)12 * C[i] * 4);
@@ -451,22 +456,27 @@ static int run_codec(vv_ctx* ctx, CodecNet& net, int sl, int F, float* out, hipS
             }
             continue;
         }
+        float* xo = s.pp ? s.xs2 + (size_t)s.hist * s.C : x;       // pp stages: each block's norm+conv writes the other buffer
         for (auto& b : s.blocks) {
-            if ((size_t)T * s.C <= 8192 && (s.C & 3) == 0) {     // one workgroup is only faster for tiny row sets
+            if (s.pp && vv_normdw_sliced_ok(T, s.C)) {
+                ctx->launches += 1;
+                VVCHK(vv_normdw_sliced_launch(x, xo, b.nb, b.norm_w, b.dw_w, b.dw_b, b.gamma, T, s.C, eps, st));
+            } else if (!s.pp && (size_t)T * s.C <= 8192 && (s.C & 3) == 0) {     // one workgroup is only faster for tiny row sets
                 ctx->launches += 1;
                 VVCHK(vv_normdw_launch(x, b.nb, b.norm_w, b.dw_w, b.dw_b, b.gamma, T, s.C, eps, st));
             } else {
                 ctx->launches += 2;
                 VVCHK(vv_rmsnorm_rows_launch(x, s.C, b.nb + 6 * (size_t)s.C, s.C, b.norm_w, T, s.C, eps, st));
-                VVCHK(vv_dwconv_res_launch(b.nb, x, b.dw_w, b.dw_b, b.gamma, T, s.C, st));
+                VVCHK(vv_dwconv_res_launch(b.nb, x, xo, b.dw_w, b.dw_b, b.gamma, T, s.C, st));
             }
-            VVGemm g1 = mk_gemm(b.w1, x, net.u, T, 4 * s.C, s.C, s.C, 4 * s.C);
+            VVGemm g1 = mk_gemm(b.w1, xo, net.u, T, 4 * s.C, s.C, s.C, 4 * s.C);
             g1.pro = VV_PRO_RMS; g1.nw = b.ffn_norm_w; g1.eps = eps; g1.epi = VV_EPI_BIAS_GELU; g1.bias = b.b1;
             g1.nt = stream_w && T <= 16;
             GEMM(g1);
-            VVGemm g2 = mk_gemm(b.w2, net.u, x, T, s.C, 4 * s.C, 4 * s.C, s.C);
+            VVGemm g2 = mk_gemm(b.w2, net.u, xo, T, s.C, 4 * s.C, 4 * s.C, s.C);
             g2.epi = VV_EPI_RESID; g2.bias = b.b2; g2.nscale = b.ffn_gamma; g2.nt = stream_w && T <= 16;
             GEMM(g2);
+            if (s.pp) std::swap(x, xo);
         }
     }
     {   // head conv

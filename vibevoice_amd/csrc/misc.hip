@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void vv_rmsnorm_rows_kernel(const float* __res
 
 // Causal depthwise conv k=7 over time on the normed buffer nb (6 history rows in front),
 // fused with bias, layer scale and the residual:  x[t][c] += gamma[c]*(sum_j w[j][c]*nb[t+j][c] + b[c])
-__global__ void vv_dwconv_res_kernel(const float* __restrict__ nb, float* __restrict__ x,
+__global__ void vv_dwconv_res_kernel(const float* __restrict__ nb, const float* __restrict__ x, float* __restrict__ xo,
                                      const float* __restrict__ w /*[7][C]*/, const float* __restrict__ b,
                                      const float* __restrict__ gamma, int T, int C) {
     const int64_t total = (int64_t)T * C;
@@ -81,7 +81,7 @@ __global__ void vv_dwconv_res_kernel(const float* __restrict__ nb, float* __rest
         float acc = b[c];
 #pragma unroll
         for (int j = 0; j < 7; ++j) acc += w[j * C + c] * nb[(int64_t)(t + j) * C + c];
-        x[e] += gamma[c] * acc;
+        xo[e] = x[e] + gamma[c] * acc;
     }
 }
 
@@ -116,6 +116,79 @@ __global__ __launch_bounds__(1024) void vv_normdw_kernel(float* __restrict__ x, 
 #pragma unroll
         for (int j = 0; j < 7; ++j) acc += w[j * C + c] * nb[(int64_t)(t + j) * C + c];
         x[e] += gamma[c] * acc;
+    }
+}
+
+// Channel-sliced form of the same fusion for the T <= 8 stages (C = 1024 / 2048): C/256 workgroups instead of one.
+// Every workgroup re-derives the T row norms from the full input rows (a few KB, L2), then owns 256 channels:
+// norm -> nb rows 6.., depthwise conv over [6 history rows ++ new rows], layer scale, residual.  Output goes to a
+// DIFFERENT buffer (the stage ping-pongs): other workgroups are still reading full rows of xin for their norms.
+// Every global load of a thread is issued before the first wait.
+__device__ __forceinline__ float wave_sum_dpp_m(float v) {
+    int x = __builtin_bit_cast(int, v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true));
+    x = __builtin_bit_cast(int, v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true));
+    x = __builtin_bit_cast(int, v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true));
+    x = __builtin_bit_cast(int, v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true));
+    x = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+template <int NCH>      // NCH = C / 1024 float4 chunks per thread and row
+__global__ __launch_bounds__(256) void vv_normdw_sliced_kernel(const float* __restrict__ xin, float* __restrict__ xout,
+                                                               float* __restrict__ nb, const float* __restrict__ nw,
+                                                               const float* __restrict__ w, const float* __restrict__ b,
+                                                               const float* __restrict__ gamma, int T, int C, float eps) {
+    constexpr int TM = 8;
+    __shared__ float red[4][TM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = blockIdx.x * 256 + tid;
+    float4 full[TM][NCH];
+    float xc[TM], hist[6], wj[7];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+            full[t][i] = (t < T) ? *reinterpret_cast<const float4*>(xin + (int64_t)t * C + (i * 256 + tid) * 4) : float4{0.f, 0.f, 0.f, 0.f};
+        xc[t] = (t < T) ? xin[(int64_t)t * C + c] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) hist[j] = nb[(int64_t)j * C + c];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) wj[j] = w[j * C + c];
+    const float nwc = nw[c], bc = b[c], gc = gamma[c];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) s += full[t][i].x * full[t][i].x + full[t][i].y * full[t][i].y + full[t][i].z * full[t][i].z + full[t][i].w * full[t][i].w;
+        s = wave_sum_dpp_m(s);
+        if (lane == 0) red[wave][t] = s;
+    }
+    __syncthreads();
+    float nrm[6 + TM];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) nrm[j] = hist[j];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        const float ss = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+        nrm[6 + t] = xc[t] * rsqrtf(ss / (float)C + eps) * nwc;
+    }
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        if (t < T) {
+            float acc = bc;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) acc += wj[j] * nrm[t + j];
+            xout[(int64_t)t * C + c] = xc[t] + gc * acc;
+            nb[(int64_t)(6 + t) * C + c] = nrm[6 + t];
+        }
     }
 }
 
@@ -261,16 +334,24 @@ int vv_rmsnorm_rows_launch(const float* x, int ldx, float* y, int ldy, const flo
         hipLaunchKernelGGL((vv_rmsnorm_rows_kernel<4>), dim3((T + 3) / 4), dim3(256), 0, s, x, ldx, y, ldy, w, T, C, eps);
     return okk();
 }
-int vv_dwconv_res_launch(const float* nb, float* x, const float* w, const float* b, const float* gamma, int T, int C, hipStream_t s) {
+int vv_dwconv_res_launch(const float* nb, const float* x, float* xo, const float* w, const float* b, const float* gamma, int T, int C, hipStream_t s) {
     int64_t total = (int64_t)T * C;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(vv_dwconv_res_kernel, dim3(blocks), dim3(256), 0, s, nb, x, w, b, gamma, T, C);
+    hipLaunchKernelGGL(vv_dwconv_res_kernel, dim3(blocks), dim3(256), 0, s, nb, x, xo, w, b, gamma, T, C);
     return okk();
 }
 int vv_normdw_launch(float* x, float* nb, const float* nw, const float* w, const float* b, const float* gamma,
                      int T, int C, float eps, hipStream_t s) {
     hipLaunchKernelGGL(vv_normdw_kernel, dim3(1), dim3(1024), 0, s, x, nb, nw, w, b, gamma, T, C, eps);
+    return okk();
+}
+int vv_normdw_sliced_ok(int T, int C) { return T >= 1 && T <= 8 && (C == 1024 || C == 2048); }
+int vv_normdw_sliced_launch(const float* xin, float* xout, float* nb, const float* nw, const float* w, const float* b,
+                            const float* gamma, int T, int C, float eps, hipStream_t s) {
+    if (!vv_normdw_sliced_ok(T, C) || xin == xout) return -1;
+    if (C == 1024) hipLaunchKernelGGL((vv_normdw_sliced_kernel<1>), dim3(C / 256), dim3(256), 0, s, xin, xout, nb, nw, w, b, gamma, T, C, eps);
+    else hipLaunchKernelGGL((vv_normdw_sliced_kernel<2>), dim3(C / 256), dim3(256), 0, s, xin, xout, nb, nw, w, b, gamma, T, C, eps);
     return okk();
 }
 int vv_shift_rows_launch(const void* tab, int n_entries, int maxC, hipStream_t s) {
