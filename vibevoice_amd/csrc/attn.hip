@@ -216,6 +216,266 @@ __global__ __launch_bounds__(256) void vv_attn_split_kernel(
     }
 }
 
+// RoPE table: tab[pos][i] = (cos, sin)(pos * inv_freq[i]); same fp32 expressions as vv_rope_append_kernel.
+__global__ void vv_rope_table_kernel(const float* __restrict__ inv_freq, float2* __restrict__ tab, int n_pos, int half) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)n_pos * half) return;
+    const int pos = (int)(e / half), i = (int)(e - (int64_t)pos * half);
+    const float ang = (float)pos * inv_freq[i];
+    tab[e] = float2{cosf(ang), sinf(ang)};
+}
+
+// One launch per layer for decode steps (every row owns a different KV cache):
+//   RoPE(q) from the table, RoPE(k)/v of the new token appended to the cache by the workgroup whose chunk ends at
+//   `pos` (and patched into its own K/V fragments, so nothing waits on that store), split-KV attention as above,
+//   then -- if the sequence needed more than one chunk -- the LAST workgroup of a (row, kv head) to finish merges
+//   the partials: partial -> release fence -> ticket (device-scope atomic) -> acquire fence -> fixed-order merge.
+//   Replaces rope_append + split + merge (3 launches, 2 extra kernel boundaries per layer).
+template <int D, int XS>
+__global__ __launch_bounds__(256) void vv_attn_fused_kernel(
+    const float* __restrict__ qkv, const VVRow* __restrict__ rows, const float2* __restrict__ rope_tab,
+    __bf16* __restrict__ kc, __bf16* __restrict__ vc, int Hq, int Hkv, int64_t cache_stride, int64_t head_stride,
+    float q_scale, float* __restrict__ part_m, float* __restrict__ part_l, float* __restrict__ part_o,
+    unsigned* __restrict__ tickets, float* __restrict__ out) {
+    constexpr int KT = D / 32, DT = D / 16, HALF = D / 2;
+    const int S = gridDim.x;
+    const int split = blockIdx.x, kvh = blockIdx.y, r = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const VVRow rw = rows[r];
+    const int pos = rw.pos, len = pos + 1;
+    const int G = Hq / Hkv;
+    const int g = lane & 15, qg = lane >> 4;
+    int chunk = (len + S - 1) / S;
+    chunk = (chunk + 127) & ~127;
+    const int start = split * chunk;
+    const int end = min(len, start + chunk);
+    if (start >= len) return;
+    const int used = (len + chunk - 1) / chunk;
+    const bool owner = (split == used - 1);            // this chunk ends at the new token
+    const int QW = (Hq + 2 * Hkv) * D;
+    const float* qrow = qkv + (int64_t)r * QW;
+    const float2* tp = rope_tab + (int64_t)pos * HALF;
+    __bf16* kbase = kc + (int64_t)rw.cache * cache_stride + (int64_t)kvh * head_stride;
+    __bf16* vbase = vc + (int64_t)rw.cache * cache_stride + (int64_t)kvh * head_stride;
+
+    // ---- new token's K (rotated) / V: LDS copy for the patch below + the cache append (fire and forget) ----
+    __shared__ __attribute__((aligned(16))) __bf16 knew[D];
+    __shared__ __attribute__((aligned(16))) __bf16 vnew[D];
+    if (owner && tid < D) {
+        const int d = tid, i = d & (HALF - 1);
+        const float* ksrc = qrow + (int64_t)(Hq + kvh) * D;
+        const float2 cs = tp[i];
+        const float x = ksrc[d], xp = ksrc[d < HALF ? d + HALF : d - HALF];
+        const float kr = d < HALF ? x * cs.x - xp * cs.y : x * cs.x + xp * cs.y;
+        const __bf16 kb = (__bf16)kr;
+        knew[d] = kb;
+        {
+            const int pt = pos >> 4, pl = pos & 15;
+            const int64_t tile = (int64_t)pt * (D / 32) + (d >> 5);
+            kbase[(tile * 64 + pl + 16 * ((d & 31) >> 3)) * 8 + (d & 7)] = kb;
+        }
+        const __bf16 vb = (__bf16)qrow[(int64_t)(Hq + Hkv + kvh) * D + d];
+        vnew[d] = vb;
+        {
+            const int blk = pos >> 5, p = pos & 31;
+            const int half = p >> 4, pp = p & 15, q4 = pp >> 2, rr = pp & 3;
+            const int64_t tile = (int64_t)blk * (D / 16) + (d >> 4);
+            vbase[(tile * 64 + (d & 15) + 16 * q4) * 8 + half * 4 + rr] = vb;
+        }
+    }
+
+    // ---- q fragments: RoPE from the table, scaled, split into bf16 terms.  lane holds q[g][kt*32 + qg*8 + j] ----
+    bf16x8 qf[KT][XS];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        const int d0 = kt * 32 + qg * 8;
+        const int i0 = d0 & (HALF - 1);
+        const bool lo = d0 < HALF;
+        float v[8];
+        if (g < G) {
+            const float* qp = qrow + (int64_t)(kvh * G + g) * D;
+            const float4 xa = *reinterpret_cast<const float4*>(qp + d0), xb = *reinterpret_cast<const float4*>(qp + d0 + 4);
+            const int dp = lo ? d0 + HALF : d0 - HALF;
+            const float4 pa = *reinterpret_cast<const float4*>(qp + dp), pb = *reinterpret_cast<const float4*>(qp + dp + 4);
+            const float4 c0 = *reinterpret_cast<const float4*>(tp + i0), c1 = *reinterpret_cast<const float4*>(tp + i0 + 2);
+            const float4 c2 = *reinterpret_cast<const float4*>(tp + i0 + 4), c3 = *reinterpret_cast<const float4*>(tp + i0 + 6);
+            const float x[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+            const float xp[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
+            const float cc[8] = {c0.x, c0.z, c1.x, c1.z, c2.x, c2.z, c3.x, c3.z};
+            const float ss[8] = {c0.y, c0.w, c1.y, c1.w, c2.y, c2.w, c3.y, c3.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (lo ? x[j] * cc[j] - xp[j] * ss[j] : x[j] * cc[j] + xp[j] * ss[j]) * q_scale;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        }
+        split8<XS>(v, qf[kt]);
+    }
+    __syncthreads();                         // knew / vnew visible to the wave that meets the new token
+
+    const u32x4* kt_base = reinterpret_cast<const u32x4*>(kbase);
+    const u32x4* vt_base = reinterpret_cast<const u32x4*>(vbase);
+    float m = -INFINITY, lsum = 0.f;
+    f32x4 o[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int p0 = start + wave * 32; p0 < end; p0 += 128) {
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+        const int64_t t0 = (int64_t)(p0 >> 4) * KT;
+        u32x4 ka[KT], kb[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            ka[kt] = kt_base[(t0 + kt) * 64 + lane];
+            kb[kt] = kt_base[(t0 + KT + kt) * 64 + lane];
+        }
+        u32x4 vt[DT];
+        const int64_t vt0 = (int64_t)(p0 >> 5) * DT;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) vt[dt] = vt_base[(vt0 + dt) * 64 + lane];
+        if (owner && (pos >> 5) == (p0 >> 5)) {
+            // the append above may not have landed: take the new token's row / column from LDS instead
+            const int p = pos & 31;
+            if ((lane & 15) == (p & 15)) {
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    const u32x4 nk = *reinterpret_cast<const u32x4*>(&knew[kt * 32 + (lane >> 4) * 8]);
+                    if (p < 16) ka[kt] = nk; else kb[kt] = nk;
+                }
+            }
+            const int half = p >> 4, pp = p & 15, q4 = pp >> 2, rr = pp & 3;
+            if ((lane >> 4) == q4) {
+                const int j = half * 4 + rr;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    bf16x8 t = __builtin_bit_cast(bf16x8, vt[dt]);
+                    const __bf16 nv = vnew[dt * 16 + (lane & 15)];
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) if (jj == j) t[jj] = nv;
+                    vt[dt] = __builtin_bit_cast(u32x4, t);
+                }
+            }
+        }
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+            for (int p = 0; p < XS; ++p) {
+                s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ka[kt]), qf[kt][p], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kb[kt]), qf[kt][p], s1, 0, 0, 0);
+            }
+        }
+        float sv[8];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int pa = p0 + qg * 4 + rr;
+            sv[rr] = (pa < end) ? s0[rr] : -INFINITY;
+            sv[4 + rr] = (pa + 16 < end) ? s1[rr] : -INFINITY;
+            mx = fmaxf(mx, fmaxf(sv[rr], sv[4 + rr]));
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mn = fmaxf(m, mx);
+        const float alpha = (m == -INFINITY) ? 0.f : expf(m - mn);
+        float pv[8];
+        float ps = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            pv[j] = (sv[j] == -INFINITY) ? 0.f : expf(sv[j] - mn);
+            ps += pv[j];
+        }
+        lsum = lsum * alpha + ps;
+        m = mn;
+        bf16x8 pb[XS];
+        split8<XS>(pv, pb);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            o[dt] *= alpha;
+#pragma unroll
+            for (int p = 0; p < XS; ++p)
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vt[dt]), pb[p], o[dt], 0, 0, 0);
+        }
+    }
+    lsum += __shfl_xor(lsum, 16);
+    lsum += __shfl_xor(lsum, 32);
+
+    // ---- combine the 4 waves (fixed order) ----
+    __shared__ float sm[4][16], sl[4][16];
+    __shared__ f32x4 so[4][DT][64];
+    if (lane < 16) { sm[wave][lane] = m; sl[wave][lane] = lsum; }
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) so[wave][dt][lane] = o[dt];
+    __syncthreads();
+    if (wave != 0) return;
+    float M = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) M = fmaxf(M, sm[w][g]);
+    float L = 0.f;
+    f32x4 O[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i) O[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const float mw = sm[w][g];
+        const float f = (mw == -INFINITY) ? 0.f : expf(mw - M);
+        L += sl[w][g] * f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) O[dt] += so[w][dt][lane] * f;
+    }
+    float* orow = out + ((int64_t)r * Hq + kvh * G + g) * D + qg * 4;
+    if (used == 1) {                          // short sequence: this workgroup saw everything
+        if (g < G) {
+            const float inv = 1.0f / L;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                *reinterpret_cast<float4*>(orow + dt * 16) = float4{O[dt][0] * inv, O[dt][1] * inv, O[dt][2] * inv, O[dt][3] * inv};
+        }
+        return;
+    }
+    const int64_t gidx = (int64_t)r * Hkv + kvh;
+    const int64_t pidx = gidx * S + split;
+    if (lane < 16) { part_m[pidx * 16 + lane] = M; part_l[pidx * 16 + lane] = L; }
+    if (g < G) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+            *reinterpret_cast<float4*>(part_o + (pidx * 16 + g) * D + dt * 16 + qg * 4) = float4{O[dt][0], O[dt][1], O[dt][2], O[dt][3]};
+    }
+    // publish, then take a ticket: the workgroup that draws the last one merges
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    unsigned old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add(tickets + gidx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (old != (unsigned)(used - 1)) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (lane == 0) tickets[gidx] = 0u;        // next launch starts from zero (kernel boundary orders it)
+    float MM = -INFINITY;
+    for (int s2 = 0; s2 < used; ++s2) MM = fmaxf(MM, part_m[(gidx * S + s2) * 16 + g]);
+    float LL = 0.f;
+    f32x4 OO[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i) OO[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s2 = 0; s2 < used; ++s2) {       // fixed order: the result does not depend on who merges
+        const int64_t pi = gidx * S + s2;
+        const float ms = part_m[pi * 16 + g];
+        const float f = (ms == -INFINITY) ? 0.f : expf(ms - MM);
+        LL += part_l[pi * 16 + g] * f;
+        if (g < G) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const float4 po = *reinterpret_cast<const float4*>(part_o + (pi * 16 + g) * D + dt * 16 + qg * 4);
+                OO[dt][0] += po.x * f; OO[dt][1] += po.y * f; OO[dt][2] += po.z * f; OO[dt][3] += po.w * f;
+            }
+        }
+    }
+    if (g < G) {
+        const float inv = 1.0f / LL;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+            *reinterpret_cast<float4*>(orow + dt * 16) = float4{OO[dt][0] * inv, OO[dt][1] * inv, OO[dt][2] * inv, OO[dt][3] * inv};
+    }
+}
+
 // grid (R, Hq), block D threads
 template <int D>
 __global__ void vv_attn_merge_kernel(const float* __restrict__ part_m, const float* __restrict__ part_l,
@@ -266,6 +526,30 @@ static void attn_go(const float* q, const VVRow* rows, const void* kc, const voi
     hipLaunchKernelGGL((vv_attn_split_kernel<D, XS>), dim3(S, Hkv, R), dim3(256), 0, s, q, rows,
                        (const __bf16*)kc, (const __bf16*)vc, Hq, Hkv, cs, hs, pm, pl, po);
     hipLaunchKernelGGL((vv_attn_merge_kernel<D>), dim3(R, Hq), dim3(D), 0, s, pm, pl, po, rows, out, Hq, Hkv, S);
+}
+
+extern "C" int vv_rope_table_launch(const float* inv_freq, void* tab, int n_pos, int half, hipStream_t s) {
+    const int64_t n = (int64_t)n_pos * half;
+    hipLaunchKernelGGL(vv_rope_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, inv_freq, (float2*)tab, n_pos, half);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// Decode-step attention in one launch; requires every row to own a different cache (the new token of row r must not
+// be visible to -- or needed by -- another row of the same launch).
+extern "C" int vv_attn_fused_launch(int D, int xs, const float* qkv, const VVRow* rows, const void* rope_tab, void* kc, void* vc,
+                                    int R, int Hq, int Hkv, int64_t cache_stride, int64_t head_stride, int S,
+                                    float* pm, float* pl, float* po, unsigned* tickets, float* out, hipStream_t s) {
+    if (Hq % Hkv != 0 || Hq / Hkv > 16) return -1;
+    const float scale = 1.0f / sqrtf((float)D);
+#define VV_F(D_, XS_)                                                                                         \
+    hipLaunchKernelGGL((vv_attn_fused_kernel<D_, XS_>), dim3(S, Hkv, R), dim3(256), 0, s, qkv, rows,          \
+                       (const float2*)rope_tab, (__bf16*)kc, (__bf16*)vc, Hq, Hkv, cache_stride, head_stride, scale, \
+                       pm, pl, po, tickets, out)
+    if (D == 128) { if (xs == 1) VV_F(128, 1); else if (xs == 2) VV_F(128, 2); else VV_F(128, 3); }
+    else if (D == 64) { if (xs == 1) VV_F(64, 1); else if (xs == 2) VV_F(64, 2); else VV_F(64, 3); }
+    else return -1;
+#undef VV_F
+    return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 extern "C" int vv_attn_launch(int D, int xs, const float* q, const VVRow* rows, const void* kc, const void* vc,

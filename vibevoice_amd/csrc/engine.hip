@@ -20,6 +20,10 @@ int vv_pack_launch(const void* src, int src_is_bf16, void* dst, int N, int K, in
                    int stride, hipStream_t s);
 int vv_rope_append_launch(int D, const float* qkv, const VVRow* rows, const float* inv_freq, float* q_out, void* kc,
                           void* vc, int R, int Hq, int Hkv, int64_t cache_stride, int64_t head_stride, hipStream_t s);
+int vv_rope_table_launch(const float* inv_freq, void* tab, int n_pos, int half, hipStream_t s);
+int vv_attn_fused_launch(int D, int xs, const float* qkv, const VVRow* rows, const void* rope_tab, void* kc, void* vc,
+                         int R, int Hq, int Hkv, int64_t cache_stride, int64_t head_stride, int S,
+                         float* pm, float* pl, float* po, unsigned* tickets, float* out, hipStream_t s);
 int vv_attn_launch(int D, int xs, const float* q, const VVRow* rows, const void* kc, const void* vc, int R, int Hq,
                    int Hkv, int64_t cache_stride, int64_t head_stride, int S, float* pm, float* pl, float* po,
                    float* out, hipStream_t s);
@@ -125,6 +129,7 @@ struct vv_ctx {
     struct Layer { float *ln1, *ln2, *bqkv; void *wqkv, *wo, *wg, *wu, *wd; };
     std::vector<Layer> layers;
     float *lm_norm = nullptr, *inv_freq = nullptr;
+    void* rope_tab = nullptr; bool rope_ready = false; unsigned* tickets = nullptr; bool fused_attn_ok = true;
     float *tts_types = nullptr, *eos_b1 = nullptr, *eos_b2 = nullptr; void *eos_w1 = nullptr, *eos_w2 = nullptr;
     void *embed = nullptr, *lm_head = nullptr;
     bool lm_head_loaded = false;
@@ -595,6 +600,9 @@ extern "C" int vv_create(const vv_config* cfg, vv_ctx** out) {
     ctx->qrot = (float*)dalloc(ctx, (size_t)R * Hq * D * 4);
     ctx->attn = (float*)dalloc(ctx, (size_t)R * Hq * D * 4);
     ctx->act = (float*)dalloc(ctx, (size_t)R * I * 4);
+    ctx->rope_tab = dalloc(ctx, (size_t)c.max_ctx * (D / 2) * 8, false);
+    ctx->tickets = (unsigned*)dalloc(ctx, (size_t)R * Hkv * 4);
+    ctx->fused_attn_ok = !getenv("VVHIP_NO_FUSED_ATTN");
     const size_t np = (size_t)R * Hkv * c.attn_splits * 16;
     ctx->pm = (float*)dalloc(ctx, np * 4); ctx->pl = (float*)dalloc(ctx, np * 4); ctx->po = (float*)dalloc(ctx, np * D * 4);
     // ---- diffusion head ----
@@ -726,6 +734,7 @@ extern "C" int vv_upload(vv_ctx* ctx, const char* name, const void* src, int src
     }
     HIPCHK(ctx, hipStreamSynchronize(st));
     w.loaded = true;
+    ctx->rope_ready = false;      // (cos, sin) table is rebuilt from the current inv_freq on the next decode step
     return 0;
 }
 
@@ -798,7 +807,7 @@ extern "C" int vv_set_schedule(vv_ctx* ctx, int n_steps, const float* t, const f
     return 0;
 }
 
-static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float* hidden_out, int l0, int l1, int final_norm) {
+static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float* hidden_out, int l0, int l1, int final_norm, bool fused_attn) {
     const vv_config& c = ctx->c;
     const int H = ctx->H, D = ctx->D, Hq = ctx->Hq, Hkv = ctx->Hkv, I = ctx->I, QKV = ctx->QKV;
     HIPCHK(ctx, hipMemcpyAsync(ctx->h, x_in, (size_t)R * H * 4, hipMemcpyDeviceToDevice, st));
@@ -810,16 +819,21 @@ static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float*
         g.pro = VV_PRO_RMS; g.nw = L.ln1; g.eps = c.lm_eps; g.epi = VV_EPI_BIAS; g.bias = L.bqkv; g.nt = 1;
         g.xa = ctx->h_parts; g.n_xa = hp; g.part_stride = hps;
         GEMM(g);
-        ctx->launches += 3;
-        VVCHK(vv_rope_append_launch(D, ctx->qkv, ctx->rows_dev, ctx->inv_freq, ctx->qrot,
-                                    (char*)ctx->kc + (size_t)l * ctx->layer_stride * 2, (char*)ctx->vc + (size_t)l * ctx->layer_stride * 2,
-                                    R, Hq, Hkv, ctx->cache_stride, ctx->head_stride, st));
-        VVCHK(vv_attn_launch(D, c.xsplit, ctx->qrot, ctx->rows_dev, (char*)ctx->kc + (size_t)l * ctx->layer_stride * 2,
-                             (char*)ctx->vc + (size_t)l * ctx->layer_stride * 2, R, Hq, Hkv, ctx->cache_stride,
-                             ctx->head_stride, c.attn_splits, ctx->pm, ctx->pl, ctx->po, ctx->attn, st));
-        // (a single-launch variant -- RoPE + KV append inside the split kernel, merge inside o_proj's prologue --
-        //  was built and measured 4-5 % SLOWER end to end: graph-replayed boundaries cost ~1.6 us, while the extra
-        //  work landed on the critical path of bigger kernels.  See DESIGN.md "negative results".)
+        char* kl = (char*)ctx->kc + (size_t)l * ctx->layer_stride * 2;
+        char* vl = (char*)ctx->vc + (size_t)l * ctx->layer_stride * 2;
+        if (fused_attn) {
+            // decode rows (one cache each): RoPE + KV append + split attention + last-arriver merge in ONE launch
+            ctx->launches += 1;
+            VVCHK(vv_attn_fused_launch(D, c.xsplit, ctx->qkv, ctx->rows_dev, ctx->rope_tab, kl, vl, R, Hq, Hkv, ctx->cache_stride,
+                                       ctx->head_stride, c.attn_splits, ctx->pm, ctx->pl, ctx->po, ctx->tickets, ctx->attn, st));
+        } else {
+            // rows of one launch share caches (prefill chunks): every append must land before any row attends
+            ctx->launches += 3;
+            VVCHK(vv_rope_append_launch(D, ctx->qkv, ctx->rows_dev, ctx->inv_freq, ctx->qrot, kl, vl,
+                                        R, Hq, Hkv, ctx->cache_stride, ctx->head_stride, st));
+            VVCHK(vv_attn_launch(D, c.xsplit, ctx->qrot, ctx->rows_dev, kl, vl, R, Hq, Hkv, ctx->cache_stride,
+                                 ctx->head_stride, c.attn_splits, ctx->pm, ctx->pl, ctx->po, ctx->attn, st));
+        }
         VVGemm go = mk_gemm(L.wo, ctx->attn, ctx->h, R, H, Hq * D, Hq * D, H);
         go.epi = VV_EPI_RESID; go.nt = 1;
         go.ya = ctx->h_parts; go.n_ya = hp; go.part_stride = hps;     // o_proj folds the parts back: h is whole again
@@ -859,8 +873,15 @@ extern "C" int vv_lm_forward_range(vv_ctx* ctx, void* stream, int n_rows, const 
     HIPCHK(ctx, hipMemcpyAsync(ctx->rows_dev, pin, sizeof(VVRow) * n_rows, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipEventRecord(ctx->ring_ev[slot], st));
     ctx->launches = 0;
-    char key[128]; snprintf(key, 128, "lm:%d:%p:%p:%d:%d:%d", n_rows, (const void*)x_in_dev, (void*)hidden_out_dev, l0, l1, final_norm);
-    return graphed(ctx, key, st, [&]() { return lm_body(ctx, st, n_rows, x_in_dev, hidden_out_dev, l0, l1, final_norm); });
+    bool fused = ctx->fused_attn_ok;
+    for (int i = 0; i < n_rows && fused; ++i)
+        for (int j = 0; j < i; ++j) if (rows[i].cache == rows[j].cache) { fused = false; break; }
+    if (fused && !ctx->rope_ready) {          // (cos, sin) table of every position, once the inv_freq parameter is in place
+        VVCHK(vv_rope_table_launch(ctx->inv_freq, ctx->rope_tab, ctx->c.max_ctx, ctx->D / 2, st));
+        ctx->rope_ready = true;
+    }
+    char key[128]; snprintf(key, 128, "lm:%d:%p:%p:%d:%d:%d:%d", n_rows, (const void*)x_in_dev, (void*)hidden_out_dev, l0, l1, final_norm, fused ? 1 : 0);
+    return graphed(ctx, key, st, [&]() { return lm_body(ctx, st, n_rows, x_in_dev, hidden_out_dev, l0, l1, final_norm, fused); });
 }
 
 extern "C" int vv_kv_import(vv_ctx* ctx, void* stream, int cache, int layer, int n_pos, const void* k_dev, const void* v_dev, int src_dtype) {
