@@ -20,6 +20,14 @@
 
 namespace {
 
+// positions per split: at least 512 (below that one workgroup walking the sequence beats a cross-workgroup merge),
+// a multiple of 128 (4 waves x 32), and few enough splits to fit the grid
+__device__ __forceinline__ int attn_chunk(int len, int S) {
+    int chunk = (len + S - 1) / S;
+    chunk = (chunk + 127) & ~127;
+    return chunk < 512 ? 512 : chunk;
+}
+
 template <int XS>
 __device__ __forceinline__ void split8(const float (&v)[8], bf16x8 (&out)[XS]) {
 #pragma unroll
@@ -100,8 +108,7 @@ __global__ __launch_bounds__(256) void vv_attn_split_kernel(
     const int G = Hq / Hkv;
     const int g = lane & 15;
     const int qg = lane >> 4;
-    int chunk = (len + S - 1) / S;
-    chunk = (chunk + 127) & ~127;
+    const int chunk = attn_chunk(len, S);
     const int start = split * chunk;
     const int end = min(len, start + chunk);
     if (start >= len) return;                   // whole block: the merge kernel never reads unused splits
@@ -246,8 +253,7 @@ __global__ __launch_bounds__(256) void vv_attn_fused_kernel(
     const int pos = rw.pos, len = pos + 1;
     const int G = Hq / Hkv;
     const int g = lane & 15, qg = lane >> 4;
-    int chunk = (len + S - 1) / S;
-    chunk = (chunk + 127) & ~127;
+    const int chunk = attn_chunk(len, S);
     const int start = split * chunk;
     const int end = min(len, start + chunk);
     if (start >= len) return;
@@ -321,19 +327,28 @@ __global__ __launch_bounds__(256) void vv_attn_fused_kernel(
 #pragma unroll
     for (int i = 0; i < DT; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int p0 = start + wave * 32; p0 < end; p0 += 128) {
-        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+    // K/V fragments of the next 32-position block are requested before the current one is consumed
+    u32x4 nka[KT], nkb[KT], nvt[DT];
+    auto kv_load = [&](int p0) {
         const int64_t t0 = (int64_t)(p0 >> 4) * KT;
-        u32x4 ka[KT], kb[KT];
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
-            ka[kt] = kt_base[(t0 + kt) * 64 + lane];
-            kb[kt] = kt_base[(t0 + KT + kt) * 64 + lane];
+            nka[kt] = kt_base[(t0 + kt) * 64 + lane];
+            nkb[kt] = kt_base[(t0 + KT + kt) * 64 + lane];
         }
-        u32x4 vt[DT];
         const int64_t vt0 = (int64_t)(p0 >> 5) * DT;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) vt[dt] = vt_base[(vt0 + dt) * 64 + lane];
+        for (int dt = 0; dt < DT; ++dt) nvt[dt] = vt_base[(vt0 + dt) * 64 + lane];
+    };
+    if (start + wave * 32 < end) kv_load(start + wave * 32);
+    for (int p0 = start + wave * 32; p0 < end; p0 += 128) {
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+        u32x4 ka[KT], kb[KT], vt[DT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) { ka[kt] = nka[kt]; kb[kt] = nkb[kt]; }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) vt[dt] = nvt[dt];
+        if (p0 + 128 < end) kv_load(p0 + 128);
         if (owner && (pos >> 5) == (p0 >> 5)) {
             // the append above may not have landed: take the new token's row / column from LDS instead
             const int p = pos & 31;
@@ -487,8 +502,7 @@ __global__ void vv_attn_merge_kernel(const float* __restrict__ part_m, const flo
     const int64_t base = ((int64_t)r * Hkv + kvh) * S;
     // same chunking as the split kernel: only the first `used` splits hold data
     const int len = rows[r].pos + 1;
-    int chunk = (len + S - 1) / S;
-    chunk = (chunk + 127) & ~127;
+    const int chunk = attn_chunk(len, S);
     const int used = (len + chunk - 1) / chunk;
     float M = -INFINITY;
     for (int s = 0; s < used; ++s) M = fmaxf(M, part_m[(base + s) * 16 + g]);
