@@ -85,8 +85,11 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
     constexpr bool DUAL = (EPI == VV_EPI_SWIGLU);
     constexpr int NM = DUAL ? 2 : 1;
     // LDS: [wave][XS][U][4][MR] x 16 B staging tiles, then [wave][NM][64] f32x4 partials, then [wave][MR] ssq
-    __shared__ __attribute__((aligned(16))) unsigned char stg_all[WPB * XS * U * 4 * MR * 16];
-    __shared__ f32x4 red[WPB][NM][64];
+    // adaLN-modulated norm: y = rs * W.(x*nw*(1+scale)) + W.shift -- two B operands and two accumulator sets, so the
+    // 1/rms of the row is only needed in the epilogue (as for plain RMSNorm) and no pre-pass over x exists
+    constexpr int NOP = (PRO == VV_PRO_RMS_MOD) ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) unsigned char stg_all[WPB * NOP * XS * U * 4 * MR * 16];
+    __shared__ f32x4 red[WPB][NM * NOP][64];
     __shared__ float ssq_sh[WPB][MR];
     // Pull every kernel argument into SGPRs with ONE batch of s_loads: left alone the compiler fetches
     // them lazily behind branches, i.e. 3-4 dependent ~600-cycle round trips on a launch's critical path.
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
     const unsigned kt1 = min(kb1, kt0 + kper);
     const bool has_k = kt0 < kt1;
     const int frow = lane & 15, fq = lane >> 4;
-    unsigned char* stg = stg_all + (size_t)wave * (XS * U * 4 * MR * 16);
+    unsigned char* stg = stg_all + (size_t)wave * (NOP * XS * U * 4 * MR * 16);
     const unsigned kk = lane * 4;
     const unsigned st_off = (((kk >> 5) * 4 + ((kk & 31) >> 3)) * MR) * 16 + (kk & 7) * 2;
 
@@ -187,44 +190,9 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
         }
     }
 
-    // ---- adaLN-modulated norm: 1/rms of the whole row is needed before staging ----
-    float rstd[MR];
+    f32x4 acc[NM * NOP];            // [NM, 2NM): the shift operand's products (RMS_MOD)
 #pragma unroll
-    for (int r = 0; r < MR; ++r) rstd[r] = 1.f;
-    if constexpr (PRO == VV_PRO_RMS_MOD) {
-#pragma unroll
-        for (int r = 0; r < MR; ++r) {
-            float s = 0.f;
-            if (r < T) {
-                const float* xr = a.X + (unsigned)((t_base + r) * a.ldx);
-                for (unsigned k = kt0 * 32 + kk; k < min(kt1 * 32, (unsigned)a.K); k += 256) {
-                    float4 v = *reinterpret_cast<const float4*>(xr + k);
-                    if constexpr (PARTS == 1) {
-                        const float* xp = a.xa + (unsigned)((t_base + r) * a.ldx);
-                        const float4 p0 = *reinterpret_cast<const float4*>(xp + k);
-                        const float4 p1 = *reinterpret_cast<const float4*>(xp + a.part_stride + k);
-                        v.x = (v.x + p0.x) + p1.x; v.y = (v.y + p0.y) + p1.y; v.z = (v.z + p0.z) + p1.z; v.w = (v.w + p0.w) + p1.w;
-                    }
-                    s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-                }
-                s = wave_sum_dpp(s);
-            }
-            if (lane == 0) ssq_sh[wave][r] = s;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < MR; ++r) {
-            float s = 0.f;
-#pragma unroll
-            for (int w = 0; w < WPB; ++w) s += ssq_sh[w][r];
-            rstd[r] = rsqrtf(s / (float)a.K + a.eps);
-        }
-        __syncthreads();          // ssq_sh is reused by the epilogue path of PRO_RMS only, but keep phases apart
-    }
-
-    f32x4 acc[NM];
-#pragma unroll
-    for (int i = 0; i < NM; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NM * NOP; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     float ssq[MR];
 #pragma unroll
     for (int r = 0; r < MR; ++r) ssq[r] = 0.f;
@@ -245,11 +213,15 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
                     ssq[r] += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
                     v[0] *= R.nwv.x; v[1] *= R.nwv.y; v[2] *= R.nwv.z; v[3] *= R.nwv.w;
                 } else if constexpr (PRO == VV_PRO_RMS_MOD) {
-                    const float rs = rstd[r];
-                    v[0] = ((v[0] * rs * R.nwv.x) * (1.f + R.sc[r].x) + R.sh[r].x) * msk;
-                    v[1] = ((v[1] * rs * R.nwv.y) * (1.f + R.sc[r].y) + R.sh[r].y) * msk;
-                    v[2] = ((v[2] * rs * R.nwv.z) * (1.f + R.sc[r].z) + R.sh[r].z) * msk;
-                    v[3] = ((v[3] * rs * R.nwv.w) * (1.f + R.sc[r].w) + R.sh[r].w) * msk;
+                    ssq[r] += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+                    v[0] = (v[0] * R.nwv.x) * (1.f + R.sc[r].x); v[1] = (v[1] * R.nwv.y) * (1.f + R.sc[r].y);
+                    v[2] = (v[2] * R.nwv.z) * (1.f + R.sc[r].z); v[3] = (v[3] * R.nwv.w) * (1.f + R.sc[r].w);
+                    float sh4[4] = {R.sh[r].x * msk, R.sh[r].y * msk, R.sh[r].z * msk, R.sh[r].w * msk};
+                    uint2 sparts[XS];
+                    split4<XS>(sh4, sparts);
+#pragma unroll
+                    for (int p = 0; p < XS; ++p)
+                        *reinterpret_cast<uint2*>(stg + (XS + p) * (U * 4 * MR * 16) + st_off + r * 16) = sparts[p];
                 } else if constexpr (PRO == VV_PRO_ADD_SILU) {
                     v[0] = silu_acc(v[0] + R.addv[r].x) * msk; v[1] = silu_acc(v[1] + R.addv[r].y) * msk;
                     v[2] = silu_acc(v[2] + R.addv[r].z) * msk; v[3] = silu_acc(v[3] + R.addv[r].w) * msk;
@@ -274,6 +246,14 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
 #pragma unroll
                     for (int i = 0; i < NM; ++i)
                         acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wb[u][i]), xb, acc[i], 0, 0, 0);
+                    if constexpr (NOP == 2) {
+                        u32x4 f2 = u32x4{0u, 0u, 0u, 0u};
+                        if (frow < MR) f2 = *reinterpret_cast<const u32x4*>(stg + (size_t)(((XS + p) * U + u) * 4 + fq) * (MR * 16) + frow * 16);
+                        const bf16x8 sb = __builtin_bit_cast(bf16x8, f2);
+#pragma unroll
+                        for (int i = 0; i < NM; ++i)
+                            acc[NM + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wb[u][i]), sb, acc[NM + i], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -311,8 +291,8 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
     VV_STAMP(3);
     // ---- split-K partials -> LDS, one barrier, wave 0 finishes ----
 #pragma unroll
-    for (int i = 0; i < NM; ++i) red[wave][i][lane] = acc[i];
-    if constexpr (PRO == VV_PRO_RMS) {
+    for (int i = 0; i < NM * NOP; ++i) red[wave][i][lane] = acc[i];
+    if constexpr (PRO == VV_PRO_RMS || PRO == VV_PRO_RMS_MOD) {
 #pragma unroll
         for (int r = 0; r < MR; ++r) {
             const float s = (r < T) ? wave_sum_dpp(ssq[r]) : 0.f;
@@ -326,16 +306,22 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
 #pragma unroll
     for (int w = 1; w < WPB; ++w)
 #pragma unroll
-        for (int i = 0; i < NM; ++i) acc[i] += red[w][i][lane];
+        for (int i = 0; i < NM * NOP; ++i) acc[i] += red[w][i][lane];
     if (!epi_lane) return;
     float rs = 1.0f;
-    if constexpr (PRO == VV_PRO_RMS) {
+    if constexpr (PRO == VV_PRO_RMS || PRO == VV_PRO_RMS_MOD) {
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < WPB; ++w) s += ssq_sh[w][frow];
         rs = rsqrtf(s / (float)a.K + a.eps);
     }
     float o[4] = {acc[0][0] * rs, acc[0][1] * rs, acc[0][2] * rs, acc[0][3] * rs};
+    float up[4] = {0.f, 0.f, 0.f, 0.f};            // SwiGLU: the "up" half
+    if constexpr (DUAL) { up[0] = acc[1][0] * rs; up[1] = acc[1][1] * rs; up[2] = acc[1][2] * rs; up[3] = acc[1][3] * rs; }
+    if constexpr (NOP == 2) {                      // + W.shift
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { o[r] += acc[NM][r]; if constexpr (DUAL) up[r] += acc[NM + 1][r]; }
+    }
     const float pb[4] = {pre_b.x, pre_b.y, pre_b.z, pre_b.w};
     const float py[4] = {(pre_y.x + pre_y0.x) + pre_y1.x, (pre_y.y + pre_y0.y) + pre_y1.y, (pre_y.z + pre_y0.z) + pre_y1.z, (pre_y.w + pre_y0.w) + pre_y1.w};
     const float pg[4] = {pre_g.x, pre_g.y, pre_g.z, pre_g.w};
@@ -347,7 +333,7 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
         for (int r = 0; r < 4; ++r) o[r] = gelu_erf_f(o[r] + pb[r]);
     } else if constexpr (EPI == VV_EPI_SWIGLU) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = silu_acc(o[r]) * (acc[NM - 1][r] * rs);
+        for (int r = 0; r < 4; ++r) o[r] = silu_acc(o[r]) * up[r];
     } else if constexpr (EPI == VV_EPI_RESID) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = (ksb == 0) ? py[r] + pg[r] * (o[r] + pb[r]) : pg[r] * o[r];
