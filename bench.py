@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--text-tokens", type=int, default=220)
     ap.add_argument("--voice-frames", type=int, default=75)
     ap.add_argument("--speakers", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=1, help="utterances decoded together on each GPU (1 = the BASELINE config; "
+                    "up to 8 share every LM / diffusion-head weight pass)")
     ap.add_argument("--max-ctx", type=int, default=0)
     ap.add_argument("--kv-start", type=int, default=0,
                     help="pretend the positive KV cache already holds this many tokens after the prefill "
@@ -109,12 +111,13 @@ def main():
     if "streaming" in args.model:
         return bench_streaming(args, cfg, rank, world, device)
     K, W, NS = args.steps, max(1, args.warmup), args.solver_steps
+    B = max(1, min(8, args.batch))
     inputs = synthetic.synthetic_inputs(cfg, n_speakers=args.speakers, text_tokens=args.text_tokens,
-                                        voice_frames=args.voice_frames, seed=100 + rank)
+                                        voice_frames=args.voice_frames, seed=100 + rank, batch=B)
     L0 = inputs["input_ids"].shape[1]
     total_steps = W + K + 2
     max_ctx = args.max_ctx or ((max(L0, args.kv_start) + total_steps + 256 + 127) // 128 * 128)
-    ecfg = engine_config_from_reference(cfg, n_slots=1, max_ctx=max_ctx, xsplit=args.xsplit,
+    ecfg = engine_config_from_reference(cfg, n_slots=B, max_ctx=max_ctx, xsplit=args.xsplit,
                                         use_graph=not args.no_graph, enc_frames=5)
     t_load0 = time.time()
     eng = Engine(ecfg, device)
@@ -140,10 +143,10 @@ def main():
     model.set_ddpm_inference_steps(NS)
     load_s = time.time() - t_load0
 
-    forced = [synthetic.forced_schedule(total_steps, turn=150)]
+    forced = [synthetic.forced_schedule(total_steps, turn=150) for _ in range(B)]
     g = torch.Generator(device=device)
     g.manual_seed(1234 + rank)
-    noise_bank = torch.randn(total_steps + 1, 2, cfg["acoustic_vae_dim"], generator=g, device=device)
+    noise_bank = torch.randn(total_steps + 1, 2 * B, cfg["acoustic_vae_dim"], generator=g, device=device)
     torch.cuda.synchronize()
 
     marks = {}
@@ -169,7 +172,7 @@ def main():
     t_gen1 = time.perf_counter()
     wall = marks[W + K] - marks[W]
     # steps W..W+K-1: count the <speech_diffusion> frames among them (the schedule inserts 2 control tokens per 150)
-    frames = sum(1 for t in forced[0][W:W + K] if t == synthetic.TOKENS.speech_diffusion_id)
+    frames = B * sum(1 for t in forced[0][W:W + K] if t == synthetic.TOKENS.speech_diffusion_id)
     frames_all, wall_max = parallel.aggregate_throughput(frames, wall, device)   # sum over ranks / max over ranks
     value = frames_all * FRAME_SEC / wall_max
     audio_total = out.speech_outputs[0].shape[-1] / 24000.0
@@ -183,7 +186,7 @@ def main():
     roof = None
     if rank == 0 and not args.no_roofline:
         kprof = 8
-        forced_p = [synthetic.forced_schedule(kprof + 3, turn=150)]
+        forced_p = [synthetic.forced_schedule(kprof + 3, turn=150) for _ in range(B)]
         prof = {}
 
         def prof_cb(step):
@@ -193,7 +196,7 @@ def main():
             if step == 2 + kprof:
                 prof["res"] = eng.profile_end()
         inp2 = synthetic.synthetic_inputs(cfg, n_speakers=args.speakers, text_tokens=args.text_tokens,
-                                          voice_frames=args.voice_frames, seed=100)
+                                          voice_frames=args.voice_frames, seed=100, batch=B)
         model.generate(tokenizer=synthetic.TOKENS, cfg_scale=args.cfg_scale, generation_config={"do_sample": False},
                        max_new_tokens=kprof + 3, show_progress_bar=False, _forced_tokens=forced_p,
                        _noise_fn=lambda step, n2: noise_bank[step], _step_callback=prof_cb, **inp2)
@@ -231,7 +234,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"VibeVoice-{args.model.upper()} shapes, {args.speakers} speaker, "
                                    f"{L0}-token prompt ({args.text_tokens} text + {args.voice_frames}-frame voice), "
-                                   f"{NS} solver steps, cfg {args.cfg_scale}, 1 utterance per GPU, forced token schedule",
+                                   f"{NS} solver steps, cfg {args.cfg_scale}, {B} utterance{'s' if B > 1 else ''} per GPU, forced token schedule",
                        "model": f"VibeVoice-{args.model}", "solver_steps": NS, "prompt_tokens": L0,
                        "xsplit": args.xsplit, "hipgraph": not args.no_graph, "kv_start": args.kv_start, "parallelism": f"utterance-dp{world}"},
             "roofline": roof, "cpu_baseline": cpu,

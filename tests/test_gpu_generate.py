@@ -153,6 +153,34 @@ def test_generate_with_graphs():
         s.eng.close()
 
 
+def test_speculative_sampler_is_invisible(sm):
+    """The sampler is enqueued before the token is known (modeling.py).  With the CPU global RNG as the noise source
+    (the reference's, :701) a wrong guess must restore the RNG state: speculation on/off give bit-identical output."""
+    from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference
+    ids, mask, sim, st, spm = make_inputs(sm, 1, False, 77)
+    cfgd = {"decoder_config": {"max_position_embeddings": sm.lmcfg.max_pos},
+            "diffusion_head_config": {"ddpm_num_inference_steps": 5},
+            "acoustic_tokenizer_config": {"fix_std": 0.5, "std_dist_type": "gaussian"}}
+    tok = types.SimpleNamespace(speech_start_id=TOK.speech_start_id, speech_end_id=TOK.speech_end_id,
+                                speech_diffusion_id=TOK.speech_diffusion_id, eos_token_id=TOK.eos_token_id,
+                                bos_token_id=None, pad_token_id=TOK.pad_token_id)
+    forced = [[D, D, D, E, S, D, D, E, S, D, X]]       # every <speech_end> is a wrong guess
+    outs = []
+    for spec in (True, False):
+        m = VibeVoiceForConditionalGenerationInference(cfgd, sm.eng, model_dtype=torch.float32)
+        m.set_speech_factors(sm.scaling, sm.bias)
+        m.set_ddpm_inference_steps(5)
+        m.speculate_sampling = spec
+        torch.manual_seed(1234)
+        out = m.generate(input_ids=ids, attention_mask=mask, cfg_scale=1.3, tokenizer=tok, generation_config={"do_sample": False},
+                         _forced_tokens=forced, show_progress_bar=False)
+        outs.append((out.sequences.cpu(), out.speech_outputs[0].cpu(), torch.rand(1)))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert outs[0][1].shape[-1] == 6 * 3200
+    assert torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[0][2], outs[1][2])          # the RNG stream ends in the same state
+
+
 class FakeStreamer:
     """Records the AudioStreamer calls generate() must make (streamer.py:42-76)."""
 

@@ -482,7 +482,10 @@ extern "C" int vv_gemv_launch(VVGemm a, int xs, hipStream_t s);
 // Chooses the kernel and its decomposition.  `xs` in {1,2,3}.
 extern "C" int vv_gemm_launch(VVGemm a, int xs, hipStream_t s) {
     static const bool no_gemv = getenv("VVHIP_NO_GEMV") != nullptr;
-    if (!no_gemv && a.ksplit <= 0 && vv_gemv_ok(&a) && (a.T <= 4 || xs <= 2)) return vv_gemv_launch(a, xs, s);
+    if (!no_gemv && a.ksplit <= 0 && vv_gemv_ok(&a) && (a.T <= 4 || xs <= 2)) {
+        const int r = vv_gemv_launch(a, xs, s);
+        if (r != -3) return r;                 // -3: no instantiation for this (pair, rows, split mode): general kernel
+    }
     if (a.kgrid > 1 || a.n_xa > 0 || a.n_ya > 0) return -4;      // part tensors exist only on the decode GEMV path
     const int n_tiles = (a.N + 15) / 16;
     const int k_tiles = (a.K + 31) / 32;

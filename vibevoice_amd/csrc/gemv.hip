@@ -406,11 +406,14 @@ extern "C" int vv_gemv_ok(const VVGemm* a) {
 #define VV_GEMV_WIDE(X)                                                                        \
     X(VV_PRO_NONE, VV_EPI_STORE) X(VV_PRO_NONE, VV_EPI_BIAS) X(VV_PRO_NONE, VV_EPI_RESID)      \
     X(VV_PRO_RMS, VV_EPI_BIAS) X(VV_PRO_RMS, VV_EPI_BIAS_GELU) X(VV_PRO_RMS, VV_EPI_SWIGLU)    \
-    X(VV_PRO_ADD_SILU, VV_EPI_STORE)
+    X(VV_PRO_ADD_SILU, VV_EPI_STORE) X(VV_PRO_NONE, VV_EPI_GATED_RESID)
+// 16-row diffusion-head pairs (8 utterances x {cond, uncond} rows): two B operands -> 4-wave workgroups only (LDS)
+#define VV_GEMV_WIDE_MOD(X)                                                                    \
+    X(VV_PRO_RMS_MOD, VV_EPI_SWIGLU) X(VV_PRO_RMS_MOD, VV_EPI_CFG_DPM) X(VV_PRO_RMS_MOD, VV_EPI_STORE)
 
 static bool gemv_combo_ok(int pro, int epi, bool wide) {
 #define X(P, E) if (pro == P && epi == E) return true;
-    if (wide) { VV_GEMV_WIDE(X) } else { VV_GEMV_COMBOS(X) }
+    if (wide) { VV_GEMV_WIDE(X) VV_GEMV_WIDE_MOD(X) } else { VV_GEMV_COMBOS(X) }
 #undef X
     return false;
 }
@@ -453,6 +456,9 @@ extern "C" int vv_gemv_launch(VVGemm a, int xs, hipStream_t s) {
         }
 #define X(P, E) if (a.pro == P && a.epi == E) { if (xs == 1) VV_GO(1, P, E, 16, 8); else VV_GO(2, P, E, 16, 8); }
         VV_GEMV_WIDE(X)
+#undef X
+#define X(P, E) if (a.pro == P && a.epi == E) { if (xs == 1) VV_GO(1, P, E, 16, 4); else return -3; }
+        VV_GEMV_WIDE_MOD(X)
 #undef X
         return -3;
     }
