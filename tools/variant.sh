@@ -4,7 +4,7 @@
 set -e
 R="$(cd "$(dirname "$0")/.." && pwd)"; C=$R/vibevoice_amd/csrc; O=$R/build/obj; V=$R/build/variants
 mkdir -p $O $V
-FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-unused-result"
+FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-unused-result -mllvm -amdgpu-kernarg-preload-count=16"
 SFX=""; XF=""
 if [ "$3" = "all" ]; then SFX="_$1"; XF="$2"; fi
 for f in gemm attn misc block1d engine; do

@@ -33,7 +33,7 @@ def build(force=False, verbose=True):
     if not force and not stale():
         return LIB
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-value", "-Wno-unused-result"] + os.environ.get("VVHIP_CFLAGS", "").split() + \
+           "-Wno-unused-value", "-Wno-unused-result", "-mllvm", "-amdgpu-kernarg-preload-count=16"] + os.environ.get("VVHIP_CFLAGS", "").split() + \
           [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
     if verbose:
         print("[vibevoice_amd] building libvvhip.so:", " ".join(cmd), file=sys.stderr)

@@ -81,7 +81,13 @@ constexpr int U = 8;       // k-steps per batch (256 k = one float4 per lane per
 // PARTS: the activation (prologue side) or residual (epilogue side) tensor arrives as base + 2 part tensors (the producer
 // split K over 3 workgroup columns): the three loads are issued together and summed in a fixed order.
 template <int XS, int PRO, int EPI, int MR, int WPB, int PARTS = 0>      // PARTS: 0 none, 1 activation side, 2 residual side
-__global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
+// The operands every wave needs before its first load (weight / activation bases, shape, strides) are separate leading
+// scalar parameters: with -mllvm -amdgpu-kernarg-preload-count=16 the dispatcher delivers them in SGPRs at wave launch,
+// so the first addresses do not wait for a scalar-cache round trip; the rest of VVGemm is fetched by one s_load batch.
+__global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const u32x4* __restrict__ pW, const u32x4* __restrict__ pW2,
+                                                           const float* __restrict__ pX, float* __restrict__ pY,
+                                                           const float* __restrict__ pnw, int pT, int pN, int pK, int pldx,
+                                                           int pldy, const VVGemm a) {
     constexpr bool DUAL = (EPI == VV_EPI_SWIGLU);
     constexpr int NM = DUAL ? 2 : 1;
     // LDS: [wave][XS][U][4][MR] x 16 B staging tiles, then [wave][NM][64] f32x4 partials, then [wave][MR] ssq
@@ -93,9 +99,8 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
     __shared__ float ssq_sh[WPB][MR];
     // Pull every kernel argument into SGPRs with ONE batch of s_loads: left alone the compiler fetches
     // them lazily behind branches, i.e. 3-4 dependent ~600-cycle round trips on a launch's critical path.
-    asm volatile("" ::"s"(a.W), "s"(a.W2), "s"(a.X), "s"(a.Y), "s"(a.nw), "s"(a.mod_scale), "s"(a.mod_shift),
-                 "s"(a.addvec), "s"(a.bias), "s"(a.nscale), "s"(a.gate));
-    asm volatile("" ::"s"(a.T), "s"(a.N), "s"(a.K), "s"(a.ldx), "s"(a.ldy), "s"(a.ld_mod), "s"(a.ld_gate), "s"(a.x_row_mod), "s"(a.add_rows_per_vec),
+    asm volatile("" ::"s"(a.mod_scale), "s"(a.mod_shift), "s"(a.addvec), "s"(a.bias), "s"(a.nscale), "s"(a.gate));
+    asm volatile("" ::"s"(a.ld_mod), "s"(a.ld_gate), "s"(a.x_row_mod), "s"(a.add_rows_per_vec),
                  "s"(a.eps), "s"(a.z), "s"(a.x0p), "s"(a.coef), "s"(a.cfg), "s"(a.n_cfg));
     asm volatile("" ::"s"(a.yparts), "s"(a.xa), "s"(a.ya), "s"(a.n_xa), "s"(a.n_ya), "s"(a.part_stride));
     VV_STAMP(0);
@@ -104,9 +109,9 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // 16-row form: grid.y walks 16-row tiles of a tall activation (tokenizer stages, prefill chunks)
     const int t_base = (MR == 16) ? (int)blockIdx.y * 16 : 0;
-    const int T = min(MR, a.T - t_base);
+    const int T = min(MR, pT - t_base);
     const unsigned tile = blockIdx.x;
-    const unsigned k_tiles = (unsigned)(a.K + 31) >> 5;
+    const unsigned k_tiles = (unsigned)(pK + 31) >> 5;
     // K range of this workgroup (grid.y splits K for few-tile x long-K shapes so that all CUs stream), then of this wave
     const unsigned KSB = (MR == 4) ? gridDim.y : 1u;
     const unsigned ksb = (MR == 4) ? blockIdx.y : 0u;
@@ -121,8 +126,8 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
     const unsigned kk = lane * 4;
     const unsigned st_off = (((kk >> 5) * 4 + ((kk & 31) >> 3)) * MR) * 16 + (kk & 7) * 2;
 
-    const u32x4* wbase = a.W + (size_t)tile * k_tiles * 64 + lane;
-    const u32x4* wbase2 = DUAL ? a.W2 + (size_t)tile * k_tiles * 64 + lane : nullptr;
+    const u32x4* wbase = pW + (size_t)tile * k_tiles * 64 + lane;
+    const u32x4* wbase2 = DUAL ? pW2 + (size_t)tile * k_tiles * 64 + lane : nullptr;
 
     constexpr int MODR = (PRO == VV_PRO_RMS_MOD) ? MR : 1;
     constexpr int ADDR = (PRO == VV_PRO_ADD_SILU) ? MR : 1;
@@ -130,22 +135,22 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
     struct XR { float4 x[MR]; float4 p0[PR]; float4 p1[PR]; float4 sc[MODR]; float4 sh[MODR]; float4 addv[ADDR]; float4 nwv; };
     auto x_load = [&](unsigned ktb, XR& R) {
         unsigned k = ktb * 32 + kk;
-        const bool kin = k < min(kt1 * 32, (unsigned)a.K);
+        const bool kin = k < min(kt1 * 32, (unsigned)pK);
         if (!kin) k = 0;                                   // clamped: always a legal address, masked later
-        R.nwv = a.nw ? *reinterpret_cast<const float4*>(a.nw + k) : float4{1.f, 1.f, 1.f, 1.f};
+        R.nwv = pnw ? *reinterpret_cast<const float4*>(pnw + k) : float4{1.f, 1.f, 1.f, 1.f};
 #pragma unroll
         for (int r = 0; r < MR; ++r) {
             if (r < T) {
                 const int rg = t_base + r;
                 const int xr_idx = a.x_row_mod > 0 ? rg % a.x_row_mod : rg;
-                R.x[r] = *reinterpret_cast<const float4*>(a.X + (unsigned)(xr_idx * a.ldx) + k);
+                R.x[r] = *reinterpret_cast<const float4*>(pX + (unsigned)(xr_idx * pldx) + k);
                 if constexpr (PARTS == 1) {
-                    R.p0[r] = *reinterpret_cast<const float4*>(a.xa + (unsigned)(xr_idx * a.ldx) + k);
-                    R.p1[r] = *reinterpret_cast<const float4*>(a.xa + (unsigned)(a.part_stride + xr_idx * a.ldx) + k);
+                    R.p0[r] = *reinterpret_cast<const float4*>(a.xa + (unsigned)(xr_idx * pldx) + k);
+                    R.p1[r] = *reinterpret_cast<const float4*>(a.xa + (unsigned)(a.part_stride + xr_idx * pldx) + k);
                 }
                 if constexpr (PRO == VV_PRO_ADD_SILU) {
                     const int av = a.add_rows_per_vec > 0 ? rg / a.add_rows_per_vec : 0;
-                    R.addv[r] = *reinterpret_cast<const float4*>(a.addvec + (unsigned)(av * a.K) + k);
+                    R.addv[r] = *reinterpret_cast<const float4*>(a.addvec + (unsigned)(av * pK) + k);
                 }
                 if constexpr (PRO == VV_PRO_RMS_MOD) {
                     R.sc[r] = *reinterpret_cast<const float4*>(a.mod_scale + (unsigned)(rg * a.ld_mod) + k);
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
 
     // ---- epilogue operands: requested now, consumed ~one weight stream later (wave 0 only) ----
     const int n0 = tile * 16 + fq * 4;
-    const bool epi_lane = (wave == 0) && frow < T && n0 < a.N;
+    const bool epi_lane = (wave == 0) && frow < T && n0 < pN;
     float4 pre_y = {0.f, 0.f, 0.f, 0.f}, pre_b = {0.f, 0.f, 0.f, 0.f}, pre_g = {1.f, 1.f, 1.f, 1.f};
     float4 pre_y0 = {0.f, 0.f, 0.f, 0.f}, pre_y1 = {0.f, 0.f, 0.f, 0.f};
     if (epi_lane) {            // N % 4 == 0 and 16-B aligned operands are launch preconditions (vv_gemv_ok)
@@ -179,9 +184,9 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
             if (a.bias) pre_b = *reinterpret_cast<const float4*>(a.bias + n0);
         }
         if constexpr (EPI == VV_EPI_RESID || EPI == VV_EPI_GATED_RESID) {
-            pre_y = *reinterpret_cast<const float4*>(a.Y + (unsigned)((t_base + frow) * a.ldy + n0));
+            pre_y = *reinterpret_cast<const float4*>(pY + (unsigned)((t_base + frow) * pldy + n0));
             if constexpr (PARTS == 2) {
-                const float* yp0 = a.ya + (unsigned)((t_base + frow) * a.ldy + n0);
+                const float* yp0 = a.ya + (unsigned)((t_base + frow) * pldy + n0);
                 pre_y0 = *reinterpret_cast<const float4*>(yp0);
                 pre_y1 = *reinterpret_cast<const float4*>(yp0 + a.part_stride);
             }
@@ -199,7 +204,7 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
 
     auto x_stage = [&](unsigned ktb, const XR& R) {
         const unsigned k = ktb * 32 + kk;
-        const float msk = (k < min(kt1 * 32, (unsigned)a.K)) ? 1.f : 0.f;
+        const float msk = (k < min(kt1 * 32, (unsigned)pK)) ? 1.f : 0.f;
 #pragma unroll
         for (int r = 0; r < MR; ++r) {
             if (r < T) {
@@ -313,7 +318,7 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < WPB; ++w) s += ssq_sh[w][frow];
-        rs = rsqrtf(s / (float)a.K + a.eps);
+        rs = rsqrtf(s / (float)pK + a.eps);
     }
     float o[4] = {acc[0][0] * rs, acc[0][1] * rs, acc[0][2] * rs, acc[0][3] * rs};
     float up[4] = {0.f, 0.f, 0.f, 0.f};            // SwiGLU: the "up" half
@@ -348,20 +353,20 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const VVGemm a) {
         for (int r = 0; r < 4; ++r) {
             const float vu = __shfl(o[r], lane + nc);
             const int n = n0 + r;
-            if (frow < nc && n < a.N) {
+            if (frow < nc && n < pN) {
                 const float v = vu + a.cfg * (o[r] - vu);
-                const unsigned zi = (unsigned)(frow * a.N + n);
+                const unsigned zi = (unsigned)(frow * pN + n);
                 const float zo = a.z[zi];
                 const float x0 = ca * zo - cs_ * v;
                 const float zn = csx * zo + c0 * x0 + c1 * (x0 - a.x0p[zi]);
                 a.x0p[zi] = x0;
                 a.z[zi] = zn;
-                a.z[zi + (unsigned)(nc * a.N)] = zn;
+                a.z[zi + (unsigned)(nc * pN)] = zn;
             }
         }
         return;
     }
-    float* yp = (ksb == 0 ? a.Y : a.yparts + (unsigned)((ksb - 1) * a.part_stride)) + (unsigned)((t_base + frow) * a.ldy + n0);
+    float* yp = (ksb == 0 ? pY : a.yparts + (unsigned)((ksb - 1) * a.part_stride)) + (unsigned)((t_base + frow) * pldy + n0);
     *reinterpret_cast<float4*>(yp) = float4{o[0], o[1], o[2], o[3]};
     VV_STAMP(6);
     VV_BSTAMP(1);
@@ -444,7 +449,7 @@ extern "C" int vv_gemv_launch(VVGemm a, int xs, hipStream_t s) {
     if (a.epi == VV_EPI_SWIGLU && !a.W2) return -1;
     dim3 grid(n_tiles);
 #define VV_GO(XS_, P, E, MR_, WP_)                                                                      \
-    do { hipLaunchKernelGGL((vv_gemv_kernel<XS_, P, E, MR_, WP_>), grid, dim3(WP_ * 64), 0, s, a);       \
+    do { hipLaunchKernelGGL((vv_gemv_kernel<XS_, P, E, MR_, WP_>), grid, dim3(WP_ * 64), 0, s, a.W, a.W2, a.X, a.Y, a.nw, a.T, a.N, a.K, a.ldx, a.ldy, a);       \
          return hipGetLastError() == hipSuccess ? 0 : -2; } while (0)
     if (a.T > 4) {
         if (xs > 2) return -3;       // 16-row staging tiles of the exact mode exceed the LDS: general kernel
@@ -465,7 +470,7 @@ extern "C" int vv_gemv_launch(VVGemm a, int xs, hipStream_t s) {
     if (a.n_xa > 0 || a.n_ya > 0) {           // consumers of a K-split tensor (decode rows only)
         if (a.kgrid > 1) grid.y = a.kgrid;
 #define VV_GOP(XS_, P, E, WP_, S_)                                                                      \
-    do { hipLaunchKernelGGL((vv_gemv_kernel<XS_, P, E, 4, WP_, S_>), grid, dim3(WP_ * 64), 0, s, a);     \
+    do { hipLaunchKernelGGL((vv_gemv_kernel<XS_, P, E, 4, WP_, S_>), grid, dim3(WP_ * 64), 0, s, a.W, a.W2, a.X, a.Y, a.nw, a.T, a.N, a.K, a.ldx, a.ldy, a);     \
          return hipGetLastError() == hipSuccess ? 0 : -2; } while (0)
 #define X(P, E)                                                                                         \
     if (a.pro == P && a.epi == E) {                                                                     \
