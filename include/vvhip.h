@@ -40,7 +40,7 @@ typedef struct vv_config {
     /* runtime */
     int n_slots;       /* concurrent utterances: 2 KV caches (cond/uncond) + 2 conv states each */
     int max_ctx;       /* KV positions per cache (rounded up to 128) */
-    int max_rows;      /* max LM rows per step (<=16) */
+    int max_rows;      /* max LM rows per launch (<=2048): decode uses 2 per utterance, prompt prefill fills it */
     int xsplit;        /* activation precision inside MFMA: 1 bf16, 2 ~fp24, 3 fp32-exact */
     int attn_splits;   /* flash-decoding splits along the sequence */
     int enc_frames;    /* frames per chunk of the voice-prompt encoder (>=1) */

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -168,6 +169,7 @@ struct vv_ctx {
     // staging
     void* stage = nullptr; size_t stage_bytes = 0;
     std::map<std::string, GraphEntry> graphs;
+    std::set<std::string> seen;
     int64_t launches = 0;
     // optional per-GEMM-launch hipEvent timing (vv_profile_begin/end)
     bool prof_on = false;
@@ -512,20 +514,20 @@ static int graphed(vv_ctx* ctx, const std::string& key, hipStream_t st, F&& body
     if (!ctx->c.use_graph || ctx->prof_on) return body();
     auto it = ctx->graphs.find(key);
     if (it == ctx->graphs.end()) {
-        // warm run first (lazy allocations, shift tables), then capture
-        int r = body();
-        if (r) return r;
+        // first sight of a key: run eagerly (lazy allocations, shift tables) and remember it; a key that comes back is
+        // captured then.  One-off launch shapes (prompt prefill chunks: unique pointers) never pay for a capture.
+        if (ctx->seen.size() > 8192) ctx->seen.clear();
+        if (ctx->seen.insert(key).second) return body();
         hipGraph_t graph;
         HIPCHK(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
-        r = body();
+        int r = body();
         hipError_t e = hipStreamEndCapture(st, &graph);
         if (r) return r;
         HIPCHK(ctx, e);
         GraphEntry ge;
         HIPCHK(ctx, hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0));
         hipGraphDestroy(graph);
-        ctx->graphs[key] = ge;
-        return 0;       // the warm run already produced this call's result
+        it = ctx->graphs.emplace(key, ge).first;
     }
     HIPCHK(ctx, hipGraphLaunch(it->second.exec, st));
     return 0;
@@ -538,7 +540,7 @@ extern "C" int vv_create(const vv_config* cfg, vv_ctx** out) {
     vv_ctx* ctx = new vv_ctx();
     ctx->c = *cfg; ctx->err[0] = 0;
     vv_config& c = ctx->c;
-    if (c.max_rows < 1 || c.max_rows > 16) { delete ctx; return fail(nullptr, "max_rows must be in [1,16]"); }
+    if (c.max_rows < 1 || c.max_rows > 2048) { delete ctx; return fail(nullptr, "max_rows must be in [1,2048]"); }
     if (c.lm_head_dim != 64 && c.lm_head_dim != 128) { delete ctx; return fail(nullptr, "head_dim must be 64 or 128"); }
     if (c.xsplit < 1 || c.xsplit > 3) c.xsplit = 2;
     if (c.attn_splits < 1) c.attn_splits = 32;
@@ -588,8 +590,8 @@ extern "C" int vv_create(const vv_config* cfg, vv_ctx** out) {
     ctx->cache_stride = ctx->layer_stride * c.lm_layers;
     ctx->kc = dalloc(ctx, (size_t)ctx->cache_stride * n_caches * 2);
     ctx->vc = dalloc(ctx, (size_t)ctx->cache_stride * n_caches * 2);
-    ctx->rows_dev = (VVRow*)dalloc(ctx, sizeof(VVRow) * 16);
-    hipHostMalloc((void**)&ctx->rows_pin, sizeof(VVRow) * 16 * vv_ctx::RING);
+    ctx->rows_dev = (VVRow*)dalloc(ctx, sizeof(VVRow) * 2048);
+    hipHostMalloc((void**)&ctx->rows_pin, sizeof(VVRow) * 2048 * vv_ctx::RING);
     for (int i = 0; i < vv_ctx::RING; ++i) hipEventCreateWithFlags(&ctx->ring_ev[i], hipEventDisableTiming);
     ctx->ids_dev = (int*)dalloc(ctx, sizeof(int) * 64);
     hipHostMalloc((void**)&ctx->ids_pin, sizeof(int) * 64 * vv_ctx::RING);
@@ -868,7 +870,7 @@ extern "C" int vv_lm_forward_range(vv_ctx* ctx, void* stream, int n_rows, const 
         if (rows[i].pos < 0 || rows[i].pos >= ctx->c.max_ctx) return fail(ctx, "row %d: position %d exceeds max_ctx %d", i, rows[i].pos, ctx->c.max_ctx);
     }
     const int slot = ring_acquire(ctx);
-    VVRow* pin = ctx->rows_pin + (size_t)slot * 16;
+    VVRow* pin = ctx->rows_pin + (size_t)slot * 2048;
     for (int i = 0; i < n_rows; ++i) { pin[i].cache = rows[i].cache; pin[i].pos = rows[i].pos; }
     HIPCHK(ctx, hipMemcpyAsync(ctx->rows_dev, pin, sizeof(VVRow) * n_rows, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipEventRecord(ctx->ring_ev[slot], st));

@@ -27,6 +27,7 @@ Differences from the reference that do not change results:
 """
 import json
 import os
+import time
 from dataclasses import dataclass
 from typing import Callable, List, Optional
 
@@ -123,6 +124,7 @@ class VibeVoiceForConditionalGenerationInference:
     @classmethod
     def from_state_dict(cls, config: dict, state_dict, model_dtype=torch.bfloat16, device=None, **runtime):
         """state_dict: mapping (or iterable of (key, tensor)) keyed like the reference checkpoint."""
+        runtime.setdefault("max_rows", 512)          # prompt rows per LM weight pass (MFMA tile GEMM above ~128 workgroups)
         ecfg = engine_config_from_reference(config, **runtime)
         eng = Engine(ecfg, device)
         items = state_dict.items() if hasattr(state_dict, "items") else state_dict
@@ -292,6 +294,7 @@ class VibeVoiceForConditionalGenerationInference:
         H = e.cfg.lm_hidden
         have_embeds = False
         n_frames = 0
+        time_prefill = os.environ.get("VVHIP_TIME_PREFILL") is not None     # debug: sync + time the two prefill phases
 
         if tqdm_class is not None and kwargs.get("show_progress_bar", True):
             progress = tqdm_class(range(max_steps), desc="Generating", leave=False)
@@ -321,8 +324,11 @@ class VibeVoiceForConditionalGenerationInference:
                 # ---------------- positive (+ speculative negative) LM pass ----------------
                 if step == 0:
                     sp_embeds = None
+                    t_pf = [time.perf_counter()] if time_prefill else None
                     if is_prefill and speech_tensors is not None and speech_masks is not None:
                         _, sp_embeds = self._process_speech_inputs(speech_tensors, speech_masks, prefill_noise)
+                    if time_prefill:
+                        e.sync(); t_pf.append(time.perf_counter())
                     sp_off = 0
                     for b in range(B):
                         m = attention_mask[b].bool()
@@ -336,12 +342,16 @@ class VibeVoiceForConditionalGenerationInference:
                             if cnt:
                                 emb[sm] = sp_embeds[sp_off:sp_off + cnt]
                                 sp_off += cnt
-                        hid = e.new(16, H)
-                        for i0 in range(0, n, 16):
-                            k = min(16, n - i0)
+                        CH = e.cfg.max_rows          # prompt rows per weight pass (the 16-row GEMV form walks row tiles)
+                        hid = e.new(CH, H)
+                        for i0 in range(0, n, CH):
+                            k = min(CH, n - i0)
                             e.lm_forward([(2 * b, i0 + j) for j in range(k)], emb[i0:i0 + k], hid)
                         pos_len[b] = max(n, kv_start)
-                        self._hidden[b].copy_(hid[(n - 1) % 16])
+                        self._hidden[b].copy_(hid[(n - 1) % CH])
+                    if time_prefill:
+                        e.sync(); t_pf.append(time.perf_counter())
+                        self.last_prefill = {"voice_encode_s": round(t_pf[1] - t_pf[0], 5), "lm_prefill_s": round(t_pf[2] - t_pf[1], 5)}
                     spec = False
                 else:
                     rows = [(2 * b, pos_len[b]) for b in act]
