@@ -491,6 +491,108 @@ __global__ __launch_bounds__(256) void vv_attn_fused_kernel(
     }
 }
 
+// Prompt prefill: the rows of the launch are consecutive positions of ONE cache (rows[0] = first).  A workgroup owns 16
+// consecutive query rows x one kv head; the 16 rows are the MFMA columns, so every K / V fragment is read once per 16
+// queries (the decode kernel above would read it once per query).  Wave w walks the whole causal prefix for query heads
+// w, w+4, ... of the group (online softmax, no cross-wave merge) and writes the normalised output rows directly.
+// Runs after vv_rope_append_kernel (q rotated + scaled in q_rot, the chunk's own K/V already in the cache).
+template <int D, int XS>
+__global__ __launch_bounds__(256) void vv_attn_prefill_kernel(
+    const float* __restrict__ q, const VVRow* __restrict__ rows, const __bf16* __restrict__ kc,
+    const __bf16* __restrict__ vc, int R, int Hq, int Hkv, int64_t cache_stride, int64_t head_stride,
+    float* __restrict__ out) {
+    constexpr int KT = D / 32, DT = D / 16;
+    const int r0 = blockIdx.x * 16, kvh = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const VVRow rw = rows[0];
+    const int G = Hq / Hkv;
+    const int col = lane & 15, qg = lane >> 4;
+    const int row = r0 + col;                            // query row of this lane's column
+    const int plim = rw.pos + min(row, R - 1);           // last position that row may attend (causal)
+    const int pend = rw.pos + min(r0 + 15, R - 1) + 1;   // positions the tile walks
+    const u32x4* kt_base = reinterpret_cast<const u32x4*>(kc + (int64_t)rw.cache * cache_stride + (int64_t)kvh * head_stride);
+    const u32x4* vt_base = reinterpret_cast<const u32x4*>(vc + (int64_t)rw.cache * cache_stride + (int64_t)kvh * head_stride);
+    for (int g = wave; g < G; g += 4) {
+        const int h = kvh * G + g;
+        bf16x8 qf[KT][XS];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            float v[8];
+            const float* qp = q + ((int64_t)min(row, R - 1) * Hq + h) * D + kt * 32 + qg * 8;
+            const float4 a0 = *reinterpret_cast<const float4*>(qp), a1 = *reinterpret_cast<const float4*>(qp + 4);
+            v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+            split8<XS>(v, qf[kt]);
+        }
+        float m = -INFINITY, lsum = 0.f;
+        f32x4 o[DT];
+#pragma unroll
+        for (int i = 0; i < DT; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int p0 = 0; p0 < pend; p0 += 32) {
+            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+            const int64_t t0 = (int64_t)(p0 >> 4) * KT;
+            u32x4 ka[KT], kb[KT], vt[DT];
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                ka[kt] = kt_base[(t0 + kt) * 64 + lane];
+                kb[kt] = kt_base[(t0 + KT + kt) * 64 + lane];
+            }
+            const int64_t vt0 = (int64_t)(p0 >> 5) * DT;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) vt[dt] = vt_base[(vt0 + dt) * 64 + lane];
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+                for (int p = 0; p < XS; ++p) {
+                    s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ka[kt]), qf[kt][p], s0, 0, 0, 0);
+                    s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kb[kt]), qf[kt][p], s1, 0, 0, 0);
+                }
+            }
+            float sv[8];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int pa = p0 + qg * 4 + rr;
+                sv[rr] = (pa <= plim) ? s0[rr] : -INFINITY;
+                sv[4 + rr] = (pa + 16 <= plim) ? s1[rr] : -INFINITY;
+                mx = fmaxf(mx, fmaxf(sv[rr], sv[4 + rr]));
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mn = fmaxf(m, mx);
+            // a column whose whole block is masked (query earlier than this block) keeps its state untouched
+            const float alpha = (m == -INFINITY) ? 0.f : expf(m - mn);
+            float pv[8];
+            float ps = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                pv[j] = (sv[j] == -INFINITY) ? 0.f : expf(sv[j] - mn);
+                ps += pv[j];
+            }
+            if (mn != -INFINITY) { lsum = lsum * alpha + ps; m = mn; }
+            bf16x8 pb[XS];
+            split8<XS>(pv, pb);
+            const float al = (mn == -INFINITY) ? 1.f : alpha;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                o[dt] *= al;
+#pragma unroll
+                for (int p = 0; p < XS; ++p)
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vt[dt]), pb[p], o[dt], 0, 0, 0);
+            }
+        }
+        lsum += __shfl_xor(lsum, 16);
+        lsum += __shfl_xor(lsum, 32);
+        if (row < R) {
+            const float inv = 1.0f / lsum;
+            float* orow = out + ((int64_t)row * Hq + h) * D + qg * 4;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                *reinterpret_cast<float4*>(orow + dt * 16) = float4{o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv};
+        }
+    }
+}
+
 // grid (R, Hq), block D threads
 template <int D>
 __global__ void vv_attn_merge_kernel(const float* __restrict__ part_m, const float* __restrict__ part_l,
@@ -540,6 +642,20 @@ static void attn_go(const float* q, const VVRow* rows, const void* kc, const voi
     hipLaunchKernelGGL((vv_attn_split_kernel<D, XS>), dim3(S, Hkv, R), dim3(256), 0, s, q, rows,
                        (const __bf16*)kc, (const __bf16*)vc, Hq, Hkv, cs, hs, pm, pl, po);
     hipLaunchKernelGGL((vv_attn_merge_kernel<D>), dim3(R, Hq), dim3(D), 0, s, pm, pl, po, rows, out, Hq, Hkv, S);
+}
+
+// rows = consecutive positions of one cache (rows[0] first); q_rot / cache already written by vv_rope_append_launch
+extern "C" int vv_attn_prefill_launch(int D, int xs, const float* q, const VVRow* rows, const void* kc, const void* vc, int R,
+                                      int Hq, int Hkv, int64_t cache_stride, int64_t head_stride, float* out, hipStream_t s) {
+    if (Hq % Hkv != 0) return -1;
+#define VV_P(D_, XS_)                                                                                              \
+    hipLaunchKernelGGL((vv_attn_prefill_kernel<D_, XS_>), dim3((R + 15) / 16, Hkv), dim3(256), 0, s, q, rows,      \
+                       (const __bf16*)kc, (const __bf16*)vc, R, Hq, Hkv, cache_stride, head_stride, out)
+    if (D == 128) { if (xs == 1) VV_P(128, 1); else if (xs == 2) VV_P(128, 2); else VV_P(128, 3); }
+    else if (D == 64) { if (xs == 1) VV_P(64, 1); else if (xs == 2) VV_P(64, 2); else VV_P(64, 3); }
+    else return -1;
+#undef VV_P
+    return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 extern "C" int vv_rope_table_launch(const float* inv_freq, void* tab, int n_pos, int half, hipStream_t s) {

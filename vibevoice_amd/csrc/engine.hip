@@ -21,6 +21,8 @@ int vv_pack_launch(const void* src, int src_is_bf16, void* dst, int N, int K, in
                    int stride, hipStream_t s);
 int vv_rope_append_launch(int D, const float* qkv, const VVRow* rows, const float* inv_freq, float* q_out, void* kc,
                           void* vc, int R, int Hq, int Hkv, int64_t cache_stride, int64_t head_stride, hipStream_t s);
+int vv_attn_prefill_launch(int D, int xs, const float* q, const VVRow* rows, const void* kc, const void* vc, int R,
+                           int Hq, int Hkv, int64_t cache_stride, int64_t head_stride, float* out, hipStream_t s);
 int vv_rope_table_launch(const float* inv_freq, void* tab, int n_pos, int half, hipStream_t s);
 int vv_attn_fused_launch(int D, int xs, const float* qkv, const VVRow* rows, const void* rope_tab, void* kc, void* vc,
                          int R, int Hq, int Hkv, int64_t cache_stride, int64_t head_stride, int S,
@@ -809,7 +811,7 @@ extern "C" int vv_set_schedule(vv_ctx* ctx, int n_steps, const float* t, const f
     return 0;
 }
 
-static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float* hidden_out, int l0, int l1, int final_norm, bool fused_attn) {
+static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float* hidden_out, int l0, int l1, int final_norm, bool fused_attn, bool contiguous) {
     const vv_config& c = ctx->c;
     const int H = ctx->H, D = ctx->D, Hq = ctx->Hq, Hkv = ctx->Hkv, I = ctx->I, QKV = ctx->QKV;
     HIPCHK(ctx, hipMemcpyAsync(ctx->h, x_in, (size_t)R * H * 4, hipMemcpyDeviceToDevice, st));
@@ -833,8 +835,12 @@ static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float*
             ctx->launches += 3;
             VVCHK(vv_rope_append_launch(D, ctx->qkv, ctx->rows_dev, ctx->inv_freq, ctx->qrot, kl, vl,
                                         R, Hq, Hkv, ctx->cache_stride, ctx->head_stride, st));
-            VVCHK(vv_attn_launch(D, c.xsplit, ctx->qrot, ctx->rows_dev, kl, vl, R, Hq, Hkv, ctx->cache_stride,
-                                 ctx->head_stride, c.attn_splits, ctx->pm, ctx->pl, ctx->po, ctx->attn, st));
+            if (contiguous)      // prompt chunk: 16 query rows share every K/V fragment
+                VVCHK(vv_attn_prefill_launch(D, c.xsplit, ctx->qrot, ctx->rows_dev, kl, vl, R, Hq, Hkv, ctx->cache_stride,
+                                             ctx->head_stride, ctx->attn, st));
+            else
+                VVCHK(vv_attn_launch(D, c.xsplit, ctx->qrot, ctx->rows_dev, kl, vl, R, Hq, Hkv, ctx->cache_stride,
+                                     ctx->head_stride, c.attn_splits, ctx->pm, ctx->pl, ctx->po, ctx->attn, st));
         }
         VVGemm go = mk_gemm(L.wo, ctx->attn, ctx->h, R, H, Hq * D, Hq * D, H);
         go.epi = VV_EPI_RESID; go.nt = 1;
@@ -882,8 +888,12 @@ extern "C" int vv_lm_forward_range(vv_ctx* ctx, void* stream, int n_rows, const 
         VVCHK(vv_rope_table_launch(ctx->inv_freq, ctx->rope_tab, ctx->c.max_ctx, ctx->D / 2, st));
         ctx->rope_ready = true;
     }
-    char key[128]; snprintf(key, 128, "lm:%d:%p:%p:%d:%d:%d:%d", n_rows, (const void*)x_in_dev, (void*)hidden_out_dev, l0, l1, final_norm, fused ? 1 : 0);
-    return graphed(ctx, key, st, [&]() { return lm_body(ctx, st, n_rows, x_in_dev, hidden_out_dev, l0, l1, final_norm, fused); });
+    bool contiguous = !fused && n_rows >= 8 && !getenv("VVHIP_NO_PREFILL_ATTN");      // one cache, consecutive positions
+    for (int i = 1; i < n_rows && contiguous; ++i)
+        if (rows[i].cache != rows[0].cache || rows[i].pos != rows[0].pos + i) contiguous = false;
+    char key[128]; snprintf(key, 128, "lm:%d:%p:%p:%d:%d:%d:%d", n_rows, (const void*)x_in_dev, (void*)hidden_out_dev, l0, l1, final_norm,
+                            fused ? 1 : (contiguous ? 2 : 0));
+    return graphed(ctx, key, st, [&]() { return lm_body(ctx, st, n_rows, x_in_dev, hidden_out_dev, l0, l1, final_norm, fused, contiguous); });
 }
 
 extern "C" int vv_kv_import(vv_ctx* ctx, void* stream, int cache, int layer, int n_pos, const void* k_dev, const void* v_dev, int src_dtype) {
