@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="utterances decoded together on each GPU (1 = the BASELINE config; "
                     "up to 8 share every LM / diffusion-head weight pass)")
     ap.add_argument("--max-ctx", type=int, default=0)
+    ap.add_argument("--enc-frames", type=int, default=5, help="voice-prompt frames per acoustic-encoder pass")
     ap.add_argument("--prefill-rows", type=int, default=512, help="prompt rows per LM weight pass (engine max_rows)")
     ap.add_argument("--kv-start", type=int, default=0,
                     help="pretend the positive KV cache already holds this many tokens after the prefill "
@@ -119,7 +120,7 @@ def main():
     total_steps = W + K + 2
     max_ctx = args.max_ctx or ((max(L0, args.kv_start) + total_steps + 256 + 127) // 128 * 128)
     ecfg = engine_config_from_reference(cfg, n_slots=B, max_ctx=max_ctx, xsplit=args.xsplit,
-                                        use_graph=not args.no_graph, enc_frames=5, max_rows=max(2 * B, args.prefill_rows))
+                                        use_graph=not args.no_graph, enc_frames=args.enc_frames, max_rows=max(2 * B, args.prefill_rows))
     t_load0 = time.time()
     eng = Engine(ecfg, device)
     exp = eng.expected_weights()

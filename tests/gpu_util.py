@@ -39,7 +39,7 @@ class Small:
             max_position_embeddings=self.lmcfg.max_pos, head_eps=self.hc.eps, codec_eps=self.cc.eps)
 
 
-def build_small(lmcfg=None, xsplit=3, use_graph=False, n_slots=2, max_ctx=512, tied=False):
+def build_small(lmcfg=None, xsplit=3, use_graph=False, n_slots=2, max_ctx=512, tied=False, max_rows=16):
     from vibevoice_amd.engine import Engine, EngineConfig
     lmcfg = lmcfg or synth.LMCfg()
     H = lmcfg.hidden
@@ -57,7 +57,7 @@ def build_small(lmcfg=None, xsplit=3, use_graph=False, n_slots=2, max_ctx=512, t
                         lm_inter=lmcfg.inter, lm_vocab=lmcfg.vocab, lm_eps=lmcfg.eps, rope_theta=lmcfg.theta,
                         head_layers=hc.layers, head_ffn_ratio=hc.ffn_ratio, head_eps=hc.eps,
                         n_filters=cc.n_filters, ratios=cc.ratios, enc_depths=cc.enc_depths, sem_dim=128,
-                        codec_eps=cc.eps, n_slots=n_slots, max_ctx=max_ctx, xsplit=xsplit, use_graph=use_graph,
+                        codec_eps=cc.eps, n_slots=n_slots, max_ctx=max_ctx, xsplit=xsplit, use_graph=use_graph, max_rows=max_rows,
                         enc_frames=2)
     eng = Engine(ecfg)
     sd = {}

@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def sm():
-    s = build_small(synth.LMCfg(), xsplit=3)
+    s = build_small(synth.LMCfg(), xsplit=3, max_rows=160)
     yield s
     s.eng.close()
 
@@ -63,6 +63,64 @@ def test_gemm_transpose_detecting(sm):
         eng.gemm_raw(wp, dev(x, eng), y, N, K, xsplit=3)
     eng.sync()
     assert max_err(y, x) < 1e-6
+
+
+@pytest.mark.parametrize("pro,epi", [(1, 1), (1, 2), (0, 4), (1, 3), (0, 0), (0, 1), (1, 0)])
+@pytest.mark.parametrize("xs,tol", [(2, 2e-4), (1, 2e-2)])
+def test_gemm_tile_prefill_shapes(sm, pro, epi, xs, tol):
+    """MFMA tile GEMM (tile.hip): taken for launches with >= 128 workgroups -- prompt-prefill sized problems.
+    Ragged T (not a multiple of 64), K not a multiple of the 256-k chunk, N not a multiple of the 128-feature tile."""
+    eng = sm.eng
+    T, N, K = 333, 4112, 416
+    g = synth.Gen(991 + pro * 10 + epi)
+    w = g.normal((N, K), 1.0 / np.sqrt(K))
+    w2 = g.normal((N, K), 1.0 / np.sqrt(K))
+    x = g.normal((T, K), 1.0, mat=False)
+    nw = g.vec(K, 0.1, 1.0)
+    bias = g.vec(N, 0.3)
+    nscale = g.uniform((N,), 0.5, 1.5)
+    y0 = g.normal((T, N), 1.0, mat=False)
+    xin = x
+    if pro == 1:
+        xin = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-5) * nw
+    acc = xin @ w.t()
+    if epi == 1:
+        ref = acc + bias
+    elif epi == 2:
+        ref = torch.nn.functional.gelu(acc + bias)
+    elif epi == 3:
+        ref = torch.nn.functional.silu(acc) * (xin @ w2.t())
+    elif epi == 4:
+        ref = y0 + nscale * (acc + bias)
+    else:
+        ref = acc
+    y = dev(y0.clone(), eng)
+    with torch.cuda.stream(eng.stream):
+        eng.gemm_raw(eng.pack_matrix(w), dev(x, eng), y, N, K, pro=pro, epi=epi,
+                     w2p=eng.pack_matrix(w2) if epi == 3 else None, nw=dev(nw, eng), eps=1e-5,
+                     bias=dev(bias, eng), nscale=dev(nscale, eng), xsplit=xs)
+    eng.sync()
+    assert rel_err(y, ref) <= tol, rel_err(y, ref)
+
+
+def test_lm_prefill_one_pass_matches_chunked(sm):
+    """A 150-token prompt prefilled in one launch (prefill attention kernel: 16 query rows per workgroup) gives the same
+    last hidden state / next-step output as the 16-row chunking the other LM tests use."""
+    from vibevoice_amd.engine import Engine
+    eng = sm.eng
+    H = sm.lmcfg.hidden
+    g = synth.Gen(4242)
+    n = min(150, eng.cfg.max_rows)
+    x = dev(g.normal((n, H), 1.0, mat=False), eng)
+    hid_a = eng.new(n, H)
+    hid_b = eng.new(n, H)
+    with torch.cuda.stream(eng.stream):
+        eng.lm_forward([(0, j) for j in range(n)], x, hid_a)                 # cache 0: one pass (or the largest the engine allows)
+        for i0 in range(0, n, 7):                                            # cache 1: ragged 7-row chunks (split + merge path below 8 rows)
+            k = min(7, n - i0)
+            eng.lm_forward([(1, i0 + j) for j in range(k)], x[i0:i0 + k], hid_b[i0:i0 + k])
+    eng.sync()
+    assert rel_err(hid_a, hid_b) <= 5e-4, rel_err(hid_a, hid_b)
 
 
 @pytest.mark.parametrize("T", [8, 40, 203])
