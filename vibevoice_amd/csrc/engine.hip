@@ -111,7 +111,7 @@ struct CodecNet {
     std::vector<float*> in_buf;            // per slot: [6 + Tin][in_dim]
     std::vector<std::vector<Stage>> st;    // per slot
     ConvG head;
-    float* u = nullptr;                    // FFN hidden scratch (shared)
+    std::vector<float*> u;                 // FFN hidden scratch, one per slot (slots may run concurrently on different streams)
     std::vector<std::map<int, void*>> shift_tab;   // per slot: F -> device table
     std::vector<int> shift_n;
     std::vector<void*> zero_tab;
@@ -319,7 +319,8 @@ static int build_codec(vv_ctx* ctx, CodecNet& net, const std::string& pfx, bool 
         add_mat(ctx, pfx + "head.conv.conv.weight", g.N, g.K, g.w, 0, 1, Cin, g.N, 7, 1);
         g.bias = add_vec(ctx, pfx + "head.conv.conv.bias", g.N);
     }
-    net.u = (float*)dalloc(ctx, umax);
+    net.u.resize(n_slots);
+    for (int sl = 0; sl < n_slots; ++sl) net.u[sl] = (float*)dalloc(ctx, umax, false);
     // ---- per-slot buffers + shift tables ----
     net.in_buf.resize(n_slots); net.st.resize(n_slots); net.shift_tab.resize(n_slots); net.zero_tab.resize(n_slots);
     net.shift_n.resize(n_slots);
@@ -478,11 +479,11 @@ static int run_codec(vv_ctx* ctx, CodecNet& net, int sl, int F, float* out, hipS
                 VVCHK(vv_rmsnorm_rows_launch(x, s.C, b.nb + 6 * (size_t)s.C, s.C, b.norm_w, T, s.C, eps, st));
                 VVCHK(vv_dwconv_res_launch(b.nb, x, xo, b.dw_w, b.dw_b, b.gamma, T, s.C, st));
             }
-            VVGemm g1 = mk_gemm(b.w1, xo, net.u, T, 4 * s.C, s.C, s.C, 4 * s.C);
+            VVGemm g1 = mk_gemm(b.w1, xo, net.u[sl], T, 4 * s.C, s.C, s.C, 4 * s.C);
             g1.pro = VV_PRO_RMS; g1.nw = b.ffn_norm_w; g1.eps = eps; g1.epi = VV_EPI_BIAS_GELU; g1.bias = b.b1;
             g1.nt = stream_w && T <= 16;
             GEMM(g1);
-            VVGemm g2 = mk_gemm(b.w2, net.u, xo, T, s.C, 4 * s.C, 4 * s.C, s.C);
+            VVGemm g2 = mk_gemm(b.w2, net.u[sl], xo, T, s.C, 4 * s.C, 4 * s.C, s.C);
             g2.epi = VV_EPI_RESID; g2.bias = b.b2; g2.nscale = b.ffn_gamma; g2.nt = stream_w && T <= 16;
             GEMM(g2);
             if (s.pp) std::swap(x, xo);

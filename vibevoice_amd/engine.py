@@ -277,12 +277,16 @@ class Engine:
         self._chk(self.lib.vv_head_forward(self._ctx, self._s, n, self._p(noisy), tarr, self._p(cond), self._p(out)),
                   "vv_head_forward")
 
-    def codec_decode(self, slot: int, latent: torch.Tensor, audio_out: torch.Tensor, apply_speech_factors=True):
-        self._chk(self.lib.vv_codec_decode(self._ctx, self._s, slot, 1, self._p(latent), self._p(audio_out),
+    def _sp(self, stream):
+        """hipStream_t of an optional torch stream (default: the engine's own stream)"""
+        return self._s if stream is None else C.c_void_p(stream.cuda_stream)
+
+    def codec_decode(self, slot: int, latent: torch.Tensor, audio_out: torch.Tensor, apply_speech_factors=True, stream=None):
+        self._chk(self.lib.vv_codec_decode(self._ctx, self._sp(stream), slot, 1, self._p(latent), self._p(audio_out),
                                            int(apply_speech_factors)), "vv_codec_decode")
 
-    def semantic_encode(self, slot: int, audio: torch.Tensor, sem_out: torch.Tensor):
-        self._chk(self.lib.vv_semantic_encode(self._ctx, self._s, slot, 1, self._p(audio), self._p(sem_out)),
+    def semantic_encode(self, slot: int, audio: torch.Tensor, sem_out: torch.Tensor, stream=None):
+        self._chk(self.lib.vv_semantic_encode(self._ctx, self._sp(stream), slot, 1, self._p(audio), self._p(sem_out)),
                   "vv_semantic_encode")
 
     def acoustic_encode(self, frames: int, wav: torch.Tensor, mean_out: torch.Tensor):

@@ -117,6 +117,10 @@ class VibeVoiceForConditionalGenerationInference:
         self._noise_pin = [torch.empty(8, engine.cfg.latent_dim, dtype=torch.float32).pin_memory() for _ in range(4)]
         self._noise_i = 0
         self._lg_event = torch.cuda.Event()
+        self._fork_ev = torch.cuda.Event()
+        self._join_ev = torch.cuda.Event()
+        self._side_streams = [torch.cuda.Stream(device=self.device) for _ in range(min(8, engine.cfg.n_slots))] if engine.cfg.n_slots > 1 else []
+        self.concurrent_codecs = os.environ.get("VVHIP_SERIAL_CODECS") is None
         self.speculate_sampling = os.environ.get("VVHIP_NO_SPEC") is None
         self.last_stats = {}
 
@@ -467,10 +471,24 @@ class VibeVoiceForConditionalGenerationInference:
                     e.diffusion_sample(n, self._cond, self._noise, cfg_scale, self._latent)
                 if diff:
                     # ---- codec decode, semantic encode, connectors (:636-672) ----
-                    for j, b in enumerate(diff):
-                        e.codec_decode(b, self._latent[j:j + 1], self._audio[j])
-                        if e.cfg.sem_dim > 0:
-                            e.semantic_encode(b, self._audio[j], self._sem[j])
+                    if len(diff) > 1 and self.concurrent_codecs:
+                        # each utterance's tokenizer chain (decode -> semantic re-encode) is an independent, launch-latency
+                        # bound graph: fork them onto side streams so they overlap, join before the connectors
+                        self._fork_ev.record(e.stream)
+                        for j, b in enumerate(diff):
+                            ss = self._side_streams[j % len(self._side_streams)]
+                            ss.wait_event(self._fork_ev)
+                            e.codec_decode(b, self._latent[j:j + 1], self._audio[j], stream=ss)
+                            if e.cfg.sem_dim > 0:
+                                e.semantic_encode(b, self._audio[j], self._sem[j], stream=ss)
+                        for ss in self._side_streams[:min(len(diff), len(self._side_streams))]:
+                            self._join_ev.record(ss)
+                            e.stream.wait_event(self._join_ev)
+                    else:
+                        for j, b in enumerate(diff):
+                            e.codec_decode(b, self._latent[j:j + 1], self._audio[j])
+                            if e.cfg.sem_dim > 0:
+                                e.semantic_encode(b, self._audio[j], self._sem[j])
                     e.connect(n, self._latent, self._sem if e.cfg.sem_dim > 0 else None, self._emb_out)
                     chunk = self._audio[:n].clone()
                     for j, b in enumerate(diff):
