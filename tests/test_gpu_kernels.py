@@ -401,3 +401,26 @@ def test_bf16_activation_mode_tolerance():
         assert rel_err(out, ref) <= 5e-2, rel_err(out, ref)
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("n", [3, 8])
+def test_bf16_mode_batched_sampler_rows(n):
+    """8 utterances diffusing together = 16 head rows: the 16-row adaLN / gated-residual / CFG+DPM GEMV forms (bench mode
+    only) against the oracle sampler, SURVEY 8d tolerance for bf16 activations."""
+    s = build_small(synth.LMCfg(), xsplit=1, n_slots=8)
+    eng = s.eng
+    try:
+        g = synth.Gen(610 + n)
+        pos = g.normal((n, s.hc.hidden), 1.0, mat=False)
+        neg = g.normal((n, s.hc.hidden), 1.0, mat=False)
+        noise = g.normal((2 * n, 64), 1.0, mat=False)
+        ref = dpm.sample_speech_tokens(lambda x, t, c: head.head_forward(s.head_w, x, t, c, s.hc.layers, s.hc.eps),
+                                       pos, neg, 1.3, 10, noise)
+        eng.set_num_steps(10)
+        out = eng.new(n, 64)
+        with torch.cuda.stream(eng.stream):
+            eng.diffusion_sample(n, dev(torch.cat([pos, neg]), eng), dev(noise[:n], eng), 1.3, out)
+        eng.sync()
+        assert rel_err(out, ref) <= 5e-2, rel_err(out, ref)
+    finally:
+        eng.close()
