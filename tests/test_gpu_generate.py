@@ -232,3 +232,30 @@ def test_streamer_contract_and_stop_check(sm):
     with pytest.raises(ValueError):
         big = torch.cat([ids, ids, ids], 0)
         m.generate(input_ids=big, attention_mask=torch.ones_like(big), tokenizer=tok)
+
+
+def test_pinned_ring_streamer_delivers_the_generated_audio(sm):
+    """vibevoice_amd.AudioStreamer (async D2H into a pinned ring, background hand-off): the chunks a consumer reads are,
+    in order, exactly the waveform generate() returns."""
+    from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference
+    from vibevoice_amd.streamer import AudioStreamer
+    ids, mask, sim, st, spm = make_inputs(sm, 2, False, 55)
+    cfgd = {"decoder_config": {"max_position_embeddings": sm.lmcfg.max_pos},
+            "diffusion_head_config": {"ddpm_num_inference_steps": 5},
+            "acoustic_tokenizer_config": {"fix_std": 0.5, "std_dist_type": "gaussian"}}
+    tok = types.SimpleNamespace(speech_start_id=TOK.speech_start_id, speech_end_id=TOK.speech_end_id,
+                                speech_diffusion_id=TOK.speech_diffusion_id, eos_token_id=TOK.eos_token_id,
+                                bos_token_id=None, pad_token_id=TOK.pad_token_id)
+    m = VibeVoiceForConditionalGenerationInference(cfgd, sm.eng, model_dtype=torch.float32)
+    m.set_speech_factors(sm.scaling, sm.bias)
+    m.set_ddpm_inference_steps(5)
+    streamer = AudioStreamer(batch_size=2, timeout=20.0)
+    # both samples end on the same step: like the reference (:443-447) generate() stops as soon as ANY stream has been ended
+    forced = [[D, D, D, E, S, D, X], [D, D, D, D, D, D, X]]
+    torch.manual_seed(7)
+    out = m.generate(input_ids=ids, attention_mask=mask, cfg_scale=1.3, tokenizer=tok, generation_config={"do_sample": False},
+                     _forced_tokens=forced, show_progress_bar=False, audio_streamer=streamer)
+    for b in range(2):
+        chunks = [c.flatten() for c in streamer.get_stream(b)]
+        assert len(chunks) == (4, 6)[b]
+        assert torch.equal(torch.cat(chunks), out.speech_outputs[b].cpu().flatten())

@@ -15,6 +15,7 @@ import torch
 import synth
 from gpu_util import build_small, max_err, rel_err
 from oracle import codec, connector, dpm, head
+from oracle import lm as olm
 
 pytestmark = pytest.mark.gpu
 
@@ -422,5 +423,46 @@ def test_bf16_mode_batched_sampler_rows(n):
             eng.diffusion_sample(n, dev(torch.cat([pos, neg]), eng), dev(noise[:n], eng), 1.3, out)
         eng.sync()
         assert rel_err(out, ref) <= 5e-2, rel_err(out, ref)
+    finally:
+        eng.close()
+
+
+def test_lora_merge_reaches_the_engine(tmp_path):
+    """load_lora_assets(): a peft-format LM adapter is folded into the packed weights; the LM then matches the oracle
+    run on W + (alpha/r) B A."""
+    import json as _json
+    import types as _types
+    from safetensors.torch import save_file
+    from vibevoice_amd import lora
+    s = build_small(synth.LMCfg(), xsplit=3)
+    eng = s.eng
+    try:
+        g = synth.Gen(8080)
+        r = 4
+        targets = ["layers.0.self_attn.q_proj", "layers.1.mlp.down_proj", "layers.0.self_attn.o_proj"]
+        sd, merged = {}, dict(s.lm_w)
+        for t in targets:
+            w = s.lm_w[t + ".weight"]
+            a = g.normal((r, w.shape[1]), 0.3)
+            b = g.normal((w.shape[0], r), 0.3)
+            sd[f"base_model.model.{t}.lora_A.weight"] = a.contiguous()
+            sd[f"base_model.model.{t}.lora_B.weight"] = b.contiguous()
+            merged[t + ".weight"] = (w + (8 / r) * (b @ a)).to(torch.bfloat16).to(torch.float32)   # engine stores bf16
+        root = tmp_path / "ft" / "lora"
+        root.mkdir(parents=True)
+        save_file(sd, str(root / "adapter_model.safetensors"))
+        (root / "adapter_config.json").write_text(_json.dumps({"r": r, "lora_alpha": 8}))
+        model = _types.SimpleNamespace(engine=eng)
+        rep = lora.load_lora_assets(model, str(tmp_path / "ft"), base_state=lambda k: s.lm_w[k[len(lora.LM_PREFIX):]])
+        assert rep.language_model and rep.merged_tensors == 3
+        c = s.lmcfg
+        orc = olm.Qwen2Oracle(merged, c.layers, c.heads, c.kv_heads, c.head_dim, c.theta, c.eps, kv_round_bf16=True)
+        x = g.normal((6, c.hidden), 1.0, mat=False)
+        ref = orc.forward(x, olm.KVCache(c.layers))
+        hid = eng.new(6, c.hidden)
+        with torch.cuda.stream(eng.stream):
+            eng.lm_forward([(0, j) for j in range(6)], dev(x, eng), hid)
+        eng.sync()
+        assert rel_err(hid, ref) <= 5e-4, rel_err(hid, ref)
     finally:
         eng.close()

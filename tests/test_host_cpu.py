@@ -206,3 +206,64 @@ def test_streaming_oracle_windows_cpu():
     assert reach and not fin
     assert calls == list(range(len(calls))) and len(calls) == 15         # 6 + 6 + 3: the cap hits inside the third speech window
     assert audio.shape[-1] == 15 * 3200
+
+
+# ---------------------------------------------------------------- LoRA merge at snapshot time
+def test_lora_merge_math_and_key_mapping(tmp_path):
+    import json as _json
+    from safetensors.torch import save_file
+    from vibevoice_amd import lora
+    torch.manual_seed(3)
+    base = {"model.language_model.layers.0.self_attn.q_proj.weight": torch.randn(12, 8),
+            "model.language_model.layers.1.mlp.down_proj.weight": torch.randn(8, 20),
+            "model.prediction_head.layers.0.ffn.gate_proj.weight": torch.randn(24, 8)}
+    r = 2
+    lm_sd, hd_sd = {}, {}
+    for k, w in base.items():
+        a, b = torch.randn(r, w.shape[1]), torch.randn(w.shape[0], r)
+        if k.startswith(lora.LM_PREFIX):
+            mod = k[len(lora.LM_PREFIX):-len(".weight")]
+            lm_sd[f"base_model.model.{mod}.lora_A.weight"] = a
+            lm_sd[f"base_model.model.{mod}.lora_B.weight"] = b
+        else:
+            mod = k[len(lora.HEAD_PREFIX):-len(".weight")]                 # peft saw the head through the shim's `base`
+            hd_sd[f"base_model.model.base.{mod}.lora_A.default.weight"] = a
+            hd_sd[f"base_model.model.base.{mod}.lora_B.default.weight"] = b
+    root = tmp_path / "ckpt" / "lora"
+    (root / "diffusion_head").mkdir(parents=True)
+    (root / "acoustic_connector").mkdir()
+    save_file(lm_sd, str(root / "adapter_model.safetensors"))
+    (root / "adapter_config.json").write_text(_json.dumps({"r": r, "lora_alpha": 32}))
+    torch.save(hd_sd, str(root / "diffusion_head" / "adapter_model.bin"))
+    (root / "diffusion_head" / "adapter_config.json").write_text(_json.dumps({"r": r, "lora_alpha": 4, "use_rslora": True}))
+    torch.save({"fc1.weight": torch.ones(8, 4)}, str(root / "acoustic_connector" / "pytorch_model.bin"))
+    assert lora.resolve_adapter_root(str(tmp_path / "ckpt")) == str(root)
+    ups = {k: (t, kind) for k, t, kind in lora.planned_updates(str(root), lambda k: base[k])}
+    assert set(ups) == set(base) | {"model.acoustic_connector.fc1.weight"}
+    for k, w in base.items():
+        sd = lm_sd if k.startswith(lora.LM_PREFIX) else hd_sd
+        scale = 32 / r if k.startswith(lora.LM_PREFIX) else 4 / r ** 0.5
+        pairs = lora.lora_pairs(sd, lora.LM_PREFIX if k.startswith(lora.LM_PREFIX) else lora.HEAD_PREFIX,
+                                strip="" if k.startswith(lora.LM_PREFIX) else "base.")
+        A, B = pairs[k]
+        assert torch.allclose(ups[k][0], w + scale * (B @ A), atol=1e-5)
+    assert ups["model.acoustic_connector.fc1.weight"][1] == "acoustic_connector"
+    with pytest.raises(ValueError):
+        lora.merge_lora(torch.zeros(3, 3), torch.zeros(2, 4), torch.zeros(3, 2), 1.0)
+
+
+def test_streamer_surface_and_ordering_cpu():
+    from vibevoice_amd.streamer import AudioStreamer
+    s = AudioStreamer(batch_size=2, stop_signal=None, timeout=5.0)
+    s.put(torch.full((2, 1, 4), 1.0), torch.tensor([0, 1]))
+    s.put(torch.full((1, 1, 4), 2.0), torch.tensor([1]))
+    s.end(torch.tensor([0]))
+    s.put(torch.full((2, 1, 4), 3.0), torch.tensor([0, 1]))          # sample 0 already ended: dropped (streamer.py:52)
+    s.end()
+    assert s.finished_flags == [True, True]
+    got0 = [c.flatten().tolist() for c in s.get_stream(0)]
+    got1 = [c.flatten().tolist() for c in s.get_stream(1)]
+    assert got0 == [[1.0] * 4]
+    assert got1 == [[1.0] * 4, [2.0] * 4, [3.0] * 4]
+    with pytest.raises(ValueError):
+        s.get_stream(2)

@@ -171,7 +171,17 @@ class VibeVoiceForConditionalGenerationInference:
         device = None
         if isinstance(device_map, (str, torch.device)) and str(device_map) not in ("auto", "cpu"):
             device = torch.device(device_map)
-        return cls.from_state_dict(config, it(), torch_dtype or torch.bfloat16, device, **runtime)
+        m = cls.from_state_dict(config, it(), torch_dtype or torch.bfloat16, device, **runtime)
+        m.source_path = path
+
+        def base_tensor(key):          # lazy access to the checkpoint's own tensors (LoRA merge: vibevoice_amd/lora.py)
+            for fn in files:
+                with safe_open(os.path.join(path, fn), framework="pt", device="cpu") as sf:
+                    if key in sf.keys():
+                        return sf.get_tensor(key)
+            raise KeyError(key)
+        m.base_tensor = base_tensor
+        return m
 
     def set_speech_factors(self, scaling, bias):
         self.speech_scaling_factor = float(scaling)
