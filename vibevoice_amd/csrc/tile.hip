@@ -62,7 +62,10 @@ __global__ __launch_bounds__(256) void vv_gemm_tile_kernel(const u32x4* __restri
     constexpr int NF = 2;                             // weight fragments per wave and k-step (2 tiles, or gate + up)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // [2 buffers][XS][UU][4 q][BM rows] x 16 B  = B fragments of row tile rt at rows rt*16..rt*16+15
-    constexpr int BUF = XS * UU * 4 * BM * 16;
+    // each (k-step, k-group) plane of BM x 16 B is padded by 16 B: the 16 planes a staging store instruction touches land
+    // in 16 different bank groups instead of one (16-way conflict without the pad)
+    constexpr int GS = BM * 16 + 16;
+    constexpr int BUF = XS * UU * 4 * GS;
     float* rs_sh = reinterpret_cast<float*>(smem + 2 * BUF);      // [BM]
     asm volatile("" ::"s"(a.bias), "s"(a.nscale), "s"(a.eps));
     const int tid = threadIdx.x, lane = tid & 63;
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(256) void vv_gemm_tile_kernel(const u32x4* __restri
     const bool wact = tile0 < n_tiles;                             // wave has at least one live feature tile
     const int n_chunks = (pK + KC - 1) / KC;
     const unsigned kk = lane * 4;
-    const unsigned st_off = (((kk >> 5) * 4 + ((kk & 31) >> 3)) * BM) * 16 + (kk & 7) * 2;
+    const unsigned st_off = ((kk >> 5) * 4 + ((kk & 31) >> 3)) * (BM * 16 + 16) + (kk & 7) * 2;
 
     // ---- staging: wave w owns rows t0 + w*16 .. +15 ----
     float4 xr[16];
@@ -108,18 +111,20 @@ __global__ __launch_bounds__(256) void vv_gemm_tile_kernel(const u32x4* __restri
             t_split4<XS>(v, parts);
 #pragma unroll
             for (int p = 0; p < XS; ++p)
-                *reinterpret_cast<uint2*>(buf + p * (UU * 4 * BM * 16) + st_off + (wave * 16 + r) * 16) = parts[p];
+                *reinterpret_cast<uint2*>(buf + p * (UU * 4 * GS) + st_off + (wave * 16 + r) * 16) = parts[p];
         }
     };
-    // ---- weights: NF fragments per k-step, a whole chunk (UU k-steps) per buffer, loaded one chunk ahead ----
-    u32x4 wq[2][UU][NF];
+    // ---- weights: NF fragments per k-step, HALF a chunk (4 k-steps) per register buffer, loaded one half ahead: two
+    //      buffers of 32 VGPRs keep the kernel at two workgroups per CU (a second wave per SIMD hides the LDS waits) ----
+    constexpr int HU = UU / 2;
+    u32x4 wq[2][HU][NF];
     const u32x4* wb0 = pW + (size_t)tile0 * k_tiles * 64 + lane;
     const u32x4* wb1 = DUAL ? pW2 + (size_t)tile0 * k_tiles * 64 + lane
                             : pW + (size_t)min(tile0 + 1, n_tiles - 1) * k_tiles * 64 + lane;   // 2nd tile (clamped, masked at the store)
-    auto w_load = [&](int c, u32x4 (&dst)[UU][NF]) {
+    auto w_load = [&](int c, int half, u32x4 (&dst)[HU][NF]) {
 #pragma unroll
-        for (int u = 0; u < UU; ++u) {
-            const int kt = min(c * UU + u, k_tiles - 1);
+        for (int u = 0; u < HU; ++u) {
+            const int kt = min(c * UU + half * HU + u, k_tiles - 1);
             dst[u][0] = wb0[(size_t)kt * 64];
             dst[u][1] = wb1[(size_t)kt * 64];
         }
@@ -131,19 +136,20 @@ __global__ __launch_bounds__(256) void vv_gemm_tile_kernel(const u32x4* __restri
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) acc[i][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto compute = [&](int c, const unsigned char* buf, const u32x4 (&w)[UU][NF]) {
+    auto compute = [&](int c, int half, const unsigned char* buf, const u32x4 (&w)[HU][NF]) {
 #pragma unroll
-        for (int u = 0; u < UU; ++u) {
+        for (int uu = 0; uu < HU; ++uu) {
+            const int u = half * HU + uu;
             if (c * UU + u < k_tiles) {
 #pragma unroll
                 for (int p = 0; p < XS; ++p) {
 #pragma unroll
                     for (int rt = 0; rt < 4; ++rt) {
                         const bf16x8 xb = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(
-                            buf + (size_t)((p * UU + u) * 4 + fq) * (BM * 16) + (rt * 16 + frow) * 16));
+                            buf + (size_t)((p * UU + u) * 4 + fq) * GS + (rt * 16 + frow) * 16));
 #pragma unroll
                         for (int i = 0; i < NF; ++i)
-                            acc[i][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[u][i]), xb, acc[i][rt], 0, 0, 0);
+                            acc[i][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[uu][i]), xb, acc[i][rt], 0, 0, 0);
                     }
                 }
             }
@@ -151,23 +157,19 @@ __global__ __launch_bounds__(256) void vv_gemm_tile_kernel(const u32x4* __restri
     };
 
     x_load(0);
-    if (wact) w_load(0, wq[0]);
+    if (wact) w_load(0, 0, wq[0]);
     x_stage(0, smem);
     __syncthreads();
 #pragma unroll 1
-    for (int c = 0; c < n_chunks; c += 2) {
-        // even chunk from buffer 0 / wq[0], odd chunk from buffer 1 / wq[1]
-        const bool n1 = c + 1 < n_chunks, n2 = c + 2 < n_chunks;
-        if (n1) { x_load(c + 1); if (wact) w_load(c + 1, wq[1]); }
-        if (wact) compute(c, smem, wq[0]);
-        if (n1) x_stage(c + 1, smem + BUF);
+    for (int c = 0; c < n_chunks; ++c) {
+        unsigned char* cur = smem + (c & 1) * BUF;
+        unsigned char* nxt = smem + ((c + 1) & 1) * BUF;
+        const bool n1 = c + 1 < n_chunks;
+        if (n1) x_load(c + 1);
+        if (wact) { w_load(c, 1, wq[1]); compute(c, 0, cur, wq[0]); }
+        if (wact) { if (n1) w_load(c + 1, 0, wq[0]); compute(c, 1, cur, wq[1]); }
+        if (n1) x_stage(c + 1, nxt);
         __syncthreads();
-        if (n1) {
-            if (n2) { x_load(c + 2); if (wact) w_load(c + 2, wq[0]); }
-            if (wact) compute(c + 1, smem + BUF, wq[1]);
-            if (n2) x_stage(c + 2, smem);
-            __syncthreads();
-        }
     }
     // ---- per-row 1/rms ----
     if constexpr (PRO == VV_PRO_RMS) {
@@ -250,7 +252,7 @@ static int tile_go(const VVGemm& a, hipStream_t s) {
     const int n_tiles = (a.N + 15) / 16;
     const int per_wg = 4 * (DUAL ? 1 : 2);
     dim3 grid((n_tiles + per_wg - 1) / per_wg, (a.T + BM - 1) / BM);
-    const size_t smem = (size_t)2 * XS * UU * 4 * BM * 16 + BM * 4;
+    const size_t smem = (size_t)2 * XS * UU * 4 * (BM * 16 + 16) + BM * 4;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_gemm_tile_kernel<XS, PRO, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
