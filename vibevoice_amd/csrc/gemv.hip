@@ -94,7 +94,10 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const u32x4* __restri
     // adaLN-modulated norm: y = rs * W.(x*nw*(1+scale)) + W.shift -- two B operands and two accumulator sets, so the
     // 1/rms of the row is only needed in the epilogue (as for plain RMSNorm) and no pre-pass over x exists
     constexpr int NOP = (PRO == VV_PRO_RMS_MOD) ? 2 : 1;
-    __shared__ __attribute__((aligned(16))) unsigned char stg_all[WPB * NOP * XS * U * 4 * MR * 16];
+    // one (k-step, k-group) plane of the staging tile = MR rows x 16 B; the 16-row form pads it by 16 B so that the planes
+    // one staging store touches fall into different bank groups (unpadded: 256-B stride = the same 4 banks, 16-way conflict)
+    constexpr int GSB = MR * 16 + (MR == 16 ? 16 : 0);
+    __shared__ __attribute__((aligned(16))) unsigned char stg_all[WPB * NOP * XS * U * 4 * GSB];
     __shared__ f32x4 red[WPB][NM * NOP][64];
     __shared__ float ssq_sh[WPB][MR];
     // Pull every kernel argument into SGPRs with ONE batch of s_loads: left alone the compiler fetches
@@ -122,9 +125,9 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const u32x4* __restri
     const unsigned kt1 = min(kb1, kt0 + kper);
     const bool has_k = kt0 < kt1;
     const int frow = lane & 15, fq = lane >> 4;
-    unsigned char* stg = stg_all + (size_t)wave * (NOP * XS * U * 4 * MR * 16);
+    unsigned char* stg = stg_all + (size_t)wave * (NOP * XS * U * 4 * GSB);
     const unsigned kk = lane * 4;
-    const unsigned st_off = (((kk >> 5) * 4 + ((kk & 31) >> 3)) * MR) * 16 + (kk & 7) * 2;
+    const unsigned st_off = ((kk >> 5) * 4 + ((kk & 31) >> 3)) * GSB + (kk & 7) * 2;
 
     const u32x4* wbase = pW + (size_t)tile * k_tiles * 64 + lane;
     const u32x4* wbase2 = DUAL ? pW2 + (size_t)tile * k_tiles * 64 + lane : nullptr;
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const u32x4* __restri
                     split4<XS>(sh4, sparts);
 #pragma unroll
                     for (int p = 0; p < XS; ++p)
-                        *reinterpret_cast<uint2*>(stg + (XS + p) * (U * 4 * MR * 16) + st_off + r * 16) = sparts[p];
+                        *reinterpret_cast<uint2*>(stg + (XS + p) * (U * 4 * GSB) + st_off + r * 16) = sparts[p];
                 } else if constexpr (PRO == VV_PRO_ADD_SILU) {
                     v[0] = silu_acc(v[0] + R.addv[r].x) * msk; v[1] = silu_acc(v[1] + R.addv[r].y) * msk;
                     v[2] = silu_acc(v[2] + R.addv[r].z) * msk; v[3] = silu_acc(v[3] + R.addv[r].w) * msk;
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const u32x4* __restri
                 split4<XS>(v, parts);
 #pragma unroll
                 for (int p = 0; p < XS; ++p)
-                    *reinterpret_cast<uint2*>(stg + p * (U * 4 * MR * 16) + st_off + r * 16) = parts[p];
+                    *reinterpret_cast<uint2*>(stg + p * (U * 4 * GSB) + st_off + r * 16) = parts[p];
             }
         }
     };
@@ -246,14 +249,14 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const u32x4* __restri
 #pragma unroll
                 for (int p = 0; p < XS; ++p) {
                     u32x4 f = u32x4{0u, 0u, 0u, 0u};
-                    if (frow < MR) f = *reinterpret_cast<const u32x4*>(stg + (size_t)((p * U + u) * 4 + fq) * (MR * 16) + frow * 16);
+                    if (frow < MR) f = *reinterpret_cast<const u32x4*>(stg + (size_t)((p * U + u) * 4 + fq) * GSB + frow * 16);
                     const bf16x8 xb = __builtin_bit_cast(bf16x8, f);
 #pragma unroll
                     for (int i = 0; i < NM; ++i)
                         acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wb[u][i]), xb, acc[i], 0, 0, 0);
                     if constexpr (NOP == 2) {
                         u32x4 f2 = u32x4{0u, 0u, 0u, 0u};
-                        if (frow < MR) f2 = *reinterpret_cast<const u32x4*>(stg + (size_t)(((XS + p) * U + u) * 4 + fq) * (MR * 16) + frow * 16);
+                        if (frow < MR) f2 = *reinterpret_cast<const u32x4*>(stg + (size_t)(((XS + p) * U + u) * 4 + fq) * GSB + frow * 16);
                         const bf16x8 sb = __builtin_bit_cast(bf16x8, f2);
 #pragma unroll
                         for (int i = 0; i < NM; ++i)
