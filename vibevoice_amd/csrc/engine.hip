@@ -132,6 +132,7 @@ struct vv_ctx {
     struct Layer { float *ln1, *ln2, *bqkv; void *wqkv, *wo, *wg, *wu, *wd; };
     std::vector<Layer> layers;
     float *lm_norm = nullptr, *inv_freq = nullptr;
+    int ws_rows = 0;
     void* rope_tab = nullptr; bool rope_ready = false; unsigned* tickets = nullptr; bool fused_attn_ok = true;
     float *tts_types = nullptr, *eos_b1 = nullptr, *eos_b2 = nullptr; void *eos_w1 = nullptr, *eos_w2 = nullptr;
     void *embed = nullptr, *lm_head = nullptr;
@@ -608,7 +609,9 @@ extern "C" int vv_create(const vv_config* cfg, vv_ctx** out) {
     ctx->rope_tab = dalloc(ctx, (size_t)c.max_ctx * (D / 2) * 8, false);
     ctx->tickets = (unsigned*)dalloc(ctx, (size_t)R * Hkv * 4);
     ctx->fused_attn_ok = !getenv("VVHIP_NO_FUSED_ATTN");
-    const size_t np = (size_t)R * Hkv * c.attn_splits * 16;
+    // split-attention partials exist for decode rows and short ragged launches only (prompt chunks use the prefill kernel)
+    ctx->ws_rows = std::min(R, 64);
+    const size_t np = (size_t)ctx->ws_rows * Hkv * c.attn_splits * 16;
     ctx->pm = (float*)dalloc(ctx, np * 4); ctx->pl = (float*)dalloc(ctx, np * 4); ctx->po = (float*)dalloc(ctx, np * D * 4);
     // ---- diffusion head ----
     const int L = c.latent_dim, HL = c.head_layers, HF = ctx->HF = c.head_ffn;
@@ -892,6 +895,8 @@ extern "C" int vv_lm_forward_range(vv_ctx* ctx, void* stream, int n_rows, const 
     bool contiguous = !fused && n_rows >= 8 && !getenv("VVHIP_NO_PREFILL_ATTN");      // one cache, consecutive positions
     for (int i = 1; i < n_rows && contiguous; ++i)
         if (rows[i].cache != rows[0].cache || rows[i].pos != rows[0].pos + i) contiguous = false;
+    if (!contiguous && n_rows > ctx->ws_rows)
+        return fail(ctx, "a launch of %d rows must be consecutive positions of one cache (decode / ragged launches take <= %d rows)", n_rows, ctx->ws_rows);
     char key[128]; snprintf(key, 128, "lm:%d:%p:%p:%d:%d:%d:%d", n_rows, (const void*)x_in_dev, (void*)hidden_out_dev, l0, l1, final_norm,
                             fused ? 1 : (contiguous ? 2 : 0));
     return graphed(ctx, key, st, [&]() { return lm_body(ctx, st, n_rows, x_in_dev, hidden_out_dev, l0, l1, final_norm, fused, contiguous); });

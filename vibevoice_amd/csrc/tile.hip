@@ -12,6 +12,7 @@
 //     one per row tile: 4x the arithmetic per weight byte of the GEMV, 4x fewer weight passes per prompt;
 //   * RMSNorm: sum(x^2) per row is gathered while staging and applied to the accumulators in the epilogue.
 // Prologues NONE / RMS; epilogues STORE / BIAS / BIAS_GELU / SWIGLU / RESID (what the LM and the tokenizer stages issue).
+#include <cstdlib>
 #include "vv_common.h"
 
 namespace {
@@ -232,7 +233,8 @@ extern "C" int vv_tile_ok(const VVGemm* a, int xs) {
     {   // enough workgroups to occupy the chip; smaller problems (tokenizer stages at decode) stay on the row-tiled GEMV
         const int per_wg = 4 * (a->epi == VV_EPI_SWIGLU ? 1 : 2);
         const int64_t wgs = (int64_t)(((a->N + 15) / 16 + per_wg - 1) / per_wg) * ((a->T + BM - 1) / BM);
-        if (wgs < 128) return 0;
+        static const int min_wgs = getenv("VVHIP_TILE_MIN_WGS") ? atoi(getenv("VVHIP_TILE_MIN_WGS")) : 128;
+        if (wgs < min_wgs) return 0;
     }
     if ((a->K & 3) || (a->ldx & 3) || (a->N & 3) || (a->ldy & 3)) return 0;
     if ((((uintptr_t)a->X) | ((uintptr_t)a->Y)) & 15) return 0;
