@@ -20,8 +20,16 @@ Pinning status ("how do we know the oracle is the reference?"):
     reference's pyproject.toml:22, NOT vendored under /root/reference).  The
     golden vectors come from the installed transformers 5.15 Qwen2Model (same
     math for dense Qwen2), again via make_golden.py.
-  * G (generate loop): restated from modeling_vibevoice_inference.py:326-710.
-    The reference's generate() cannot execute under transformers 5.x
-    (SURVEY.md 8c) so the loop orchestration itself is "parity unpinned";
-    every arithmetic stage it calls is pinned as above.
+  * G (generate loop): PINNED.  oracle/refshim.install_generate_shims() adapts the handful of transformers
+    signatures that drifted between 4.51.3 (pinned by the reference) and the installed 5.15 -- and restores
+    4.51.3's attention-mask-derived position_ids in prepare_inputs_for_generation -- so the reference's own
+    VibeVoiceForConditionalGenerationInference.generate() runs here on a tiny seeded model.  make_golden.py
+    records it (forced token plans through a LogitsProcessor, every torch.randn draw captured):
+    generate_forced_b1 / generate_forced_b2 (desynchronised batch) / generate_greedy_b1.  The oracle loop,
+    fed the same inputs and noise, reproduces token sequences exactly and waveforms to rel-L2 <= 1e-4.
+    (This pinning found and fixed a real deviation: after <speech_start> the reference's negative context
+    restarts EMPTY, not with one kept entry.)
+  * Z (Streaming-0.5B loop): restated from modeling_vibevoice_streaming_inference.py; its generate() is
+    "parity unpinned" (no golden recorded from the reference's streaming class yet); the arithmetic stages
+    it shares with G are pinned.
 """

@@ -169,8 +169,11 @@ def oracle_generate(m: OracleModel, tok: TokenIds, input_ids, attention_mask,
             codec.zero_state(sem_state[b])
         # ---- <speech_start>: reset the negative branch (:549-565) ----
         for b in (~finished & (nxt == tok.speech_start_id)).nonzero().flatten().tolist():
-            if neg_cache[b].length > 0:
-                neg_cache[b].truncate(1)
+            # The reference zeroes the negative attention mask except its LAST slot -- the slot of the token that will be fed
+            # next -- and copies K/V[0] into the last *cached* slot, which that mask then hides (:551-560).  Net effect
+            # (pinned by tests/golden/generate_forced_*.npz, recorded from the reference's own generate()): the negative
+            # context restarts EMPTY; the next negative pass consumes the <speech_start> embedding at position 0.
+            neg_cache[b].truncate(0)
         next_embeds = m.lm.embed(nxt)                          # [B, H]
         diff = (~finished & (nxt == tok.speech_diffusion_id)).nonzero().flatten().tolist()
         if diff:

@@ -69,3 +69,78 @@ def install():
     pkg = types.ModuleType("vibevoice.modular")
     pkg.__path__ = [REF_ROOT + "/vibevoice/modular"]
     sys.modules["vibevoice.modular"] = pkg
+
+
+def install_generate_shims():
+    """Lets the reference's VibeVoiceForConditionalGenerationInference.generate() itself run under transformers 5.x
+    (it was written against 4.51.3).  Pure API adaptation -- signatures that drifted, a module that moved -- so that
+    tests/golden/make_golden.py can record the REFERENCE's loop on tiny seeded weights.  No arithmetic."""
+    install()
+    import transformers
+
+    def _stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+
+    try:
+        import transformers.models.qwen2.tokenization_qwen2_fast  # noqa: F401
+    except Exception:
+        _stub("transformers.models.qwen2.tokenization_qwen2_fast",
+              Qwen2TokenizerFast=type("Qwen2TokenizerFast", (transformers.PreTrainedTokenizerFast,), {}))
+    try:
+        from transformers.models.qwen2.tokenization_qwen2 import Qwen2Tokenizer  # noqa: F401
+    except Exception:
+        _stub("transformers.models.qwen2.tokenization_qwen2",
+              Qwen2Tokenizer=type("Qwen2Tokenizer", (transformers.PreTrainedTokenizer,), {}))
+    from transformers.generation.configuration_utils import GenerationMode
+    from transformers.generation.utils import GenerationMixin
+    from vibevoice.modular.modeling_vibevoice_inference import VibeVoiceForConditionalGenerationInference as Ref
+    if getattr(Ref, "_vv_shimmed", False):
+        return Ref
+    # 4.51: _prepare_generation_config(gc, use_model_defaults, **kw); 5.x: (gc, **kw)
+    Ref._prepare_generation_config = lambda self, gc, use_model_defaults=None, **kw: \
+        GenerationMixin._prepare_generation_config(self, gc, **kw)
+    # 4.51: (..., assistant_model, batch_size, max_cache_length, device); 5.x: (..., generation_mode, batch_size, max_cache_length)
+    Ref._prepare_cache_for_generation = lambda self, gc, mk, assistant, bs, mcl, device=None: \
+        GenerationMixin._prepare_cache_for_generation(self, gc, mk, GenerationMode.GREEDY_SEARCH, bs, mcl)
+    # 4.51 always returned an 'inputs_embeds' entry (None when ids are used); 5.x omits the key
+    _pifg = Ref.prepare_inputs_for_generation
+
+    def _prepare_inputs(self, input_ids, *a, **k):
+        # transformers 4.51.3 (the version the reference pins, pyproject.toml:22), generation/utils.py
+        # prepare_inputs_for_generation step 3: with an attention_mask and no position_ids it sets
+        #     position_ids = attention_mask.long().cumsum(-1) - 1 ; masked_fill_(attention_mask == 0, 1)
+        # (sliced to the new tokens further down).  5.x dropped this and lets the model count positions from the
+        # cache length -- which changes the reference's behaviour wherever the mask has holes: left-padded batches
+        # and the negative branch after its <speech_start> reset (:549-565).  Restore the pinned behaviour.
+        am = k.get("attention_mask")
+        if am is not None and k.get("position_ids") is None:
+            pos = am.long().cumsum(-1) - 1
+            pos.masked_fill_(am == 0, 1)
+            pkv = k.get("past_key_values")
+            seen = pkv.get_seq_length() if pkv is not None else 0
+            n_new = max(1, input_ids.shape[1] - int(seen))        # 4.51 slices to the not-yet-cached tokens (cache_position)
+            k["position_ids"] = pos[:, -n_new:]
+        out = _pifg(self, input_ids, *a, **k)
+        out.setdefault("inputs_embeds", None)
+        return out
+    Ref.prepare_inputs_for_generation = _prepare_inputs
+    # 4.51's DynamicCache exposed per-layer tensor lists (the reference edits them in place, :549-565, :609-616); 5.x keeps
+    # them as cache.layers[i].keys / .values -- same tensors, so in-place edits through these views behave identically
+    from transformers.cache_utils import DynamicCache
+    if not hasattr(DynamicCache, "key_cache"):
+        DynamicCache.key_cache = property(lambda self: [l.keys for l in self.layers])
+        DynamicCache.value_cache = property(lambda self: [l.values for l in self.layers])
+    _tie = Ref.tie_weights
+    Ref.tie_weights = lambda self, *a, **k: _tie(self)          # 5.x passes recompute_mapping=
+    Ref._vv_shimmed = True
+    return Ref
+
+
+def expose_text_config(cfg):
+    """transformers 5.x sizes its DynamicCache from config.num_hidden_layers & co; VibeVoiceConfig keeps them in
+    decoder_config (4.51 did not look)."""
+    for a in ("num_hidden_layers", "num_attention_heads", "num_key_value_heads", "hidden_size", "max_position_embeddings"):
+        setattr(cfg, a, getattr(cfg.decoder_config, a))
+    return cfg

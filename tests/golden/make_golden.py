@@ -198,9 +198,144 @@ def gen_lm():
              decode_hidden=torch.cat(hs[1:], dim=0), wsum=synth.checksum(w))
 
 
+def _tok_cfg(c):
+    return dict(causal=True, channels=1, conv_bias=True, conv_norm="none", disable_last_norm=True,
+                encoder_depths=c.depth_str, encoder_n_filters=c.n_filters, encoder_ratios=list(c.ratios),
+                layer_scale_init_value=1e-6, layernorm="RMSNorm", layernorm_elementwise_affine=True, layernorm_eps=c.eps,
+                mixer_layer="depthwise_conv", pad_mode="constant", weight_init_value=0.01, vae_dim=c.vae_dim,
+                fix_std=0.5, std_dist_type="gaussian", decoder_n_filters=c.n_filters, decoder_ratios=list(c.ratios),
+                decoder_depths=None)
+
+
+class _Tok:
+    speech_start_id, speech_end_id, speech_diffusion_id, eos_token_id = 301, 302, 303, 304
+    bos_token_id, pad_token_id, pad_id = None, 305, 305
+
+
+@torch.no_grad()
+def gen_generate():
+    """Row G: the reference's OWN generate() loop (modeling_vibevoice_inference.py:326-710), tiny seeded weights, CPU
+    fp32.  The token choice is forced through a LogitsProcessor (random weights would never emit <speech_diffusion>);
+    every torch.randn / randn_like draw is recorded so the oracle can be fed the same noise."""
+    from transformers import LogitsProcessor, LogitsProcessorList
+    Ref = refshim.install_generate_shims()
+    from vibevoice.modular.configuration_vibevoice import VibeVoiceConfig
+    lc = synth.LMCfg()
+    hc = synth.HeadCfg(hidden=lc.hidden, layers=2)
+    cc, sc = synth.CodecCfg(), synth.CodecCfg(vae_dim=128)
+    cfg = VibeVoiceConfig(
+        acoustic_tokenizer_config=_tok_cfg(cc), semantic_tokenizer_config=dict(_tok_cfg(sc), fix_std=0, std_dist_type="none"),
+        decoder_config=dict(model_type="qwen2", hidden_size=lc.hidden, intermediate_size=lc.inter, num_hidden_layers=lc.layers,
+                            num_attention_heads=lc.heads, num_key_value_heads=lc.kv_heads, vocab_size=lc.vocab,
+                            rms_norm_eps=lc.eps, rope_theta=lc.theta, max_position_embeddings=lc.max_pos,
+                            tie_word_embeddings=False, hidden_act="silu"),
+        diffusion_head_config=dict(hidden_size=lc.hidden, head_layers=hc.layers, head_ffn_ratio=hc.ffn_ratio, rms_norm_eps=hc.eps,
+                                   latent_size=64, speech_vae_dim=64, prediction_type="v_prediction", diffusion_type="ddpm",
+                                   ddpm_num_steps=1000, ddpm_num_inference_steps=5, ddpm_beta_schedule="cosine", ddpm_batch_mul=4),
+        acoustic_vae_dim=64, semantic_vae_dim=128)
+    refshim.expose_text_config(cfg)
+    m = Ref(cfg).eval()
+    sd = {}
+    sd.update({"model.language_model." + k: v for k, v in synth.lm_weights(lc).items()})
+    sd["lm_head.weight"] = synth.lm_head_weight(lc)
+    sd.update({"model.prediction_head." + k: v for k, v in synth.head_weights(hc).items()})
+    ac_w = {**synth.encoder_weights(cc, 2), **synth.decoder_weights(cc, 3)}
+    sd.update({"model.acoustic_tokenizer." + k: v for k, v in ac_w.items()})
+    sd.update({"model.semantic_tokenizer." + k: v for k, v in synth.encoder_weights(sc, 7).items()})
+    sd.update({"model.acoustic_connector." + k: v for k, v in synth.connector_weights(64, lc.hidden, 4).items()})
+    sd.update({"model.semantic_connector." + k: v for k, v in synth.connector_weights(128, lc.hidden, 8).items()})
+    sd["model.speech_scaling_factor"] = torch.tensor(0.2)
+    sd["model.speech_bias_factor"] = torch.tensor(-0.05)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all("rotary" in k or "inv_freq" in k for k in missing), missing
+    m.set_ddpm_inference_steps(5)
+    T = _Tok
+    D, E, S, X = T.speech_diffusion_id, T.speech_end_id, T.speech_start_id, T.eos_token_id
+
+    class Force(LogitsProcessor):
+        def __init__(self, plan):
+            self.plan, self.step = plan, 0
+
+        def __call__(self, input_ids, scores):
+            out = torch.full_like(scores, -float("inf"))
+            for b in range(scores.shape[0]):
+                tok = self.plan[b][self.step] if self.step < len(self.plan[b]) else T.eos_token_id
+                out[b, tok] = 0.0
+            self.step += 1
+            return out
+
+    def run(name, B, plans, seed, max_new_tokens=None):
+        g = synth.Gen(seed)
+        lens = [21, 17][:B]
+        L0 = max(lens)
+        ids = torch.full((B, L0), T.pad_token_id, dtype=torch.long)
+        mask = torch.zeros((B, L0), dtype=torch.long)
+        sim = torch.zeros((B, L0), dtype=torch.bool)
+        n_fr = [2, 3]
+        for b in range(B):
+            n = lens[b]
+            row = torch.from_numpy(g.rng.integers(0, 300, (n,)))
+            row[-1] = T.speech_start_id
+            ids[b, L0 - n:] = row
+            mask[b, L0 - n:] = 1
+            st0 = L0 - n + 3
+            ids[b, st0:st0 + n_fr[b]] = T.speech_diffusion_id
+            sim[b, st0:st0 + n_fr[b]] = True
+        speech = g.uniform((B, 3 * 3200), -0.5, 0.5)
+        smask = torch.zeros((B, 3), dtype=torch.bool)
+        for b in range(B):
+            smask[b, :n_fr[b]] = True
+        force = Force(plans) if plans is not None else None
+        orig_glp = Ref._get_logits_processor
+
+        def glp(self, *a, **k):
+            lst = orig_glp(self, *a, **k)
+            if force is not None:
+                lst = LogitsProcessorList([force] + list(lst))
+            return lst
+        draws = []
+        o_randn, o_like = torch.randn, torch.randn_like
+
+        def rec_randn(*a, **k):
+            t = o_randn(*a, **k)
+            draws.append(t.detach().clone().reshape(-1))
+            return t
+
+        def rec_like(x, **k):
+            t = o_like(x, **k)
+            draws.append(t.detach().clone().reshape(-1))
+            return t
+        Ref._get_logits_processor = glp
+        torch.randn, torch.randn_like = rec_randn, rec_like
+        try:
+            torch.manual_seed(seed)
+            out = m.generate(input_ids=ids, attention_mask=mask, tokenizer=T(), cfg_scale=1.3, max_new_tokens=max_new_tokens,
+                             generation_config={"do_sample": False}, show_progress_bar=False, return_speech=True,
+                             speech_tensors=speech, speech_masks=smask, speech_input_mask=sim)
+        finally:
+            torch.randn, torch.randn_like = o_randn, o_like
+            Ref._get_logits_processor = orig_glp
+        arrs = dict(input_ids=ids, attention_mask=mask, speech_input_mask=sim, speech_tensors=speech, speech_masks=smask,
+                    sequences=out.sequences, reach_max=out.reach_max_step_sample, n_draws=len(draws),
+                    forced=np.array([p + [X] * (64 - len(p)) for p in plans]) if plans is not None else np.zeros((0,)),
+                    forced_len=np.array([len(p) for p in plans]) if plans is not None else np.zeros((0,)))
+        for i, d in enumerate(draws):
+            arrs[f"draw_{i}"] = d
+        for b in range(B):
+            a = out.speech_outputs[b]
+            arrs[f"audio_{b}"] = a.reshape(-1) if a is not None else torch.zeros(0)
+        save(name, **arrs)
+
+    run("generate_forced_b1.npz", 1, [[D, D, D, D, E, S, D, D, D, X]], seed=11)
+    run("generate_forced_b2.npz", 2, [[D, D, D, E, S, D, D, X], [D, D, E, S, D, X]], seed=23)
+    run("generate_greedy_b1.npz", 1, None, seed=31, max_new_tokens=10)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     gen_dpm_and_head()
     gen_codec()
     gen_connector()
     gen_lm()
+    gen_generate()

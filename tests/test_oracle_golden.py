@@ -128,3 +128,61 @@ def test_lm(tag):
     close(h, g["prefill_hidden"], 1e-4)
     outs = [m.forward(g["dec_in"][i][None], c)[0] for i in range(g["dec_in"].shape[0])]
     close(torch.stack(outs), g["decode_hidden"], 1e-4)
+
+
+# ---------------------------------------------------------------- row G: the generate() loop itself
+def _oracle_small(kv_round_bf16=False):
+    """The tiny model of tests/gpu_util.build_small, oracle side only (no engine)."""
+    import gpu_util
+    lmcfg = synth.LMCfg()
+    hc = synth.HeadCfg(hidden=lmcfg.hidden, layers=2)
+    cc, sc = synth.CodecCfg(), synth.CodecCfg(vae_dim=128)
+    s = gpu_util.Small(eng=None, lmcfg=lmcfg, hc=hc, cc=cc, sc=sc, lm_w=synth.lm_weights(lmcfg), lm_head=synth.lm_head_weight(lmcfg),
+                       head_w=synth.head_weights(hc), ac_w={**synth.encoder_weights(cc, 2), **synth.decoder_weights(cc, 3)},
+                       sem_w=synth.encoder_weights(sc, 7), ac_conn=synth.connector_weights(64, lmcfg.hidden, 4),
+                       sem_conn=synth.connector_weights(128, lmcfg.hidden, 8))
+    return s.oracle_model(kv_round_bf16=kv_round_bf16)
+
+
+@pytest.mark.parametrize("name", ["generate_forced_b1", "generate_forced_b2", "generate_greedy_b1"])
+def test_generate_loop_matches_the_reference_generate(name):
+    """Golden = the REFERENCE's own generate() (modeling_vibevoice_inference.py:326-710) run on the tiny seeded model
+    (tests/golden/make_golden.py::gen_generate, through oracle/refshim.install_generate_shims).  The oracle loop gets
+    the same inputs, the same forced token plan and the recorded noise draws: token sequences identical, waveform
+    rel-L2 <= 1e-4 (fp32 both sides; different summation order only).  Covers voice-prompt prefill, the negative branch's
+    reset on <speech_start>, the cache fix-ups for non-diffusing rows of a desynchronised batch, the codec cache reset
+    on <speech_end>, EOS / max-length bookkeeping."""
+    from oracle import generate as ogen
+    z = np.load(os.path.join(G, name + ".npz"))
+    tok = ogen.TokenIds(speech_start_id=301, speech_end_id=302, speech_diffusion_id=303, eos_token_id=304,
+                        bos_token_id=None, pad_token_id=305)
+    ids = torch.from_numpy(z["input_ids"])
+    B = ids.shape[0]
+    draws = [torch.from_numpy(z[f"draw_{i}"]) for i in range(int(z["n_draws"]))]
+    pre = (draws[0].reshape(B), draws[1].reshape(B, 3, 64))
+    it = iter(draws[2:])
+
+    def noise_fn(step, n2):
+        d = next(it)
+        assert d.numel() == n2 * 64, (d.numel(), n2)
+        return d.reshape(n2, 64)
+    forced = None
+    if z["forced"].size:
+        forced = [z["forced"][b][:int(z["forced_len"][b])].tolist() for b in range(B)]
+    mnt = 10 if name == "generate_greedy_b1" else None
+    seq, audio, reach = ogen.oracle_generate(_oracle_small(), tok, ids, torch.from_numpy(z["attention_mask"]),
+                                             torch.from_numpy(z["speech_tensors"]), torch.from_numpy(z["speech_masks"]),
+                                             torch.from_numpy(z["speech_input_mask"]), cfg_scale=1.3, num_steps=5,
+                                             max_new_tokens=mnt, noise_fn=noise_fn, prefill_noise=pre, forced_tokens=forced)
+    assert torch.equal(seq, torch.from_numpy(z["sequences"]))
+    assert torch.equal(reach, torch.from_numpy(z["reach_max"]))
+    assert next(it, None) is None                      # every recorded draw was consumed, in order
+    for b in range(B):
+        ref = torch.from_numpy(z[f"audio_{b}"])
+        if ref.numel() == 0:
+            assert audio[b] is None
+            continue
+        got = audio[b].reshape(-1)
+        assert got.shape == ref.shape
+        err = float((got - ref).norm() / ref.norm())
+        assert err <= 1e-4, err

@@ -435,8 +435,10 @@ class VibeVoiceForConditionalGenerationInference:
                 for b in (nxt == end_id).nonzero().flatten().tolist():
                     e.codec_reset(b)
                 for b in (~finished & (nxt == start_id)).nonzero().flatten().tolist():
-                    if neg_len[b] > 0:
-                        neg_len[b] = 1          # keep only the first entry (<speech_start> @ position 0), :549-565
+                    # :549-565 -- the reference masks the whole negative cache and un-masks only the slot of the NEXT token, so the
+                    # negative context restarts empty and the next negative pass re-feeds <speech_start> at position 0
+                    # (pinned against the reference's generate(): tests/golden/generate_forced_*.npz)
+                    neg_len[b] = 0
                 # ---------------- next input embeddings (:569) ----------------
                 live = [b for b in range(B) if not finished[b]]
                 diff = [b for b in live if int(nxt[b]) == diff_id]
