@@ -29,7 +29,9 @@ Pinning status ("how do we know the oracle is the reference?"):
     fed the same inputs and noise, reproduces token sequences exactly and waveforms to rel-L2 <= 1e-4.
     (This pinning found and fixed a real deviation: after <speech_start> the reference's negative context
     restarts EMPTY, not with one kept entry.)
-  * Z (Streaming-0.5B loop): restated from modeling_vibevoice_streaming_inference.py; its generate() is
-    "parity unpinned" (no golden recorded from the reference's streaming class yet); the arithmetic stages
-    it shares with G are pinned.
+  * Z (Streaming-0.5B loop): PINNED the same way (refshim.install_streaming_shims): the reference's
+    VibeVoiceStreamingForConditionalGenerationInference.generate() runs on a tiny seeded split model from
+    prefilled branches made with its own forward_lm / forward_tts_lm; streaming_text12_cap40 /
+    streaming_text3_cap20 record caches, noise and outputs; oracle/generate_streaming.py reproduces token
+    count, stop reason and waveform (rel-L2 <= 1e-4).
 """

@@ -122,6 +122,7 @@ def install_generate_shims():
             seen = pkv.get_seq_length() if pkv is not None else 0
             n_new = max(1, input_ids.shape[1] - int(seen))        # 4.51 slices to the not-yet-cached tokens (cache_position)
             k["position_ids"] = pos[:, -n_new:]
+            k.setdefault("next_sequence_length", n_new)           # 5.x slices input_ids only when told how many are new
         out = _pifg(self, input_ids, *a, **k)
         out.setdefault("inputs_embeds", None)
         return out
@@ -144,3 +145,38 @@ def expose_text_config(cfg):
     for a in ("num_hidden_layers", "num_attention_heads", "num_key_value_heads", "hidden_size", "max_position_embeddings"):
         setattr(cfg, a, getattr(cfg.decoder_config, a))
     return cfg
+
+
+def install_streaming_shims():
+    """Same adaptation for the reference's Streaming-0.5B inference class (row Z)."""
+    install_generate_shims()
+    from transformers.generation.configuration_utils import GenerationMode
+    from transformers.generation.utils import GenerationMixin
+    import vibevoice.modular.modeling_vibevoice_streaming_inference as msi
+    Ref = msi.VibeVoiceStreamingForConditionalGenerationInference
+    if getattr(Ref, "_vv_shimmed", False):
+        return Ref
+    Ref._prepare_generation_config = lambda self, gc, use_model_defaults=None, **kw: \
+        GenerationMixin._prepare_generation_config(self, gc, **kw)
+    Ref._prepare_cache_for_generation = lambda self, gc, mk, assistant, bs, mcl, device=None: \
+        GenerationMixin._prepare_cache_for_generation(self, gc, mk, GenerationMode.GREEDY_SEARCH, bs, mcl)
+    _pifg = Ref.prepare_inputs_for_generation
+
+    def _prepare_inputs(self, input_ids, *a, **k):          # see install_generate_shims: 4.51.3's mask-derived position_ids
+        am = k.get("attention_mask")
+        if am is not None and k.get("position_ids") is None:
+            pos = am.long().cumsum(-1) - 1
+            pos.masked_fill_(am == 0, 1)
+            pkv = k.get("past_key_values")
+            seen = pkv.get_seq_length() if pkv is not None else 0
+            n_new = max(1, input_ids.shape[1] - int(seen))
+            k["position_ids"] = pos[:, -n_new:]
+            k.setdefault("next_sequence_length", n_new)
+        out = _pifg(self, input_ids, *a, **k)
+        out.setdefault("inputs_embeds", None)
+        return out
+    Ref.prepare_inputs_for_generation = _prepare_inputs
+    _tie = Ref.tie_weights
+    Ref.tie_weights = lambda self, *a, **k: _tie(self)
+    Ref._vv_shimmed = True
+    return Ref

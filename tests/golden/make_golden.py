@@ -332,6 +332,111 @@ def gen_generate():
     run("generate_greedy_b1.npz", 1, None, seed=31, max_new_tokens=10)
 
 
+@torch.no_grad()
+def gen_generate_streaming():
+    """Row Z: the reference's Streaming-0.5B generate() (modeling_vibevoice_streaming_inference.py:412-751) on a tiny
+    seeded model.  The four prefilled branches (what demo/voices/streaming_model/*.pt hold) are produced with the
+    reference's own forward_lm / forward_tts_lm on a random prompt and stored, so the oracle starts from identical
+    caches; every torch.randn draw is recorded."""
+    RefS = refshim.install_streaming_shims()
+    from vibevoice.modular.configuration_vibevoice_streaming import VibeVoiceStreamingConfig
+    n_lm, n_tts = 1, 2
+    lc = synth.LMCfg(hidden=128, layers=n_lm + n_tts, heads=2, kv_heads=1, inter=256, vocab=320)
+    hc = synth.HeadCfg(hidden=lc.hidden, layers=2)
+    cc = synth.CodecCfg()
+    cfg = VibeVoiceStreamingConfig(
+        acoustic_tokenizer_config=_tok_cfg(cc),
+        decoder_config=dict(model_type="qwen2", hidden_size=lc.hidden, intermediate_size=lc.inter, num_hidden_layers=lc.layers,
+                            num_attention_heads=lc.heads, num_key_value_heads=lc.kv_heads, vocab_size=lc.vocab, rms_norm_eps=lc.eps,
+                            rope_theta=lc.theta, max_position_embeddings=512, tie_word_embeddings=False, hidden_act="silu"),
+        diffusion_head_config=dict(hidden_size=lc.hidden, head_layers=hc.layers, head_ffn_ratio=hc.ffn_ratio, rms_norm_eps=hc.eps,
+                                   latent_size=64, speech_vae_dim=64, prediction_type="v_prediction", diffusion_type="ddpm",
+                                   ddpm_num_steps=1000, ddpm_num_inference_steps=5, ddpm_beta_schedule="cosine", ddpm_batch_mul=4),
+        tts_backbone_num_hidden_layers=n_tts, acoustic_vae_dim=64)
+    refshim.expose_text_config(cfg)
+    m = RefS(cfg).eval()
+    # the same weights tests/test_gpu_streaming.py::build gives the oracle and the engine
+    w = synth.lm_weights(lc)
+    g = synth.Gen(900)
+    tts_types = g.normal((2, lc.hidden), 0.5, mat=False)
+    eos = {"fc1.weight": g.linear(lc.hidden, lc.hidden), "fc1.bias": g.vec(lc.hidden, 0.1),
+           "fc2.weight": g.linear(1, lc.hidden, 0.3), "fc2.bias": g.vec(1, 0.1, -1.5)}
+    sd = {"model.language_model.embed_tokens.weight": w["embed_tokens.weight"],
+          "model.tts_language_model.embed_tokens.weight": w["embed_tokens.weight"],
+          "model.tts_language_model.norm.weight": w["norm.weight"], "model.tts_input_types.weight": tts_types}
+    for k, v in w.items():
+        if k.startswith("layers."):
+            li = int(k.split(".")[1])
+            rest = k.split(".", 2)[2]
+            if li < n_lm:
+                sd[f"model.language_model.layers.{li}.{rest}"] = v
+            else:
+                sd[f"model.tts_language_model.layers.{li - n_lm}.{rest}"] = v
+    sd.update({"tts_eos_classifier." + k: v for k, v in eos.items()})
+    sd.update({"model.prediction_head." + k: v for k, v in synth.head_weights(hc).items()})
+    sd.update({"model.acoustic_tokenizer." + k: v for k, v in synth.decoder_weights(cc, 3).items()})
+    sd.update({"model.acoustic_connector." + k: v for k, v in synth.connector_weights(64, lc.hidden, 4).items()})
+    sd["model.speech_scaling_factor"] = torch.tensor(0.2)
+    sd["model.speech_bias_factor"] = torch.tensor(-0.05)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(("rotary" in k or "inv_freq" in k or "acoustic_tokenizer.encoder" in k) for k in missing), missing
+    m.set_ddpm_inference_steps(5)
+
+    class Tok:
+        bos_token_id, eos_token_id, pad_token_id = None, 304, 305
+        speech_start_id, speech_end_id, speech_diffusion_id = 301, 302, 303
+
+        def convert_tokens_to_ids(self, t):
+            return 305
+
+    def run(name, n_text, max_new, seed):
+        gg = synth.Gen(seed)
+        prompt = torch.from_numpy(gg.rng.integers(0, 300, (23,)))[None]
+        text = torch.from_numpy(gg.rng.integers(0, 300, (n_text,)))[None]
+        ones = torch.ones_like(prompt)
+        # prefilled branches with the reference's own forwards (text positions: type 1)
+        lm_o = m.forward_lm(input_ids=prompt, attention_mask=ones, use_cache=True, return_dict=True)
+        tts_o = m.forward_tts_lm(input_ids=prompt, attention_mask=ones, use_cache=True, return_dict=True,
+                                 lm_last_hidden_state=lm_o.last_hidden_state, tts_text_masks=torch.ones_like(prompt))
+        neg = torch.full((1, 1), 305, dtype=torch.long)
+        nlm_o = m.forward_lm(input_ids=neg, attention_mask=torch.ones_like(neg), use_cache=True, return_dict=True)
+        ntts_o = m.forward_tts_lm(input_ids=neg, attention_mask=torch.ones_like(neg), use_cache=True, return_dict=True,
+                                  lm_last_hidden_state=nlm_o.last_hidden_state, tts_text_masks=torch.ones_like(neg))
+        arrs = dict(prompt=prompt[0], text=text[0], max_new=max_new)
+        for tag, o in (("lm", lm_o), ("tts", tts_o), ("neg_tts", ntts_o)):
+            kc = [t for t in o.past_key_values.key_cache if t is not None]      # the cache object has a slot per decoder_config
+            vc = [t for t in o.past_key_values.value_cache if t is not None]    # layer; each half of the split LM fills its own
+            for li in range(len(kc)):
+                arrs[f"{tag}_k{li}"] = kc[li][0].clone()
+                arrs[f"{tag}_v{li}"] = vc[li][0].clone()
+            arrs[f"{tag}_last"] = o.last_hidden_state[0, -1].clone()
+            arrs[f"{tag}_layers"] = len(kc)
+        draws = []
+        o_randn = torch.randn
+
+        def rec_randn(*a, **k):
+            t = o_randn(*a, **k)
+            draws.append(t.detach().clone().reshape(-1))
+            return t
+        torch.randn = rec_randn
+        try:
+            torch.manual_seed(seed)
+            out = m.generate(input_ids=prompt, attention_mask=ones, tts_lm_input_ids=prompt.clone(), tts_lm_attention_mask=ones.clone(),
+                             tts_text_ids=text, all_prefilled_outputs={"lm": lm_o, "tts_lm": tts_o, "neg_lm": nlm_o, "neg_tts_lm": ntts_o},
+                             tokenizer=Tok(), cfg_scale=1.5, max_new_tokens=max_new, show_progress_bar=False, return_speech=True)
+        finally:
+            torch.randn = o_randn
+        arrs.update(n_draws=len(draws), n_tokens=out.sequences.shape[1], reach_max=out.reach_max_step_sample,
+                    audio=out.speech_outputs[0].reshape(-1) if out.speech_outputs[0] is not None else torch.zeros(0))
+        for i, d in enumerate(draws):
+            arrs[f"draw_{i}"] = d
+        save(name, **arrs)
+
+    run("streaming_text12_cap40.npz", 12, 40, seed=5)
+    run("streaming_text3_cap20.npz", 3, 20, seed=6)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     gen_dpm_and_head()
@@ -339,3 +444,4 @@ if __name__ == "__main__":
     gen_connector()
     gen_lm()
     gen_generate()
+    gen_generate_streaming()

@@ -186,3 +186,58 @@ def test_generate_loop_matches_the_reference_generate(name):
         assert got.shape == ref.shape
         err = float((got - ref).norm() / ref.norm())
         assert err <= 1e-4, err
+
+
+# ---------------------------------------------------------------- row Z: the Streaming-0.5B loop
+@pytest.mark.parametrize("name", ["streaming_text12_cap40", "streaming_text3_cap20"])
+def test_streaming_loop_matches_the_reference_generate(name):
+    """Golden = the reference's VibeVoiceStreamingForConditionalGenerationInference.generate()
+    (modeling_vibevoice_streaming_inference.py:412-751) on the tiny seeded split model, started from prefilled branches
+    produced by its own forward_lm / forward_tts_lm (stored in the golden).  The oracle loop starts from the same caches
+    and gets the recorded noise: same number of tokens, same stop reason, waveform rel-L2 <= 1e-4."""
+    from oracle import generate_streaming as ogs
+    from oracle import lm as olm
+    z = np.load(os.path.join(G, name + ".npz"))
+    n_lm, n_tts = 1, 2
+    cfg = synth.LMCfg(hidden=128, layers=n_lm + n_tts, heads=2, kv_heads=1, inter=256, vocab=320)
+    H = cfg.hidden
+    w = synth.lm_weights(cfg)
+    hc = synth.HeadCfg(hidden=H, layers=2)
+    cc = synth.CodecCfg()
+    g = synth.Gen(900)
+    tts_types = g.normal((2, H), 0.5, mat=False)
+    eos = {"fc1.weight": g.linear(H, H), "fc1.bias": g.vec(H, 0.1), "fc2.weight": g.linear(1, H, 0.3), "fc2.bias": g.vec(1, 0.1, -1.5)}
+    lm_w = {k: v for k, v in w.items() if k.startswith("embed") or any(k.startswith(f"layers.{i}.") for i in range(n_lm))}
+    tts_w = {"norm.weight": w["norm.weight"], "embed_tokens.weight": w["embed_tokens.weight"]}
+    for j in range(n_tts):
+        for k, v in w.items():
+            if k.startswith(f"layers.{n_lm + j}."):
+                tts_w[f"layers.{j}." + k[len(f"layers.{n_lm + j}."):]] = v
+    mk = lambda ww, L: olm.Qwen2Oracle(ww, L, cfg.heads, cfg.kv_heads, cfg.head_dim, cfg.theta, cfg.eps, kv_round_bf16=False)
+    om = ogs.StreamingOracleModel(lm=mk(lm_w, n_lm), tts_lm=mk(tts_w, n_tts), tts_types=tts_types, eos=eos,
+                                  head_w=synth.head_weights(hc), head_layers=hc.layers, ac_w=synth.decoder_weights(cc, 3),
+                                  ac_conn=synth.connector_weights(64, H, 4), ratios=cc.ratios, dec_depths=cc.dec_depths,
+                                  scaling=0.2, bias=-0.05)
+
+    def cache(tag, oracle_lm):
+        c = oracle_lm.new_cache()
+        n = int(z[f"{tag}_layers"])
+        for li in range(n):
+            c.k[li] = torch.from_numpy(z[f"{tag}_k{li}"]).clone()
+            c.v[li] = torch.from_numpy(z[f"{tag}_v{li}"]).clone()
+        c.length = c.k[0].shape[1]
+        return c
+    preset = ogs.Preset(cache("lm", om.lm), cache("tts", om.tts_lm), cache("neg_tts", om.tts_lm),
+                        torch.from_numpy(z["tts_last"]), torch.from_numpy(z["neg_tts_last"]))
+    draws = iter([torch.from_numpy(z[f"draw_{i}"]) for i in range(int(z["n_draws"]))])
+    max_length = preset.tts_cache.length + int(z["max_new"])
+    n_tok, audio, reach, fin = ogs.oracle_generate_streaming(om, preset, torch.from_numpy(z["text"]), 1.5, 5,
+                                                             lambda frame, n2: next(draws).reshape(n2, 64), max_length)
+    assert next(draws, None) is None
+    assert n_tok == int(z["n_tokens"])
+    assert bool(reach) == bool(z["reach_max"][0])
+    ref = torch.from_numpy(z["audio"])
+    got = audio.reshape(-1)
+    assert got.shape == ref.shape
+    err = float((got - ref).norm() / ref.norm())
+    assert err <= 1e-4, err
