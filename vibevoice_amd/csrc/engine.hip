@@ -173,6 +173,7 @@ struct vv_ctx {
     void* stage = nullptr; size_t stage_bytes = 0;
     std::map<std::string, GraphEntry> graphs;
     std::set<std::string> seen;
+    std::set<void*> allocs;                // every dalloc() of this engine: released by vv_destroy
     int64_t launches = 0;
     // optional per-GEMM-launch hipEvent timing (vv_profile_begin/end)
     bool prof_on = false;
@@ -213,7 +214,13 @@ static void* dalloc(vv_ctx* ctx, size_t bytes, bool zero = true) {
     if (bytes == 0) bytes = 16;
     if (hipMalloc(&p, bytes) != hipSuccess) { fail(ctx, "hipMalloc(%zu) failed", bytes); return nullptr; }
     if (zero) hipMemset(p, 0, bytes);
+    if (ctx) ctx->allocs.insert(p);
     return p;
+}
+static void dfree(vv_ctx* ctx, void* p) {
+    if (!p) return;
+    if (ctx) ctx->allocs.erase(p);
+    hipFree(p);
 }
 
 static int add_w(vv_ctx* ctx, const std::string& name, int kind, int64_t nelem, bool optional = false) {
@@ -668,9 +675,8 @@ extern "C" void vv_destroy(vv_ctx* ctx) {
     if (!ctx) return;
     hipDeviceSynchronize();
     for (auto& g : ctx->graphs) hipGraphExecDestroy(g.second.exec);
-    // device memory is released with the process/context; explicit frees for the big pools
-    hipFree(ctx->kc); hipFree(ctx->vc); hipFree(ctx->embed);
-    if (ctx->lm_head_loaded) hipFree(ctx->lm_head);
+    for (void* p : ctx->allocs) hipFree(p);          // weights, KV caches, state and scratch buffers
+    ctx->allocs.clear();
     if (ctx->stage) hipFree(ctx->stage);
     hipHostFree(ctx->rows_pin); hipHostFree(ctx->ids_pin);
     for (int i = 0; i < vv_ctx::RING; ++i) if (ctx->ring_ev[i]) hipEventDestroy(ctx->ring_ev[i]);
@@ -738,7 +744,7 @@ extern "C" int vv_upload(vv_ctx* ctx, const char* name, const void* src, int src
             HIPCHK(ctx, hipMemcpyAsync(w.dev, f32, (size_t)nelem * 4, hipMemcpyDeviceToDevice, st));
         }
         HIPCHK(ctx, hipStreamSynchronize(st));
-        if (tmp) hipFree(tmp);
+        dfree(ctx, tmp);
     }
     HIPCHK(ctx, hipStreamSynchronize(st));
     w.loaded = true;
@@ -767,7 +773,7 @@ extern "C" int vv_set_valid_tokens(vv_ctx* ctx, const int* ids, int n) {
     if (!ctx->valid_w) ctx->valid_w = alloc_packed(ctx, 16, H);
     VVCHK(vv_pack_launch(rows, 1, ctx->valid_w, n, H, 0, 0, 0, 0, 0, 0));
     HIPCHK(ctx, hipDeviceSynchronize());
-    hipFree(rows);
+    dfree(ctx, rows);
     ctx->n_valid = n;
     return 0;
 }
@@ -802,8 +808,8 @@ extern "C" int vv_set_schedule(vv_ctx* ctx, int n_steps, const float* t, const f
     {   // room for the batched adaLN modulations of up to 8 sampled utterances (16 rows) per step
         const size_t need = (size_t)n_steps * 16 * ctx->MODW * 4;
         if (need > ctx->mod_all_bytes) {
-            if (ctx->mod_all) hipFree(ctx->mod_all);
-            if (ctx->ada_in) hipFree(ctx->ada_in);
+            dfree(ctx, ctx->mod_all);
+            dfree(ctx, ctx->ada_in);
             ctx->mod_all = (float*)dalloc(ctx, need, false);
             ctx->ada_in = (float*)dalloc(ctx, (size_t)n_steps * 16 * ctx->H * 4, false);
             ctx->mod_all_bytes = (ctx->mod_all && ctx->ada_in) ? need : 0;
