@@ -82,7 +82,10 @@ typedef struct vv_row { int cache; int pos; } vv_row;
  * (== the cache length before this token).  Replaces self(**model_inputs, ...)
  * (modeling_vibevoice_inference.py:480-482 -> modeling_vibevoice.py:187-199 -> HF Qwen2Model)
  * for the positive rows and :583-585 for the negative rows -- both in ONE pass
- * over the weights.  hidden_out = last_hidden_state (after the final RMSNorm). */
+ * over the weights.  hidden_out = last_hidden_state (after the final RMSNorm).
+ * Row sets: (a) every row a different cache (decode steps; one fused attention launch per layer), or (b) consecutive
+ * positions of one cache (prompt prefill, up to max_rows rows; MFMA tile GEMM + prefill attention), or (c) any other
+ * mix of at most 64 rows (3-launch attention: all appends land before any row attends). */
 int vv_lm_forward(vv_ctx* ctx, void* stream, int n_rows, const vv_row* rows,
                   const float* x_in_dev, float* hidden_out_dev);
 /* Same over the layer range [layer_begin, layer_end) only; final_norm selects whether lm.norm is applied.
