@@ -69,7 +69,7 @@ def test_gemm_transpose_detecting(sm):
 @pytest.mark.parametrize("pro,epi", [(1, 1), (1, 2), (0, 4), (1, 3), (0, 0), (0, 1), (1, 0)])
 @pytest.mark.parametrize("xs,tol", [(2, 2e-4), (1, 2e-2)])
 def test_gemm_tile_prefill_shapes(sm, pro, epi, xs, tol):
-    """MFMA tile GEMM (tile.hip): taken for launches with >= 128 workgroups -- prompt-prefill sized problems.
+    """MFMA tile GEMM (tile.hip): taken for launches with >= 48 workgroups -- prompt-prefill sized problems.
     Ragged T (not a multiple of 64), K not a multiple of the 256-k chunk, N not a multiple of the 128-feature tile."""
     eng = sm.eng
     T, N, K = 333, 4112, 416

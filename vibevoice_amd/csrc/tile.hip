@@ -227,13 +227,13 @@ __global__ __launch_bounds__(256) void vv_gemm_tile_kernel(const u32x4* __restri
     X(VV_PRO_RMS, VV_EPI_BIAS) X(VV_PRO_RMS, VV_EPI_BIAS_GELU) X(VV_PRO_RMS, VV_EPI_SWIGLU)    \
     X(VV_PRO_RMS, VV_EPI_STORE)
 
-// Eligibility: tall, aligned, one of the pairs above, bench / two-term activation modes, no row re-mapping or part tensors.
+// Eligibility: tall, aligned, enough workgroups (>= 48), one of the pairs above, bench / two-term activation modes, no row re-mapping or part tensors.
 extern "C" int vv_tile_ok(const VVGemm* a, int xs) {
     if (a->T < 32 || xs > 2) return 0;
     {   // enough workgroups to occupy the chip; smaller problems (tokenizer stages at decode) stay on the row-tiled GEMV
         const int per_wg = 4 * (a->epi == VV_EPI_SWIGLU ? 1 : 2);
         const int64_t wgs = (int64_t)(((a->N + 15) / 16 + per_wg - 1) / per_wg) * ((a->T + BM - 1) / BM);
-        static const int min_wgs = getenv("VVHIP_TILE_MIN_WGS") ? atoi(getenv("VVHIP_TILE_MIN_WGS")) : 128;
+        static const int min_wgs = getenv("VVHIP_TILE_MIN_WGS") ? atoi(getenv("VVHIP_TILE_MIN_WGS")) : 48;
         if (wgs < min_wgs) return 0;
     }
     if ((a->K & 3) || (a->ldx & 3) || (a->N & 3) || (a->ldy & 3)) return 0;
