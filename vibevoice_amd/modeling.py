@@ -128,7 +128,7 @@ class VibeVoiceForConditionalGenerationInference:
     @classmethod
     def from_state_dict(cls, config: dict, state_dict, model_dtype=torch.bfloat16, device=None, **runtime):
         """state_dict: mapping (or iterable of (key, tensor)) keyed like the reference checkpoint."""
-        runtime.setdefault("max_rows", 512)          # prompt rows per LM weight pass (MFMA tile GEMM above ~128 workgroups)
+        runtime.setdefault("max_rows", 512)          # prompt rows per LM weight pass (MFMA tile GEMM above ~48 workgroups)
         ecfg = engine_config_from_reference(config, **runtime)
         eng = Engine(ecfg, device)
         items = state_dict.items() if hasattr(state_dict, "items") else state_dict
