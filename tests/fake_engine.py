@@ -1,0 +1,122 @@
+"""CPU stand-in for vibevoice_amd.engine.Engine, built from the ORACLE's arithmetic (tests only).
+
+Purpose: run the product's host orchestration -- vibevoice_amd/modeling.py::generate, unmodified -- on a machine
+without a GPU and compare it with the goldens recorded from the reference's own generate().  Every numeric stage is
+delegated to oracle/ (itself pinned to the reference); what is under test is the host logic: row tables, negative-branch
+bookkeeping, speculation, codec state resets, EOS / max-length handling, output assembly.
+"""
+import contextlib
+import types
+
+import torch
+import torch.nn.functional as F
+
+from oracle import codec, connector, dpm, head
+
+
+class _Event:
+    def record(self, stream=None):
+        pass
+
+    def synchronize(self):
+        pass
+
+
+class _Stream:
+    def wait_event(self, ev):
+        pass
+
+
+@contextlib.contextmanager
+def cpu_cuda_shims(monkeypatch):
+    """modeling.py talks to torch.cuda streams / events / pinned memory; give it inert CPU versions."""
+    monkeypatch.setattr(torch.cuda, "Event", lambda *a, **k: _Event())
+    monkeypatch.setattr(torch.cuda, "Stream", lambda *a, **k: _Stream())
+    monkeypatch.setattr(torch.cuda, "stream", lambda s: contextlib.nullcontext())
+    monkeypatch.setattr(torch.Tensor, "pin_memory", lambda self, *a, **k: self)
+    yield
+
+
+class FakeEngine:
+    def __init__(self, om, n_slots=2, max_rows=16, max_ctx=512):
+        self.om = om
+        self.device = torch.device("cpu")
+        self.stream = None
+        self.max_ctx = max_ctx
+        self.cfg = types.SimpleNamespace(lm_hidden=om.lm_head.shape[1], latent_dim=64, hop=3200, sem_dim=128,
+                                         n_slots=n_slots, max_rows=max_rows)
+        self.caches = {}
+        self.ac_state = [dict() for _ in range(n_slots)]
+        self.sem_state = [dict() for _ in range(n_slots)]
+        self.valid = None
+        self.n_steps = 10
+        self.calls = {"lm_rows": 0, "samples": 0, "spec_wasted": 0}
+
+    # ---- plumbing ----
+    def new(self, *shape):
+        return torch.zeros(*shape, dtype=torch.float32)
+
+    def sync(self):
+        pass
+
+    def set_valid_tokens(self, valid):
+        self.valid = list(valid)
+
+    def set_num_steps(self, n, t_cast_bf16=False):
+        self.n_steps = n
+
+    def set_speech_factors(self, scaling, bias):
+        pass
+
+    # ---- LM ----
+    def embed(self, ids, out):
+        out[:len(ids)] = self.om.lm.embed(torch.tensor(ids, dtype=torch.long))
+
+    def lm_forward(self, rows, x_in, hidden):
+        for i, (cache, pos) in enumerate(rows):
+            c = self.caches.setdefault(cache, self.om.lm.new_cache())
+            if pos < c.length:
+                c.truncate(pos)                      # a row table may rewind a cache (negative-branch reset)
+            assert pos == c.length, (cache, pos, c.length)
+            hidden[i] = self.om.lm.forward(x_in[i][None], c)[-1]
+            self.calls["lm_rows"] += 1
+
+    def lm_logits(self, n, hidden, out):
+        out[:n, :len(self.valid)] = F.linear(hidden[:n], self.om.lm_head)[:, self.valid]
+
+    # ---- diffusion ----
+    def diffusion_sample(self, n, cond, noise, cfg_scale, latent_out):
+        om = self.om
+        nz = torch.cat([noise[:n], noise[:n]])
+        lat = dpm.sample_speech_tokens(lambda x, t, c: head.head_forward(om.head_w, x, t, c, om.head_layers, om.head_eps),
+                                       cond[:n].clone(), cond[n:2 * n].clone(), cfg_scale, self.n_steps, nz, om.t_cast_dtype)
+        latent_out[:n] = lat
+        self.calls["samples"] += 1
+
+    # ---- tokenizers / connectors ----
+    def codec_decode(self, slot, latent, audio_out, apply_speech_factors=True, stream=None):
+        om = self.om
+        x = latent[0] / om.scaling - om.bias if apply_speech_factors else latent[0]
+        chunk = codec.decoder_forward(om.ac_w, x[None, :, None], om.ratios, om.dec_depths, state=self.ac_state[slot], eps=om.codec_eps)
+        audio_out.copy_(chunk[0, 0])
+
+    def semantic_encode(self, slot, audio, sem_out, stream=None):
+        om = self.om
+        sem = codec.encoder_forward(om.sem_w, audio[None, None, :], om.ratios, om.sem_depths, state=self.sem_state[slot], eps=om.codec_eps)
+        sem_out.copy_(sem[0, :, 0])
+
+    def acoustic_encode(self, frames, wav, mean_out):
+        om = self.om
+        lat = codec.encoder_forward(om.ac_w, wav[None, None, :], om.ratios, om.enc_depths, state=None, eps=om.codec_eps)
+        mean_out.copy_(lat[0].t())
+
+    def connect(self, n, latent, sem, out):
+        om = self.om
+        e = connector.connector_forward(om.ac_conn, latent[:n])
+        if sem is not None:
+            e = e + connector.connector_forward(om.sem_conn, sem[:n])
+        out[:n] = e
+
+    def codec_reset(self, slot):
+        codec.zero_state(self.ac_state[slot])
+        codec.zero_state(self.sem_state[slot])

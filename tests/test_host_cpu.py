@@ -267,3 +267,67 @@ def test_streamer_surface_and_ordering_cpu():
     assert got1 == [[1.0] * 4, [2.0] * 4, [3.0] * 4]
     with pytest.raises(ValueError):
         s.get_stream(2)
+
+
+# ---------------------------------------------------------------- the product's host loop vs the reference's generate()
+@pytest.mark.parametrize("name", ["generate_forced_b1", "generate_forced_b2", "generate_greedy_b1"])
+@pytest.mark.parametrize("speculate", [True, False])
+def test_host_generate_loop_matches_reference_goldens(monkeypatch, name, speculate):
+    """vibevoice_amd/modeling.py::generate -- the code that ships -- driven on CPU through tests/fake_engine.FakeEngine
+    (every numeric stage delegated to the pinned oracle), against the goldens recorded from the reference's own
+    generate(): identical token sequences / stop flags, waveform rel-L2 <= 1e-4.  Pins the host orchestration: row tables,
+    negative-branch reset and fix-ups for desynchronised rows, speculative sampler (on and off), codec resets."""
+    import types as _types
+    import fake_engine
+    from test_oracle_golden import G as GOLD, _oracle_small
+    from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    ids = torch.from_numpy(z["input_ids"])
+    B = ids.shape[0]
+    draws = [torch.from_numpy(z[f"draw_{i}"]) for i in range(int(z["n_draws"]))]
+    pre = (draws[0].reshape(B), draws[1].reshape(B, 3, 64))
+    # the reference drew noise only on steps where some row emitted <speech_diffusion>: map those steps to the recorded draws
+    seqs = z["sequences"]
+    L0 = ids.shape[1]
+    per_step, di = {}, 2
+    for step in range(seqs.shape[1] - L0):
+        if (seqs[:, L0 + step] == 303).any():
+            per_step[step] = draws[di].reshape(-1, 64)
+            di += 1
+    assert di == len(draws)
+
+    def noise_fn(step, n2):                       # a wrong speculative guess asks for a step that never diffused: discarded
+        if step not in per_step:
+            return torch.zeros(n2, 64)
+        d = per_step[step]
+        return d if d.shape[0] == n2 else torch.zeros(n2, 64)     # speculation assumes every active row diffuses
+    forced = None
+    if z["forced"].size:
+        forced = [z["forced"][b][:int(z["forced_len"][b])].tolist() for b in range(B)]
+    with fake_engine.cpu_cuda_shims(monkeypatch):
+        eng = fake_engine.FakeEngine(_oracle_small(), n_slots=2)
+        cfgd = {"decoder_config": {"max_position_embeddings": 4096}, "diffusion_head_config": {"ddpm_num_inference_steps": 5},
+                "acoustic_tokenizer_config": {"fix_std": 0.5, "std_dist_type": "gaussian"}}
+        m = VibeVoiceForConditionalGenerationInference(cfgd, eng, model_dtype=torch.float32)
+        m.set_speech_factors(0.2, -0.05)
+        m.set_ddpm_inference_steps(5)
+        m.speculate_sampling = speculate
+        m.concurrent_codecs = False
+        tok = _types.SimpleNamespace(speech_start_id=301, speech_end_id=302, speech_diffusion_id=303, eos_token_id=304,
+                                     bos_token_id=None, pad_token_id=305)
+        out = m.generate(input_ids=ids, attention_mask=torch.from_numpy(z["attention_mask"]),
+                         speech_tensors=torch.from_numpy(z["speech_tensors"]), speech_masks=torch.from_numpy(z["speech_masks"]),
+                         speech_input_mask=torch.from_numpy(z["speech_input_mask"]), cfg_scale=1.3, tokenizer=tok,
+                         max_new_tokens=10 if name == "generate_greedy_b1" else None, generation_config={"do_sample": False},
+                         _forced_tokens=forced, _noise_fn=noise_fn, _prefill_noise=pre, show_progress_bar=False)
+    assert torch.equal(out.sequences.cpu(), torch.from_numpy(z["sequences"]))
+    assert torch.equal(out.reach_max_step_sample.cpu(), torch.from_numpy(z["reach_max"]))
+    for b in range(B):
+        ref = torch.from_numpy(z[f"audio_{b}"])
+        if ref.numel() == 0:
+            assert out.speech_outputs[b] is None
+            continue
+        got = out.speech_outputs[b].reshape(-1)
+        assert got.shape == ref.shape
+        err = float((got - ref).norm() / ref.norm())
+        assert err <= 1e-4, err
