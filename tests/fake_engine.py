@@ -120,3 +120,74 @@ class FakeEngine:
     def codec_reset(self, slot):
         codec.zero_state(self.ac_state[slot])
         codec.zero_state(self.sem_state[slot])
+
+
+class FakeStreamingEngine:
+    """Same idea for the Streaming-0.5B host loop (vibevoice_amd/modeling_streaming.py): the split LM is two oracle
+    stacks (text LM = layers [0, n_lm) without final norm, TTS LM = the rest), caches 0 / 1 / 2 = lm / tts / neg tts."""
+
+    def __init__(self, om, n_lm, n_tts, max_ctx=512):
+        self.om, self.n_lm, self.n_tts = om, n_lm, n_tts
+        self.device = torch.device("cpu")
+        self.stream = None
+        self.max_ctx = max_ctx
+        self.cfg = types.SimpleNamespace(lm_hidden=om.tts_types.shape[1], latent_dim=64, hop=3200, sem_dim=0, n_slots=1, max_rows=16,
+                                         lm_layers=n_lm + n_tts, tts_layers=n_tts)
+        self.caches = {0: om.lm.new_cache(), 1: om.tts_lm.new_cache(), 2: om.tts_lm.new_cache()}
+        self.state = {}
+        self.n_steps = 5
+
+    def new(self, *shape):
+        return torch.zeros(*shape, dtype=torch.float32)
+
+    def sync(self):
+        pass
+
+    def set_num_steps(self, n, t_cast_bf16=False):
+        self.n_steps = n
+
+    def set_speech_factors(self, scaling, bias):
+        pass
+
+    def codec_reset(self, slot):
+        codec.zero_state(self.state)
+
+    def kv_import(self, cache, layer, k, v):
+        c = self.caches[cache]
+        li = layer if cache == 0 else layer - self.n_lm
+        c.k[li] = k.clone().float()
+        c.v[li] = v.clone().float()
+        c.length = k.shape[1]
+
+    def embed(self, ids, out):
+        out[:len(ids)] = self.om.lm.embed(torch.tensor(ids, dtype=torch.long))
+
+    def lm_forward_range(self, rows, x_in, hidden, l0, l1, final_norm):
+        stack = self.om.lm if l0 == 0 else self.om.tts_lm
+        for i, (cache, pos) in enumerate(rows):
+            c = self.caches[cache]
+            assert pos == c.length, (cache, pos, c.length)
+            hidden[i] = stack.forward(x_in[i][None], c, final_norm=bool(final_norm))[-1]
+
+    def add_type_embedding(self, n, x, type_id, out):
+        out[:n] = x[:n] + self.om.tts_types[type_id]
+
+    def eos_logit(self, n, hidden, out):
+        from oracle.generate_streaming import eos_logit
+        out[:n] = eos_logit(self.om.eos, hidden[:n]).reshape(-1)
+
+    def diffusion_sample(self, n, cond, noise, cfg_scale, latent_out):
+        om = self.om
+        nz = torch.cat([noise[:n], noise[:n]])
+        lat = dpm.sample_speech_tokens(lambda x, t, c: head.head_forward(om.head_w, x, t, c, om.head_layers, om.head_eps),
+                                       cond[:n].clone(), cond[n:2 * n].clone(), cfg_scale, self.n_steps, nz, None)
+        latent_out[:n] = lat
+
+    def codec_decode(self, slot, latent, audio_out, apply_speech_factors=True, stream=None):
+        om = self.om
+        x = latent[0] / om.scaling - om.bias
+        chunk = codec.decoder_forward(om.ac_w, x[None, :, None], om.ratios, om.dec_depths, state=self.state, eps=om.codec_eps)
+        audio_out.copy_(chunk[0, 0])
+
+    def connect(self, n, latent, sem, out):
+        out[:n] = connector.connector_forward(self.om.ac_conn, latent[:n])

@@ -331,3 +331,41 @@ def test_host_generate_loop_matches_reference_goldens(monkeypatch, name, specula
         assert got.shape == ref.shape
         err = float((got - ref).norm() / ref.norm())
         assert err <= 1e-4, err
+
+
+@pytest.mark.parametrize("name", ["streaming_text12_cap40", "streaming_text3_cap20"])
+def test_host_streaming_loop_matches_reference_goldens(monkeypatch, name):
+    """vibevoice_amd/modeling_streaming.py::generate on CPU through FakeStreamingEngine (oracle arithmetic), started from
+    the prefilled branches the reference produced, against the goldens recorded from the reference's streaming
+    generate(): token count, stop flag, waveform rel-L2 <= 1e-4."""
+    import types as _types
+    import fake_engine
+    from test_oracle_golden import G as GOLD, _oracle_streaming_small
+    from vibevoice_amd.modeling_streaming import VibeVoiceStreamingForConditionalGenerationInference
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    draws = [torch.from_numpy(z[f"draw_{i}"]).reshape(2, 64) for i in range(int(z["n_draws"]))]
+
+    def branch(tag):
+        n = int(z[f"{tag}_layers"])
+        kv = [(torch.from_numpy(z[f"{tag}_k{li}"])[None], torch.from_numpy(z[f"{tag}_v{li}"])[None]) for li in range(n)]
+        L = kv[0][0].shape[2]
+        hid = torch.zeros(1, L, 128)
+        hid[0, -1] = torch.from_numpy(z[f"{tag}_last"])
+        return _types.SimpleNamespace(past_key_values=kv, last_hidden_state=hid)
+    pre = {"lm": branch("lm"), "tts_lm": branch("tts"), "neg_lm": None, "neg_tts_lm": branch("neg_tts")}
+    with fake_engine.cpu_cuda_shims(monkeypatch):
+        eng = fake_engine.FakeStreamingEngine(_oracle_streaming_small(), 1, 2)
+        cfgd = {"decoder_config": {"max_position_embeddings": 512}, "diffusion_head_config": {"ddpm_num_inference_steps": 5},
+                "tts_backbone_num_hidden_layers": 2}
+        m = VibeVoiceStreamingForConditionalGenerationInference(cfgd, eng, model_dtype=torch.float32)
+        m.set_speech_factors(0.2, -0.05)
+        m.set_ddpm_inference_steps(5)
+        out = m.generate(tts_text_ids=torch.from_numpy(z["text"])[None], all_prefilled_outputs=pre, cfg_scale=1.5,
+                         max_new_tokens=int(z["max_new"]), _noise_fn=lambda frame, n2: draws[frame])
+    assert int(z["prompt"].shape[0]) + out.sequences.shape[1] == int(z["n_tokens"])
+    assert bool(out.reach_max_step_sample[0]) == bool(z["reach_max"][0])
+    ref = torch.from_numpy(z["audio"])
+    got = out.speech_outputs[0].reshape(-1)
+    assert got.shape == ref.shape
+    err = float((got - ref).norm() / ref.norm())
+    assert err <= 1e-4, err

@@ -188,17 +188,10 @@ def test_generate_loop_matches_the_reference_generate(name):
         assert err <= 1e-4, err
 
 
-# ---------------------------------------------------------------- row Z: the Streaming-0.5B loop
-@pytest.mark.parametrize("name", ["streaming_text12_cap40", "streaming_text3_cap20"])
-def test_streaming_loop_matches_the_reference_generate(name):
-    """Golden = the reference's VibeVoiceStreamingForConditionalGenerationInference.generate()
-    (modeling_vibevoice_streaming_inference.py:412-751) on the tiny seeded split model, started from prefilled branches
-    produced by its own forward_lm / forward_tts_lm (stored in the golden).  The oracle loop starts from the same caches
-    and gets the recorded noise: same number of tokens, same stop reason, waveform rel-L2 <= 1e-4."""
+def _oracle_streaming_small(n_lm=1, n_tts=2):
+    """The tiny split model of tests/test_gpu_streaming.py::build, oracle side only."""
     from oracle import generate_streaming as ogs
     from oracle import lm as olm
-    z = np.load(os.path.join(G, name + ".npz"))
-    n_lm, n_tts = 1, 2
     cfg = synth.LMCfg(hidden=128, layers=n_lm + n_tts, heads=2, kv_heads=1, inter=256, vocab=320)
     H = cfg.hidden
     w = synth.lm_weights(cfg)
@@ -214,10 +207,23 @@ def test_streaming_loop_matches_the_reference_generate(name):
             if k.startswith(f"layers.{n_lm + j}."):
                 tts_w[f"layers.{j}." + k[len(f"layers.{n_lm + j}."):]] = v
     mk = lambda ww, L: olm.Qwen2Oracle(ww, L, cfg.heads, cfg.kv_heads, cfg.head_dim, cfg.theta, cfg.eps, kv_round_bf16=False)
-    om = ogs.StreamingOracleModel(lm=mk(lm_w, n_lm), tts_lm=mk(tts_w, n_tts), tts_types=tts_types, eos=eos,
-                                  head_w=synth.head_weights(hc), head_layers=hc.layers, ac_w=synth.decoder_weights(cc, 3),
-                                  ac_conn=synth.connector_weights(64, H, 4), ratios=cc.ratios, dec_depths=cc.dec_depths,
-                                  scaling=0.2, bias=-0.05)
+    return ogs.StreamingOracleModel(lm=mk(lm_w, n_lm), tts_lm=mk(tts_w, n_tts), tts_types=tts_types, eos=eos,
+                                    head_w=synth.head_weights(hc), head_layers=hc.layers, ac_w=synth.decoder_weights(cc, 3),
+                                    ac_conn=synth.connector_weights(64, H, 4), ratios=cc.ratios, dec_depths=cc.dec_depths,
+                                    scaling=0.2, bias=-0.05)
+
+
+# ---------------------------------------------------------------- row Z: the Streaming-0.5B loop
+@pytest.mark.parametrize("name", ["streaming_text12_cap40", "streaming_text3_cap20"])
+def test_streaming_loop_matches_the_reference_generate(name):
+    """Golden = the reference's VibeVoiceStreamingForConditionalGenerationInference.generate()
+    (modeling_vibevoice_streaming_inference.py:412-751) on the tiny seeded split model, started from prefilled branches
+    produced by its own forward_lm / forward_tts_lm (stored in the golden).  The oracle loop starts from the same caches
+    and gets the recorded noise: same number of tokens, same stop reason, waveform rel-L2 <= 1e-4."""
+    from oracle import generate_streaming as ogs
+    from oracle import lm as olm
+    z = np.load(os.path.join(G, name + ".npz"))
+    om = _oracle_streaming_small()
 
     def cache(tag, oracle_lm):
         c = oracle_lm.new_cache()
