@@ -369,3 +369,17 @@ def test_host_streaming_loop_matches_reference_goldens(monkeypatch, name):
     assert got.shape == ref.shape
     err = float((got - ref).norm() / ref.norm())
     assert err <= 1e-4, err
+
+
+def test_bench_algorithmic_bytes_match_the_survey_figures():
+    """bench.py's roofline numerator = SURVEY 8(d)'s per-frame formula: 1.5B N=10 L~400 -> 6.44 GB, 7B -> 27.7 GB,
+    7B N=20 L=32K -> 42.65 GB."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from vibevoice_amd.configs import CONFIGS
+    gb = lambda m, n, lp, ln: bench.algorithmic_bytes_per_frame(CONFIGS[m], n, lp, ln) / 1e9
+    assert abs(gb("1.5b", 10, 400, 75) - 6.44) < 0.03
+    assert abs(gb("7b", 10, 400, 75) - 27.7) < 0.1
+    assert abs(gb("7b", 20, 32000, 75) - 42.65) < 0.3
