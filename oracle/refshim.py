@@ -131,8 +131,9 @@ def install_generate_shims():
     # them as cache.layers[i].keys / .values -- same tensors, so in-place edits through these views behave identically
     from transformers.cache_utils import DynamicCache
     if not hasattr(DynamicCache, "key_cache"):
-        DynamicCache.key_cache = property(lambda self: [l.keys for l in self.layers])
-        DynamicCache.value_cache = property(lambda self: [l.values for l in self.layers])
+        # (4.51's lists only hold layers that have been written: an untouched cache is an empty list)
+        DynamicCache.key_cache = property(lambda self: [l.keys for l in self.layers if getattr(l, "keys", None) is not None])
+        DynamicCache.value_cache = property(lambda self: [l.values for l in self.layers if getattr(l, "values", None) is not None])
     _tie = Ref.tie_weights
     Ref.tie_weights = lambda self, *a, **k: _tie(self)          # 5.x passes recompute_mapping=
     Ref._vv_shimmed = True

@@ -44,7 +44,7 @@ class FakeEngine:
         self.stream = None
         self.max_ctx = max_ctx
         self.cfg = types.SimpleNamespace(lm_hidden=om.lm_head.shape[1], latent_dim=64, hop=3200, sem_dim=128,
-                                         n_slots=n_slots, max_rows=max_rows)
+                                         n_slots=n_slots, max_rows=max_rows, lm_vocab=om.lm_head.shape[0])
         self.caches = {}
         self.ac_state = [dict() for _ in range(n_slots)]
         self.sem_state = [dict() for _ in range(n_slots)]

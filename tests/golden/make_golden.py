@@ -232,9 +232,11 @@ def gen_generate():
         diffusion_head_config=dict(hidden_size=lc.hidden, head_layers=hc.layers, head_ffn_ratio=hc.ffn_ratio, rms_norm_eps=hc.eps,
                                    latent_size=64, speech_vae_dim=64, prediction_type="v_prediction", diffusion_type="ddpm",
                                    ddpm_num_steps=1000, ddpm_num_inference_steps=5, ddpm_beta_schedule="cosine", ddpm_batch_mul=4),
-        acoustic_vae_dim=64, semantic_vae_dim=128)
+        acoustic_vae_dim=64, semantic_vae_dim=128,
+        tie_word_embeddings=False)      # PretrainedConfig defaults to True; tie_weights() (:119-128) would alias lm_head to embed_tokens
     refshim.expose_text_config(cfg)
     m = Ref(cfg).eval()
+    assert m.lm_head.weight.data_ptr() != m.model.language_model.embed_tokens.weight.data_ptr()
     sd = {}
     sd.update({"model.language_model." + k: v for k, v in synth.lm_weights(lc).items()})
     sd["lm_head.weight"] = synth.lm_head_weight(lc)
@@ -265,7 +267,7 @@ def gen_generate():
             self.step += 1
             return out
 
-    def run(name, B, plans, seed, max_new_tokens=None):
+    def run(name, B, plans, seed, max_new_tokens=None, do_sample=False):
         g = synth.Gen(seed)
         lens = [21, 17][:B]
         L0 = max(lens)
@@ -311,13 +313,16 @@ def gen_generate():
         try:
             torch.manual_seed(seed)
             out = m.generate(input_ids=ids, attention_mask=mask, tokenizer=T(), cfg_scale=1.3, max_new_tokens=max_new_tokens,
-                             generation_config={"do_sample": False}, show_progress_bar=False, return_speech=True,
+                             # top_k=0: HF's default top-50 warper runs BEFORE the reference's valid-token constraint; with random
+                             # weights the 4 valid ids can all fall outside the top 50 (all -inf -> NaN probabilities)
+                             generation_config=({"do_sample": True, "top_k": 0} if do_sample else {"do_sample": False}),
+                             show_progress_bar=False, return_speech=True,
                              speech_tensors=speech, speech_masks=smask, speech_input_mask=sim)
         finally:
             torch.randn, torch.randn_like = o_randn, o_like
             Ref._get_logits_processor = orig_glp
         arrs = dict(input_ids=ids, attention_mask=mask, speech_input_mask=sim, speech_tensors=speech, speech_masks=smask,
-                    sequences=out.sequences, reach_max=out.reach_max_step_sample, n_draws=len(draws),
+                    sequences=out.sequences, reach_max=out.reach_max_step_sample, n_draws=len(draws), seed=seed,
                     forced=np.array([p + [X] * (64 - len(p)) for p in plans]) if plans is not None else np.zeros((0,)),
                     forced_len=np.array([len(p) for p in plans]) if plans is not None else np.zeros((0,)))
         for i, d in enumerate(draws):
@@ -330,6 +335,9 @@ def gen_generate():
     run("generate_forced_b1.npz", 1, [[D, D, D, D, E, S, D, D, D, X]], seed=11)
     run("generate_forced_b2.npz", 2, [[D, D, D, E, S, D, D, X], [D, D, E, S, D, X]], seed=23)
     run("generate_greedy_b1.npz", 1, None, seed=31, max_new_tokens=10)
+    # multinomial token sampling from the CPU global RNG, interleaved with the noise draws: pins the RNG consumption order
+    run("generate_sampled_b1.npz", 1, None, seed=47, max_new_tokens=14, do_sample=True)
+    arrs_seed = 47
 
 
 @torch.no_grad()

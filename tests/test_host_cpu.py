@@ -383,3 +383,33 @@ def test_bench_algorithmic_bytes_match_the_survey_figures():
     assert abs(gb("1.5b", 10, 400, 75) - 6.44) < 0.03
     assert abs(gb("7b", 10, 400, 75) - 27.7) < 0.1
     assert abs(gb("7b", 20, 32000, 75) - 42.65) < 0.3
+
+
+def test_host_generate_sampling_keeps_the_reference_rng_stream(monkeypatch):
+    """do_sample=True, nothing injected: tokens come from torch.multinomial, prefill and diffusion noise from torch.randn,
+    all on the global generator.  Seeded like the reference run that produced generate_sampled_b1.npz, the product's host
+    loop must consume the generator in the same order and shapes -> identical tokens and waveform."""
+    import types as _types
+    import fake_engine
+    from test_oracle_golden import G as GOLD, _oracle_small
+    from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference
+    z = np.load(os.path.join(GOLD, "generate_sampled_b1.npz"))
+    with fake_engine.cpu_cuda_shims(monkeypatch):
+        eng = fake_engine.FakeEngine(_oracle_small(), n_slots=1)
+        cfgd = {"decoder_config": {"max_position_embeddings": 4096}, "diffusion_head_config": {"ddpm_num_inference_steps": 5},
+                "acoustic_tokenizer_config": {"fix_std": 0.5, "std_dist_type": "gaussian"}}
+        m = VibeVoiceForConditionalGenerationInference(cfgd, eng, model_dtype=torch.float32)
+        m.set_speech_factors(0.2, -0.05)
+        m.set_ddpm_inference_steps(5)
+        tok = _types.SimpleNamespace(speech_start_id=301, speech_end_id=302, speech_diffusion_id=303, eos_token_id=304,
+                                     bos_token_id=None, pad_token_id=305)
+        torch.manual_seed(int(z["seed"]))
+        out = m.generate(input_ids=torch.from_numpy(z["input_ids"]), attention_mask=torch.from_numpy(z["attention_mask"]),
+                         speech_tensors=torch.from_numpy(z["speech_tensors"]), speech_masks=torch.from_numpy(z["speech_masks"]),
+                         speech_input_mask=torch.from_numpy(z["speech_input_mask"]), cfg_scale=1.3, tokenizer=tok,
+                         max_new_tokens=14, generation_config={"do_sample": True}, show_progress_bar=False)
+    assert torch.equal(out.sequences.cpu(), torch.from_numpy(z["sequences"]))
+    ref = torch.from_numpy(z["audio_0"])
+    got = out.speech_outputs[0].reshape(-1)
+    assert got.shape == ref.shape
+    assert float((got - ref).norm() / ref.norm()) <= 1e-4

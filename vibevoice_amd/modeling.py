@@ -228,13 +228,17 @@ class VibeVoiceForConditionalGenerationInference:
             if prefill_noise is None:
                 # VibeVoiceTokenizerEncoderOutput.sample('gaussian'), modular_vibevoice_tokenizer.py:980-989:
                 # two draws from the device generator
+                # two draws from the device generator.  The reference's `mean` is latents.permute(0, 2, 1) (:1085) and its noise is
+                # randn_like(mean): the same call on a tensor with the same strides is what stays on the reference's RNG stream
+                # (a contiguous draw takes a different generator path).  Pinned by tests/golden/generate_sampled_b1.npz.
                 r1 = torch.randn(n_spk, device=self.device, dtype=torch.float32)
-                r2 = torch.randn(mean.shape, device=self.device, dtype=torch.float32)
+                r2 = torch.randn_like(torch.empty(n_spk, mean.shape[2], mean.shape[1], device=self.device, dtype=torch.float32).permute(0, 2, 1))
             else:
                 r1, r2 = (t.to(self.device, torch.float32) for t in prefill_noise)
             lat = mean + (r1 * (self.fix_std / 0.8))[:, None, None] * r2
         elif self.std_dist_type == "fix":
-            r2 = torch.randn(mean.shape, device=self.device) if prefill_noise is None else prefill_noise[1].to(self.device)
+            r2 = (torch.randn_like(torch.empty(n_spk, mean.shape[2], mean.shape[1], device=self.device).permute(0, 2, 1))
+                  if prefill_noise is None else prefill_noise[1].to(self.device))
             lat = mean + self.fix_std * r2
         else:
             lat = mean
@@ -406,9 +410,15 @@ class VibeVoiceForConditionalGenerationInference:
                     for b in act:
                         nxt[b] = forced_tokens[b][step] if step < len(forced_tokens[b]) else eos_id
                 elif do_sample:
-                    pick = torch.multinomial(torch.softmax(logits, -1), 1).squeeze(1)
+                    # the reference samples torch.multinomial(softmax(scores)) over the FULL vocabulary row (-inf outside the
+                    # valid ids, :490-496) on the model's device.  One-sample multinomial spends one exponential variate per
+                    # category, so the same call on the same-shaped tensor is what keeps a seeded run on the same RNG stream
+                    # (pinned on CPU by tests/golden/generate_sampled_b1.npz)
+                    full = torch.full((nA, e.cfg.lm_vocab), float("-inf"), device=self.device, dtype=torch.float32)
+                    full[:, valid_t.to(self.device)] = self._logits[:nA, :nv].float()
+                    pick_ids = torch.multinomial(torch.softmax(full, dim=-1), num_samples=1).squeeze(1).cpu()
                     for i, b in enumerate(act):
-                        nxt[b] = valid_t[pick[i]]
+                        nxt[b] = pick_ids[i]
                 else:
                     pick = torch.argmax(logits, dim=-1)
                     for i, b in enumerate(act):
