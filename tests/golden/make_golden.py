@@ -337,7 +337,8 @@ def gen_generate():
     run("generate_greedy_b1.npz", 1, None, seed=31, max_new_tokens=10)
     # multinomial token sampling from the CPU global RNG, interleaved with the noise draws: pins the RNG consumption order
     run("generate_sampled_b1.npz", 1, None, seed=47, max_new_tokens=14, do_sample=True)
-    arrs_seed = 47
+    # length cap: the forced plan would go on, max_new_tokens stops it (reach_max_step_sample bookkeeping, :523-539)
+    run("generate_cap_b1.npz", 1, [[D] * 50], seed=41, max_new_tokens=6)
 
 
 @torch.no_grad()
@@ -398,7 +399,9 @@ def gen_generate_streaming():
         def convert_tokens_to_ids(self, t):
             return 305
 
-    def run(name, n_text, max_new, seed):
+    def run(name, n_text, max_new, seed, eos_bias=None):
+        if eos_bias is not None:                       # make the binary EOS head fire (the seeded bias of -1.5 never does)
+            m.tts_eos_classifier.fc2.bias.data.fill_(eos_bias)
         gg = synth.Gen(seed)
         prompt = torch.from_numpy(gg.rng.integers(0, 300, (23,)))[None]
         text = torch.from_numpy(gg.rng.integers(0, 300, (n_text,)))[None]
@@ -411,7 +414,7 @@ def gen_generate_streaming():
         nlm_o = m.forward_lm(input_ids=neg, attention_mask=torch.ones_like(neg), use_cache=True, return_dict=True)
         ntts_o = m.forward_tts_lm(input_ids=neg, attention_mask=torch.ones_like(neg), use_cache=True, return_dict=True,
                                   lm_last_hidden_state=nlm_o.last_hidden_state, tts_text_masks=torch.ones_like(neg))
-        arrs = dict(prompt=prompt[0], text=text[0], max_new=max_new)
+        arrs = dict(prompt=prompt[0], text=text[0], max_new=max_new, eos_bias=float(m.tts_eos_classifier.fc2.bias.data[0]))
         for tag, o in (("lm", lm_o), ("tts", tts_o), ("neg_tts", ntts_o)):
             kc = [t for t in o.past_key_values.key_cache if t is not None]      # the cache object has a slot per decoder_config
             vc = [t for t in o.past_key_values.value_cache if t is not None]    # layer; each half of the split LM fills its own
@@ -443,6 +446,7 @@ def gen_generate_streaming():
 
     run("streaming_text12_cap40.npz", 12, 40, seed=5)
     run("streaming_text3_cap20.npz", 3, 20, seed=6)
+    run("streaming_eos.npz", 12, 60, seed=7, eos_bias=0.35)
 
 
 if __name__ == "__main__":

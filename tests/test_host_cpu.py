@@ -270,7 +270,7 @@ def test_streamer_surface_and_ordering_cpu():
 
 
 # ---------------------------------------------------------------- the product's host loop vs the reference's generate()
-@pytest.mark.parametrize("name", ["generate_forced_b1", "generate_forced_b2", "generate_greedy_b1"])
+@pytest.mark.parametrize("name", ["generate_forced_b1", "generate_forced_b2", "generate_greedy_b1", "generate_cap_b1"])
 @pytest.mark.parametrize("speculate", [True, False])
 def test_host_generate_loop_matches_reference_goldens(monkeypatch, name, speculate):
     """vibevoice_amd/modeling.py::generate -- the code that ships -- driven on CPU through tests/fake_engine.FakeEngine
@@ -318,7 +318,7 @@ def test_host_generate_loop_matches_reference_goldens(monkeypatch, name, specula
         out = m.generate(input_ids=ids, attention_mask=torch.from_numpy(z["attention_mask"]),
                          speech_tensors=torch.from_numpy(z["speech_tensors"]), speech_masks=torch.from_numpy(z["speech_masks"]),
                          speech_input_mask=torch.from_numpy(z["speech_input_mask"]), cfg_scale=1.3, tokenizer=tok,
-                         max_new_tokens=10 if name == "generate_greedy_b1" else None, generation_config={"do_sample": False},
+                         max_new_tokens={"generate_greedy_b1": 10, "generate_cap_b1": 6}.get(name), generation_config={"do_sample": False},
                          _forced_tokens=forced, _noise_fn=noise_fn, _prefill_noise=pre, show_progress_bar=False)
     assert torch.equal(out.sequences.cpu(), torch.from_numpy(z["sequences"]))
     assert torch.equal(out.reach_max_step_sample.cpu(), torch.from_numpy(z["reach_max"]))
@@ -333,7 +333,7 @@ def test_host_generate_loop_matches_reference_goldens(monkeypatch, name, specula
         assert err <= 1e-4, err
 
 
-@pytest.mark.parametrize("name", ["streaming_text12_cap40", "streaming_text3_cap20"])
+@pytest.mark.parametrize("name", ["streaming_text12_cap40", "streaming_text3_cap20", "streaming_eos"])
 def test_host_streaming_loop_matches_reference_goldens(monkeypatch, name):
     """vibevoice_amd/modeling_streaming.py::generate on CPU through FakeStreamingEngine (oracle arithmetic), started from
     the prefilled branches the reference produced, against the goldens recorded from the reference's streaming
@@ -354,7 +354,7 @@ def test_host_streaming_loop_matches_reference_goldens(monkeypatch, name):
         return _types.SimpleNamespace(past_key_values=kv, last_hidden_state=hid)
     pre = {"lm": branch("lm"), "tts_lm": branch("tts"), "neg_lm": None, "neg_tts_lm": branch("neg_tts")}
     with fake_engine.cpu_cuda_shims(monkeypatch):
-        eng = fake_engine.FakeStreamingEngine(_oracle_streaming_small(), 1, 2)
+        eng = fake_engine.FakeStreamingEngine(_oracle_streaming_small(eos_bias=float(z["eos_bias"]) if name == "streaming_eos" else None), 1, 2)
         cfgd = {"decoder_config": {"max_position_embeddings": 512}, "diffusion_head_config": {"ddpm_num_inference_steps": 5},
                 "tts_backbone_num_hidden_layers": 2}
         m = VibeVoiceStreamingForConditionalGenerationInference(cfgd, eng, model_dtype=torch.float32)

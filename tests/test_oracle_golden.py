@@ -144,7 +144,7 @@ def _oracle_small(kv_round_bf16=False):
     return s.oracle_model(kv_round_bf16=kv_round_bf16)
 
 
-@pytest.mark.parametrize("name", ["generate_forced_b1", "generate_forced_b2", "generate_greedy_b1"])
+@pytest.mark.parametrize("name", ["generate_forced_b1", "generate_forced_b2", "generate_greedy_b1", "generate_cap_b1"])
 def test_generate_loop_matches_the_reference_generate(name):
     """Golden = the REFERENCE's own generate() (modeling_vibevoice_inference.py:326-710) run on the tiny seeded model
     (tests/golden/make_golden.py::gen_generate, through oracle/refshim.install_generate_shims).  The oracle loop gets
@@ -169,7 +169,7 @@ def test_generate_loop_matches_the_reference_generate(name):
     forced = None
     if z["forced"].size:
         forced = [z["forced"][b][:int(z["forced_len"][b])].tolist() for b in range(B)]
-    mnt = 10 if name == "generate_greedy_b1" else None
+    mnt = {"generate_greedy_b1": 10, "generate_cap_b1": 6}.get(name)
     seq, audio, reach = ogen.oracle_generate(_oracle_small(), tok, ids, torch.from_numpy(z["attention_mask"]),
                                              torch.from_numpy(z["speech_tensors"]), torch.from_numpy(z["speech_masks"]),
                                              torch.from_numpy(z["speech_input_mask"]), cfg_scale=1.3, num_steps=5,
@@ -188,7 +188,7 @@ def test_generate_loop_matches_the_reference_generate(name):
         assert err <= 1e-4, err
 
 
-def _oracle_streaming_small(n_lm=1, n_tts=2):
+def _oracle_streaming_small(n_lm=1, n_tts=2, eos_bias=None):
     """The tiny split model of tests/test_gpu_streaming.py::build, oracle side only."""
     from oracle import generate_streaming as ogs
     from oracle import lm as olm
@@ -200,6 +200,8 @@ def _oracle_streaming_small(n_lm=1, n_tts=2):
     g = synth.Gen(900)
     tts_types = g.normal((2, H), 0.5, mat=False)
     eos = {"fc1.weight": g.linear(H, H), "fc1.bias": g.vec(H, 0.1), "fc2.weight": g.linear(1, H, 0.3), "fc2.bias": g.vec(1, 0.1, -1.5)}
+    if eos_bias is not None:
+        eos["fc2.bias"] = torch.full((1,), float(eos_bias))
     lm_w = {k: v for k, v in w.items() if k.startswith("embed") or any(k.startswith(f"layers.{i}.") for i in range(n_lm))}
     tts_w = {"norm.weight": w["norm.weight"], "embed_tokens.weight": w["embed_tokens.weight"]}
     for j in range(n_tts):
@@ -214,7 +216,7 @@ def _oracle_streaming_small(n_lm=1, n_tts=2):
 
 
 # ---------------------------------------------------------------- row Z: the Streaming-0.5B loop
-@pytest.mark.parametrize("name", ["streaming_text12_cap40", "streaming_text3_cap20"])
+@pytest.mark.parametrize("name", ["streaming_text12_cap40", "streaming_text3_cap20", "streaming_eos"])
 def test_streaming_loop_matches_the_reference_generate(name):
     """Golden = the reference's VibeVoiceStreamingForConditionalGenerationInference.generate()
     (modeling_vibevoice_streaming_inference.py:412-751) on the tiny seeded split model, started from prefilled branches
@@ -223,7 +225,7 @@ def test_streaming_loop_matches_the_reference_generate(name):
     from oracle import generate_streaming as ogs
     from oracle import lm as olm
     z = np.load(os.path.join(G, name + ".npz"))
-    om = _oracle_streaming_small()
+    om = _oracle_streaming_small(eos_bias=float(z["eos_bias"]) if name == "streaming_eos" else None)
 
     def cache(tag, oracle_lm):
         c = oracle_lm.new_cache()
