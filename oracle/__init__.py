@@ -25,7 +25,8 @@ Pinning status ("how do we know the oracle is the reference?"):
     4.51.3's attention-mask-derived position_ids in prepare_inputs_for_generation -- so the reference's own
     VibeVoiceForConditionalGenerationInference.generate() runs here on a tiny seeded model.  make_golden.py
     records it (forced token plans through a LogitsProcessor, every torch.randn draw captured):
-    generate_forced_b1 / generate_forced_b2 (desynchronised batch) / generate_greedy_b1 / generate_sampled_b1
+    generate_forced_b1 / generate_forced_b2 (desynchronised batch) / generate_greedy_b1 / generate_cap_b1 (length cap) /
+    generate_ragged_voice_b1 (voice sample of 2.5 frames) / generate_sampled_b1
     (do_sample=True: pins the order and shapes in which the torch generator is consumed).  The oracle loop,
     fed the same inputs and noise, reproduces token sequences exactly and waveforms to rel-L2 <= 1e-4.
     (This pinning found and fixed a real deviation: after <speech_start> the reference's negative context

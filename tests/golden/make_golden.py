@@ -267,7 +267,7 @@ def gen_generate():
             self.step += 1
             return out
 
-    def run(name, B, plans, seed, max_new_tokens=None, do_sample=False):
+    def run(name, B, plans, seed, max_new_tokens=None, do_sample=False, wav_len=3 * 3200):
         g = synth.Gen(seed)
         lens = [21, 17][:B]
         L0 = max(lens)
@@ -284,7 +284,7 @@ def gen_generate():
             st0 = L0 - n + 3
             ids[b, st0:st0 + n_fr[b]] = T.speech_diffusion_id
             sim[b, st0:st0 + n_fr[b]] = True
-        speech = g.uniform((B, 3 * 3200), -0.5, 0.5)
+        speech = g.uniform((B, wav_len), -0.5, 0.5)
         smask = torch.zeros((B, 3), dtype=torch.bool)
         for b in range(B):
             smask[b, :n_fr[b]] = True
@@ -337,6 +337,8 @@ def gen_generate():
     run("generate_greedy_b1.npz", 1, None, seed=31, max_new_tokens=10)
     # multinomial token sampling from the CPU global RNG, interleaved with the noise draws: pins the RNG consumption order
     run("generate_sampled_b1.npz", 1, None, seed=47, max_new_tokens=14, do_sample=True)
+    # voice sample that is not a whole number of 3200-sample frames (2.5 frames; the prompt reserves ceil = 3 positions)
+    run("generate_ragged_voice_b1.npz", 1, [[D, D, X]], seed=53, wav_len=8000)
     # length cap: the forced plan would go on, max_new_tokens stops it (reach_max_step_sample bookkeeping, :523-539)
     run("generate_cap_b1.npz", 1, [[D] * 50], seed=41, max_new_tokens=6)
 

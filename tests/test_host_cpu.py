@@ -270,7 +270,7 @@ def test_streamer_surface_and_ordering_cpu():
 
 
 # ---------------------------------------------------------------- the product's host loop vs the reference's generate()
-@pytest.mark.parametrize("name", ["generate_forced_b1", "generate_forced_b2", "generate_greedy_b1", "generate_cap_b1"])
+@pytest.mark.parametrize("name", ["generate_forced_b1", "generate_forced_b2", "generate_greedy_b1", "generate_cap_b1", "generate_ragged_voice_b1"])
 @pytest.mark.parametrize("speculate", [True, False])
 def test_host_generate_loop_matches_reference_goldens(monkeypatch, name, speculate):
     """vibevoice_amd/modeling.py::generate -- the code that ships -- driven on CPU through tests/fake_engine.FakeEngine

@@ -144,7 +144,7 @@ def _oracle_small(kv_round_bf16=False):
     return s.oracle_model(kv_round_bf16=kv_round_bf16)
 
 
-@pytest.mark.parametrize("name", ["generate_forced_b1", "generate_forced_b2", "generate_greedy_b1", "generate_cap_b1"])
+@pytest.mark.parametrize("name", ["generate_forced_b1", "generate_forced_b2", "generate_greedy_b1", "generate_cap_b1", "generate_ragged_voice_b1"])
 def test_generate_loop_matches_the_reference_generate(name):
     """Golden = the REFERENCE's own generate() (modeling_vibevoice_inference.py:326-710) run on the tiny seeded model
     (tests/golden/make_golden.py::gen_generate, through oracle/refshim.install_generate_shims).  The oracle loop gets
