@@ -267,7 +267,21 @@ def gen_generate():
             self.step += 1
             return out
 
-    def run(name, B, plans, seed, max_new_tokens=None, do_sample=False, wav_len=3 * 3200):
+    class RecStreamer:                      # what generate() tells an AudioStreamer (streamer.py:42-76), in order
+        def __init__(self, batch):
+            self.finished_flags = [False] * batch
+            self.log = []
+
+        def put(self, chunk, idx):
+            self.log.append([0, int(chunk.shape[0])] + [int(i) for i in idx.tolist()])
+
+        def end(self, idx=None):
+            ids = list(range(len(self.finished_flags))) if idx is None else [int(i) for i in idx.tolist()]
+            self.log.append([1, len(ids)] + ids)
+            # NOTE: finished_flags deliberately left untouched -- the reference's own streamer sets them, which makes
+            # generate() stop at the first finished sample (:443-447); here the whole batch is recorded.
+
+    def run(name, B, plans, seed, max_new_tokens=None, do_sample=False, wav_len=3 * 3200, streamer=False):
         g = synth.Gen(seed)
         lens = [21, 17][:B]
         L0 = max(lens)
@@ -296,6 +310,7 @@ def gen_generate():
             if force is not None:
                 lst = LogitsProcessorList([force] + list(lst))
             return lst
+        rec = RecStreamer(B) if streamer else None
         draws = []
         o_randn, o_like = torch.randn, torch.randn_like
 
@@ -316,7 +331,7 @@ def gen_generate():
                              # top_k=0: HF's default top-50 warper runs BEFORE the reference's valid-token constraint; with random
                              # weights the 4 valid ids can all fall outside the top 50 (all -inf -> NaN probabilities)
                              generation_config=({"do_sample": True, "top_k": 0} if do_sample else {"do_sample": False}),
-                             show_progress_bar=False, return_speech=True,
+                             show_progress_bar=False, return_speech=True, audio_streamer=rec,
                              speech_tensors=speech, speech_masks=smask, speech_input_mask=sim)
         finally:
             torch.randn, torch.randn_like = o_randn, o_like
@@ -327,13 +342,16 @@ def gen_generate():
                     forced_len=np.array([len(p) for p in plans]) if plans is not None else np.zeros((0,)))
         for i, d in enumerate(draws):
             arrs[f"draw_{i}"] = d
+        if rec is not None:
+            w = max(len(r) for r in rec.log)
+            arrs["streamer_log"] = np.array([r + [-1] * (w - len(r)) for r in rec.log])
         for b in range(B):
             a = out.speech_outputs[b]
             arrs[f"audio_{b}"] = a.reshape(-1) if a is not None else torch.zeros(0)
         save(name, **arrs)
 
     run("generate_forced_b1.npz", 1, [[D, D, D, D, E, S, D, D, D, X]], seed=11)
-    run("generate_forced_b2.npz", 2, [[D, D, D, E, S, D, D, X], [D, D, E, S, D, X]], seed=23)
+    run("generate_forced_b2.npz", 2, [[D, D, D, E, S, D, D, X], [D, D, E, S, D, X]], seed=23, streamer=True)
     run("generate_greedy_b1.npz", 1, None, seed=31, max_new_tokens=10)
     # multinomial token sampling from the CPU global RNG, interleaved with the noise draws: pins the RNG consumption order
     run("generate_sampled_b1.npz", 1, None, seed=47, max_new_tokens=14, do_sample=True)

@@ -315,11 +315,26 @@ def test_host_generate_loop_matches_reference_goldens(monkeypatch, name, specula
         m.concurrent_codecs = False
         tok = _types.SimpleNamespace(speech_start_id=301, speech_end_id=302, speech_diffusion_id=303, eos_token_id=304,
                                      bos_token_id=None, pad_token_id=305)
+        class RecStreamer:                  # same recorder the golden run used (make_golden.py)
+            def __init__(self, batch):
+                self.finished_flags = [False] * batch
+                self.log = []
+
+            def put(self, chunk, idx):
+                self.log.append([0, int(chunk.shape[0])] + [int(i) for i in idx.tolist()])
+
+            def end(self, idx=None):
+                ids_ = list(range(len(self.finished_flags))) if idx is None else [int(i) for i in idx.tolist()]
+                self.log.append([1, len(ids_)] + ids_)
+        rec = RecStreamer(B) if "streamer_log" in z.files else None
         out = m.generate(input_ids=ids, attention_mask=torch.from_numpy(z["attention_mask"]),
                          speech_tensors=torch.from_numpy(z["speech_tensors"]), speech_masks=torch.from_numpy(z["speech_masks"]),
                          speech_input_mask=torch.from_numpy(z["speech_input_mask"]), cfg_scale=1.3, tokenizer=tok,
                          max_new_tokens={"generate_greedy_b1": 10, "generate_cap_b1": 6}.get(name), generation_config={"do_sample": False},
-                         _forced_tokens=forced, _noise_fn=noise_fn, _prefill_noise=pre, show_progress_bar=False)
+                         _forced_tokens=forced, _noise_fn=noise_fn, _prefill_noise=pre, show_progress_bar=False, audio_streamer=rec)
+    if rec is not None:                       # the AudioStreamer sees the same put / end calls, in the same order, as from the reference
+        ref_log = [[int(v) for v in row if v >= 0] for row in z["streamer_log"]]
+        assert rec.log == ref_log, (rec.log, ref_log)
     assert torch.equal(out.sequences.cpu(), torch.from_numpy(z["sequences"]))
     assert torch.equal(out.reach_max_step_sample.cpu(), torch.from_numpy(z["reach_max"]))
     for b in range(B):
