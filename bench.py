@@ -202,7 +202,11 @@ def main():
         model.generate(tokenizer=synthetic.TOKENS, cfg_scale=args.cfg_scale, generation_config={"do_sample": False},
                        max_new_tokens=kprof + 3, show_progress_bar=False, _forced_tokens=forced_p,
                        _noise_fn=lambda step, n2: noise_bank[step], _step_callback=prof_cb, **inp2)
-        (n_l, ms, by), (n_o, ms_o, by_o) = prof["res"]       # [decode GEMV kernel], [general GEMM kernel]
+        (n_l, ms_cal, by), (n_o, ms_o, by_o) = prof["res"]       # [decode GEMV kernel], [general GEMM kernel]
+        # launch duration = hipEvent pair around each launch minus the in-stream cost of an empty pair (vv_profile_end);
+        # cross-check against rocprofv3's per-kernel average: profiles/r01_1p5b_gemv_summary.txt
+        ms = ms_cal
+        ms_raw = eng.stat(2) / 1e6
         ach = by / 1e9 / (ms / 1e3) if ms > 0 else 0.0
         traffic = None
         try:
@@ -210,10 +214,20 @@ def main():
                 traffic = json.load(f).get(args.model, {}).get("hbm_bytes_per_launch")
         except Exception:
             pass
+        rp = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "rocprof_gemv.json")) as f:
+                rp = json.load(f).get(args.model, {}).get("avg_launch_us")
+        except Exception:
+            pass
         formula = algorithmic_bytes_per_frame(cfg, NS, max(L0, args.kv_start) + W + K // 2, 1 + min(150, K) // 2)
         roof = {"bound": "hbm", "kernel": "vv_gemv_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "launches_per_step": round(n_l / kprof, 1), "avg_launch_us": round(ms * 1e3 / max(1, n_l), 3),
+                "avg_launch_us_raw_event_pair": round(ms_raw * 1e3 / max(1, n_l), 3), "empty_event_pair_us": round(eng.stat(3) / 1e3, 3),
+                # cross-check from the committed rocprofv3 summary of this workload (graph replay: per-kernel intervals overlap,
+                # an upper bound on the launch duration -> a lower bound on the fraction); profiles/rocprof_gemv.json
+                "rocprof_avg_launch_us": rp, "frac_at_rocprof_duration": round(by / max(1, n_l) / 1e3 / rp / HBM_PEAK_GBS, 4) if rp else None,
                 "bytes_per_launch": round(by / max(1, n_l), 1),
                 "gemv_bytes_per_step": round(by / kprof, 1),
                 "other_gemm": {"kernel": "vv_gemm_kernel", "launches_per_step": round(n_o / kprof, 1),

@@ -24,3 +24,12 @@ timeout 250 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tm
 python $R/tools/pmc_traffic.py /tmp/pmc/pm_counter_collection.csv 1.5b 26 $O/r01_1p5b_pmc_fetch_size_by_kernel.csv > /dev/null
 cp $R/profiles/pmc_traffic.json $O/pmc_traffic.json
 for f in $O/r01_*.json; do echo $(basename $f) $(python -c "import json,sys; d=json.load(open('$f')); e=d.get('extra') or {}; print(d.get('value'), d.get('ms_per_step'), (d.get('roofline') or {}).get('frac'), (d.get('cpu_baseline') or {}).get('value'), e.get('prefill_phases'), e.get('p50_first_audio_ms'))" 2>/dev/null); done
+python - <<PY
+import csv, json
+rows = list(csv.DictReader(open("$O/r01_1p5b_bench_kernel_stats.csv")))
+tot = sum(float(r["TotalDurationNs"]) for r in rows if "vv_gemv_kernel" in r["Name"]); calls = sum(int(r["Calls"]) for r in rows if "vv_gemv_kernel" in r["Name"])
+allk = sum(float(r["TotalDurationNs"]) for r in rows)
+json.dump({"1.5b": {"kernel": "vv_gemv_kernel (all instantiations)", "avg_launch_us": round(tot / calls / 1e3, 3), "dispatches": calls,
+                    "sum_all_kernels_ms": round(allk / 1e6, 2), "note": "rocprofv3 --kernel-trace --stats of the default bench; under hipGraph replay per-kernel intervals overlap (their sum exceeds the wall time), so this is an upper bound on a launch's own duration"}},
+          open("$O/rocprof_gemv.json", "w"), indent=1)
+PY
