@@ -1,8 +1,9 @@
-"""Import shims that let the reference's *math* modules load under
-transformers 5.x without diffusers (SURVEY.md "Oracle import recipe").
+"""Import shims that let the reference's modules load -- and its two generate() loops run -- under transformers 5.x
+without diffusers (SURVEY.md "Oracle import recipe").
 
-Only tests/golden/make_golden.py uses this, and only inside the build
-container where /root/reference exists.  No arithmetic lives here.
+Only tests/golden/make_golden.py uses this, and only inside the build container where /root/reference exists.
+No arithmetic of the path lives here; the one computation is the attention-mask-derived position_ids that
+transformers 4.51.3 (the version the reference pins) produced inside prepare_inputs_for_generation and 5.x no longer does.
 """
 import dataclasses
 import enum

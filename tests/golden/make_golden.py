@@ -9,6 +9,12 @@ What is executed is reference code, imported through oracle/refshim.py:
   vibevoice.modular.modular_vibevoice_tokenizer.{VibeVoiceAcousticTokenizerModel,
       VibeVoiceSemanticTokenizerModel, VibeVoiceTokenizerStreamingCache}
   vibevoice.modular.modeling_vibevoice.SpeechConnector
+  vibevoice.modular.modeling_vibevoice_inference.VibeVoiceForConditionalGenerationInference.generate   (gen_generate:
+      forced single / desynchronised batch of 2 + AudioStreamer call log / greedy / length cap / ragged voice sample /
+      do_sample=True, every torch.randn draw recorded)
+  vibevoice.modular.modeling_vibevoice_streaming_inference.VibeVoiceStreamingForConditionalGenerationInference.generate
+      (gen_generate_streaming: text windows + length cap, EOS inside a window; prefilled branches from its own forwards)
+  (both through oracle/refshim.install_*_shims: transformers 4.51.3 -> 5.x API adaptation, no arithmetic)
 and, for the LM (third-party arithmetic, see oracle/lm.py), the installed
 transformers Qwen2Model.  Weights come from tests/synth.py (seeded, small
 shapes); only inputs/outputs + a weight checksum are stored.
