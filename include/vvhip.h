@@ -98,6 +98,10 @@ int vv_lm_forward_range(vv_ctx* ctx, void* stream, int n_rows, const vv_row* row
  * (demo/voices/streaming_model/ presets -> all_prefilled_outputs). */
 int vv_kv_import(vv_ctx* ctx, void* stream, int cache, int layer, int n_pos, const void* k_dev, const void* v_dev,
                  int src_dtype);
+/* The same for cache positions [pos0, pos0 + n_pos): source row i lands at position pos0 + i.  Lets a caller resume an
+ * utterance from KV state computed elsewhere (and the long-context tests / bench place known K/V at chosen positions). */
+int vv_kv_import_at(vv_ctx* ctx, void* stream, int cache, int layer, int pos0, int n_pos, const void* k_dev,
+                    const void* v_dev, int src_dtype);
 /* y[t][:] = x[t][:] + tts_input_types[type]  (forward_tts_lm, :293) */
 int vv_add_type_embedding(vv_ctx* ctx, void* stream, int n, const float* x_dev, int type, float* out_dev);
 /* tts_eos_classifier: fc2(relu(fc1(h))) -> out_dev[n] logits (BinaryClassifier, modeling_vibevoice_streaming.py:42-53) */
@@ -127,6 +131,10 @@ int vv_semantic_encode(vv_ctx* ctx, void* stream, int slot, int frames, const fl
 /* acoustic_tokenizer.encode(wav).mean, non-streaming (:154; modular_vibevoice_tokenizer.py:1081-1085):
  * wav_dev [frames*hop] -> mean_out_dev [frames][latent] */
 int vv_acoustic_encode(vv_ctx* ctx, void* stream, int frames, const float* wav_dev, float* mean_out_dev);
+/* 16-bit PCM of n chunks of `samples` fp32 samples each, on device, before the chunk leaves for the host: the arithmetic
+ * of convert_to_16_bit_wav (demo/gradio_demo.py:1058-1073, applied per streamed chunk at :404-418): peak = max|x| of the
+ * chunk; x /= peak when peak > 1; int16(trunc(x * 32767)).  audio_dev [n][samples] fp32 -> pcm_out_dev [n][samples] int16. */
+int vv_audio_to_pcm16(vv_ctx* ctx, void* stream, int n, int samples, const float* audio_dev, int16_t* pcm_out_dev);
 /* acoustic_cache.set_to_zero + semantic_cache.set_to_zero for a slot (:542-546) */
 int vv_codec_reset(vv_ctx* ctx, void* stream, int slot);
 /* acoustic_connector(latent) [+ semantic_connector(sem)] (:667-669, :161); sem_dev may be NULL */
@@ -148,6 +156,12 @@ int vv_gemm_raw(void* stream, const void* w_packed_dev, const void* w2_packed_de
  * [1] the general vv_gemm_kernel.  Used by bench.py's roofline. */
 int vv_profile_begin(vv_ctx* ctx);
 int vv_profile_end(vv_ctx* ctx, int64_t* launches, double* total_ms, double* bytes);
+/* The vv_gemv_kernel launches recorded by the last begin/end window, captured in issue order into one hipGraph and replayed
+ * `reps` times between two events on `stream`: launches = recorded x reps, total_ms, algorithmic bytes.  total_ms/launches
+ * is the start-to-start period of a GEMV launch inside a dependent graph chain (kernel + boundary) -- the execution mode of
+ * the timed region, and what rocprofv3 --kernel-trace reports per kernel under graph replay.  Clobbers engine scratch and
+ * streaming-codec state: call it last. */
+int vv_profile_replay(vv_ctx* ctx, void* stream, int reps, int64_t* launches, double* total_ms, double* bytes);
 /* number of kernel launches issued by the last engine call (graph nodes when replayed) */
 int64_t vv_stat(vv_ctx* ctx, int what);
 

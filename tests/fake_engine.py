@@ -82,7 +82,9 @@ class FakeEngine:
             self.calls["lm_rows"] += 1
 
     def lm_logits(self, n, hidden, out):
-        out[:n, :len(self.valid)] = F.linear(hidden[:n], self.om.lm_head)[:, self.valid]
+        # the C ABI's layout: a dense [n][n_valid] block at the start of `out` (include/vvhip.h, vv_lm_logits)
+        nv = len(self.valid)
+        out.reshape(-1)[:n * nv].copy_(F.linear(hidden[:n], self.om.lm_head)[:, self.valid].reshape(-1))
 
     # ---- diffusion ----
     def diffusion_sample(self, n, cond, noise, cfg_scale, latent_out):

@@ -38,6 +38,7 @@ _SIGS = {
     "vv_lm_forward": (C.c_int, [_P, _P, C.c_int, C.POINTER(VVRow), _P, _P]),
     "vv_lm_forward_range": (C.c_int, [_P, _P, C.c_int, C.POINTER(VVRow), _P, _P, C.c_int, C.c_int, C.c_int]),
     "vv_kv_import": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int]),
+    "vv_kv_import_at": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int]),
     "vv_add_type_embedding": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P]),
     "vv_eos_logit": (C.c_int, [_P, _P, C.c_int, _P, _P]),
     "vv_embed": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int), _P]),
@@ -47,6 +48,7 @@ _SIGS = {
     "vv_codec_decode": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, C.c_int]),
     "vv_semantic_encode": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     "vv_acoustic_encode": (C.c_int, [_P, _P, C.c_int, _P, _P]),
+    "vv_audio_to_pcm16": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     "vv_codec_reset": (C.c_int, [_P, _P, C.c_int]),
     "vv_connect": (C.c_int, [_P, _P, C.c_int, _P, _P, _P]),
     "vv_packed_bytes": (C.c_int64, [C.c_int, C.c_int]),
@@ -55,6 +57,7 @@ _SIGS = {
                               _P, C.c_float, _P, _P, C.c_int, C.c_int, C.c_int]),
     "vv_profile_begin": (C.c_int, [_P]),
     "vv_profile_end": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "vv_profile_replay": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "vv_stat": (C.c_int64, [_P, C.c_int]),
 }
 

@@ -48,11 +48,13 @@ int vv_silu_launch(float* x, int n, hipStream_t s);
 int vv_ada_in_launch(const float* cproj, const float* temb, float* out, int rows, int n_steps, int H, hipStream_t s);
 int vv_add_rows_launch(const float* x, const float* v, float* y, int n, int C, hipStream_t s);
 int vv_relu_launch(float* x, int n, hipStream_t s);
-int vv_kv_import_launch(const void* k, const void* v, int src_bf16, void* kc, void* vc, int L, int Hkv, int D, int64_t head_stride, hipStream_t s);
+int vv_kv_import_launch(const void* k, const void* v, int src_bf16, void* kc, void* vc, int L, int Hkv, int D, int64_t head_stride, int pos0, hipStream_t s);
+int vv_pcm16_launch(const float* x, short* out, int n, int samples, hipStream_t s);
 int vv_cvt_launch(const void* src, void* dst, int64_t n, int to_bf16, hipStream_t s);
 int vv_dw_transpose_launch(const float* src, float* dst, int C, hipStream_t s);
 int vv_block1d_supported(int C);
 int vv_gemv_ok(const VVGemm* a);
+int vv_tile_ok(const VVGemm* a, int xs);
 int vv_block1d_launch(int C, int xs, const float* xin, float* xout, float* nst, const float* norm_w,
                       const float* ffn_norm_w, const float* gamma, const float* ffn_gamma, const float* dw_w,
                       const float* dw_b, const float* b1, const float* b2, const void* w1, const void* w2, int T,
@@ -118,7 +120,7 @@ struct CodecNet {
     int maxC = 1;
 };
 
-struct GraphEntry { hipGraphExec_t exec; };
+struct GraphEntry { hipGraphExec_t exec; uint64_t last_use; };
 
 }  // namespace
 
@@ -171,7 +173,8 @@ struct vv_ctx {
     int hop = 3200;
     // staging
     void* stage = nullptr; size_t stage_bytes = 0;
-    std::map<std::string, GraphEntry> graphs;
+    std::map<std::string, GraphEntry> graphs;      // bounded: least-recently-used entries are destroyed beyond graph_cap
+    uint64_t graph_tick = 0; size_t graph_cap = 512;
     std::set<std::string> seen;
     std::set<void*> allocs;                // every dalloc() of this engine: released by vv_destroy
     int64_t launches = 0;
@@ -182,6 +185,8 @@ struct vv_ctx {
     double prof_bytes = 0.0;
     struct ProfRec { int T, N, K, pro, epi, dual; double bytes; int gemv; };
     std::vector<ProfRec> prof_rec;
+    std::vector<VVGemm> prof_gemv;          // the decode-GEMV launches of the last profile window, in issue order (vv_profile_replay)
+    double prof_gemv_bytes = 0.0;
     int64_t prof_raw_ns = 0, prof_ev_over_ns = 0;
     hipStream_t prof_stream = nullptr;     // last vv_profile_end: uncalibrated GEMV total, one empty event pair
 #ifdef VV_GEMM_TIMING
@@ -415,7 +420,10 @@ static int gemm_prof(vv_ctx* ctx, const VVGemm& g, hipStream_t st) {
     hipEventRecord(ctx->prof_ev[2 * ctx->prof_n + 1], st);
     ctx->prof_n++;
     ctx->prof_bytes += gemm_bytes(g);
-    ctx->prof_rec.push_back({g.T, g.N, g.K, g.pro, g.epi, g.W2 ? 1 : 0, gemm_bytes(g), vv_gemv_ok(&g) && (g.T <= 4 || ctx->c.xsplit <= 2)});
+    // which kernel vv_gemm_launch picks (gemm.hip): MFMA tile GEMM, decode GEMV, or the general kernel
+    const bool is_gemv = !vv_tile_ok(&g, ctx->c.xsplit) && g.ksplit <= 0 && vv_gemv_ok(&g) && (g.T <= 4 || ctx->c.xsplit <= 2);
+    ctx->prof_rec.push_back({g.T, g.N, g.K, g.pro, g.epi, g.W2 ? 1 : 0, gemm_bytes(g), is_gemv});
+    if (is_gemv) { ctx->prof_gemv.push_back(g); ctx->prof_gemv_bytes += gemm_bytes(g); }
     return r;
 }
 #ifdef VV_GEMM_TIMING
@@ -538,11 +546,26 @@ static int graphed(vv_ctx* ctx, const std::string& key, hipStream_t st, F&& body
         hipError_t e = hipStreamEndCapture(st, &graph);
         if (r) return r;
         HIPCHK(ctx, e);
-        GraphEntry ge;
+        GraphEntry ge; ge.last_use = 0;
         HIPCHK(ctx, hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0));
         hipGraphDestroy(graph);
+        if (ctx->graphs.size() >= ctx->graph_cap) {
+            // a long-running process with varied launch shapes (prefill remainders over temporary buffers) must not
+            // accumulate executables: drop the least-recently-used quarter (their work has been enqueued already;
+            // hipGraphExecDestroy defers the release until the launches in flight have finished)
+            std::vector<std::pair<uint64_t, std::string>> order;
+            for (auto& g : ctx->graphs) order.push_back({g.second.last_use, g.first});
+            std::sort(order.begin(), order.end());
+            HIPCHK(ctx, hipStreamSynchronize(st));
+            for (size_t i = 0; i < order.size() / 4 + 1; ++i) {
+                auto v = ctx->graphs.find(order[i].second);
+                hipGraphExecDestroy(v->second.exec);
+                ctx->graphs.erase(v);
+            }
+        }
         it = ctx->graphs.emplace(key, ge).first;
     }
+    it->second.last_use = ++ctx->graph_tick;
     HIPCHK(ctx, hipGraphLaunch(it->second.exec, st));
     return 0;
 }
@@ -556,9 +579,16 @@ extern "C" int vv_create(const vv_config* cfg, vv_ctx** out) {
     vv_config& c = ctx->c;
     if (c.max_rows < 1 || c.max_rows > 2048) { delete ctx; return fail(nullptr, "max_rows must be in [1,2048]"); }
     if (c.lm_head_dim != 64 && c.lm_head_dim != 128) { delete ctx; return fail(nullptr, "head_dim must be 64 or 128"); }
+    // the attention kernels put the query heads of a GQA group on the 16 MFMA columns (attn.hip)
+    if (c.lm_kv_heads < 1 || c.lm_heads % c.lm_kv_heads != 0 || c.lm_heads / c.lm_kv_heads > 16) {
+        const int hq = c.lm_heads, hkv = c.lm_kv_heads;
+        delete ctx;
+        return fail(nullptr, "lm_heads=%d / lm_kv_heads=%d: the GQA group size must be an integer <= 16", hq, hkv);
+    }
     if (c.xsplit < 1 || c.xsplit > 3) c.xsplit = 2;
     if (c.attn_splits < 1) c.attn_splits = 32;
     if (c.enc_frames < 1) c.enc_frames = 1;
+    if (getenv("VVHIP_GRAPH_CAP")) ctx->graph_cap = (size_t)std::max(4, atoi(getenv("VVHIP_GRAPH_CAP")));
     c.max_ctx = (c.max_ctx + 127) & ~127;
     const int H = ctx->H = c.lm_hidden, D = ctx->D = c.lm_head_dim, Hq = ctx->Hq = c.lm_heads, Hkv = ctx->Hkv = c.lm_kv_heads;
     const int I = ctx->I = c.lm_inter;
@@ -911,14 +941,24 @@ extern "C" int vv_lm_forward_range(vv_ctx* ctx, void* stream, int n_rows, const 
     return graphed(ctx, key, st, [&]() { return lm_body(ctx, st, n_rows, x_in_dev, hidden_out_dev, l0, l1, final_norm, fused, contiguous); });
 }
 
-extern "C" int vv_kv_import(vv_ctx* ctx, void* stream, int cache, int layer, int n_pos, const void* k_dev, const void* v_dev, int src_dtype) {
+extern "C" int vv_kv_import_at(vv_ctx* ctx, void* stream, int cache, int layer, int pos0, int n_pos, const void* k_dev, const void* v_dev, int src_dtype) {
     hipStream_t st = (hipStream_t)stream;
     if (cache < 0 || cache >= 2 * ctx->c.n_slots) return fail(ctx, "cache id %d out of range", cache);
     if (layer < 0 || layer >= ctx->c.lm_layers) return fail(ctx, "layer %d out of range", layer);
-    if (n_pos < 0 || n_pos > ctx->c.max_ctx) return fail(ctx, "n_pos %d exceeds max_ctx", n_pos);
+    if (pos0 < 0 || n_pos < 0 || (int64_t)pos0 + n_pos > ctx->c.max_ctx) return fail(ctx, "positions [%d, %d) exceed max_ctx %d", pos0, pos0 + n_pos, ctx->c.max_ctx);
     if (n_pos == 0) return 0;
     const size_t off = ((size_t)cache * ctx->cache_stride + (size_t)layer * ctx->layer_stride) * 2;
-    VVCHK(vv_kv_import_launch(k_dev, v_dev, src_dtype, (char*)ctx->kc + off, (char*)ctx->vc + off, n_pos, ctx->Hkv, ctx->D, ctx->head_stride, st));
+    VVCHK(vv_kv_import_launch(k_dev, v_dev, src_dtype, (char*)ctx->kc + off, (char*)ctx->vc + off, n_pos, ctx->Hkv, ctx->D, ctx->head_stride, pos0, st));
+    return 0;
+}
+extern "C" int vv_kv_import(vv_ctx* ctx, void* stream, int cache, int layer, int n_pos, const void* k_dev, const void* v_dev, int src_dtype) {
+    return vv_kv_import_at(ctx, stream, cache, layer, 0, n_pos, k_dev, v_dev, src_dtype);
+}
+
+extern "C" int vv_audio_to_pcm16(vv_ctx* ctx, void* stream, int n, int samples, const float* audio_dev, int16_t* pcm_out_dev) {
+    hipStream_t st = (hipStream_t)stream;
+    if (n < 1 || samples < 1) return fail(ctx, "vv_audio_to_pcm16: n and samples must be positive");
+    VVCHK(vv_pcm16_launch(audio_dev, (short*)pcm_out_dev, n, samples, st));
     return 0;
 }
 
@@ -1160,6 +1200,7 @@ extern "C" int vv_gemm_raw(void* stream, const void* w, const void* w2, const fl
 extern "C" int vv_profile_begin(vv_ctx* ctx) {
     HIPCHK(ctx, hipDeviceSynchronize());
     ctx->prof_on = true; ctx->prof_n = 0; ctx->prof_bytes = 0.0; ctx->prof_rec.clear();
+    ctx->prof_gemv.clear(); ctx->prof_gemv_bytes = 0.0;
     return 0;
 }
 extern "C" int vv_profile_end(vv_ctx* ctx, int64_t* launches, double* total_ms, double* bytes) {
@@ -1203,6 +1244,43 @@ extern "C" int vv_profile_end(vv_ctx* ctx, int64_t* launches, double* total_ms, 
     if (bytes) { bytes[0] = ctx->prof_bytes - by_other; bytes[1] = by_other; }
     ctx->prof_raw_ns = (int64_t)(raw_ms * 1e6); ctx->prof_ev_over_ns = (int64_t)(ev_over * 1e6);
     ctx->prof_on = false;
+    return 0;
+}
+// Launch duration of the dominant kernel in the execution mode of the timed region: the vv_gemv_kernel launches recorded by
+// the last profile window are captured, in issue order, into ONE hipGraph (a dependent chain on `stream`, as inside the step
+// graphs) and replayed `reps` times between two events.  total_ms / (launches * reps) = start-to-start period of a GEMV
+// launch in a dependent chain = kernel time + the kernel boundary, which is what rocprofv3 --kernel-trace reports per kernel
+// under graph replay (profiles/): an upper bound on the kernel's own duration.  The replay re-runs residual epilogues on the
+// engine's scratch / codec state buffers: call it after the measurements that need those states.
+extern "C" int vv_profile_replay(vv_ctx* ctx, void* stream, int reps, int64_t* launches, double* total_ms, double* bytes) {
+    hipStream_t st = (hipStream_t)stream;
+    if (ctx->prof_on) return fail(ctx, "vv_profile_replay: call vv_profile_end first");
+    if (ctx->prof_gemv.empty()) return fail(ctx, "vv_profile_replay: the last profile window recorded no GEMV launches");
+    if (reps < 1) reps = 1;
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    hipGraph_t graph; hipGraphExec_t exec;
+    HIPCHK(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+    int rr = 0;
+    for (const VVGemm& g : ctx->prof_gemv) { rr = vv_gemm_launch(g, ctx->c.xsplit, st); if (rr) break; }
+    hipError_t e = hipStreamEndCapture(st, &graph);
+    if (rr) return fail(ctx, "vv_profile_replay: launch failed (%d)", rr);
+    HIPCHK(ctx, e);
+    HIPCHK(ctx, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    hipGraphDestroy(graph);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    HIPCHK(ctx, hipGraphLaunch(exec, st));                  // warm-up replay
+    HIPCHK(ctx, hipEventRecord(e0, st));
+    for (int i = 0; i < reps; ++i) HIPCHK(ctx, hipGraphLaunch(exec, st));
+    HIPCHK(ctx, hipEventRecord(e1, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    float ms = 0.f;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipGraphExecDestroy(exec);
+    if (launches) *launches = (int64_t)ctx->prof_gemv.size() * reps;
+    if (total_ms) *total_ms = ms;
+    if (bytes) *bytes = ctx->prof_gemv_bytes * reps;
     return 0;
 }
 extern "C" int64_t vv_stat(vv_ctx* ctx, int what) {

@@ -262,9 +262,10 @@ __global__ void vv_relu_kernel(float* __restrict__ x, int n) {
 // HF KV layout [kvh][L][D] -> tiled cache layout (attn.hip header).  grid (L, kvh), block D threads
 template <typename ST>
 __global__ void vv_kv_import_kernel(const ST* __restrict__ k, const ST* __restrict__ v, __bf16* __restrict__ kc,
-                                    __bf16* __restrict__ vc, int L, int D, int64_t head_stride) {
-    const int pos = blockIdx.x, h = blockIdx.y, d = threadIdx.x;
-    const int64_t si = ((int64_t)h * L + pos) * D + d;
+                                    __bf16* __restrict__ vc, int L, int D, int64_t head_stride, int pos0) {
+    const int h = blockIdx.y, d = threadIdx.x;
+    const int64_t si = ((int64_t)h * L + blockIdx.x) * D + d;
+    const int pos = pos0 + (int)blockIdx.x;                  // cache position of source row blockIdx.x
     __bf16* kb = kc + (int64_t)h * head_stride;
     __bf16* vb = vc + (int64_t)h * head_stride;
     {
@@ -277,6 +278,26 @@ __global__ void vv_kv_import_kernel(const ST* __restrict__ k, const ST* __restri
         const int64_t tile = (int64_t)(pos >> 5) * (D / 16) + (d >> 4);
         const int ln = (d & 15) + 16 * q4;
         vb[(tile * 64 + ln) * 8 + half * 4 + rr] = (__bf16)(float)v[si];
+    }
+}
+
+// 16-bit PCM of one chunk per workgroup, the arithmetic of the reference's convert_to_16_bit_wav (demo/gradio_demo.py:1058-1073):
+// peak = max|x|; if peak > 1: x /= peak (fp32, IEEE division); (x * 32767) truncated toward zero to int16.
+__global__ __launch_bounds__(256) void vv_pcm16_kernel(const float* __restrict__ x, short* __restrict__ out, int samples) {
+    const float* xr = x + (size_t)blockIdx.x * samples;
+    short* orow = out + (size_t)blockIdx.x * samples;
+    float mx = 0.f;
+    for (int i = threadIdx.x; i < samples; i += 256) mx = fmaxf(mx, fabsf(xr[i]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    __shared__ float wmx[4];
+    if ((threadIdx.x & 63) == 0) wmx[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    const float peak = fmaxf(fmaxf(wmx[0], wmx[1]), fmaxf(wmx[2], wmx[3]));
+    for (int i = threadIdx.x; i < samples; i += 256) {
+        float v = xr[i];
+        if (peak > 1.0f) v = __fdiv_rn(v, peak);
+        orow[i] = (short)(int)__fmul_rn(v, 32767.0f);
     }
 }
 
@@ -388,9 +409,13 @@ int vv_relu_launch(float* x, int n, hipStream_t s) {
     return okk();
 }
 int vv_kv_import_launch(const void* k, const void* v, int src_bf16, void* kc, void* vc, int L, int Hkv, int D,
-                        int64_t head_stride, hipStream_t s) {
-    if (src_bf16) hipLaunchKernelGGL((vv_kv_import_kernel<__bf16>), dim3(L, Hkv), dim3(D), 0, s, (const __bf16*)k, (const __bf16*)v, (__bf16*)kc, (__bf16*)vc, L, D, head_stride);
-    else hipLaunchKernelGGL((vv_kv_import_kernel<float>), dim3(L, Hkv), dim3(D), 0, s, (const float*)k, (const float*)v, (__bf16*)kc, (__bf16*)vc, L, D, head_stride);
+                        int64_t head_stride, int pos0, hipStream_t s) {
+    if (src_bf16) hipLaunchKernelGGL((vv_kv_import_kernel<__bf16>), dim3(L, Hkv), dim3(D), 0, s, (const __bf16*)k, (const __bf16*)v, (__bf16*)kc, (__bf16*)vc, L, D, head_stride, pos0);
+    else hipLaunchKernelGGL((vv_kv_import_kernel<float>), dim3(L, Hkv), dim3(D), 0, s, (const float*)k, (const float*)v, (__bf16*)kc, (__bf16*)vc, L, D, head_stride, pos0);
+    return okk();
+}
+int vv_pcm16_launch(const float* x, short* out, int n, int samples, hipStream_t s) {
+    hipLaunchKernelGGL(vv_pcm16_kernel, dim3(n), dim3(256), 0, s, x, out, samples);
     return okk();
 }
 int vv_ada_in_launch(const float* cproj, const float* temb, float* out, int rows, int n_steps, int H, hipStream_t s) {

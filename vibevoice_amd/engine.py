@@ -253,6 +253,16 @@ class Engine:
         self._chk(self.lib.vv_kv_import(self._ctx, self._s, cache, layer, k.shape[1], self._p(k), self._p(v),
                                         1 if k.dtype == torch.bfloat16 else 0), "vv_kv_import")
 
+    def kv_import_at(self, cache: int, layer: int, pos0: int, k: torch.Tensor, v: torch.Tensor):
+        """k, v: [kv_heads, n_pos, head_dim] -> cache positions [pos0, pos0 + n_pos)."""
+        assert k.shape == v.shape and k.dim() == 3
+        k = k.contiguous()
+        v = v.contiguous()
+        if k.dtype not in (torch.float32, torch.bfloat16):
+            k, v = k.float(), v.float()
+        self._chk(self.lib.vv_kv_import_at(self._ctx, self._s, cache, layer, int(pos0), k.shape[1], self._p(k), self._p(v),
+                                           1 if k.dtype == torch.bfloat16 else 0), "vv_kv_import_at")
+
     def add_type_embedding(self, n: int, x: torch.Tensor, type_id: int, out: torch.Tensor):
         self._chk(self.lib.vv_add_type_embedding(self._ctx, self._s, n, self._p(x), int(type_id), self._p(out)),
                   "vv_add_type_embedding")
@@ -293,6 +303,14 @@ class Engine:
         self._chk(self.lib.vv_acoustic_encode(self._ctx, self._s, frames, self._p(wav), self._p(mean_out)),
                   "vv_acoustic_encode")
 
+    def audio_to_pcm16(self, audio: torch.Tensor, pcm_out: torch.Tensor, stream=None):
+        """audio [n, samples] fp32 (contiguous) -> pcm_out [n, samples] int16, per-chunk peak normalisation as the reference's
+        convert_to_16_bit_wav (demo/gradio_demo.py:1058-1073)."""
+        n, samples = audio.shape
+        assert audio.is_contiguous() and pcm_out.is_contiguous() and pcm_out.dtype == torch.int16 and audio.dtype == torch.float32
+        self._chk(self.lib.vv_audio_to_pcm16(self._ctx, self._sp(stream), n, samples, self._p(audio), self._p(pcm_out)),
+                  "vv_audio_to_pcm16")
+
     def codec_reset(self, slot: int):
         self._chk(self.lib.vv_codec_reset(self._ctx, self._s, slot), "vv_codec_reset")
 
@@ -306,6 +324,12 @@ class Engine:
         n, ms, by = (C.c_int64 * 2)(), (C.c_double * 2)(), (C.c_double * 2)()
         self._chk(self.lib.vv_profile_end(self._ctx, n, ms, by), "vv_profile_end")
         return (n[0], ms[0], by[0]), (n[1], ms[1], by[1])
+
+    def profile_replay(self, reps=3):
+        """(launches, total_ms, bytes) of the recorded decode-GEMV launches replayed as one dependent hipGraph chain."""
+        n, ms, by = C.c_int64(), C.c_double(), C.c_double()
+        self._chk(self.lib.vv_profile_replay(self._ctx, self._s, int(reps), C.byref(n), C.byref(ms), C.byref(by)), "vv_profile_replay")
+        return n.value, ms.value, by.value
 
     def stat(self, what=0):
         return int(self.lib.vv_stat(self._ctx, what))

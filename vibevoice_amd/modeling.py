@@ -4,6 +4,7 @@
 surface for this path (vibevoice/modular/modeling_vibevoice_inference.py):
 
     from_pretrained(path, torch_dtype=..., device_map=..., attn_implementation=...)   demo/inference_from_file.py:297-317
+    .model.{language_model, prediction_head, acoustic_connector, semantic_connector, ...}   :87-117, lora_loading.py:88-169
     eval(), set_ddpm_inference_steps(num_steps)                                         :146-147
     generate(**processor_outputs, max_new_tokens, cfg_scale, tokenizer, generation_config,
              verbose, is_prefill, audio_streamer, stop_check_fn, refresh_negative, ...)  :326-348
@@ -24,6 +25,12 @@ Differences from the reference that do not change results:
   * finished rows are not forwarded (the reference forwards them and discards);
   * lm_head is evaluated only on the <=5 ids the constraint processor allows
     (:53-66, :405-419): identical argmax / identical softmax over the allowed set.
+
+Beyond the reference: `generate_continuous()` keeps up to n_slots
+utterances in flight on one GPU and admits the next queued utterance into a slot the
+moment its occupant finishes, without draining the batch; every utterance comes out
+exactly as generate() would have produced it alone (the reference's batched loop has
+no cross-sample arithmetic, :393-394,549,573,594).
 """
 import json
 import os
@@ -35,6 +42,8 @@ import numpy as np
 import torch
 
 from .engine import Engine, EngineConfig, map_param_name
+
+MAX_BATCH = 8          # rows of one diffusion-head pass (2 per utterance, 16-row MFMA tile); vv_diffusion_sample's limit
 
 
 @dataclass
@@ -82,11 +91,145 @@ def engine_config_from_reference(cfg: dict, **runtime) -> EngineConfig:
     return EngineConfig(**kw)
 
 
+# ---------------------------------------------------------------------- the attribute surface callers read
+class _Ns(dict):
+    """dict with attribute access (config objects: `model.config.decoder_config.hidden_size`)."""
+
+    def __getattr__(self, k):
+        try:
+            v = self[k]
+        except KeyError:
+            raise AttributeError(k)
+        return _Ns(v) if isinstance(v, dict) and not isinstance(v, _Ns) else v
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def to_dict(self):
+        return dict(self)
+
+
+class WeightHandle:
+    """What `model.model.<component>` is on the HIP path: the reference keeps an nn.Module there; here the weights live
+    repacked inside the engine, and this handle is the write side of that snapshot.  It supports what the reference's
+    callers do with the attribute (lora_loading.py:71-84,112-131,163-169; demo/inference_from_file.py:367-368):
+    `load_state_dict(sd, strict=False)` (uploads -> the engine re-packs), `.to(device)`, `.eval()`, `.config`,
+    `.device`, `parameters()` (one placeholder tensor, enough for `next(model.parameters()).device`)."""
+
+    def __init__(self, owner, ref_prefix: str, config: Optional[dict] = None):
+        self._owner = owner
+        self._ref_prefix = ref_prefix
+        self.config = _Ns(config or {})
+
+    @property
+    def device(self):
+        return self._owner.device
+
+    @property
+    def dtype(self):
+        return self._owner.dtype
+
+    def to(self, *a, **k):
+        return self
+
+    def eval(self):
+        return self
+
+    def parameters(self):
+        yield self._owner._param_placeholder
+
+    def expected_keys(self):
+        """state_dict keys (relative to this component) the engine holds"""
+        out = []
+        for name in self._owner.engine.expected_weights():
+            for a, b in _PREFIX_BACK:
+                if name.startswith(b) and a.startswith(self._ref_prefix):
+                    out.append((a + name[len(b):])[len(self._ref_prefix):])
+        return out
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        """Upload a (partial) state dict of this component; returns (missing, unexpected) like nn.Module."""
+        eng = self._owner.engine
+        exp = eng.expected_weights()
+        seen, unexpected = set(), []
+        for k, v in state_dict.items():
+            name = map_param_name(self._ref_prefix + k)
+            if name is None or name not in exp:
+                unexpected.append(k)
+                continue
+            eng.upload(name, v)
+            seen.add(k)
+        missing = [k for k in self.expected_keys() if k not in seen]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"load_state_dict({self._ref_prefix}): missing {missing[:4]}, unexpected {unexpected[:4]}")
+        import collections
+        return collections.namedtuple("IncompatibleKeys", "missing_keys unexpected_keys")(missing, unexpected)
+
+
+_PREFIX_BACK = tuple((a, b) for a, b in (
+    ("model.language_model.", "lm."), ("model.prediction_head.", "head."),
+    ("model.acoustic_tokenizer.decoder.", "dec."), ("model.acoustic_tokenizer.encoder.", "aenc."),
+    ("model.semantic_tokenizer.encoder.", "senc."), ("model.acoustic_connector.", "ac_conn."),
+    ("model.semantic_connector.", "sem_conn.")))
+
+
+class _ModelNamespace:
+    """`model.model` (VibeVoiceModel, modeling_vibevoice.py:108-146) as far as callers read it."""
+
+    def __init__(self, owner, config: dict, attn_implementation: str):
+        d = dict(config.get("decoder_config", {}))
+        d["_attn_implementation"] = attn_implementation
+        self.language_model = WeightHandle(owner, "model.language_model.", d)
+        self.prediction_head = WeightHandle(owner, "model.prediction_head.", config.get("diffusion_head_config"))
+        self.acoustic_tokenizer = WeightHandle(owner, "model.acoustic_tokenizer.", config.get("acoustic_tokenizer_config"))
+        self.acoustic_connector = WeightHandle(owner, "model.acoustic_connector.")
+        if config.get("semantic_tokenizer_config") is not None:
+            self.semantic_tokenizer = WeightHandle(owner, "model.semantic_tokenizer.", config.get("semantic_tokenizer_config"))
+            self.semantic_connector = WeightHandle(owner, "model.semantic_connector.")
+        self._owner = owner
+
+    @property
+    def speech_scaling_factor(self):
+        return torch.tensor(self._owner._scaling)
+
+    @property
+    def speech_bias_factor(self):
+        return torch.tensor(self._owner._bias)
+
+    @property
+    def noise_scheduler(self):
+        return self._owner.noise_scheduler
+
+
+class _Utt:
+    """One utterance in flight: its engine slot (KV caches 2*slot / 2*slot+1, codec states), lengths and outputs."""
+    __slots__ = ("idx", "slot", "ids", "seq_len0", "init_len", "max_length", "max_steps", "max_step_sample", "step", "pos_len",
+                 "neg_len", "have_embeds", "finished", "reach_max", "tokens", "chunks", "last", "forced", "noise_fn", "req",
+                 "t_admit", "t_done")
+
+    def __init__(self, idx, slot, ids, seq_len0, max_length, max_length_times, start_id):
+        self.idx, self.slot, self.ids = idx, slot, ids
+        self.seq_len0 = seq_len0                      # width of the (padded) prompt batch this utterance arrived in
+        self.init_len = len(ids)
+        self.max_length = max_length
+        self.max_steps = min(max_length - seq_len0, int(max_length_times * seq_len0))               # :421 (loop length)
+        self.max_step_sample = min(max_length - self.init_len, int(max_length_times * self.init_len))    # :422
+        self.step = 0
+        self.pos_len = self.neg_len = 0
+        self.have_embeds = False
+        self.finished = self.reach_max = False
+        self.tokens, self.chunks = [], []
+        self.last = ids[-1] if ids else start_id
+        self.forced = self.noise_fn = self.req = None
+        self.t_admit = self.t_done = None
+
+
 class VibeVoiceForConditionalGenerationInference:
     """Drop-in for the reference class on the generate() path, backed by libvvhip.so."""
 
-    def __init__(self, config: dict, engine: Engine, model_dtype=torch.bfloat16):
+    def __init__(self, config: dict, engine: Engine, model_dtype=torch.bfloat16, attn_implementation: Optional[str] = None):
         self.config_dict = config
+        self.config = _Ns(config)
         self.engine = engine
         self.dtype = model_dtype
         self.device = engine.device
@@ -95,38 +238,46 @@ class VibeVoiceForConditionalGenerationInference:
         self.acoustic_vae_dim = config.get("acoustic_vae_dim", 64)
         self.fix_std = config["acoustic_tokenizer_config"].get("fix_std", 0.5)
         self.std_dist_type = config["acoustic_tokenizer_config"].get("std_dist_type", "gaussian")
-        self.speech_scaling_factor = float("nan")
-        self.speech_bias_factor = float("nan")
+        self._scaling = float("nan")
+        self._bias = float("nan")
         self._valid_key = None
+        # what the attention really is on this path; the value the caller asked for is kept beside it
+        self.requested_attn_implementation = attn_implementation
+        self._param_placeholder = torch.empty(0, dtype=model_dtype, device=self.device)
+        self.model = _ModelNamespace(self, config, "vvhip_mfma_flash_decoding_gfx950")
         H = engine.cfg.lm_hidden
         e = engine
-        R = e.cfg.max_rows
-        self._x_in = e.new(R, H)
-        self._hidden = e.new(R, H)
-        self._logits = e.new(R, 16)
-        self._cond = e.new(16, H)
-        self._noise = e.new(8, engine.cfg.latent_dim)
-        self._latent = e.new(8, engine.cfg.latent_dim)
-        self._audio = e.new(8, engine.cfg.hop)
-        self._sem = e.new(8, max(1, engine.cfg.sem_dim))
-        self._emb_out = e.new(8, H)
+        NB = MAX_BATCH
+        self._x_in = e.new(2 * NB, H)
+        self._hidden = e.new(2 * NB, H)
+        self._hid_fresh = e.new(max(1, engine.cfg.n_slots), H)       # last prompt row of a freshly prefilled utterance, per slot
+        self._logits = e.new(2 * NB * 16)                            # dense [n][n_valid] blocks, as vv_lm_logits writes them
+        self._cond = e.new(2 * NB, H)
+        self._noise = e.new(NB, engine.cfg.latent_dim)
+        self._latent = e.new(NB, engine.cfg.latent_dim)
+        self._audio = e.new(NB, engine.cfg.hop)
+        self._sem = e.new(NB, max(1, engine.cfg.sem_dim))
+        self._emb_out = e.new(NB, H)
         self._start_emb = e.new(1, H)
-        self._neg_hidden = e.new(8, H)
+        self._neg_hidden = e.new(NB, H)
+        self._nxt_x = e.new(NB, H)
+        self._tmp_emb = e.new(NB, H)
         # pinned host staging: the logits come back without a blocking copy, noise goes out without one
-        self._logits_pin = torch.empty(R, 16, dtype=torch.float32).pin_memory()
-        self._noise_pin = [torch.empty(8, engine.cfg.latent_dim, dtype=torch.float32).pin_memory() for _ in range(4)]
+        self._logits_pin = torch.empty(2 * NB * 16, dtype=torch.float32).pin_memory()
+        self._noise_pin = [torch.empty(NB, engine.cfg.latent_dim, dtype=torch.float32).pin_memory() for _ in range(4)]
         self._noise_i = 0
         self._lg_event = torch.cuda.Event()
         self._fork_ev = torch.cuda.Event()
         self._join_ev = torch.cuda.Event()
-        self._side_streams = [torch.cuda.Stream(device=self.device) for _ in range(min(8, engine.cfg.n_slots))] if engine.cfg.n_slots > 1 else []
+        self._side_streams = [torch.cuda.Stream(device=self.device) for _ in range(min(NB, engine.cfg.n_slots))] if engine.cfg.n_slots > 1 else []
+        self._audio_blocks = []                                       # output frames, 64 steps per block (no per-step allocation)
         self.concurrent_codecs = os.environ.get("VVHIP_SERIAL_CODECS") is None
         self.speculate_sampling = os.environ.get("VVHIP_NO_SPEC") is None
         self.last_stats = {}
 
     # ------------------------------------------------------------------ construction
     @classmethod
-    def from_state_dict(cls, config: dict, state_dict, model_dtype=torch.bfloat16, device=None, **runtime):
+    def from_state_dict(cls, config: dict, state_dict, model_dtype=torch.bfloat16, device=None, attn_implementation=None, **runtime):
         """state_dict: mapping (or iterable of (key, tensor)) keyed like the reference checkpoint."""
         runtime.setdefault("max_rows", 512)          # prompt rows per LM weight pass (MFMA tile GEMM above ~48 workgroups)
         ecfg = engine_config_from_reference(config, **runtime)
@@ -147,7 +298,7 @@ class VibeVoiceForConditionalGenerationInference:
         miss = eng.missing_weights()
         if miss:
             raise RuntimeError(f"checkpoint is missing {len(miss)} parameters, e.g. {miss[:4]}")
-        m = cls(config, eng, model_dtype)
+        m = cls(config, eng, model_dtype, attn_implementation=attn_implementation)
         if scaling is not None and bias is not None:
             m.set_speech_factors(scaling, bias)
         return m
@@ -171,7 +322,7 @@ class VibeVoiceForConditionalGenerationInference:
         device = None
         if isinstance(device_map, (str, torch.device)) and str(device_map) not in ("auto", "cpu"):
             device = torch.device(device_map)
-        m = cls.from_state_dict(config, it(), torch_dtype or torch.bfloat16, device, **runtime)
+        m = cls.from_state_dict(config, it(), torch_dtype or torch.bfloat16, device, attn_implementation=attn_implementation, **runtime)
         m.source_path = path
 
         def base_tensor(key):          # lazy access to the checkpoint's own tensors (LoRA merge: vibevoice_amd/lora.py)
@@ -183,9 +334,55 @@ class VibeVoiceForConditionalGenerationInference:
         m.base_tensor = base_tensor
         return m
 
+    @classmethod
+    def from_reference(cls, live_model, device=None, **runtime):
+        """Snapshot a live reference `VibeVoiceForConditionalGenerationInference` (an nn.Module, e.g. one that already carries
+        merged adapters) into a HIP-path model: its config.to_dict() + state_dict() + scalar speech factors."""
+        cfg = live_model.config.to_dict() if hasattr(live_model.config, "to_dict") else dict(live_model.config)
+        sd = live_model.state_dict()
+        dt = next(iter(live_model.parameters())).dtype
+        m = cls.from_state_dict(cfg, sd, dt, device, **runtime)
+        m.base_tensor = lambda key: sd[key].detach().cpu()
+        steps = getattr(live_model, "ddpm_inference_steps", None)
+        if steps:
+            m.set_ddpm_inference_steps(steps)
+        return m
+
+    # ---- reference properties (:87-117) ----
+    @property
+    def speech_scaling_factor(self):
+        return self._scaling
+
+    @property
+    def speech_bias_factor(self):
+        return self._bias
+
+    @property
+    def noise_scheduler(self):
+        from . import schedule as _schedule
+        tv, _ = _schedule.make_table(self.ddpm_inference_steps, False)
+        return _Ns(num_inference_steps=self.ddpm_inference_steps, timesteps=torch.from_numpy(np.asarray(tv)).long(),
+                   config=_Ns(self.config_dict["diffusion_head_config"]))
+
+    prediction_head = property(lambda self: self.model.prediction_head)
+    acoustic_tokenizer = property(lambda self: self.model.acoustic_tokenizer)
+    semantic_tokenizer = property(lambda self: getattr(self.model, "semantic_tokenizer", None))
+    acoustic_connector = property(lambda self: self.model.acoustic_connector)
+    semantic_connector = property(lambda self: getattr(self.model, "semantic_connector", None))
+
+    def parameters(self):
+        yield self._param_placeholder
+
+    def to(self, *a, **k):
+        return self
+
+    def tie_weights(self):
+        """the engine reads lm_head rows from embed_tokens when no lm_head.weight was uploaded (vv_set_valid_tokens)"""
+        self._valid_key = None
+
     def set_speech_factors(self, scaling, bias):
-        self.speech_scaling_factor = float(scaling)
-        self.speech_bias_factor = float(bias)
+        self._scaling = float(scaling)
+        self._bias = float(bias)
         self.engine.set_speech_factors(scaling, bias)
 
     def eval(self):
@@ -227,7 +424,6 @@ class VibeVoiceForConditionalGenerationInference:
         if self.std_dist_type == "gaussian":
             if prefill_noise is None:
                 # VibeVoiceTokenizerEncoderOutput.sample('gaussian'), modular_vibevoice_tokenizer.py:980-989:
-                # two draws from the device generator
                 # two draws from the device generator.  The reference's `mean` is latents.permute(0, 2, 1) (:1085) and its noise is
                 # randn_like(mean): the same call on a tensor with the same strides is what stays on the reference's RNG stream
                 # (a contiguous draw takes a different generator path).  Pinned by tests/golden/generate_sampled_b1.npz.
@@ -242,11 +438,286 @@ class VibeVoiceForConditionalGenerationInference:
             lat = mean + self.fix_std * r2
         else:
             lat = mean
-        feats = ((lat + self.speech_bias_factor) * self.speech_scaling_factor).contiguous()
+        feats = ((lat + self._bias) * self._scaling).contiguous()
         sel = feats[speech_masks.to(self.device)].contiguous()            # [n_valid, 64]
         out = e.new(sel.shape[0], e.cfg.lm_hidden)
         e.connect(sel.shape[0], sel, None, out)
         return feats, out
+
+    @staticmethod
+    def _generation_options(generation_config):
+        """generation_config: None, a dict (what every reference caller passes: the reference does
+        GenerationConfig(**generation_config), :261-266) or an object with to_dict() (an HF GenerationConfig)."""
+        if generation_config is None:
+            gc = {}
+        elif isinstance(generation_config, dict):
+            gc = dict(generation_config)
+        elif hasattr(generation_config, "to_dict"):
+            gc = {k: v for k, v in generation_config.to_dict().items() if v is not None}
+            # an HF GenerationConfig object carries its class defaults (top_k=50, ...): only what differs from them is a request
+            for k, dflt in (("top_k", 50), ("top_p", 1.0), ("repetition_penalty", 1.0), ("temperature", 1.0)):
+                if gc.get(k) == dflt:
+                    gc.pop(k)
+        else:
+            raise TypeError(f"generation_config must be a dict, None or have to_dict(); got {type(generation_config).__name__}")
+        do_sample = bool(gc.get("do_sample", False))
+        temperature = float(gc.get("temperature", 1.0) or 1.0)
+        # warpers that act on the FULL-vocabulary distribution before the constraint mask cannot be reproduced from the <=5
+        # logits this path evaluates: refuse them instead of silently sampling from something else
+        for k in ("top_k", "top_p", "min_p", "typical_p", "repetition_penalty", "no_repeat_ngram_size", "bad_words_ids", "num_beams"):
+            v = gc.get(k)
+            if do_sample and v not in (None, 0, 0.0, 1, 1.0, [], ()):
+                raise NotImplementedError(f"generation_config[{k!r}]={v!r}: full-vocabulary logits processors are not available on the "
+                                          "HIP path (the lm_head is evaluated on the valid speech tokens only)")
+        return do_sample, temperature
+
+    # ------------------------------------------------------------------ prompt prefill of one utterance
+    def _prefill(self, u: _Utt, ids: List[int], speech_rows: Optional[torch.Tensor], speech_pos: Optional[torch.Tensor],
+                 kv_start: int = 0, kv_fill_fn=None):
+        """LM prefill of one utterance's prompt into KV cache 2*slot; the last row's hidden state -> _hid_fresh[slot]."""
+        e = self.engine
+        H = e.cfg.lm_hidden
+        n = len(ids)
+        emb = e.new(n, H)
+        self._embed_ids(ids, emb)
+        if speech_rows is not None and speech_pos is not None and speech_rows.shape[0]:
+            emb[speech_pos] = speech_rows
+        CH = e.cfg.max_rows          # prompt rows per weight pass
+        hid = e.new(min(CH, n), H)
+        for i0 in range(0, n, CH):
+            k = min(CH, n - i0)
+            e.lm_forward([(2 * u.slot, i0 + j) for j in range(k)], emb[i0:i0 + k], hid)
+        self._hid_fresh[u.slot].copy_(hid[(n - 1) % CH])
+        u.pos_len = n
+        if kv_start > n:             # bench hook: decode measured at a long context (kv_fill_fn supplies the cache contents)
+            if kv_fill_fn is not None:
+                kv_fill_fn(e, 2 * u.slot, n, kv_start)
+            u.pos_len = kv_start
+
+    def _block_rows(self, i: int):
+        """row i of the frame store: [utterances in flight, hop] fp32, 64 rows per block"""
+        b, r = divmod(i, 64)
+        while len(self._audio_blocks) <= b:
+            self._audio_blocks.append(self.engine.new(64, min(MAX_BATCH, max(1, self.engine.cfg.n_slots)), self.engine.cfg.hop))
+        return self._audio_blocks[b][r]
+
+    # ------------------------------------------------------------------ one iteration of the hot loop over the active utterances
+    def _iterate(self, S, act: List[_Utt]):
+        """modeling_vibevoice_inference.py:466-672 for the utterances in `act`; returns the utterances still live."""
+        e = self.engine
+        nv, valid_t = S["nv"], S["valid_t"]
+        start_id, end_id, diff_id, eos_id = S["start_id"], S["end_id"], S["diff_id"], S["eos_id"]
+        cfg_scale, trace, audio_streamer, verbose = S["cfg_scale"], S["trace"], S["audio_streamer"], S["verbose"]
+        run = [u for u in act if u.have_embeds]
+        fresh = [u for u in act if not u.have_embeds]
+        order = run + fresh
+        nR, nA = len(run), len(order)
+        # ---------------- positive (+ speculative negative) LM pass ----------------
+        if run:
+            rows = [(2 * u.slot, u.pos_len) for u in run] + [(2 * u.slot + 1, u.neg_len) for u in run]
+            self._x_in[nR:2 * nR].copy_(self._x_in[:nR])
+            e.lm_forward(rows, self._x_in, self._hidden)
+            for u in run:
+                u.pos_len += 1
+            e.lm_logits(nR, self._hidden, self._logits)
+        if fresh:
+            if not run and [u.slot for u in fresh] == list(range(len(fresh))):
+                e.lm_logits(len(fresh), self._hid_fresh, self._logits)
+            else:
+                for i, u in enumerate(fresh):
+                    e.lm_logits(1, self._hid_fresh[u.slot:u.slot + 1], self._logits[(nR + i) * nv:])
+        self._logits_pin.copy_(self._logits, non_blocking=True)      # whole (contiguous) buffer: a true async D2H
+        self._lg_event.record(e.stream)
+
+        def pos_hidden(i):                      # hidden state of order[i]'s positive row, [1, H]
+            return self._hidden[i:i + 1] if i < nR else self._hid_fresh[order[i].slot:order[i].slot + 1]
+        # ---- speculative sampling: a row that has just emitted <speech_diffusion>/<speech_start> almost always
+        # emits <speech_diffusion> next.  The sampler (stateless: cond + noise -> latent) is enqueued behind the LM
+        # pass BEFORE the host waits for the logits, so the token decision below overlaps GPU work instead of
+        # leaving the GPU idle; if the guess is wrong the latent is discarded and the RNG state restored.
+        spec_sample, rng_state = False, None
+        do_sample = S["do_sample"]
+        if (run and not fresh and self.speculate_sampling
+                and not (do_sample and S["noise_fn"] is None and S["forced"] is None)   # keep the reference's RNG draw order
+                and all(u.last in (diff_id, start_id) for u in run)):
+            nz = self._draw_noise(S, run)
+            if nz is None:
+                rng_state = torch.get_rng_state()
+                nz = torch.randn(2 * nR, e.cfg.latent_dim)
+            self._stage_noise(nz, nR)
+            # all active rows diffusing, in order: cond rows == [hidden[:nR]; hidden[nR:2nR]]
+            e.diffusion_sample(nR, self._hidden, self._noise, cfg_scale, self._latent)
+            spec_sample = True
+        self._lg_event.synchronize()
+        logits = self._logits_pin[:nA * nv].view(nA, nv).clone()
+        if trace is not None:
+            trace.pos_hidden.append(torch.cat([pos_hidden(i) for i in range(nA)]).cpu())
+        # ---------------- token selection (:488-501) ----------------
+        if S["forced"] is not None or any(u.forced is not None for u in order):
+            for u in order:
+                f = u.forced if u.forced is not None else S["forced"][u.idx]
+                u.last = int(f[u.step]) if u.step < len(f) else eos_id
+        elif do_sample:
+            # the reference samples torch.multinomial(softmax(scores)) over the FULL vocabulary rows of the WHOLE batch (-inf
+            # outside the valid ids, :490-496; finished rows included, their draw is overwritten by eos, :499) on the model's
+            # device.  One-sample multinomial spends one exponential variate per (row, category), so the same call on the
+            # same-shaped tensor keeps a seeded run on the reference's RNG stream (pinned on CPU by generate_sampled_b1.npz)
+            rows_of = S["sample_rows"](order)            # batch mode: every batch row; continuous mode: one row per utterance
+            full = torch.full((len(rows_of), e.cfg.lm_vocab), float("-inf"), device=self.device, dtype=torch.float32)
+            vt = valid_t.to(self.device)
+            full[:, vt] = 0.0                              # finished rows: any proper distribution, the draw is discarded
+            lg = self._logits[:nA * nv].view(nA, nv).float() / S["temperature"]
+            for i, u in enumerate(order):
+                full[rows_of.index(u.idx), vt] = lg[i]
+            pick_ids = torch.multinomial(torch.softmax(full, dim=-1), num_samples=1).squeeze(1).cpu()
+            for u in order:
+                u.last = int(pick_ids[rows_of.index(u.idx)])
+        else:
+            pick = torch.argmax(logits, dim=-1)
+            for i, u in enumerate(order):
+                u.last = int(valid_t[pick[i]])
+        for u in order:
+            u.tokens.append(u.last)
+        if trace is not None:
+            nxt = torch.full((S["n_rows"],), eos_id, dtype=torch.long)
+            for u in order:
+                nxt[u.idx] = u.last
+            trace.tokens.append(nxt)
+        # ---------------- bookkeeping (:518-539) ----------------
+        new_eos = [u for u in order if u.last == eos_id]
+        if new_eos:
+            for u in new_eos:
+                u.finished = True
+            if verbose:
+                print(f"Samples {sorted(u.idx for u in new_eos)} reached EOS token at step {new_eos[0].step + 1}.", flush=True)
+            if audio_streamer is not None:
+                audio_streamer.end(torch.tensor(sorted(u.idx for u in new_eos)))
+        hit = [u for u in order if not u.finished and u.step >= u.max_step_sample]
+        if hit:
+            for u in hit:
+                u.finished = u.reach_max = True
+            if verbose:
+                print(f"Samples {sorted(u.idx for u in hit)} reached max generation length at step {hit[0].step + 1}.", flush=True)
+            if audio_streamer is not None:
+                audio_streamer.end(torch.tensor(sorted(u.idx for u in hit)))
+        for u in order:
+            if u.last == end_id:
+                e.codec_reset(u.slot)
+            if not u.finished and u.last == start_id:
+                # :549-565 -- the reference masks the whole negative cache and un-masks only the slot of the NEXT token, so the
+                # negative context restarts empty and the next negative pass re-feeds <speech_start> at position 0
+                # (pinned against the reference's generate(): tests/golden/generate_forced_*.npz)
+                u.neg_len = 0
+        # ---------------- next input embeddings (:569) ----------------
+        live = [u for u in order if not u.finished]
+        diff = [u for u in live if u.last == diff_id]
+        nxt_x = self._nxt_x                     # rows re-packed to the next step's active order
+        plain = [u for u in live if u.last != diff_id]
+        if plain:
+            self._embed_ids([u.last for u in plain], self._tmp_emb)
+            for i, u in enumerate(plain):
+                nxt_x[live.index(u)].copy_(self._tmp_emb[i])
+        if spec_sample and diff != order:
+            spec_sample = False                                  # wrong guess: drop the latent, undo the draw
+            if rng_state is not None:
+                torch.set_rng_state(rng_state)
+        cond_used = self._hidden if spec_sample else self._cond
+        n = len(diff)
+        if diff and spec_sample:
+            for u in diff:
+                u.neg_len += 1
+        elif diff:
+            # ---- negative condition ----
+            for j, u in enumerate(diff):
+                oi = order.index(u)
+                self._cond[j].copy_(pos_hidden(oi)[0])
+                if u.have_embeds:
+                    self._cond[n + j].copy_(self._hidden[nR + oi])
+                else:
+                    # first negative step of a fresh utterance: the lone <speech_start> prompt token (:379-386)
+                    e.lm_forward([(2 * u.slot + 1, u.neg_len)], self._start_emb, self._neg_hidden[j:j + 1])
+                    self._cond[n + j].copy_(self._neg_hidden[j])
+                u.neg_len += 1
+            # ---- diffusion sampling (:697-710) ----
+            nz = self._draw_noise(S, diff)
+            if nz is None:
+                nz = torch.randn(2 * n, e.cfg.latent_dim)      # CPU global RNG, as the reference (:701)
+            self._stage_noise(nz, n)
+            e.diffusion_sample(n, self._cond, self._noise, cfg_scale, self._latent)
+        if diff:
+            # ---- codec decode, semantic encode, connectors (:636-672) ----
+            if len(diff) > 1 and self.concurrent_codecs and self._side_streams:
+                # each utterance's tokenizer chain (decode -> semantic re-encode) is an independent, launch-latency
+                # bound graph: fork them onto side streams so they overlap, join before the connectors
+                self._fork_ev.record(e.stream)
+                for j, u in enumerate(diff):
+                    ss = self._side_streams[j % len(self._side_streams)]
+                    ss.wait_event(self._fork_ev)
+                    e.codec_decode(u.slot, self._latent[j:j + 1], self._audio[j], stream=ss)
+                    if e.cfg.sem_dim > 0:
+                        e.semantic_encode(u.slot, self._audio[j], self._sem[j], stream=ss)
+                for ss in self._side_streams[:min(len(diff), len(self._side_streams))]:
+                    self._join_ev.record(ss)
+                    e.stream.wait_event(self._join_ev)
+            else:
+                for j, u in enumerate(diff):
+                    e.codec_decode(u.slot, self._latent[j:j + 1], self._audio[j])
+                    if e.cfg.sem_dim > 0:
+                        e.semantic_encode(u.slot, self._audio[j], self._sem[j])
+            e.connect(n, self._latent, self._sem if e.cfg.sem_dim > 0 else None, self._emb_out)
+            chunk = self._block_rows(S["frame_rows"])
+            S["frame_rows"] += 1
+            chunk[:n].copy_(self._audio[:n])
+            for j, u in enumerate(diff):
+                u.chunks.append(chunk[j])
+                nxt_x[live.index(u)].copy_(self._emb_out[j])
+            if audio_streamer is not None:
+                audio_streamer.put(chunk[:n, None, :].to(self.dtype), torch.tensor([u.idx for u in diff]))
+            S["n_frames"] += n
+            if trace is not None:
+                trace.neg_hidden.append(cond_used[n:2 * n].cpu())
+                trace.latents.append(self._latent[:n].cpu())
+                trace.semantic.append(self._sem[:n].cpu())
+        if live:
+            self._x_in[:len(live)].copy_(nxt_x[:len(live)])
+            if trace is not None:
+                trace.next_embeds.append(nxt_x[:len(live)].cpu())
+        for u in order:
+            u.step += 1
+        for u in live:
+            u.have_embeds = True
+        return live
+
+    @staticmethod
+    def _draw_noise(S, utts):
+        """explicit noise for `utts` (test / bench hooks), or None: draw torch.randn as the reference does"""
+        if any(u.noise_fn is not None for u in utts):
+            rows = [u.noise_fn(u.step, 2)[:1].to(torch.float32) for u in utts]
+            return torch.cat(rows + rows)
+        if S["noise_fn"] is not None:
+            return S["noise_fn"](S["step"], 2 * len(utts))
+        return None
+
+    def _session(self, tokenizer, generation_config, cfg_scale, kwargs, audio_streamer, n_rows):
+        e = self.engine
+        if tokenizer is None:
+            raise ValueError("generate() needs tokenizer= (speech_start_id / speech_end_id / speech_diffusion_id / eos_token_id)")
+        if not kwargs.get("refresh_negative", True):
+            raise NotImplementedError("refresh_negative=False is not supported by the HIP path")
+        do_sample, temperature = self._generation_options(generation_config)
+        start_id, end_id, diff_id = tokenizer.speech_start_id, tokenizer.speech_end_id, tokenizer.speech_diffusion_id
+        eos_id = tokenizer.eos_token_id
+        bos_id = getattr(tokenizer, "bos_token_id", None)
+        valid = [start_id, end_id, diff_id, eos_id] + ([bos_id] if bos_id is not None else [])
+        if self._valid_key != tuple(valid):
+            e.set_valid_tokens(valid)
+            self._valid_key = tuple(valid)
+        e.set_num_steps(self.ddpm_inference_steps, t_cast_bf16=(self.dtype == torch.bfloat16 and kwargs.get("_t_cast", True)))
+        return dict(nv=len(valid), valid_t=torch.tensor(valid, dtype=torch.long), start_id=start_id, end_id=end_id, diff_id=diff_id,
+                    eos_id=eos_id, cfg_scale=cfg_scale, do_sample=do_sample, temperature=temperature,
+                    trace=kwargs.pop("_trace", None), audio_streamer=audio_streamer, verbose=kwargs.get("verbose", False),
+                    forced=kwargs.pop("_forced_tokens", None), noise_fn=kwargs.pop("_noise_fn", None), n_rows=n_rows,
+                    frame_rows=0, n_frames=0, step=0, sample_rows=None)
 
     # ------------------------------------------------------------------ generate
     @torch.no_grad()
@@ -255,20 +726,17 @@ class VibeVoiceForConditionalGenerationInference:
                  negative_prompt_ids=None, negative_prompt_attention_mask=None, speech_tensors=None,
                  speech_masks=None, speech_input_mask=None, is_prefill=True, return_speech=True,
                  cfg_scale=1.0, stop_check_fn: Optional[Callable[[], bool]] = None, tqdm_class=None, **kwargs):
+        """logits_processor / stopping_criteria are accepted and unused, as in the reference (its generate() overwrites the
+        arguments with the lists it builds itself, :375-377)."""
         e = self.engine
         tokenizer = kwargs.pop("tokenizer", None)
         kwargs.pop("parsed_scripts", None)
         kwargs.pop("all_speakers_list", None)
         max_length_times = kwargs.pop("max_length_times", 2)
-        verbose = kwargs.get("verbose", False)
-        if not kwargs.get("refresh_negative", True):
-            raise NotImplementedError("refresh_negative=False is not supported by the HIP path")
-        forced_tokens = kwargs.pop("_forced_tokens", None)        # test/bench hook
-        noise_fn = kwargs.pop("_noise_fn", None)                  # test hook: explicit diffusion noise
         prefill_noise = kwargs.pop("_prefill_noise", None)
-        trace = kwargs.pop("_trace", None)
         step_cb = kwargs.pop("_step_callback", None)             # bench hook: called at the top of every step
         kv_start = kwargs.pop("_kv_start", 0)                     # bench hook: long-context decode measurement
+        kv_fill_fn = kwargs.pop("_kv_fill_fn", None)
         input_ids = kwargs["input_ids"] if inputs is None else inputs
         attention_mask = kwargs.get("attention_mask")
         input_ids = input_ids.cpu()
@@ -276,54 +744,38 @@ class VibeVoiceForConditionalGenerationInference:
             attention_mask = torch.ones_like(input_ids)
         attention_mask = attention_mask.cpu()
         B, L0 = input_ids.shape
+        if B > MAX_BATCH:
+            raise ValueError(f"batch {B} exceeds {MAX_BATCH} utterances per generate() call (one diffusion-head pass carries 2 rows "
+                             "per utterance); use generate_continuous() to queue more")
         if B > e.cfg.n_slots:
             raise ValueError(f"batch {B} exceeds the engine's n_slots={e.cfg.n_slots}")
         if 2 * B > e.cfg.max_rows:
             raise ValueError(f"batch {B} needs {2*B} LM rows > max_rows={e.cfg.max_rows}")
-        gc = dict(generation_config) if isinstance(generation_config, dict) else {}
-        do_sample = bool(gc.get("do_sample", False))
+        S = self._session(tokenizer, generation_config, cfg_scale, kwargs, audio_streamer, B)
+        S["sample_rows"] = lambda order: list(range(B))
         if kwargs.get("max_new_tokens", None) is None:
             max_new_tokens = self.max_position_embeddings - L0
         else:
             max_new_tokens = kwargs["max_new_tokens"]
-        max_length = L0 + max_new_tokens
-        if max_length > e.max_ctx:
-            max_length = e.max_ctx
-        start_id, end_id, diff_id = tokenizer.speech_start_id, tokenizer.speech_end_id, tokenizer.speech_diffusion_id
-        eos_id = tokenizer.eos_token_id
-        bos_id = getattr(tokenizer, "bos_token_id", None)
-        valid = [start_id, end_id, diff_id, eos_id] + ([bos_id] if bos_id is not None else [])
-        if self._valid_key != tuple(valid):
-            e.set_valid_tokens(valid)
-            self._valid_key = tuple(valid)
-        nv = len(valid)
-        valid_t = torch.tensor(valid, dtype=torch.long)
-        e.set_num_steps(self.ddpm_inference_steps, t_cast_bf16=(self.dtype == torch.bfloat16 and kwargs.get("_t_cast", True)))
-
-        init_len = attention_mask.sum(-1)
+        max_length = min(L0 + max_new_tokens, e.max_ctx)
+        utts = []
+        for b in range(B):
+            m = attention_mask[b].bool()
+            utts.append(_Utt(b, b, input_ids[b][m].tolist(), L0, max_length, max_length_times, S["start_id"]))
         max_steps = min(max_length - L0, int(max_length_times * L0))
-        max_step_per_sample = torch.min(max_length - init_len, (max_length_times * init_len).long())
-        finished = torch.zeros(B, dtype=torch.bool)
-        reach_max = torch.zeros(B, dtype=torch.bool)
-        pos_len = [0] * B
-        neg_len = [0] * B
-        audio_chunks = [[] for _ in range(B)]
-        seq = input_ids.clone()
-        H = e.cfg.lm_hidden
-        have_embeds = False
-        n_frames = 0
         time_prefill = os.environ.get("VVHIP_TIME_PREFILL") is not None     # debug: sync + time the two prefill phases
-
         if tqdm_class is not None and kwargs.get("show_progress_bar", True):
             progress = tqdm_class(range(max_steps), desc="Generating", leave=False)
         else:
             progress = range(max_steps)
-
+        n_steps = 0
         with torch.cuda.stream(e.stream):
             for b in range(B):
                 e.codec_reset(b)
-            e.embed([start_id], self._start_emb)
+            e.embed([S["start_id"]], self._start_emb)
+            active = list(utts)
             for step in progress:
+                S["step"] = step
                 if step_cb is not None:
                     step_cb(step)
                 if stop_check_fn is not None and stop_check_fn():
@@ -332,15 +784,14 @@ class VibeVoiceForConditionalGenerationInference:
                     break
                 if audio_streamer is not None and hasattr(audio_streamer, "finished_flags") and any(audio_streamer.finished_flags):
                     break
-                if bool(finished.all()):
+                if not active:
                     break
-                if seq.shape[-1] >= max_length:
-                    reach_max[~finished] = True
+                if L0 + step >= max_length:
+                    for u in active:
+                        u.reach_max = True
                     break
-                act = [b for b in range(B) if not finished[b]]
-                nA = len(act)
-                # ---------------- positive (+ speculative negative) LM pass ----------------
                 if step == 0:
+                    # ---------------- prompt prefill (:467-474, _process_speech_inputs) ----------------
                     sp_embeds = None
                     t_pf = [time.perf_counter()] if time_prefill else None
                     if is_prefill and speech_tensors is not None and speech_masks is not None:
@@ -348,193 +799,138 @@ class VibeVoiceForConditionalGenerationInference:
                     if time_prefill:
                         e.sync(); t_pf.append(time.perf_counter())
                     sp_off = 0
-                    for b in range(B):
-                        m = attention_mask[b].bool()
-                        ids = input_ids[b][m].tolist()
-                        n = len(ids)
-                        emb = e.new(n, H)
-                        self._embed_ids(ids, emb)
+                    for u in utts:
+                        rows = pos = None
                         if sp_embeds is not None and speech_input_mask is not None:
-                            sm = speech_input_mask[b][m].to(self.device)
+                            sm = speech_input_mask[u.idx][attention_mask[u.idx].bool()].to(self.device)
                             cnt = int(sm.sum())
                             if cnt:
-                                emb[sm] = sp_embeds[sp_off:sp_off + cnt]
+                                rows, pos = sp_embeds[sp_off:sp_off + cnt], sm
                                 sp_off += cnt
-                        CH = e.cfg.max_rows          # prompt rows per weight pass (the 16-row GEMV form walks row tiles)
-                        hid = e.new(CH, H)
-                        for i0 in range(0, n, CH):
-                            k = min(CH, n - i0)
-                            e.lm_forward([(2 * b, i0 + j) for j in range(k)], emb[i0:i0 + k], hid)
-                        pos_len[b] = max(n, kv_start)
-                        self._hidden[b].copy_(hid[(n - 1) % CH])
+                        self._prefill(u, u.ids, rows, pos, kv_start, kv_fill_fn)
                     if time_prefill:
                         e.sync(); t_pf.append(time.perf_counter())
                         self.last_prefill = {"voice_encode_s": round(t_pf[1] - t_pf[0], 5), "lm_prefill_s": round(t_pf[2] - t_pf[1], 5)}
-                    spec = False
-                else:
-                    rows = [(2 * b, pos_len[b]) for b in act]
-                    spec = have_embeds
-                    if spec:
-                        rows += [(2 * b + 1, neg_len[b]) for b in act]
-                        self._x_in[nA:2 * nA].copy_(self._x_in[:nA])
-                    e.lm_forward(rows, self._x_in, self._hidden)
-                    for b in act:
-                        pos_len[b] += 1
-                e.lm_logits(nA, self._hidden, self._logits)
-                self._logits_pin.copy_(self._logits, non_blocking=True)      # whole (contiguous) buffer: a true async D2H
-                self._lg_event.record(e.stream)
-                # ---- speculative sampling: a row that has just emitted <speech_diffusion>/<speech_start> almost always
-                # emits <speech_diffusion> next.  The sampler (stateless: cond + noise -> latent) is enqueued behind the LM
-                # pass BEFORE the host waits for the logits, so the token decision below overlaps GPU work instead of
-                # leaving the GPU idle; if the guess is wrong the latent is discarded and the RNG state restored.
-                spec_sample, rng_state = False, None
-                if (spec and self.speculate_sampling and step > 0
-                        and not (do_sample and noise_fn is None and forced_tokens is None)   # keep the reference's RNG draw order
-                        and all(int(seq[b, -1]) in (diff_id, start_id) for b in act)):
-                    if noise_fn is not None:
-                        nz = noise_fn(step, 2 * nA)
-                    else:
-                        rng_state = torch.get_rng_state()
-                        nz = torch.randn(2 * nA, e.cfg.latent_dim)
-                    self._stage_noise(nz, nA)
-                    # all active rows diffusing, in order: cond rows == [hidden[:nA]; hidden[nA:2nA]]
-                    e.diffusion_sample(nA, self._hidden, self._noise, cfg_scale, self._latent)
-                    spec_sample = True
-                self._lg_event.synchronize()
-                logits = self._logits_pin[:nA, :nv].clone()
-                if trace is not None:
-                    trace.pos_hidden.append(self._hidden[:nA].cpu())
-                # ---------------- token selection (:488-501) ----------------
-                nxt = torch.full((B,), eos_id, dtype=torch.long)
-                if forced_tokens is not None:
-                    for b in act:
-                        nxt[b] = forced_tokens[b][step] if step < len(forced_tokens[b]) else eos_id
-                elif do_sample:
-                    # the reference samples torch.multinomial(softmax(scores)) over the FULL vocabulary row (-inf outside the
-                    # valid ids, :490-496) on the model's device.  One-sample multinomial spends one exponential variate per
-                    # category, so the same call on the same-shaped tensor is what keeps a seeded run on the same RNG stream
-                    # (pinned on CPU by tests/golden/generate_sampled_b1.npz)
-                    full = torch.full((nA, e.cfg.lm_vocab), float("-inf"), device=self.device, dtype=torch.float32)
-                    full[:, valid_t.to(self.device)] = self._logits[:nA, :nv].float()
-                    pick_ids = torch.multinomial(torch.softmax(full, dim=-1), num_samples=1).squeeze(1).cpu()
-                    for i, b in enumerate(act):
-                        nxt[b] = pick_ids[i]
-                else:
-                    pick = torch.argmax(logits, dim=-1)
-                    for i, b in enumerate(act):
-                        nxt[b] = valid_t[pick[i]]
-                seq = torch.cat([seq, nxt[:, None]], dim=-1)
-                if trace is not None:
-                    trace.tokens.append(nxt.clone())
-                # ---------------- bookkeeping (:518-539) ----------------
-                new_eos = (nxt == eos_id) & ~finished
-                if new_eos.any():
-                    finished |= new_eos
-                    if verbose:
-                        print(f"Samples {new_eos.nonzero().flatten().tolist()} reached EOS token at step {step + 1}.", flush=True)
+                active = self._iterate(S, active)
+                n_steps += 1
+            if audio_streamer is not None:
+                audio_streamer.end()
+            outs = [torch.cat(u.chunks, dim=-1)[None].to(self.dtype) if u.chunks else None for u in utts]
+            seq = torch.full((B, L0 + n_steps), S["eos_id"], dtype=torch.long)
+            seq[:, :L0] = input_ids
+            for u in utts:
+                if u.tokens:
+                    seq[u.idx, L0:L0 + len(u.tokens)] = torch.tensor(u.tokens, dtype=torch.long)
+        e.sync()
+        self.last_stats = {"frames": S["n_frames"], "steps": n_steps}
+        return VibeVoiceGenerationOutput(
+            sequences=seq.to(self.device), speech_outputs=outs if return_speech else None,
+            reach_max_step_sample=torch.tensor([u.reach_max for u in utts], dtype=torch.bool).to(self.device))
+
+    # ------------------------------------------------------------------ continuous batching
+    @torch.no_grad()
+    def generate_continuous(self, requests: List[dict], tokenizer=None, generation_config=None, cfg_scale=1.0,
+                            audio_streamer=None, is_prefill=True, return_speech=True, max_new_tokens=None,
+                            max_length_times=2, stop_check_fn: Optional[Callable[[], bool]] = None,
+                            max_concurrent: Optional[int] = None, **kwargs) -> List[VibeVoiceGenerationOutput]:
+        """Decode a queue of single-utterance requests (each a dict of processor outputs with batch dimension 1) with up to
+        `max_concurrent` (default: the engine's n_slots, at most 8) in flight.  A slot freed by EOS / length cap is refilled by
+        the next queued request on the following iteration -- the running utterances never wait for a batch to drain; all rows
+        in flight share every LM / diffusion-head weight pass.  Each request ends exactly as generate() on it alone would
+        (greedy / forced decoding; with do_sample the draws interleave on the global generator).  Returns one
+        VibeVoiceGenerationOutput per request, in request order; `audio_streamer` (batch_size = len(requests)) sees
+        sample index = request index."""
+        e = self.engine
+        n_req = len(requests)
+        cap = min(max_concurrent or e.cfg.n_slots, e.cfg.n_slots, MAX_BATCH, e.cfg.max_rows // 2)
+        if cap < 1:
+            raise ValueError("no engine slot available")
+        kwargs = dict(kwargs)
+        step_cb = kwargs.pop("_step_callback", None)
+        S = self._session(tokenizer, generation_config, cfg_scale, kwargs, audio_streamer, n_req)
+        S["sample_rows"] = lambda order: [u.idx for u in order]
+        queue = list(range(n_req))
+        free = list(range(cap))
+        done = [None] * n_req
+        active: List[_Utt] = []
+        it = 0
+        stats = {"iterations": 0, "admissions": [], "max_in_flight": 0}
+        with torch.cuda.stream(e.stream):
+            e.embed([S["start_id"]], self._start_emb)
+            while queue or active:
+                S["step"] = it
+                if step_cb is not None:
+                    step_cb(it)
+                if stop_check_fn is not None and stop_check_fn():
                     if audio_streamer is not None:
-                        audio_streamer.end(new_eos.nonzero().flatten())
-                hit = (step >= max_step_per_sample) & ~finished
-                if hit.any():
-                    finished |= hit
-                    reach_max |= hit
-                    if verbose:
-                        print(f"Samples {hit.nonzero().flatten().tolist()} reached max generation length at step {step + 1}.", flush=True)
-                    if audio_streamer is not None:
-                        audio_streamer.end(hit.nonzero().flatten())
-                for b in (nxt == end_id).nonzero().flatten().tolist():
-                    e.codec_reset(b)
-                for b in (~finished & (nxt == start_id)).nonzero().flatten().tolist():
-                    # :549-565 -- the reference masks the whole negative cache and un-masks only the slot of the NEXT token, so the
-                    # negative context restarts empty and the next negative pass re-feeds <speech_start> at position 0
-                    # (pinned against the reference's generate(): tests/golden/generate_forced_*.npz)
-                    neg_len[b] = 0
-                # ---------------- next input embeddings (:569) ----------------
-                live = [b for b in range(B) if not finished[b]]
-                diff = [b for b in live if int(nxt[b]) == diff_id]
-                # rows of _x_in are re-packed to the next step's active order
-                nxt_x = e.new(max(1, len(live)), H)
-                plain = [b for b in live if b not in diff]
-                if plain:
-                    tmp = e.new(len(plain), H)
-                    self._embed_ids([int(nxt[b]) for b in plain], tmp)
-                    for i, b in enumerate(plain):
-                        nxt_x[live.index(b)].copy_(tmp[i])
-                if spec_sample and diff != act:
-                    spec_sample = False                                  # wrong guess: drop the latent, undo the draw
-                    if rng_state is not None:
-                        torch.set_rng_state(rng_state)
-                cond_used = self._hidden if spec_sample else self._cond
-                if diff and spec_sample:
-                    n = len(diff)
-                    for b in diff:
-                        neg_len[b] += 1
-                elif diff:
-                    n = len(diff)
-                    # ---- negative condition ----
-                    for j, b in enumerate(diff):
-                        ai = act.index(b)
-                        self._cond[j].copy_(self._hidden[ai])
-                        if spec:
-                            self._cond[n + j].copy_(self._hidden[nA + ai])
-                        else:
-                            # first negative step: the lone <speech_start> prompt token (:379-386) or, later,
-                            # the embedding the positive pass just consumed
-                            src = self._start_emb if not have_embeds else self._x_in[ai:ai + 1]
-                            e.lm_forward([(2 * b + 1, neg_len[b])], src, self._neg_hidden[j:j + 1])
-                            self._cond[n + j].copy_(self._neg_hidden[j])
-                        neg_len[b] += 1
-                    # ---- diffusion sampling (:697-710) ----
-                    if noise_fn is not None:
-                        nz = noise_fn(step, 2 * n)
+                        audio_streamer.end()
+                    break
+                # ---- retire by the loop-level conditions of a batch-1 generate(): range(max_steps) exhausted / max_length ----
+                keep = []
+                for u in active:
+                    if u.step >= u.max_steps:
+                        u.finished = True
+                    elif u.seq_len0 + u.step >= u.max_length:
+                        u.finished = u.reach_max = True
+                    if not u.finished:
+                        keep.append(u)
+                    elif audio_streamer is not None:
+                        audio_streamer.end(torch.tensor([u.idx]))
+                active = keep
+                # ---- refill free slots ----
+                in_flight = {u.slot for u in active}
+                free = [s for s in range(cap) if s not in in_flight]
+                while queue and free:
+                    ri = queue.pop(0)
+                    slot = free.pop(0)
+                    r = requests[ri]
+                    ids_t = r["input_ids"].cpu()
+                    am = r.get("attention_mask")
+                    am = torch.ones_like(ids_t) if am is None else am.cpu()
+                    if ids_t.shape[0] != 1:
+                        raise ValueError("generate_continuous: every request carries exactly one utterance")
+                    L0 = ids_t.shape[1]
+                    mnt = r.get("max_new_tokens", max_new_tokens)
+                    mnt = self.max_position_embeddings - L0 if mnt is None else mnt
+                    u = _Utt(ri, slot, ids_t[0][am[0].bool()].tolist(), L0, min(L0 + mnt, e.max_ctx), max_length_times, S["start_id"])
+                    u.forced, u.noise_fn, u.req = r.get("_forced_tokens"), r.get("_noise_fn"), r
+                    u.t_admit = it
+                    e.codec_reset(slot)
+                    rows = pos = None
+                    if is_prefill and r.get("speech_tensors") is not None and r.get("speech_masks") is not None:
+                        _, sp = self._process_speech_inputs(r["speech_tensors"], r["speech_masks"], r.get("_prefill_noise"))
+                        sim = r.get("speech_input_mask")
+                        if sim is not None:
+                            pos = sim[0][am[0].bool()].to(self.device)
+                            rows = sp[:int(pos.sum())]
+                    self._prefill(u, u.ids, rows, pos)
+                    done[ri] = u
+                    stats["admissions"].append((it, ri, slot))
+                    if u.max_steps > 0 and u.seq_len0 < u.max_length:
+                        active.append(u)
                     else:
-                        nz = torch.randn(2 * n, e.cfg.latent_dim)      # CPU global RNG, as the reference (:701)
-                    self._stage_noise(nz, n)
-                    e.diffusion_sample(n, self._cond, self._noise, cfg_scale, self._latent)
-                if diff:
-                    # ---- codec decode, semantic encode, connectors (:636-672) ----
-                    if len(diff) > 1 and self.concurrent_codecs:
-                        # each utterance's tokenizer chain (decode -> semantic re-encode) is an independent, launch-latency
-                        # bound graph: fork them onto side streams so they overlap, join before the connectors
-                        self._fork_ev.record(e.stream)
-                        for j, b in enumerate(diff):
-                            ss = self._side_streams[j % len(self._side_streams)]
-                            ss.wait_event(self._fork_ev)
-                            e.codec_decode(b, self._latent[j:j + 1], self._audio[j], stream=ss)
-                            if e.cfg.sem_dim > 0:
-                                e.semantic_encode(b, self._audio[j], self._sem[j], stream=ss)
-                        for ss in self._side_streams[:min(len(diff), len(self._side_streams))]:
-                            self._join_ev.record(ss)
-                            e.stream.wait_event(self._join_ev)
-                    else:
-                        for j, b in enumerate(diff):
-                            e.codec_decode(b, self._latent[j:j + 1], self._audio[j])
-                            if e.cfg.sem_dim > 0:
-                                e.semantic_encode(b, self._audio[j], self._sem[j])
-                    e.connect(n, self._latent, self._sem if e.cfg.sem_dim > 0 else None, self._emb_out)
-                    chunk = self._audio[:n].clone()
-                    for j, b in enumerate(diff):
-                        audio_chunks[b].append(chunk[j])
-                        nxt_x[live.index(b)].copy_(self._emb_out[j])
-                    if audio_streamer is not None:
-                        audio_streamer.put(chunk[:, None, :].to(self.dtype), torch.tensor(diff))
-                    n_frames += n
-                    if trace is not None:
-                        trace.neg_hidden.append(cond_used[n:2 * n].cpu())
-                        trace.latents.append(self._latent[:n].cpu())
-                        trace.semantic.append(self._sem[:n].cpu())
-                if live:
-                    self._x_in[:len(live)].copy_(nxt_x[:len(live)])
-                    if trace is not None:
-                        trace.next_embeds.append(nxt_x[:len(live)].cpu())
-                have_embeds = True
+                        u.finished = True
+                        u.reach_max = u.seq_len0 >= u.max_length
+                if not active:
+                    continue
+                stats["max_in_flight"] = max(stats["max_in_flight"], len(active))
+                active = self._iterate(S, active)
+                it += 1
             if audio_streamer is not None:
                 audio_streamer.end()
             outs = []
-            for c in audio_chunks:
-                outs.append(torch.cat(c, dim=-1)[None].to(self.dtype) if c else None)
+            for ri in range(n_req):
+                u = done[ri]
+                if u is None:                       # stopped before admission
+                    outs.append(VibeVoiceGenerationOutput(sequences=requests[ri]["input_ids"].to(self.device), speech_outputs=[None],
+                                                          reach_max_step_sample=torch.tensor([False], device=self.device)))
+                    continue
+                ids_t = requests[ri]["input_ids"].cpu()
+                seq = torch.cat([ids_t, torch.tensor([u.tokens], dtype=torch.long)], dim=-1) if u.tokens else ids_t
+                audio = torch.cat(u.chunks, dim=-1)[None].to(self.dtype) if u.chunks else None
+                outs.append(VibeVoiceGenerationOutput(sequences=seq.to(self.device), speech_outputs=[audio] if return_speech else None,
+                                                      reach_max_step_sample=torch.tensor([u.reach_max], device=self.device)))
         e.sync()
-        self.last_stats = {"frames": n_frames, "steps": seq.shape[-1] - L0}
-        return VibeVoiceGenerationOutput(
-            sequences=seq.to(self.device), speech_outputs=outs if return_speech else None,
-            reach_max_step_sample=reach_max.to(self.device))
+        stats["iterations"] = it
+        self.last_stats = {"frames": S["n_frames"], "steps": it, **stats}
+        return outs
