@@ -1,25 +1,32 @@
 #!/usr/bin/env python
 """bench.py -- audio-seconds per wall-second of the VibeVoice hot loop on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--model 1.5b|7b] [--solver-steps N]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload north-star|1p5b|streaming] [--model ...]
 
 One "step" = one iteration of the reference's hot loop emitting <speech_diffusion>
 (modeling_vibevoice_inference.py:432-675): positive + CFG-negative LM decode,
 restricted lm_head, N-step CFG DPM-Solver++ diffusion head, acoustic codec decode
 of the 3200-sample frame, semantic re-encode, connectors, token read-back.
-Workload at N=1 (BASELINE.json configs[1]): VibeVoice-1.5B shapes, 1 speaker,
-prompt sized like demo/text_examples/1p_abs.txt (~220 text tokens + a 75-frame
-voice prompt), bf16 weights, 10 solver steps (the file demo's default,
-demo/inference_from_file.py:365), synthetic seeded weights and forced token
-schedule.  With --gpus N>1 every rank decodes its own utterance
-(weak scaling, no collective inside the step loop); weights are generated on rank 0
-and broadcast over RCCL/xGMI at start-up.
+
+Default workload = the north-star configuration, BASELINE.json configs[2]: VibeVoice-7B shapes, 2 speakers, a
+10,922-token script prompt PREFILLED THROUGH THE ENGINE (MFMA tile GEMM + prefill attention), the full 20-step diffusion
+schedule, decode timed at a KV length of ~32K (the positions between the end of the prompt and the measurement point hold
+random bf16 K/V written with vv_kv_import_at -- stepping 21 K frames to get there would take minutes; the prompt part of
+the cache is the real prefill output), bf16 weights, synthetic seeded weights and forced token schedule.
+The same JSON line carries, under extra.configs, BASELINE configs[1] (VibeVoice-1.5B, 1 speaker, 1p_abs.txt-sized prompt,
+10 solver steps -- the round-1 headline) and configs[4] (Streaming-0.5B, p50 first-audio latency), measured in the same
+run with the same code.
+
+With --gpus N>1 every rank decodes its own utterance (weak scaling, no collective inside the step loop); weights are
+generated on rank 0 and broadcast as one packed blob over RCCL/xGMI at start-up.  `python bench.py --gpus N` without
+torchrun spawns the N ranks itself (torch.distributed.run, 127.0.0.1 rendezvous).
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -30,6 +37,17 @@ sys.path.insert(0, ROOT)
 
 FRAME_SEC = 3200 / 24000.0
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+# BASELINE.json configs -> bench parameters
+WORKLOADS = {
+    # configs[2]: 7B, 2 speakers, 32K-token script (L0 = 10,922 prompt tokens -> cap 2*L0 generated -> 32,766), N = 20
+    "north-star": dict(model="7b", speakers=2, text_tokens=10731, voice_frames=75, solver_steps=20, kv_target=32000,
+                       prefill_rows=2048, baseline_config="configs[2]"),
+    # configs[1]: 1.5B, 1 speaker, prompt sized like demo/text_examples/1p_abs.txt, N = 10 (the file demo's default)
+    "1p5b": dict(model="1.5b", speakers=1, text_tokens=220, voice_frames=75, solver_steps=10, kv_target=0,
+                 prefill_rows=512, baseline_config="configs[1]"),
+    "streaming": dict(model="0.5b-streaming", baseline_config="configs[4]"),
+}
 
 
 def algorithmic_bytes_per_frame(cfg, n_solver, kv_len_pos, kv_len_neg):
@@ -60,37 +78,63 @@ def algorithmic_bytes_per_frame(cfg, n_solver, kv_len_pos, kv_len_neg):
     return float(b)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=150)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--model", default="1.5b")
-    ap.add_argument("--solver-steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="north-star", choices=sorted(WORKLOADS))
+    ap.add_argument("--model", default=None, help="override the workload's model (1.5b | 7b | 0.5b-streaming)")
+    ap.add_argument("--solver-steps", type=int, default=None)
+    ap.add_argument("--text-tokens", type=int, default=None)
+    ap.add_argument("--voice-frames", type=int, default=None)
+    ap.add_argument("--speakers", type=int, default=None)
+    ap.add_argument("--kv-start", type=int, default=None,
+                    help="KV length at which decode is measured; positions past the prefilled prompt hold random K/V")
+    ap.add_argument("--prefill-rows", type=int, default=None, help="prompt rows per LM weight pass (engine max_rows)")
     ap.add_argument("--cfg-scale", type=float, default=1.3)
     ap.add_argument("--xsplit", type=int, default=int(os.environ.get("VVHIP_XSPLIT", "1")))
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true", help="skip the per-launch hipEvent pass (for rocprof runs)")
-    ap.add_argument("--cpu-frames", type=int, default=4)
-    ap.add_argument("--text-tokens", type=int, default=220)
-    ap.add_argument("--voice-frames", type=int, default=75)
-    ap.add_argument("--speakers", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=1, help="utterances decoded together on each GPU (1 = the BASELINE config; "
-                    "up to 8 share every LM / diffusion-head weight pass)")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the GEMV launch-duration passes (for rocprof --pmc runs)")
+    ap.add_argument("--skip-extra", action="store_true", help="main workload only (no extra.configs lines)")
+    ap.add_argument("--cpu-frames", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1, help="utterances decoded together on each GPU (up to 8 share every LM / "
+                    "diffusion-head weight pass)")
+    ap.add_argument("--continuous", type=int, default=0, help="queue this many utterances through generate_continuous() "
+                    "(slots = --batch) instead of one synchronous batch")
     ap.add_argument("--max-ctx", type=int, default=0)
     ap.add_argument("--enc-frames", type=int, default=5, help="voice-prompt frames per acoustic-encoder pass")
-    ap.add_argument("--prefill-rows", type=int, default=512, help="prompt rows per LM weight pass (engine max_rows)")
-    ap.add_argument("--kv-start", type=int, default=0,
-                    help="pretend the positive KV cache already holds this many tokens after the prefill "
-                         "(long-context decode measurement; the extra entries are zeros)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def respawn_ranks(args):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks (one process per GPU, RCCL rendezvous on 127.0.0.1)."""
+    import socket
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_dev} GPU(s) visible on this node")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(respawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
+    if world != args.gpus and rank == 0:
+        print(f"[bench] --gpus {args.gpus} but the launcher started {world} rank(s): reporting n_gpus={world}", file=sys.stderr)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -104,33 +148,87 @@ def main():
         vbuild.build()
     if use_dist:
         dist.barrier()
+
+    spec = dict(WORKLOADS[args.workload])
+    for k, a in (("model", args.model), ("solver_steps", args.solver_steps), ("text_tokens", args.text_tokens),
+                 ("voice_frames", args.voice_frames), ("speakers", args.speakers), ("kv_target", args.kv_start),
+                 ("prefill_rows", args.prefill_rows)):
+        if a is not None:
+            spec[k] = a
+    ctx = dict(rank=rank, world=world, device=device, use_dist=use_dist)
+    if "streaming" in spec["model"]:
+        res = bench_streaming(args, spec, ctx)
+    else:
+        res = bench_decode(args, spec, ctx, with_cpu=(world == 1 and not args.no_cpu_baseline), with_roofline=not args.no_roofline)
+        if rank == 0 and world == 1 and not args.skip_extra and args.workload == "north-star" and args.batch == 1 and not args.continuous:
+            # the other single-GPU BASELINE configs, same run, same code
+            extra = {}
+            for name in ("1p5b", "streaming"):
+                sp = dict(WORKLOADS[name])
+                try:
+                    a2 = parse_args([])
+                    a2.xsplit, a2.no_graph, a2.cfg_scale = args.xsplit, args.no_graph, args.cfg_scale
+                    if name == "streaming":
+                        a2.steps = 60
+                        r = bench_streaming(a2, sp, ctx)
+                    else:
+                        a2.steps, a2.warmup = 60, 10
+                        r = bench_decode(a2, sp, ctx, with_cpu=False, with_roofline=not args.no_roofline)
+                    keep = {k: r[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup")}
+                    keep["workload"] = r["config"]["workload"]
+                    if r.get("roofline"):
+                        keep["roofline"] = {k: r["roofline"].get(k) for k in ("kernel", "achieved", "peak", "frac", "avg_launch_us",
+                                                                            "launches_per_step", "whole_step_frac")}
+                    for k in ("p50_first_audio_ms", "p90_first_audio_ms", "prefill_plus_first_frame_s"):
+                        if k in r.get("extra", {}):
+                            keep[k] = r["extra"][k]
+                    extra[sp["baseline_config"]] = keep
+                except Exception as ex:          # an extra line must never take the main line down
+                    extra[sp["baseline_config"]] = {"error": repr(ex)[:200]}
+            res["extra"]["configs"] = extra
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def bench_decode(args, spec, ctx, with_cpu, with_roofline):
+    """One multi-speaker model workload: prefill, W warm-up steps, K timed steps; returns the JSON-line dict (rank 0)."""
+    import torch.distributed as dist
     from vibevoice_amd import parallel, synthetic
     from vibevoice_amd.configs import CONFIGS
     from vibevoice_amd.engine import Engine, map_param_name
     from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference, engine_config_from_reference
-
-    cfg = CONFIGS[args.model]
-    if "streaming" in args.model:
-        return bench_streaming(args, cfg, rank, world, device)
-    K, W, NS = args.steps, max(1, args.warmup), args.solver_steps
+    rank, world, device, use_dist = ctx["rank"], ctx["world"], ctx["device"], ctx["use_dist"]
+    model_key = spec["model"]
+    cfg = CONFIGS[model_key]
+    K, W, NS = args.steps, max(1, args.warmup), spec["solver_steps"]
     B = max(1, min(8, args.batch))
-    inputs = synthetic.synthetic_inputs(cfg, n_speakers=args.speakers, text_tokens=args.text_tokens,
-                                        voice_frames=args.voice_frames, seed=100 + rank, batch=B)
+    n_utt = max(B, args.continuous) if args.continuous else B
+    inputs = synthetic.synthetic_inputs(cfg, n_speakers=spec["speakers"], text_tokens=spec["text_tokens"],
+                                        voice_frames=spec["voice_frames"], seed=100 + rank, batch=n_utt)
     L0 = inputs["input_ids"].shape[1]
     total_steps = W + K + 2
-    max_ctx = args.max_ctx or ((max(L0, args.kv_start) + total_steps + 256 + 127) // 128 * 128)
-    ecfg = engine_config_from_reference(cfg, n_slots=B, max_ctx=max_ctx, xsplit=args.xsplit,
-                                        use_graph=not args.no_graph, enc_frames=args.enc_frames, max_rows=max(2 * B, args.prefill_rows))
+    d = cfg["decoder_config"]
+    model_ctx = d.get("max_position_embeddings", 32768)
+    kv_target = int(spec.get("kv_target") or 0)
+    if kv_target:
+        kv_target = max(L0, min(kv_target, model_ctx - total_steps - 8))       # the timed window must fit the model's context
+    max_ctx = args.max_ctx or ((max(L0, kv_target) + total_steps + 256 + 127) // 128 * 128)
+    ecfg = engine_config_from_reference(cfg, n_slots=B, max_ctx=max_ctx, xsplit=args.xsplit, use_graph=not args.no_graph,
+                                        enc_frames=args.enc_frames, max_rows=max(2 * B, spec["prefill_rows"]))
     t_load0 = time.time()
     eng = Engine(ecfg, device)
     exp = eng.expected_weights()
-    keep_cpu = (rank == 0 and world == 1 and not args.no_cpu_baseline)
+    keep_cpu = rank == 0 and with_cpu
     cpu_sd = {}
-    # rank 0 draws the weights, RCCL broadcasts them over xGMI (one collective per tensor at start-up, none later)
+    # rank 0 draws the weights; ONE packed-blob broadcast over RCCL/xGMI at start-up (SURVEY 8e), no collective later
     gen = torch.Generator(device=device)
     gen.manual_seed(0)
     make = lambda k, shape: synthetic.random_tensor(k, shape, gen, device, torch.bfloat16)
-    for k, t in parallel.broadcast_params(synthetic.param_shapes(cfg).items(), make, device, torch.bfloat16):
+    bc = {}
+    for k, t in parallel.broadcast_packed(synthetic.param_shapes(cfg).items(), make, device, torch.bfloat16, stats=bc):
         name = map_param_name(k)
         if name in exp:
             eng.upload(name, t)
@@ -145,10 +243,21 @@ def main():
     model.set_ddpm_inference_steps(NS)
     load_s = time.time() - t_load0
 
-    forced = [synthetic.forced_schedule(total_steps, turn=150) for _ in range(B)]
+    forced = [synthetic.forced_schedule(total_steps, turn=150) for _ in range(n_utt)]
     g = torch.Generator(device=device)
     g.manual_seed(1234 + rank)
     noise_bank = torch.randn(total_steps + 1, 2 * B, cfg["acoustic_vae_dim"], generator=g, device=device)
+    kvh, hd, n_layers = d["num_key_value_heads"], d["hidden_size"] // d["num_attention_heads"], d["num_hidden_layers"]
+
+    def kv_fill(e, cache, p0, p1):
+        """positions [p0, p1) of every layer of `cache`: random bf16 K/V at the scale of real keys/values (not zeros: the
+        softmax over 32K positions and the P.V accumulation then run on ordinary data)"""
+        gk = torch.Generator(device=device)
+        gk.manual_seed(4321 + cache)
+        for layer in range(n_layers):
+            k = (torch.randn(kvh, p1 - p0, hd, generator=gk, device=device) * 0.5).to(torch.bfloat16)
+            v = (torch.randn(kvh, p1 - p0, hd, generator=gk, device=device) * 0.5).to(torch.bfloat16)
+            e.kv_import_at(cache, layer, p0, k, v)
     torch.cuda.synchronize()
 
     marks = {}
@@ -165,29 +274,50 @@ def main():
             eng.sync()
             marks["prefill_done"] = time.perf_counter()
 
+    os.environ.setdefault("VVHIP_TIME_PREFILL", "1")        # sync + time the two prefill phases (outside the timed region)
     t_gen0 = time.perf_counter()
-    out = model.generate(tokenizer=synthetic.TOKENS, cfg_scale=args.cfg_scale, generation_config={"do_sample": False},
-                         max_new_tokens=total_steps, show_progress_bar=False, _forced_tokens=forced,
-                         _noise_fn=lambda step, n2: noise_bank[step], _step_callback=step_cb,
-                         _kv_start=args.kv_start, **inputs)
+    if args.continuous:
+        reqs = []
+        for i in range(n_utt):
+            r = {k: (v[i:i + 1] if k in ("input_ids", "attention_mask", "speech_input_mask") else v) for k, v in inputs.items()}
+            ns = spec["speakers"]
+            r["speech_tensors"] = inputs["speech_tensors"][i * ns:(i + 1) * ns]
+            r["speech_masks"] = inputs["speech_masks"][i * ns:(i + 1) * ns]
+            r["_forced_tokens"] = forced[i][:W + K + 1 + 7 * (i % 3)] + [synthetic.TOKENS.eos_token_id]     # staggered ends
+            reqs.append(r)
+        outs = model.generate_continuous(reqs, tokenizer=synthetic.TOKENS, cfg_scale=args.cfg_scale,
+                                         generation_config={"do_sample": False}, max_concurrent=B, _step_callback=step_cb)
+        out = outs[0]
+    else:
+        out = model.generate(tokenizer=synthetic.TOKENS, cfg_scale=args.cfg_scale, generation_config={"do_sample": False},
+                             max_new_tokens=total_steps, show_progress_bar=False, _forced_tokens=forced,
+                             _noise_fn=lambda step, n2: noise_bank[step], _step_callback=step_cb,
+                             _kv_start=kv_target, _kv_fill_fn=kv_fill if kv_target else None, **inputs)
     eng.sync()
     t_gen1 = time.perf_counter()
+    if W + K not in marks:                         # continuous mode may finish early
+        marks[W + K] = t_gen1
     wall = marks[W + K] - marks[W]
     # steps W..W+K-1: count the <speech_diffusion> frames among them (the schedule inserts 2 control tokens per 150)
     frames = B * sum(1 for t in forced[0][W:W + K] if t == synthetic.TOKENS.speech_diffusion_id)
     frames_all, wall_max = parallel.aggregate_throughput(frames, wall, device)   # sum over ranks / max over ranks
     value = frames_all * FRAME_SEC / wall_max
     audio_total = out.speech_outputs[0].shape[-1] / 24000.0
+    prefill_phases = getattr(model, "last_prefill", None)
+    cont_stats = dict(model.last_stats) if args.continuous else None
 
     if os.environ.get("VVHIP_TIMELINE") and rank == 0:      # timing builds only: tools/step_timeline.py
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import step_timeline
         step_timeline.dump(eng, os.environ["VVHIP_TIMELINE"])
 
-    # ---- roofline of the dominant kernel (vv_gemm_kernel): per-launch hipEvents over K_prof live steps ----
+    kv_mid = max(L0, kv_target) + W + K // 2
+    formula = algorithmic_bytes_per_frame(cfg, NS, kv_mid, 1 + min(150, K) // 2)
+
+    # ---- roofline of the dominant kernel (vv_gemv_kernel) ----
     roof = None
-    if rank == 0 and not args.no_roofline:
-        kprof = 8
+    if rank == 0 and with_roofline and not args.continuous:
+        kprof = 6
         forced_p = [synthetic.forced_schedule(kprof + 3, turn=150) for _ in range(B)]
         prof = {}
 
@@ -197,41 +327,40 @@ def main():
                 eng.profile_begin()
             if step == 2 + kprof:
                 prof["res"] = eng.profile_end()
-        inp2 = synthetic.synthetic_inputs(cfg, n_speakers=args.speakers, text_tokens=args.text_tokens,
-                                          voice_frames=args.voice_frames, seed=100, batch=B)
+        inp2 = synthetic.synthetic_inputs(cfg, n_speakers=spec["speakers"], text_tokens=min(spec["text_tokens"], 220),
+                                          voice_frames=spec["voice_frames"], seed=100, batch=B)
         model.generate(tokenizer=synthetic.TOKENS, cfg_scale=args.cfg_scale, generation_config={"do_sample": False},
                        max_new_tokens=kprof + 3, show_progress_bar=False, _forced_tokens=forced_p,
                        _noise_fn=lambda step, n2: noise_bank[step], _step_callback=prof_cb, **inp2)
-        (n_l, ms_cal, by), (n_o, ms_o, by_o) = prof["res"]       # [decode GEMV kernel], [general GEMM kernel]
-        # launch duration = hipEvent pair around each launch minus the in-stream cost of an empty pair (vv_profile_end);
-        # cross-check against rocprofv3's per-kernel average: profiles/r01_1p5b_gemv_summary.txt
-        ms = ms_cal
-        ms_raw = eng.stat(2) / 1e6
-        ach = by / 1e9 / (ms / 1e3) if ms > 0 else 0.0
+        (n_l, ms_cal, by), (n_o, ms_o, by_o) = prof["res"]       # [decode GEMV kernel], [other GEMM kernels]
+        # (1) launch duration in the execution mode of the timed region: the recorded GEMV launches replayed as ONE dependent
+        # hipGraph chain between two events (vv_profile_replay) = start-to-start period of a launch = what rocprofv3
+        # --kernel-trace reports per kernel under graph replay (profiles/r02_*_kernel_stats.csv)
+        n_rep, ms_rep, by_rep = eng.profile_replay(reps=3)
+        us_graph = ms_rep * 1e3 / max(1, n_rep)
+        ach = by_rep / 1e9 / (ms_rep / 1e3) if ms_rep > 0 else 0.0                      # GB/s
+        # (2) secondary: hipEvent pair around each EAGER launch minus an in-stream empty pair (a lower bound on the duration)
+        ach_pair = by / 1e9 / (ms_cal / 1e3) if ms_cal > 0 else 0.0
         traffic = None
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                traffic = json.load(f).get(args.model, {}).get("hbm_bytes_per_launch")
+                tj = json.load(f).get(model_key, {})
+                traffic = tj.get("hbm_bytes_per_launch")
         except Exception:
             pass
-        rp = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "rocprof_gemv.json")) as f:
-                rp = json.load(f).get(args.model, {}).get("avg_launch_us")
-        except Exception:
-            pass
-        formula = algorithmic_bytes_per_frame(cfg, NS, max(L0, args.kv_start) + W + K // 2, 1 + min(150, K) // 2)
         roof = {"bound": "hbm", "kernel": "vv_gemv_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "launches_per_step": round(n_l / kprof, 1), "avg_launch_us": round(ms * 1e3 / max(1, n_l), 3),
-                "avg_launch_us_raw_event_pair": round(ms_raw * 1e3 / max(1, n_l), 3), "empty_event_pair_us": round(eng.stat(3) / 1e3, 3),
-                # cross-check from the committed rocprofv3 summary of this workload (graph replay: per-kernel intervals overlap,
-                # an upper bound on the launch duration -> a lower bound on the fraction); profiles/rocprof_gemv.json
-                "rocprof_avg_launch_us": rp, "frac_at_rocprof_duration": round(by / max(1, n_l) / 1e3 / rp / HBM_PEAK_GBS, 4) if rp else None,
-                "bytes_per_launch": round(by / max(1, n_l), 1),
+                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                "traffic": traffic, "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2, committed; not re-measured in this run)",
+                "method": "recorded vv_gemv_kernel launches of 6 live steps replayed as one dependent hipGraph chain, hipEvents around 3 replays "
+                          "(vv_profile_replay): launch period = kernel + boundary, the quantity rocprofv3 --kernel-trace reports",
+                "launches_per_step": round(n_l / kprof, 1), "avg_launch_us": round(us_graph, 3),
+                "bytes_per_launch": round(by_rep / max(1, n_rep), 1),
                 "gemv_bytes_per_step": round(by / kprof, 1),
-                "other_gemm": {"kernel": "vv_gemm_kernel", "launches_per_step": round(n_o / kprof, 1),
-                               "bytes_per_step": round(by_o / kprof, 1), "GBps": round(by_o / 1e9 / (ms_o / 1e3), 1) if ms_o > 0 else None},
+                "event_pair": {"avg_launch_us": round(ms_cal * 1e3 / max(1, n_l), 3), "achieved": round(ach_pair, 1),
+                               "frac": round(ach_pair / HBM_PEAK_GBS, 4), "raw_pair_us": round(eng.stat(2) / 1e3 / max(1, n_l), 3),
+                               "empty_pair_us": round(eng.stat(3) / 1e3, 3), "note": "eager launches, per-launch event pair minus an empty pair"},
+                "other_gemm": {"launches_per_step": round(n_o / kprof, 1), "bytes_per_step": round(by_o / kprof, 1),
+                               "GBps": round(by_o / 1e9 / (ms_o / 1e3), 1) if ms_o > 0 else None},
                 "formula_bytes_per_step": round(formula, 1),
                 "whole_step_GBps": round(formula / 1e9 / (wall_max / K), 1),
                 "whole_step_frac": round(formula / 1e9 / (wall_max / K) / HBM_PEAK_GBS, 4)}
@@ -240,41 +369,56 @@ def main():
     cpu = None
     if keep_cpu:
         try:
-            cpu = cpu_baseline(cfg, cpu_sd, NS, args.cfg_scale, args.cpu_frames)
+            cpu = cpu_baseline(cfg, cpu_sd, NS, args.cfg_scale, args.cpu_frames, model_key)
         except Exception as ex:   # the baseline is a reported number, never the product path
             cpu = {"value": None, "error": repr(ex)[:200]}
-    if rank == 0:
-        res = {
-            "metric": "audio-sec/wall-sec", "value": round(value, 3), "unit": "audio-s/wall-s", "n_gpus": world,
-            "steps": K, "warmup": W, "ms_per_step": round(wall_max / K * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"VibeVoice-{args.model.upper()} shapes, {args.speakers} speaker, "
-                                   f"{L0}-token prompt ({args.text_tokens} text + {args.voice_frames}-frame voice), "
-                                   f"{NS} solver steps, cfg {args.cfg_scale}, {B} utterance{'s' if B > 1 else ''} per GPU, forced token schedule",
-                       "model": f"VibeVoice-{args.model}", "solver_steps": NS, "prompt_tokens": L0,
-                       "xsplit": args.xsplit, "hipgraph": not args.no_graph, "kv_start": args.kv_start, "parallelism": f"utterance-dp{world}"},
-            "roofline": roof, "cpu_baseline": cpu,
-            "extra": {"frames_timed": frames, "weights_load_s": round(load_s, 2),
-                      "prefill_plus_first_frame_s": round(marks.get("prefill_done", t_gen0) - t_gen0, 4),
-                      "prefill_phases": getattr(model, "last_prefill", None),
-                      "utterance_audio_s": round(audio_total, 2), "utterance_wall_s": round(t_gen1 - t_gen0, 3),
-                      "utterance_audio_per_wall": round(audio_total / (t_gen1 - t_gen0), 2)},
-        }
-        print(json.dumps(res), flush=True)
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+        cpu_sd.clear()
+    res = {
+        "metric": "audio-sec/wall-sec", "value": round(value, 3), "unit": "audio-s/wall-s", "n_gpus": world,
+        "steps": K, "warmup": W, "ms_per_step": round(wall_max / K * 1e3, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"BASELINE {spec.get('baseline_config', '?')}: VibeVoice-{model_key.upper()} shapes, {spec['speakers']} speaker(s), "
+                               f"{L0}-token prompt ({spec['text_tokens']} text + {spec['speakers']}x{spec['voice_frames']}-frame voice) prefilled through the engine, "
+                               f"{NS} solver steps, cfg {args.cfg_scale}, decode timed at KV length {max(L0, kv_target) + W}..{max(L0, kv_target) + W + K}"
+                               + (" (positions past the prompt: random bf16 K/V)" if kv_target > L0 else "")
+                               + f", {B} utterance{'s' if B > 1 else ''} per GPU"
+                               + (f" ({n_utt} queued, continuous admission)" if args.continuous else "") + ", forced token schedule",
+                   "model": f"VibeVoice-{model_key}", "solver_steps": NS, "prompt_tokens": L0, "speakers": spec["speakers"],
+                   "xsplit": args.xsplit, "hipgraph": not args.no_graph, "kv_len_timed": max(L0, kv_target) + W,
+                   "parallelism": f"utterance-dp{world}"},
+        "roofline": roof, "cpu_baseline": cpu,
+        "extra": {"frames_timed": frames, "weights_load_s": round(load_s, 2),
+                  "weights_broadcast": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in bc.items()},
+                  "prefill_plus_first_frame_s": round(marks.get("prefill_done", t_gen0) - t_gen0, 4),
+                  "prefill_phases": prefill_phases,
+                  "utterance_audio_s": round(audio_total, 2), "utterance_wall_s": round(t_gen1 - t_gen0, 3),
+                  "continuous": cont_stats},
+    }
+    if prefill_phases and prefill_phases.get("lm_prefill_s"):
+        import math
+        sh = synthetic.param_shapes(cfg)
+        n_lm = sum(math.prod(s) for k, s in sh.items() if k.startswith("model.language_model.layers."))
+        hq = d["num_attention_heads"]
+        flops = 2.0 * n_lm * L0 * B + 4.0 * hq * hd * (L0 * L0 / 2.0) * n_layers * B
+        res["extra"]["prefill_tflops"] = round(flops / prefill_phases["lm_prefill_s"] / 1e12, 1)
+        res["extra"]["prefill_frac_of_2p5PF"] = round(flops / prefill_phases["lm_prefill_s"] / 2.5e15, 4)
     eng.close()
+    del model, eng
+    torch.cuda.empty_cache()
+    return res
 
 
-def bench_streaming(args, cfg, rank, world, device):
+def bench_streaming(args, spec, ctx):
     """BASELINE.json configs[4]: Streaming-0.5B, hipGraph-captured decode+diffusion step, p50 first-audio latency.
     Synthetic weights and an Emma-shaped synthetic preset (lm 74 / tts_lm 251 cached positions)."""
     import statistics
     import types
     from vibevoice_amd import synthetic
+    from vibevoice_amd.configs import CONFIGS
     from vibevoice_amd.modeling_streaming import VibeVoiceStreamingForConditionalGenerationInference
-    NS = args.solver_steps if args.solver_steps != 10 else 5          # the streaming demo default is 5
+    device = ctx["device"]
+    cfg = CONFIGS[spec["model"]]
+    NS = spec.get("solver_steps") or 5                                 # the streaming demo default is 5
     gen = torch.Generator(device=device)
     gen.manual_seed(0)
     sd = ((k, synthetic.random_tensor(k, shp, gen, device, torch.bfloat16))
@@ -321,28 +465,31 @@ def bench_streaming(args, cfg, rank, world, device):
     res = {"metric": "audio-sec/wall-sec", "value": round(audio_s / wall, 3), "unit": "audio-s/wall-s", "n_gpus": 1,
            "steps": int(audio_s / FRAME_SEC + 0.5), "warmup": 33, "ms_per_step": round(wall / (audio_s / FRAME_SEC) * 1e3, 4),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-           "config": {"workload": f"VibeVoice-Streaming-0.5B shapes, Emma-shaped synthetic preset (lm 74 / tts 251), {NS} solver steps, "
+           "config": {"workload": f"BASELINE configs[4]: VibeVoice-Streaming-0.5B shapes, Emma-shaped synthetic preset (lm 74 / tts 251), {NS} solver steps, "
                                   "whole generate() incl. preset import, text windows of 5 / speech windows of 6",
                       "model": "VibeVoice-Streaming-0.5B", "solver_steps": NS, "hipgraph": not args.no_graph},
            "roofline": None, "cpu_baseline": None,
            "extra": {"p50_first_audio_ms": round(statistics.median(lat), 3), "p90_first_audio_ms": round(sorted(lat)[int(0.9 * len(lat))], 3),
-                     "trials": len(lat), "finished_by_eos_or_cap": True}}
-    print(json.dumps(res), flush=True)
+                     "trials": len(lat), "first_audio_definition": "generate() entry -> first 3200-sample chunk complete on the device "
+                     "(preset KV import + first text window + first frame)", "finished_by_eos_or_cap": True}}
     model.engine.close()
+    del model
+    torch.cuda.empty_cache()
+    return res
 
 
-def cpu_baseline(cfg, cpu_sd, n_solver, cfg_scale, n_frames):
+def cpu_baseline(cfg, cpu_sd, n_solver, cfg_scale, n_frames, model_key):
     """Times oracle/ (the CPU restatement of the reference loop) on this host: `n_frames` decode
-    frames after a short prompt, fp32, all host threads.  kind = "port"."""
+    frames after a short prompt, fp32, a bounded number of host threads.  kind = "port"."""
     from oracle import generate as ogen
     from oracle import lm as olm
     from vibevoice_amd import synthetic
     # the GPU box advertises hundreds of logical CPUs but the job may be cgroup-limited; a modest
     # thread count keeps torch's intra-op pool from thrashing (256 threads measured 200 s/frame)
-    ncpu = min(int(os.environ.get("VVHIP_CPU_THREADS", "16")), os.cpu_count() or 1)
+    host_cpus = os.cpu_count() or 1
+    ncpu = min(int(os.environ.get("VVHIP_CPU_THREADS", "16")), host_cpus)
     torch.set_num_threads(ncpu)
-    t_budget = float(os.environ.get("VVHIP_CPU_BUDGET_S", "45"))
-    t_start = time.perf_counter()
+    t_budget = float(os.environ.get("VVHIP_CPU_BUDGET_S", "30"))
     d = cfg["decoder_config"]
     H = d["hidden_size"]
 
@@ -372,7 +519,7 @@ def cpu_baseline(cfg, cpu_sd, n_solver, cfg_scale, n_frames):
 
     def noise_fn(step, n2):
         stamps.append(time.perf_counter())
-        if len(stamps) >= 2 and stamps[-1] - t_start > t_budget:
+        if len(stamps) >= 3 and stamps[-1] - stamps[0] > t_budget:       # at least two whole frames, then the time budget
             raise _Budget()
         return torch.randn(n2, 64, generator=g)
     forced = [[T.speech_diffusion_id] * (n_frames + 1)]
@@ -384,8 +531,11 @@ def cpu_baseline(cfg, cpu_sd, n_solver, cfg_scale, n_frames):
         pass
     per_frame = (stamps[-1] - stamps[0]) / max(1, len(stamps) - 1)
     return {"value": round(FRAME_SEC / per_frame, 4), "unit": "audio-s/wall-s", "cores": ncpu, "kind": "port",
-            "sample": f"{len(stamps) - 1} decode frames after a 48-token text-only prompt, same model shapes/weights, "
-                      f"fp32, {n_solver} solver steps, oracle loop (CPU restatement of the reference)",
+            "host_logical_cpus": host_cpus,
+            "sample": f"{len(stamps) - 1} decode frames of the same model shapes and weights (VibeVoice-{model_key}, fp32 = the reference's CPU "
+                      f"dtype, {n_solver} solver steps, CFG pos+neg passes) after a 48-token text-only prompt -- the GPU leg's 32K-token context is "
+                      f"NOT reproduced on the CPU (attention is <5% of a CPU frame); oracle loop = CPU restatement of the reference's "
+                      f"generate(), torch intra-op threads capped at {ncpu} of {host_cpus} logical CPUs",
             "ms_per_step": round(per_frame * 1e3, 2)}
 
 

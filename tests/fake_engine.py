@@ -193,3 +193,76 @@ class FakeStreamingEngine:
 
     def connect(self, n, latent, sem, out):
         out[:n] = connector.connector_forward(self.om.ac_conn, latent[:n])
+
+
+class LoadableFakeEngine(FakeEngine):
+    """`Engine(ecfg, device)` stand-in for the construction path (from_state_dict / from_pretrained / WeightHandle /
+    load_lora_assets): collects vv_upload()s under the engine's parameter names and builds the oracle model from them on
+    first use, so the class can be driven from a checkpoint directory on a machine without a GPU."""
+
+    class _Any(dict):
+        def __contains__(self, k):
+            return True
+
+    def __init__(self, ecfg, device=None):
+        self.ecfg = ecfg
+        self._w = {}
+        self._om = None
+        self._factors = (1.0, 0.0)
+        self.device = torch.device("cpu")
+        self.stream = None
+        self.max_ctx = (ecfg.max_ctx + 127) // 128 * 128
+        self.cfg = types.SimpleNamespace(lm_hidden=ecfg.lm_hidden, latent_dim=ecfg.latent_dim, hop=ecfg.hop, sem_dim=ecfg.sem_dim,
+                                         n_slots=ecfg.n_slots, max_rows=ecfg.max_rows, lm_vocab=ecfg.lm_vocab)
+        self.caches = {}
+        self.ac_state = [dict() for _ in range(ecfg.n_slots)]
+        self.sem_state = [dict() for _ in range(ecfg.n_slots)]
+        self.valid = None
+        self.n_steps = 10
+        self.calls = {"lm_rows": 0, "samples": 0, "spec_wasted": 0}
+        self.uploads = []
+        self._frozen = None
+
+    def expected_weights(self):
+        # while the checkpoint streams in, every mapped key is taken; once the load has been checked (missing_weights), the
+        # parameter set is the one the checkpoint defined -- as the real engine's registry is fixed by its config
+        return self._frozen if self._frozen is not None else self._Any()
+
+    def missing_weights(self):
+        self._frozen = {k: int(v.numel()) for k, v in self._w.items()}
+        return []
+
+    def upload(self, name, t):
+        self._w[name] = t.detach().to(torch.float32).clone()
+        self.uploads.append(name)
+        self._om = None                       # the next op sees the new snapshot
+
+    def set_speech_factors(self, scaling, bias):
+        self._factors = (float(scaling), float(bias))
+        if self._om is not None:
+            self._om.scaling, self._om.bias = self._factors
+
+    @property
+    def om(self):
+        if self._om is None:
+            from oracle import generate as ogen
+            from oracle import lm as olm
+            c = self.ecfg
+
+            def sub(p, keep=""):
+                return {keep + k[len(p):]: v for k, v in self._w.items() if k.startswith(p)}
+            lm_w = sub("lm.")
+            lm_w.pop("rope.inv_freq", None)
+            lm = olm.Qwen2Oracle(lm_w, c.lm_layers, c.lm_heads, c.lm_kv_heads, c.lm_head_dim, c.rope_theta, c.lm_eps)
+            depths = list(c.enc_depths)
+            self._om = ogen.OracleModel(
+                lm=lm, lm_head=self._w.get("lm_head.weight", lm_w["embed_tokens.weight"]), head_w=sub("head."), head_layers=c.head_layers,
+                ac_w={**sub("dec.", "decoder."), **sub("aenc.", "encoder.")}, sem_w=sub("senc.", "encoder."),
+                ac_conn=sub("ac_conn."), sem_conn=sub("sem_conn."), ratios=list(c.ratios), enc_depths=depths,
+                dec_depths=list(reversed(depths)), sem_depths=depths, scaling=self._factors[0], bias=self._factors[1],
+                max_position_embeddings=c.max_ctx, head_eps=c.head_eps, codec_eps=c.codec_eps)
+        return self._om
+
+    @om.setter
+    def om(self, v):
+        self._om = v

@@ -39,11 +39,11 @@ class Small:
             max_position_embeddings=self.lmcfg.max_pos, head_eps=self.hc.eps, codec_eps=self.cc.eps)
 
 
-def build_small(lmcfg=None, xsplit=3, use_graph=False, n_slots=2, max_ctx=512, tied=False, max_rows=16):
+def build_small(lmcfg=None, xsplit=3, use_graph=False, n_slots=2, max_ctx=512, tied=False, max_rows=16, head_layers=2, head_ffn_ratio=3.0):
     from vibevoice_amd.engine import Engine, EngineConfig
     lmcfg = lmcfg or synth.LMCfg()
     H = lmcfg.hidden
-    hc = synth.HeadCfg(hidden=H, layers=2)
+    hc = synth.HeadCfg(hidden=H, layers=head_layers, ffn_ratio=head_ffn_ratio)
     cc = synth.CodecCfg()
     sc = synth.CodecCfg(vae_dim=128)
     lm_w = synth.lm_weights(lmcfg)

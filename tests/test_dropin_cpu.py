@@ -1,0 +1,353 @@
+"""CPU tests of the drop-in surface: the reference demo's call sequence against the product class, the
+attribute tree callers read, weight-snapshot handles, continuous admission, the streamers.  The numeric stages run
+through tests/fake_engine (oracle arithmetic); what is under test is the product's host code."""
+import asyncio
+import json
+import os
+import threading
+import time
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import fake_engine
+import synth
+from test_oracle_golden import G as GOLD
+
+TOK = types.SimpleNamespace(speech_start_id=301, speech_end_id=302, speech_diffusion_id=303, eos_token_id=304,
+                            bos_token_id=None, pad_token_id=305)
+
+
+def tiny_reference_config():
+    """The tiny model of tests/gpu_util.build_small in the reference's config.json schema (vibevoice/configs/*.json)."""
+    lm, cc = synth.LMCfg(), synth.CodecCfg()
+    tok = {"causal": True, "channels": 1, "conv_bias": True, "conv_norm": "none", "encoder_depths": cc.depth_str,
+           "encoder_n_filters": cc.n_filters, "encoder_ratios": cc.ratios, "layernorm": "RMSNorm", "layernorm_eps": cc.eps,
+           "mixer_layer": "depthwise_conv", "pad_mode": "constant"}
+    return {
+        "acoustic_vae_dim": 64, "semantic_vae_dim": 128,
+        "acoustic_tokenizer_config": dict(tok, decoder_depths=None, decoder_n_filters=cc.n_filters, decoder_ratios=cc.ratios,
+                                          fix_std=0.5, std_dist_type="gaussian", vae_dim=64),
+        "semantic_tokenizer_config": dict(tok, fix_std=0, std_dist_type="none", vae_dim=128),
+        "diffusion_head_config": {"ddpm_num_inference_steps": 5, "head_ffn_ratio": 3.0, "head_layers": 2, "latent_size": 64,
+                                  "rms_norm_eps": 1e-5, "hidden_size": lm.hidden},
+        "decoder_config": {"hidden_size": lm.hidden, "intermediate_size": lm.inter, "num_attention_heads": lm.heads,
+                           "num_key_value_heads": lm.kv_heads, "num_hidden_layers": lm.layers, "vocab_size": lm.vocab,
+                           "max_position_embeddings": lm.max_pos, "rms_norm_eps": lm.eps, "rope_theta": lm.theta,
+                           "model_type": "qwen2", "tie_word_embeddings": False},
+    }
+
+
+def tiny_reference_state_dict():
+    """Same seeded weights as test_oracle_golden._oracle_small, under the reference checkpoint's key names."""
+    lm = synth.LMCfg()
+    hc = synth.HeadCfg(hidden=lm.hidden, layers=2)
+    cc, sc = synth.CodecCfg(), synth.CodecCfg(vae_dim=128)
+    sd = {"model.language_model." + k: v for k, v in synth.lm_weights(lm).items()}
+    sd["lm_head.weight"] = synth.lm_head_weight(lm)
+    sd.update({"model.prediction_head." + k: v for k, v in synth.head_weights(hc).items()})
+    sd.update({"model.acoustic_tokenizer." + k: v for k, v in {**synth.encoder_weights(cc, 2), **synth.decoder_weights(cc, 3)}.items()})
+    sd.update({"model.semantic_tokenizer." + k: v for k, v in synth.encoder_weights(sc, 7).items()})
+    sd.update({"model.acoustic_connector." + k: v for k, v in synth.connector_weights(64, lm.hidden, 4).items()})
+    sd.update({"model.semantic_connector." + k: v for k, v in synth.connector_weights(128, lm.hidden, 8).items()})
+    sd["model.speech_scaling_factor"] = torch.tensor(0.2)
+    sd["model.speech_bias_factor"] = torch.tensor(-0.05)
+    return sd
+
+
+@pytest.fixture()
+def checkpoint_dir(tmp_path):
+    from safetensors.torch import save_file
+    d = tmp_path / "tiny-vibevoice"
+    d.mkdir()
+    (d / "config.json").write_text(json.dumps(tiny_reference_config()))
+    sd = {k: v.contiguous() for k, v in tiny_reference_state_dict().items()}
+    keys = sorted(sd)
+    save_file({k: sd[k] for k in keys[::2]}, str(d / "model-00001-of-00002.safetensors"))       # two shards, like the converter
+    save_file({k: sd[k] for k in keys[1::2]}, str(d / "model-00002-of-00002.safetensors"))
+    return str(d)
+
+
+@pytest.fixture()
+def product(monkeypatch, checkpoint_dir):
+    """the product class loaded from a checkpoint directory, its Engine replaced by the oracle-backed fake"""
+    from vibevoice_amd import modeling
+    with fake_engine.cpu_cuda_shims(monkeypatch):
+        monkeypatch.setattr(modeling, "Engine", fake_engine.LoadableFakeEngine)
+        yield modeling, checkpoint_dir
+
+
+def test_reference_demo_call_sequence(product, capsys):
+    """demo/inference_from_file.py:297-431 replayed line by line: from_pretrained(path, torch_dtype, device_map,
+    attn_implementation) -> eval() -> set_ddpm_inference_steps(num_steps=10) -> the attribute read at :367-368 ->
+    processor-shaped inputs moved with .to(device) -> generate(**inputs, max_new_tokens=None, cfg_scale, tokenizer,
+    generation_config={'do_sample': False}, verbose=True, is_prefill=True) -> the fields the demo reads (:401-431).
+    Then the same call seeded with do_sample=True must land on the golden recorded from the reference's own generate()."""
+    modeling, path = product
+    model = modeling.VibeVoiceForConditionalGenerationInference.from_pretrained(
+        path, torch_dtype=torch.float32, device_map="cuda", attn_implementation="flash_attention_2")
+    model.eval()
+    model.set_ddpm_inference_steps(num_steps=10)
+    assert model.ddpm_inference_steps == 10
+    assert hasattr(model.model, "language_model")
+    print(f"Language model attention: {model.model.language_model.config._attn_implementation}")     # :367-368
+    assert "Language model attention: vvhip" in capsys.readouterr().out
+    assert model.requested_attn_implementation == "flash_attention_2"
+    # reference properties (:87-117) and what lora_loading.py touches (:88-131,163-169)
+    assert model.prediction_head is model.model.prediction_head and model.acoustic_connector is model.model.acoustic_connector
+    assert model.semantic_connector is model.model.semantic_connector and model.acoustic_tokenizer is model.model.acoustic_tokenizer
+    assert abs(float(model.speech_scaling_factor) - 0.2) < 1e-7 and abs(float(model.model.speech_bias_factor) + 0.05) < 1e-7
+    assert next(model.parameters()).device == model.device
+    assert model.config.decoder_config.hidden_size == 128 and model.config.diffusion_head_config.ddpm_num_inference_steps == 5
+    assert list(model.noise_scheduler.timesteps[:2]) == [999, 899]
+
+    z = np.load(os.path.join(GOLD, "generate_sampled_b1.npz"))
+    inputs = {"input_ids": torch.from_numpy(z["input_ids"]), "attention_mask": torch.from_numpy(z["attention_mask"]),
+              "speech_tensors": torch.from_numpy(z["speech_tensors"]), "speech_masks": torch.from_numpy(z["speech_masks"]),
+              "speech_input_mask": torch.from_numpy(z["speech_input_mask"]),
+              "parsed_scripts": [[(0, "hello")]], "all_speakers_list": [[0]]}            # what BatchEncoding carries (:374-404)
+    for k, v in inputs.items():
+        if torch.is_tensor(v):
+            inputs[k] = v.to("cpu")                                                       # the demo's .to(target_device)
+    model.set_ddpm_inference_steps(num_steps=5)
+    outputs = model.generate(**inputs, max_new_tokens=None, cfg_scale=1.3, tokenizer=TOK,
+                             generation_config={"do_sample": False}, verbose=True, is_prefill=True)
+    assert outputs.speech_outputs and outputs.speech_outputs[0] is not None
+    audio_samples = outputs.speech_outputs[0].shape[-1]
+    assert audio_samples % 3200 == 0 and audio_samples > 0
+    input_tokens = inputs["input_ids"].shape[1]
+    assert outputs.sequences.shape[1] - input_tokens > 0
+    assert outputs.reach_max_step_sample.shape == (1,)
+    # seeded sampling run == the reference's own generate() (tests/golden/generate_sampled_b1.npz)
+    torch.manual_seed(int(z["seed"]))
+    out2 = model.generate(**inputs, max_new_tokens=14, cfg_scale=1.3, tokenizer=TOK, generation_config={"do_sample": True},
+                          verbose=False, is_prefill=True, show_progress_bar=False)
+    assert torch.equal(out2.sequences.cpu(), torch.from_numpy(z["sequences"]))
+    ref = torch.from_numpy(z["audio_0"])
+    got = out2.speech_outputs[0].reshape(-1)
+    assert got.shape == ref.shape and float((got - ref).norm() / ref.norm()) <= 1e-4
+
+
+def test_generation_config_forms(product):
+    modeling, path = product
+    m = modeling.VibeVoiceForConditionalGenerationInference
+    assert m._generation_options(None) == (False, 1.0)
+    assert m._generation_options({"do_sample": True, "temperature": 0.7}) == (True, 0.7)
+    from transformers import GenerationConfig
+    assert m._generation_options(GenerationConfig(do_sample=True, temperature=0.5)) == (True, 0.5)      # an object, not a dict
+    with pytest.raises(NotImplementedError):
+        m._generation_options({"do_sample": True, "top_k": 10})
+    with pytest.raises(TypeError):
+        m._generation_options(3)
+
+
+def test_weight_handles_take_the_reference_lora_loader_calls(product, tmp_path):
+    """What lora_loading.py:71-84,112-131 does with `model.model.<component>`: load_state_dict(strict=False) + .to(device)
+    must reach the engine's weight snapshot; vibevoice_amd.load_lora_assets (merge at snapshot time) goes through the same."""
+    modeling, path = product
+    model = modeling.VibeVoiceForConditionalGenerationInference.from_pretrained(path, torch_dtype=torch.float32, device_map="cuda")
+    eng = model.engine
+    n0 = len(eng.uploads)
+    new_fc1 = torch.full((128, 64), 0.25)
+    res = model.model.acoustic_connector.load_state_dict({"fc1.weight": new_fc1, "bogus": torch.zeros(1)}, strict=False)
+    model.model.acoustic_connector.to(torch.device("cpu"))
+    assert eng.uploads[n0:] == ["ac_conn.fc1.weight"] and torch.equal(eng._w["ac_conn.fc1.weight"], new_fc1)
+    assert res.unexpected_keys == ["bogus"]
+    with pytest.raises(RuntimeError):
+        model.model.prediction_head.load_state_dict({"nope": torch.zeros(1)}, strict=True)
+    # LoRA merged into the packed weights from the checkpoint's own base tensors (model.base_tensor)
+    from safetensors.torch import save_file
+    from vibevoice_amd import load_lora_assets
+    root = tmp_path / "ft" / "lora"
+    root.mkdir(parents=True)
+    key = "model.language_model.layers.0.self_attn.q_proj.weight"
+    base = model.base_tensor(key)
+    a, b = torch.randn(2, base.shape[1]), torch.randn(base.shape[0], 2)
+    save_file({"base_model.model.layers.0.self_attn.q_proj.lora_A.weight": a, "base_model.model.layers.0.self_attn.q_proj.lora_B.weight": b},
+              str(root / "adapter_model.safetensors"))
+    (root / "adapter_config.json").write_text(json.dumps({"r": 2, "lora_alpha": 4}))
+    rep = load_lora_assets(model, str(tmp_path / "ft"))
+    assert rep.language_model and rep.merged_tensors == 1
+    assert torch.allclose(eng._w["lm.layers.0.self_attn.q_proj.weight"], base + 2.0 * (b @ a), atol=1e-5)
+
+
+def _requests(n, seed):
+    """n single-utterance requests with different prompt lengths, forced token plans that end at different steps"""
+    g = synth.Gen(seed)
+    D, E, S, X = TOK.speech_diffusion_id, TOK.speech_end_id, TOK.speech_start_id, TOK.eos_token_id
+    plans = [[D, D, D, X], [D, E, S, D, D, D, D, X], [D, D, X], [D, D, D, D, D, E, X], [D, X], [D, D, D, E, S, D, X]]
+    reqs = []
+    for i in range(n):
+        L = 9 + 3 * (i % 4)
+        ids = torch.from_numpy(g.rng.integers(0, 300, (1, L)))
+        ids[0, -1] = S
+        noise = {s: synth.Gen(1000 * (seed + i) + s).normal((2, 64), 1.0, mat=False) for s in range(16)}
+        reqs.append({"input_ids": ids, "attention_mask": torch.ones_like(ids), "_forced_tokens": plans[i % len(plans)],
+                     "_noise_fn": (lambda nz: (lambda step, n2: nz[step]))(noise)})
+    return reqs
+
+
+def test_continuous_admission_equals_one_by_one(monkeypatch):
+    """generate_continuous(): 6 queued utterances over 2 slots.  A slot freed by EOS is refilled on the next iteration while
+    the other utterance keeps decoding (the batch is never drained), and every utterance comes out exactly as generate()
+    produces it alone (tokens identical, waveform rel-L2 <= 1e-5 through the oracle-backed engine)."""
+    from test_oracle_golden import _oracle_small
+    from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference
+    cfgd = {"decoder_config": {"max_position_embeddings": 4096}, "diffusion_head_config": {"ddpm_num_inference_steps": 5},
+            "acoustic_tokenizer_config": {"fix_std": 0.5, "std_dist_type": "gaussian"}}
+    reqs = _requests(6, 3)
+    with fake_engine.cpu_cuda_shims(monkeypatch):
+        solo = []
+        for r in reqs:
+            m1 = VibeVoiceForConditionalGenerationInference(cfgd, fake_engine.FakeEngine(_oracle_small(), n_slots=1), model_dtype=torch.float32)
+            m1.set_speech_factors(0.2, -0.05)
+            m1.set_ddpm_inference_steps(5)
+            solo.append(m1.generate(input_ids=r["input_ids"], attention_mask=r["attention_mask"], cfg_scale=1.3, tokenizer=TOK,
+                                    generation_config={"do_sample": False}, _forced_tokens=[r["_forced_tokens"]],
+                                    _noise_fn=r["_noise_fn"], show_progress_bar=False))
+        eng = fake_engine.FakeEngine(_oracle_small(), n_slots=2)
+        m = VibeVoiceForConditionalGenerationInference(cfgd, eng, model_dtype=torch.float32)
+        m.set_speech_factors(0.2, -0.05)
+        m.set_ddpm_inference_steps(5)
+        m.concurrent_codecs = False
+        outs = m.generate_continuous(reqs, tokenizer=TOK, generation_config={"do_sample": False}, cfg_scale=1.3)
+    assert len(outs) == 6
+    for a, b in zip(outs, solo):
+        assert torch.equal(a.sequences.cpu(), b.sequences.cpu())
+        assert torch.equal(a.reach_max_step_sample.cpu(), b.reach_max_step_sample.cpu())
+        assert (a.speech_outputs[0] is None) == (b.speech_outputs[0] is None)
+        if b.speech_outputs[0] is not None:
+            assert a.speech_outputs[0].shape == b.speech_outputs[0].shape
+            d = (a.speech_outputs[0] - b.speech_outputs[0]).norm() / b.speech_outputs[0].norm()
+            assert float(d) <= 1e-5, float(d)         # the CPU BLAS blocks a 2-row and a 1-row matmul differently; nothing else differs
+    st = m.last_stats
+    assert st["max_in_flight"] == 2
+    adm = st["admissions"]
+    assert [a[1] for a in adm] == list(range(6))                    # queue order
+    assert adm[0][0] == 0 and adm[1][0] == 0 and all(a[0] > 0 for a in adm[2:])
+    # no drain: the total number of iterations is far below the sum of the utterances' own lengths
+    own = [len(r["_forced_tokens"]) for r in reqs]
+    assert st["iterations"] < sum(own) and st["iterations"] >= max(own)
+
+
+def test_batch_limit_is_checked_at_entry(monkeypatch):
+    from test_oracle_golden import _oracle_small
+    from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference
+    cfgd = {"decoder_config": {"max_position_embeddings": 4096}, "diffusion_head_config": {"ddpm_num_inference_steps": 5},
+            "acoustic_tokenizer_config": {"fix_std": 0.5, "std_dist_type": "gaussian"}}
+    with fake_engine.cpu_cuda_shims(monkeypatch):
+        m = VibeVoiceForConditionalGenerationInference(cfgd, fake_engine.FakeEngine(_oracle_small(), n_slots=16, max_rows=64), model_dtype=torch.float32)
+        ids = torch.full((9, 4), 301, dtype=torch.long)
+        with pytest.raises(ValueError, match="exceeds 8"):
+            m.generate(input_ids=ids, tokenizer=TOK, cfg_scale=1.3, max_new_tokens=2)
+
+
+def test_greedy_batch2_dense_logits_layout(monkeypatch):
+    """Free-running greedy decoding of a desynchronised batch of two through the C ABI's logits layout (a dense [n][n_valid]
+    block): every row must argmax over ITS OWN logits (rows >= 1 used to be read with the wrong stride)."""
+    from oracle import generate as ogen
+    from test_oracle_golden import _oracle_small
+    from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference
+    z = np.load(os.path.join(GOLD, "generate_forced_b2.npz"))
+    ids = torch.from_numpy(z["input_ids"])
+    mask = torch.from_numpy(z["attention_mask"])
+    noise = {}
+
+    def noise_fn(step, n2):
+        return noise.setdefault((step, n2), synth.Gen(77 * step + n2).normal((n2, 64), 1.0, mat=False))
+    tok = ogen.TokenIds(301, 302, 303, 304, None, 305)
+    oseq, oaud, omax = ogen.oracle_generate(_oracle_small(), tok, ids, mask, cfg_scale=1.3, num_steps=5, max_new_tokens=12, noise_fn=noise_fn)
+    cfgd = {"decoder_config": {"max_position_embeddings": 4096}, "diffusion_head_config": {"ddpm_num_inference_steps": 5},
+            "acoustic_tokenizer_config": {"fix_std": 0.5, "std_dist_type": "gaussian"}}
+    with fake_engine.cpu_cuda_shims(monkeypatch):
+        m = VibeVoiceForConditionalGenerationInference(cfgd, fake_engine.FakeEngine(_oracle_small(), n_slots=2), model_dtype=torch.float32)
+        m.set_speech_factors(0.2, -0.05)
+        m.set_ddpm_inference_steps(5)
+        m.concurrent_codecs = False
+        out = m.generate(input_ids=ids, attention_mask=mask, cfg_scale=1.3, tokenizer=TOK, max_new_tokens=12,
+                         generation_config={"do_sample": False}, _noise_fn=noise_fn, show_progress_bar=False)
+    assert torch.equal(out.sequences.cpu(), oseq)
+    assert not torch.equal(oseq[0, ids.shape[1]:], oseq[1, ids.shape[1]:])       # the two rows really decode differently
+
+
+# ---------------------------------------------------------------- streamers
+def test_streamer_thread_ends_with_the_last_sample():
+    from vibevoice_amd.streamer import AudioStreamer
+    n0 = threading.active_count()
+    streamers = []
+    for _ in range(6):
+        s = AudioStreamer(batch_size=2, timeout=5.0)
+        s.put(torch.ones(2, 1, 8), torch.tensor([0, 1]))
+        s.end()
+        assert [c.sum().item() for c in s.get_stream(0)] == [8.0]
+        streamers.append(s)
+    for s in streamers:
+        s._thread.join(timeout=5.0)
+        assert not s._thread.is_alive() and all(r is None for r in s._ring)
+    assert threading.active_count() <= n0
+    s = AudioStreamer(batch_size=1)
+    s.close()                                           # abandoned before any end(): close() stops the drain thread too
+    s._thread.join(timeout=5.0)
+    assert not s._thread.is_alive()
+
+
+def test_async_streamer_matches_the_reference_surface():
+    """AsyncAudioStreamer (streamer.py:150-264): put()/end() from a producer thread, `async for` on one sample and on the batch."""
+    from vibevoice_amd.streamer import AsyncAudioStreamer
+
+    async def run():
+        s = AsyncAudioStreamer(batch_size=2, timeout=5.0)
+
+        def producer():
+            for i in range(3):
+                s.put(torch.full((2, 1, 4), float(i)), torch.tensor([0, 1]))
+                time.sleep(0.005)
+            s.end(torch.tensor([1]))
+            s.put(torch.full((1, 1, 4), 9.0), torch.tensor([0]))
+            s.end()
+        t = threading.Thread(target=producer)
+        t.start()
+        got1 = [c.flatten()[0].item() async for c in s.get_stream(1)]
+        got0 = [c.flatten()[0].item() async for c in s.get_stream(0)]
+        t.join()
+        with pytest.raises(ValueError):
+            async for _ in s.get_stream(2):
+                pass
+        return got0, got1
+
+    got0, got1 = asyncio.run(run())
+    assert got1 == [0.0, 1.0, 2.0] and got0 == [0.0, 1.0, 2.0, 9.0]
+
+    async def run_batch():
+        s = AsyncAudioStreamer(batch_size=2, timeout=5.0)
+
+        def producer():
+            for i in range(4):
+                s.put(torch.full((2, 1, 4), float(i)), torch.tensor([0, 1]))
+            s.end()
+        threading.Thread(target=producer).start()
+        seen = {0: [], 1: []}
+        async for batch in s:
+            for idx, c in batch.items():
+                seen[idx].append(c.flatten()[0].item())
+        return seen
+    seen = asyncio.run(run_batch())
+    assert seen == {0: [0.0, 1.0, 2.0, 3.0], 1: [0.0, 1.0, 2.0, 3.0]}           # nothing lost, order kept per sample
+
+
+def test_pcm16_reference_arithmetic():
+    """The rule vv_audio_to_pcm16 implements (checked on the GPU in test_gpu_kernels.py), stated with numpy exactly as
+    demo/gradio_demo.py:1058-1073 does it."""
+    rng = np.random.default_rng(0)
+    for scale in (0.3, 2.5):
+        data = (rng.standard_normal(3200) * scale).astype(np.float32)
+        ref = data.copy()
+        if np.max(np.abs(ref)) > 1.0:
+            ref = ref / np.max(np.abs(ref))
+        ref = (ref * 32767).astype(np.int16)
+        peak = np.float32(np.abs(data).max())
+        mine = data / peak if peak > 1.0 else data
+        mine = np.trunc(mine * np.float32(32767.0)).astype(np.int16)
+        assert np.array_equal(ref, mine)

@@ -30,6 +30,7 @@ def test_generate_at_1p5b_layer_shapes():
                                                                        xsplit=3, use_graph=True, enc_frames=2)
     model.set_speech_factors(0.2, -0.05)
     model.set_ddpm_inference_steps(5)
+    model_bf16 = None
     try:
         d = cfg["decoder_config"]
 
@@ -80,5 +81,28 @@ def test_generate_at_1p5b_layer_shapes():
             assert rel_err(a, b) <= 5e-3, rel_err(a, b)
         assert out.speech_outputs[0].shape[-1] == 3 * 3200
         assert rel_err(out.speech_outputs[0][0], oaud[0][0]) <= 1e-2
+        # ---- the configuration bench.py times: xsplit=1 (bf16 activations in the MFMAs) + hipGraph replay, at these widths.
+        # Teacher-forced per step against the same oracle trace: latent / hidden rel-L2 <= 5e-2, frame RMS +-0.5 dB.
+        model.engine.close()
+        model_bf16 = VibeVoiceForConditionalGenerationInference.from_state_dict(cfg, sd, torch.float32, None, n_slots=1, max_ctx=512,
+                                                                                xsplit=1, use_graph=True, enc_frames=2)
+        model_bf16.set_speech_factors(0.2, -0.05)
+        model_bf16.set_ddpm_inference_steps(5)
+        btr = ogen.Trace()
+        outb = model_bf16.generate(input_ids=ids, attention_mask=mask, speech_tensors=wav, speech_masks=smask, speech_input_mask=sim,
+                                   cfg_scale=1.3, tokenizer=T, generation_config={"do_sample": False}, _forced_tokens=forced,
+                                   _noise_fn=noise_fn, _prefill_noise=pre, _trace=btr, show_progress_bar=False,
+                                   _teacher_embeds=lambda step, rows: otr.next_embeds[step][rows])
+        assert torch.equal(outb.sequences.cpu(), oseq)
+        for a, b in zip(btr.latents, otr.latents):
+            assert rel_err(a, b) <= 5e-2, rel_err(a, b)
+        for a, b in zip(btr.pos_hidden, otr.pos_hidden):
+            assert rel_err(a, b) <= 5e-2, rel_err(a, b)
+        wa, wb = outb.speech_outputs[0][0].float().cpu(), oaud[0][0]
+        for f in range(3):
+            fa, fb = wa[f * 3200:(f + 1) * 3200], wb[f * 3200:(f + 1) * 3200]
+            assert abs(20 * torch.log10(fa.norm() / fb.norm())) <= 0.5
     finally:
         model.engine.close()
+        if model_bf16 is not None:
+            model_bf16.engine.close()

@@ -259,3 +259,108 @@ def test_pinned_ring_streamer_delivers_the_generated_audio(sm):
         chunks = [c.flatten() for c in streamer.get_stream(b)]
         assert len(chunks) == (4, 6)[b]
         assert torch.equal(torch.cat(chunks), out.speech_outputs[b].cpu().flatten())
+
+
+def test_generate_greedy_batch2_free_running(sm):
+    """Free-running argmax on a desynchronised batch of TWO: vv_lm_logits writes a dense [n][n_valid] block
+    and every row must pick from its own logits.  Row 1 of a B=2 run used to read stale data; forced-token tests cannot
+    see that."""
+    o, h = run_both(sm, 2, None, with_speech=True, seed=61, max_new_tokens=10)
+    check(o, h)
+    oseq = o[0]
+    assert not torch.equal(oseq[0, -10:], oseq[1, -10:])      # the rows really decode different tokens
+
+
+def _mk_requests(s, n, seed):
+    g = synth.Gen(seed)
+    plans = [[D, D, D, X], [D, E, S, D, D, D, D, X], [D, D, X], [D, D, D, D, D, E, X], [D, X], [D, D, D, E, S, D, X], [D, D, D, D, X]]
+    reqs = []
+    for i in range(n):
+        L = 9 + 3 * (i % 4)
+        ids = torch.from_numpy(g.rng.integers(0, 300, (1, L)))
+        ids[0, -1] = S
+        bank = {st: synth.Gen(1000 * (seed + i) + st).normal((2, 64), 1.0, mat=False) for st in range(16)}
+        reqs.append({"input_ids": ids, "attention_mask": torch.ones_like(ids), "_forced_tokens": plans[i % len(plans)],
+                     "_noise_fn": (lambda nz: (lambda step, n2: nz[step]))(bank)})
+    return reqs
+
+
+def test_continuous_admission_on_the_engine(sm):
+    """generate_continuous(): 5 queued utterances through the engine's 2 slots -- a freed slot (KV caches, codec states) is
+    re-used by the next utterance while the other keeps decoding -- each against the oracle loop run on it alone."""
+    from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference
+    reqs = _mk_requests(sm, 5, 7)
+    cfgd = {"decoder_config": {"max_position_embeddings": sm.lmcfg.max_pos},
+            "diffusion_head_config": {"ddpm_num_inference_steps": 5},
+            "acoustic_tokenizer_config": {"fix_std": 0.5, "std_dist_type": "gaussian"}}
+    m = VibeVoiceForConditionalGenerationInference(cfgd, sm.eng, model_dtype=torch.float32)
+    m.set_speech_factors(sm.scaling, sm.bias)
+    m.set_ddpm_inference_steps(5)
+    tok = types.SimpleNamespace(speech_start_id=S, speech_end_id=E, speech_diffusion_id=D, eos_token_id=X,
+                                bos_token_id=None, pad_token_id=TOK.pad_token_id)
+    outs = m.generate_continuous(reqs, tokenizer=tok, generation_config={"do_sample": False}, cfg_scale=1.3)
+    assert m.last_stats["max_in_flight"] == 2 and len(m.last_stats["admissions"]) == 5
+    om = sm.oracle_model(kv_round_bf16=True)
+    for r, o in zip(reqs, outs):
+        oseq, oaud, omax = ogen.oracle_generate(om, TOK, r["input_ids"], r["attention_mask"], cfg_scale=1.3, num_steps=5,
+                                                noise_fn=r["_noise_fn"], forced_tokens=[r["_forced_tokens"]])
+        assert torch.equal(o.sequences.cpu(), oseq)
+        assert rel_err(o.speech_outputs[0][0], oaud[0][0]) <= 1e-2, rel_err(o.speech_outputs[0][0], oaud[0][0])
+
+
+def test_generate_batch8_desynchronised():
+    """Eight utterances in one batch (BASELINE config 4's per-GPU batch), every row on its own token plan: 16-row LM passes,
+    16-row diffusion-head GEMV forms, per-utterance codec chains on side streams -- against the oracle loop."""
+    from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference
+    s = build_small(synth.LMCfg(), xsplit=2, n_slots=8, max_ctx=256, max_rows=16, use_graph=True)
+    try:
+        B = 8
+        g = synth.Gen(88)
+        L0 = 14
+        ids = torch.full((B, L0), TOK.pad_token_id, dtype=torch.long)
+        mask = torch.zeros((B, L0), dtype=torch.long)
+        for b in range(B):
+            n = L0 - (b % 4)
+            row = torch.from_numpy(g.rng.integers(0, 300, (n,)))
+            row[-1] = S
+            ids[b, L0 - n:] = row
+            mask[b, L0 - n:] = 1
+        forced = [[D, D, D, D, X], [D, E, S, D, D, X], [D, D, X], [D, D, D, E, S, D, X], [D, X], [D, D, D, D, D, X],
+                  [D, E, S, D, E, S, D, X], [D, D, D, X]]
+        bank = {}
+
+        def noise_fn(step, n2):
+            return bank.setdefault((step, n2), synth.Gen(5000 + step * 17 + n2).normal((n2, 64), 1.0, mat=False))
+        om = s.oracle_model(kv_round_bf16=True)
+        otr = ogen.Trace()
+        oseq, oaud, omax = ogen.oracle_generate(om, TOK, ids, mask, cfg_scale=1.3, num_steps=5, noise_fn=noise_fn,
+                                                forced_tokens=forced, trace=otr)
+        cfgd = {"decoder_config": {"max_position_embeddings": s.lmcfg.max_pos},
+                "diffusion_head_config": {"ddpm_num_inference_steps": 5},
+                "acoustic_tokenizer_config": {"fix_std": 0.5, "std_dist_type": "gaussian"}}
+        m = VibeVoiceForConditionalGenerationInference(cfgd, s.eng, model_dtype=torch.float32)
+        m.set_speech_factors(s.scaling, s.bias)
+        m.set_ddpm_inference_steps(5)
+        tok = types.SimpleNamespace(speech_start_id=S, speech_end_id=E, speech_diffusion_id=D, eos_token_id=X,
+                                    bos_token_id=None, pad_token_id=TOK.pad_token_id)
+        htr = ogen.Trace()
+        out = m.generate(input_ids=ids, attention_mask=mask, cfg_scale=1.3, tokenizer=tok, generation_config={"do_sample": False},
+                         _forced_tokens=forced, _noise_fn=noise_fn, _trace=htr, show_progress_bar=False)
+        # xsplit=2 (the two-term activation mode the 16-row GEMV forms exist in): ~fp24-class arithmetic
+        check((oseq, oaud, omax, otr), (out, htr), lat_tol=2e-2, wav_tol=3e-2)
+    finally:
+        s.eng.close()
+
+
+def test_graph_cache_is_bounded(monkeypatch):
+    """the hipGraph cache must not grow without bound.  With a cap of 4 executables a generate() run keeps
+    evicting and re-capturing and still matches the oracle."""
+    monkeypatch.setenv("VVHIP_GRAPH_CAP", "4")
+    s = build_small(synth.LMCfg(), xsplit=3, n_slots=1, max_ctx=512, use_graph=True)
+    try:
+        forced = [[D, D, D, D, E, S, D, D, D, X]]
+        o, h = run_both(s, 1, forced, with_speech=True)
+        check(o, h)
+        assert 0 < s.eng.stat(1) <= 4
+    finally:
+        s.eng.close()

@@ -104,24 +104,74 @@ def test_gemm_tile_prefill_shapes(sm, pro, epi, xs, tol):
     assert rel_err(y, ref) <= tol, rel_err(y, ref)
 
 
-def test_lm_prefill_one_pass_matches_chunked(sm):
-    """A 150-token prompt prefilled in one launch (prefill attention kernel: 16 query rows per workgroup) gives the same
-    last hidden state / next-step output as the 16-row chunking the other LM tests use."""
-    from vibevoice_amd.engine import Engine
+def test_lm_prefill_one_pass_and_ragged_chunks_match_the_oracle(sm):
+    """A 150-token prompt prefilled (a) in one launch (prefill attention kernel: 16 query rows per workgroup) and (b) in ragged
+    7-row chunks (rope/append + split + merge kernels, below 8 rows): both against the oracle's causal forward."""
     eng = sm.eng
     H = sm.lmcfg.hidden
     g = synth.Gen(4242)
     n = min(150, eng.cfg.max_rows)
-    x = dev(g.normal((n, H), 1.0, mat=False), eng)
+    x = g.normal((n, H), 1.0, mat=False)
+    m = sm.oracle_lm(kv_round_bf16=True)
+    ref = m.forward(x, m.new_cache())
+    xd = dev(x, eng)
     hid_a = eng.new(n, H)
     hid_b = eng.new(n, H)
     with torch.cuda.stream(eng.stream):
-        eng.lm_forward([(0, j) for j in range(n)], x, hid_a)                 # cache 0: one pass (or the largest the engine allows)
-        for i0 in range(0, n, 7):                                            # cache 1: ragged 7-row chunks (split + merge path below 8 rows)
+        eng.lm_forward([(0, j) for j in range(n)], xd, hid_a)                # cache 0: one pass
+        for i0 in range(0, n, 7):                                            # cache 1: ragged 7-row chunks
             k = min(7, n - i0)
-            eng.lm_forward([(1, i0 + j) for j in range(k)], x[i0:i0 + k], hid_b[i0:i0 + k])
+            eng.lm_forward([(1, i0 + j) for j in range(k)], xd[i0:i0 + k], hid_b[i0:i0 + k])
     eng.sync()
-    assert rel_err(hid_a, hid_b) <= 5e-4, rel_err(hid_a, hid_b)
+    assert rel_err(hid_a, ref) <= 5e-4, rel_err(hid_a, ref)
+    assert rel_err(hid_b, ref) <= 5e-4, rel_err(hid_b, ref)
+
+
+def test_pcm16_matches_the_gradio_conversion(sm):
+    """vv_audio_to_pcm16 == demo/gradio_demo.py:1058-1073 (convert_to_16_bit_wav) applied per chunk, bit for bit: a loud
+    chunk is peak-normalised, a quiet one is not; truncation toward zero."""
+    eng = sm.eng
+    rng = np.random.default_rng(3)
+    chunks = np.stack([(rng.standard_normal(3200) * sc).astype(np.float32) for sc in (0.2, 3.0, 0.999, 1.7)])
+    chunks[2] = np.clip(chunks[2], -1.0, 1.0)
+    ref = []
+    for data in chunks:
+        d = data.copy()
+        if np.max(np.abs(d)) > 1.0:
+            d = d / np.max(np.abs(d))
+        ref.append((d * 32767).astype(np.int16))
+    ref = np.stack(ref)
+    out = torch.empty(4, 3200, dtype=torch.int16, device=eng.device)
+    with torch.cuda.stream(eng.stream):
+        eng.audio_to_pcm16(dev(torch.from_numpy(chunks), eng), out)
+    eng.sync()
+    assert np.array_equal(out.cpu().numpy(), ref)
+
+
+def test_streamer_pcm16_mode(sm):
+    """AudioStreamer(pcm16=engine): the consumer receives int16 chunks converted on the device."""
+    from vibevoice_amd.streamer import AudioStreamer
+    eng = sm.eng
+    st = AudioStreamer(batch_size=2, timeout=20.0, pcm16=eng)
+    x = (torch.randn(2, 1, 3200, generator=torch.Generator().manual_seed(1)) * 2.0).to(eng.device)
+    st.put(x.to(torch.bfloat16), torch.tensor([0, 1]))
+    st.end()
+    for b in range(2):
+        (c,) = list(st.get_stream(b))
+        assert c.dtype == torch.int16 and c.shape == (1, 3200)
+        d = x[b, 0].to(torch.bfloat16).float().cpu().numpy()
+        d = d / np.max(np.abs(d)) if np.max(np.abs(d)) > 1.0 else d
+        assert np.array_equal(c[0].numpy(), (d * 32767).astype(np.int16))
+    st._thread.join(timeout=5.0)
+    assert not st._thread.is_alive()
+
+
+def test_create_rejects_unsupported_gqa_groups():
+    from vibevoice_amd.engine import Engine, EngineConfig, EngineError
+    with pytest.raises(EngineError, match="GQA group"):
+        Engine(EngineConfig(lm_hidden=128 * 34, lm_layers=1, lm_heads=34, lm_kv_heads=2, lm_inter=256, lm_vocab=64, lm_head_dim=128))
+    with pytest.raises(EngineError, match="GQA group"):
+        Engine(EngineConfig(lm_hidden=128 * 6, lm_layers=1, lm_heads=6, lm_kv_heads=4, lm_inter=256, lm_vocab=64, lm_head_dim=128))
 
 
 @pytest.mark.parametrize("T", [8, 40, 203])

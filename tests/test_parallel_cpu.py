@@ -1,0 +1,107 @@
+"""world_size-2 gloo tests of the multi-GPU host path: packed-blob weight broadcast, utterance sharding,
+per-rank continuous decoding through the product's host loop (oracle-backed fake engine), audio gathered on rank 0."""
+import socket
+import types
+
+import torch
+
+TOK = types.SimpleNamespace(speech_start_id=301, speech_end_id=302, speech_diffusion_id=303, eos_token_id=304,
+                            bos_token_id=None, pad_token_id=305)
+CFGD = {"decoder_config": {"max_position_embeddings": 4096}, "diffusion_head_config": {"ddpm_num_inference_steps": 5},
+        "acoustic_tokenizer_config": {"fix_std": 0.5, "std_dist_type": "gaussian"}}
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _model(n_slots):
+    import fake_engine
+    from test_oracle_golden import _oracle_small
+    from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference
+    m = VibeVoiceForConditionalGenerationInference(CFGD, fake_engine.FakeEngine(_oracle_small(), n_slots=n_slots), model_dtype=torch.float32)
+    m.set_speech_factors(0.2, -0.05)
+    m.set_ddpm_inference_steps(5)
+    m.concurrent_codecs = False
+    return m
+
+
+def _worker(rank, world, port, q):
+    import contextlib
+    import torch.distributed as dist
+    import fake_engine
+    from test_dropin_cpu import _requests
+    from vibevoice_amd import parallel
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    # ---- packed-blob broadcast: 3 tensors, two buckets forced by a tiny bucket size ----
+    shapes = [("a.weight", (4, 6)), ("b.bias", (5,)), ("c.weight", (3, 2, 2)), ("d.weight", (300,))]
+
+    def make(name, shape):
+        assert dist.get_rank() == 0                      # only the source rank materialises weights
+        return torch.randn(shape, generator=torch.Generator().manual_seed(len(name) + shape[0]))
+    st = {}
+    got = {k: v.clone() for k, v in parallel.broadcast_packed(shapes, make, "cpu", torch.float32, bucket_bytes=1024, stats=st)}
+    checksum = float(sum(v.double().sum() for v in got.values()))
+    # ---- sharded generation: 5 utterances over 2 ranks, each rank 2 slots ----
+    reqs = _requests(5, 3)
+
+    class MP:                                            # monkeypatch stand-in for cpu_cuda_shims
+        def setattr(self, obj, name, val):
+            setattr(obj, name, val)
+    with fake_engine.cpu_cuda_shims(MP()):
+        res = parallel.generate_sharded(_model(2), reqs, gather_to=0, tokenizer=TOK, generation_config={"do_sample": False}, cfg_scale=1.3)
+    payload = None
+    if res is not None:
+        payload = [(r.sequences.tolist(), None if r.speech_outputs[0] is None else r.speech_outputs[0].double().sum().item(),
+                    None if r.speech_outputs[0] is None else r.speech_outputs[0].shape[-1]) for r in res]
+    q.put((rank, checksum, st["collectives"], st["bytes"], [tuple(v.shape) for v in got.values()], payload))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_packed_broadcast_and_sharded_generation():
+    import pytest
+    import torch.multiprocessing as mp
+    import fake_engine
+    from test_dropin_cpu import _requests
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, c0, n0, b0, sh0, pay0), (r1, c1, n1, b1, sh1, pay1) = res
+    assert c0 == c1 and sh0 == sh1 == [(4, 6), (5,), (3, 2, 2), (300,)]            # identical weights on both ranks
+    assert n0 == n1 == 2 and b0 == b1                                                # two buckets = two collectives, not four
+    assert pay1 is None and pay0 is not None and len(pay0) == 5                      # audio comes back to rank 0 from BOTH ranks
+    # reference: the same 5 utterances decoded in this process, one engine
+    reqs = _requests(5, 3)
+
+    class MP:
+        def setattr(self, obj, name, val):
+            setattr(obj, name, val)
+    import contextlib
+    saved = {n: getattr(torch.cuda, n) for n in ("Event", "Stream", "stream")}
+    saved_pin = torch.Tensor.pin_memory
+    try:
+        with fake_engine.cpu_cuda_shims(MP()):
+            solo = _model(2).generate_continuous(reqs, tokenizer=TOK, generation_config={"do_sample": False}, cfg_scale=1.3)
+    finally:
+        for n, v in saved.items():
+            setattr(torch.cuda, n, v)
+        torch.Tensor.pin_memory = saved_pin
+    from vibevoice_amd.parallel import shard_utterances
+    shards = shard_utterances([int(r["input_ids"].shape[-1]) for r in reqs], 2)
+    assert all(len(s) >= 2 for s in shards)                                          # both ranks really decoded something
+    for (seq, asum, alen), s in zip(pay0, solo):
+        assert seq == s.sequences.tolist()
+        a = s.speech_outputs[0]
+        assert (alen is None) == (a is None)
+        if a is not None:
+            assert alen == a.shape[-1] and abs(asum - a.double().sum().item()) <= 1e-3 * max(1.0, abs(asum))

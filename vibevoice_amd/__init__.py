@@ -5,4 +5,4 @@
 from .engine import Engine, EngineConfig, EngineError  # noqa: F401
 from .modeling import VibeVoiceForConditionalGenerationInference, VibeVoiceGenerationOutput  # noqa: F401
 from .lora import load_lora_assets  # noqa: F401
-from .streamer import AudioStreamer  # noqa: F401
+from .streamer import AsyncAudioStreamer, AudioStreamer  # noqa: F401

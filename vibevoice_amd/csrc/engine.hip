@@ -551,12 +551,12 @@ static int graphed(vv_ctx* ctx, const std::string& key, hipStream_t st, F&& body
         hipGraphDestroy(graph);
         if (ctx->graphs.size() >= ctx->graph_cap) {
             // a long-running process with varied launch shapes (prefill remainders over temporary buffers) must not
-            // accumulate executables: drop the least-recently-used quarter (their work has been enqueued already;
-            // hipGraphExecDestroy defers the release until the launches in flight have finished)
+            // accumulate executables: drop the least-recently-used quarter.  Rare (a cache miss at the cap), so it may wait
+            // for every stream: replays of the victims may still be running on this or a side stream.
             std::vector<std::pair<uint64_t, std::string>> order;
             for (auto& g : ctx->graphs) order.push_back({g.second.last_use, g.first});
             std::sort(order.begin(), order.end());
-            HIPCHK(ctx, hipStreamSynchronize(st));
+            HIPCHK(ctx, hipDeviceSynchronize());
             for (size_t i = 0; i < order.size() / 4 + 1; ++i) {
                 auto v = ctx->graphs.find(order[i].second);
                 hipGraphExecDestroy(v->second.exec);

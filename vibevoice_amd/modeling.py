@@ -679,6 +679,12 @@ class VibeVoiceForConditionalGenerationInference:
                 trace.latents.append(self._latent[:n].cpu())
                 trace.semantic.append(self._sem[:n].cpu())
         if live:
+            if S["teacher"] is not None:
+                # test hook (SURVEY 8d "teacher-forced per step"): the next step consumes the embeddings the oracle fed its LM at
+                # this step, so a bf16-mode run is compared step by step without the autoregressive feedback compounding
+                te = S["teacher"](S["step"], [u.idx for u in live])
+                if te is not None:
+                    nxt_x[:len(live)].copy_(te.to(self.device, torch.float32))
             self._x_in[:len(live)].copy_(nxt_x[:len(live)])
             if trace is not None:
                 trace.next_embeds.append(nxt_x[:len(live)].cpu())
@@ -717,6 +723,7 @@ class VibeVoiceForConditionalGenerationInference:
                     eos_id=eos_id, cfg_scale=cfg_scale, do_sample=do_sample, temperature=temperature,
                     trace=kwargs.pop("_trace", None), audio_streamer=audio_streamer, verbose=kwargs.get("verbose", False),
                     forced=kwargs.pop("_forced_tokens", None), noise_fn=kwargs.pop("_noise_fn", None), n_rows=n_rows,
+                    teacher=kwargs.pop("_teacher_embeds", None),
                     frame_rows=0, n_frames=0, step=0, sample_rows=None)
 
     # ------------------------------------------------------------------ generate

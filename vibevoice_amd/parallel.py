@@ -59,3 +59,89 @@ def aggregate_throughput(units_local: float, wall_local: float, device) -> Tuple
         dist.all_reduce(m, op=dist.ReduceOp.MAX)
         return float(s[0]), float(m[1])
     return float(t[0]), float(t[1])
+
+
+def broadcast_packed(shapes: Iterable[Tuple[str, tuple]], make: Callable[[str, tuple], torch.Tensor], device,
+                     dtype=torch.bfloat16, src: int = 0, bucket_bytes: int = 48 << 30, stats: dict = None
+                     ) -> Iterator[Tuple[str, torch.Tensor]]:
+    """The start-up collective of SURVEY 8(e): the whole parameter bundle travels as ONE packed blob per bucket (the 7B
+    bundle, 18.7 GB in bf16, is a single ncclBroadcast over the seven xGMI links of rank 0) instead of ~1000 per-tensor
+    collectives, each of which pays the RCCL launch + ring set-up latency.  Rank `src` writes make(name, shape) into its
+    slice of the blob; every rank then yields (name, view-into-the-blob).  A view is valid until the generator advances to
+    the next bucket (the engine's vv_upload re-packs it into its own storage at once).  `stats` receives bytes / seconds /
+    number of collectives.  bucket_bytes bounds the transient copy (default: one bucket for anything up to 48 GiB)."""
+    import time
+    rank, world = world_info()
+    esz = torch.empty(0, dtype=dtype).element_size()
+    items = [(n, tuple(s)) for n, s in shapes]
+    use_dist = dist.is_available() and dist.is_initialized()
+    is_cuda = torch.device(device).type == "cuda"
+    tot_bytes, tot_s, n_coll = 0, 0.0, 0
+    i = 0
+    while i < len(items):
+        # ---- one bucket: consecutive tensors, each slice 256-byte aligned ----
+        offs, j, cur = [], i, 0
+        while j < len(items):
+            ne = 1
+            for d in items[j][1]:
+                ne *= d
+            nb = (ne * esz + 255) // 256 * 256
+            if offs and cur + nb > bucket_bytes:
+                break
+            offs.append((cur // esz, ne))
+            cur += nb
+            j += 1
+        blob = torch.empty(cur // esz, dtype=dtype, device=device)
+        if rank == src:
+            for (name, shape), (o, ne) in zip(items[i:j], offs):
+                blob[o:o + ne].view(shape).copy_(make(name, shape))
+        if use_dist:
+            if is_cuda:
+                torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            dist.broadcast(blob, src=src)
+            if is_cuda:
+                torch.cuda.synchronize(device)
+            tot_s += time.perf_counter() - t0
+            n_coll += 1
+        tot_bytes += cur
+        for (name, shape), (o, ne) in zip(items[i:j], offs):
+            yield name, blob[o:o + ne].view(shape)
+        del blob
+        i = j
+    if stats is not None:
+        stats.update(bytes=tot_bytes, seconds=tot_s, collectives=n_coll, world=world,
+                     GBps=(tot_bytes / 1e9 / tot_s) if tot_s > 0 else None)
+
+
+def generate_sharded(model, requests: Sequence[dict], gather_to: int = 0, **gen_kwargs):
+    """Utterance-parallel generation over the ranks of the current process group (BASELINE config 4): the
+    requests (single-utterance processor outputs, as for model.generate_continuous) are assigned to ranks by
+    longest-prompt-first (max_steps ~ prompt length, modeling_vibevoice_inference.py:421), every rank decodes its own shard
+    with continuous batching on ITS GPU -- no collective inside the step loop -- and the finished utterances
+    (sequences, audio, stop flag; CPU tensors) are gathered once at the end.  Returns, on rank `gather_to`
+    (every rank if gather_to is None), the list of VibeVoiceGenerationOutput in request order; None elsewhere."""
+    from .modeling import VibeVoiceGenerationOutput
+    rank, world = world_info()
+    costs = [int(r["input_ids"].shape[-1]) for r in requests]
+    mine = shard_utterances(costs, world)[rank]
+    outs = model.generate_continuous([requests[i] for i in mine], **gen_kwargs) if mine else []
+    local = []
+    for i, o in zip(mine, outs):
+        audio = o.speech_outputs[0] if o.speech_outputs else None
+        local.append((i, o.sequences.cpu(), None if audio is None else audio.float().cpu(), o.reach_max_step_sample.cpu()))
+    if not (dist.is_available() and dist.is_initialized()) or world == 1:
+        gathered = [local]
+    elif gather_to is None:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, local)
+    else:
+        gathered = [None] * world if rank == gather_to else None
+        dist.gather_object(local, gathered, dst=gather_to)
+        if rank != gather_to:
+            return None
+    res = [None] * len(requests)
+    for part in gathered:
+        for i, seq, audio, flag in part:
+            res[i] = VibeVoiceGenerationOutput(sequences=seq, speech_outputs=[audio], reach_max_step_sample=flag)
+    return res
