@@ -61,12 +61,15 @@ def dev(t, eng):
     return out
 
 
+@pytest.mark.parametrize("xs,tol", [(3, 5e-4), (1, 3e-2)])
 @pytest.mark.parametrize("tag", ["7b", "0.5b"])
-def test_one_layer_at_real_widths(tag):
-    """prefill 70 tokens (one 64-row tile-GEMM pass + a 6-row remainder), 4 decode steps with a second cache in the same
-    launch, restricted logits, and the CFG sampler at the model's diffusion-head width."""
+def test_one_layer_at_real_widths(tag, xs, tol):
+    """prefill 70 tokens (one 64-row pass + a 6-row remainder), 4 decode steps with a second cache in the same launch,
+    restricted logits, and the CFG sampler at the model's diffusion-head width.  xs = 3: fp32-exact activations (general /
+    tile kernels, 16-row prefill attention); xs = 1: the bf16 mode bench.py times -- packed activations, the LDS-staged
+    128 x 128 GEMM and the 64-row prefill attention of prefill.hip at GQA group 7."""
     c = GEOM[tag]
-    s = build_fast(c, xsplit=3, max_ctx=256, max_rows=64, head_layers=1)
+    s = build_fast(c, xsplit=xs, max_ctx=256, max_rows=64, head_layers=1)
     eng = s.eng
     try:
         H = c.hidden
@@ -82,7 +85,7 @@ def test_one_layer_at_real_widths(tag):
             eng.lm_forward([(0, j) for j in range(64)], xd[:64], hid[:64])
             eng.lm_forward([(0, 64 + j) for j in range(L0 - 64)], xd[64:], hid[64:])
         eng.sync()
-        assert rel_err(hid, ref) <= 5e-4, rel_err(hid, ref)
+        assert rel_err(hid, ref) <= tol, rel_err(hid, ref)
         oc2 = m.new_cache()
         xs = g.normal((4, 2, H), 1.0, mat=False)
         for i in range(4):
@@ -92,8 +95,8 @@ def test_one_layer_at_real_widths(tag):
             with torch.cuda.stream(eng.stream):
                 eng.lm_forward([(0, L0 + i), (1, i)], dev(xs[i], eng), out)
             eng.sync()
-            assert rel_err(out[0], r1[0]) <= 5e-4, (i, rel_err(out[0], r1[0]))
-            assert rel_err(out[1], r2[0]) <= 5e-4, (i, rel_err(out[1], r2[0]))
+            assert rel_err(out[0], r1[0]) <= tol, (i, rel_err(out[0], r1[0]))
+            assert rel_err(out[1], r2[0]) <= tol, (i, rel_err(out[1], r2[0]))
         valid = [5, 17, 44, 2]
         eng.set_valid_tokens(valid)
         lg = eng.new(2 * len(valid))
@@ -101,7 +104,7 @@ def test_one_layer_at_real_widths(tag):
             eng.lm_logits(2, out, lg)
         eng.sync()
         ref_lg = torch.nn.functional.linear(torch.stack([r1[0], r2[0]]), s.lm_head)[:, valid]
-        assert rel_err(lg.view(2, len(valid)), ref_lg) <= 5e-4
+        assert rel_err(lg.view(2, len(valid)), ref_lg) <= max(tol, 5e-4)
         # diffusion head at this width: 2 utterances -> 4 head rows
         pos = g.normal((2, H), 1.0, mat=False)
         neg = g.normal((2, H), 1.0, mat=False)
@@ -113,7 +116,7 @@ def test_one_layer_at_real_widths(tag):
         with torch.cuda.stream(eng.stream):
             eng.diffusion_sample(2, dev(torch.cat([pos, neg]), eng), dev(noise[:2], eng), 1.3, lat)
         eng.sync()
-        assert rel_err(lat, refl) <= 2e-3, rel_err(lat, refl)
+        assert rel_err(lat, refl) <= (2e-3 if xs == 3 else 5e-2), rel_err(lat, refl)
     finally:
         eng.close()
 

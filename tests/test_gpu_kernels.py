@@ -104,6 +104,34 @@ def test_gemm_tile_prefill_shapes(sm, pro, epi, xs, tol):
     assert rel_err(y, ref) <= tol, rel_err(y, ref)
 
 
+@pytest.mark.parametrize("epi", [0, 1, 4, 3])
+@pytest.mark.parametrize("T,N,K", [(333, 4112, 416), (128, 128, 64), (2048, 1024, 1536), (70, 200, 96), (500, 36, 3584)])
+def test_prefill_gemm3(sm, epi, T, N, K):
+    """prefill.hip: activations packed to bf16 MFMA fragments (+ RMSNorm in the packing kernel for the BIAS case), 128 x 128
+    LDS-staged MFMA GEMM with the store / bias / residual / SwiGLU epilogues; ragged T (not a multiple of 128 / 16), N not a
+    multiple of the 128-feature block, an odd number of 32-wide k-tiles (K = 416 -> 13), one-block problems.  Against fp32
+    torch on the same bf16-representable weights: bf16 activations inside the MFMA -> rel-L2 <= 2e-2."""
+    eng = sm.eng
+    g = synth.Gen(7000 + T + N + K + epi)
+    w = g.normal((N, K), 1.0 / np.sqrt(K))
+    w2 = g.normal((N, K), 1.0 / np.sqrt(K))
+    x = g.normal((T, K), 1.0, mat=False)
+    nw = g.vec(K, 0.1, 1.0)
+    bias = g.vec(N, 0.3)
+    y0 = g.normal((T, N), 1.0, mat=False)
+    norm = epi == 1
+    xin = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-5) * nw if norm else x
+    acc = xin @ w.t()
+    ref = {0: acc, 1: acc + bias, 4: y0 + acc, 3: torch.nn.functional.silu(acc) * (xin @ w2.t())}[epi]
+    y = dev(y0.clone(), eng)
+    with torch.cuda.stream(eng.stream):
+        eng.gemm3_raw(eng.pack_matrix(w), dev(x, eng), y, N, K, epi=epi, w2p=eng.pack_matrix(w2) if epi == 3 else None,
+                      nw=dev(nw, eng) if norm else None, eps=1e-5, bias=dev(bias, eng) if epi == 1 else None)
+    eng.sync()
+    assert rel_err(y, ref) <= 2e-2, rel_err(y, ref)
+    assert max_err(y, ref) <= 6e-2, max_err(y, ref)              # no tile is missing or misplaced
+
+
 def test_lm_prefill_one_pass_and_ragged_chunks_match_the_oracle(sm):
     """A 150-token prompt prefilled (a) in one launch (prefill attention kernel: 16 query rows per workgroup) and (b) in ragged
     7-row chunks (rope/append + split + merge kernels, below 8 rows): both against the oracle's causal forward."""

@@ -38,6 +38,11 @@ int vv_normdw_sliced_launch(const float* xin, float* xout, float* nb, const floa
                             const float* gamma, int T, int C, float eps, hipStream_t s);
 int vv_normdw_launch(float* x, float* nb, const float* nw, const float* w, const float* b, const float* gamma, int T, int C,
                      float eps, hipStream_t s);
+int vv_normdw_rows_ok(int T, int C);
+int vv_normdw_rows_launch(const float* xin, float* xout, float* nb, const float* nw, const float* w, const float* b,
+                          const float* gamma, int T, int C, float eps, hipStream_t s);
+int vv_stem_conv_launch(const float* in, const void* wp, const float* bias, float* out, int T, int N, hipStream_t s);
+int vv_head_conv1_launch(const float* x, const void* wp, const float* bias, float* out, int T, int Cin, hipStream_t s);
 int vv_shift_rows_launch(const void* tab, int n_entries, int maxC, hipStream_t s);
 int vv_zero_hist_launch(const void* tab, int n_entries, hipStream_t s);
 int vv_cfg_dpm_launch(const float* eps, float* x, float* x0_prev, const float* coef, float cfg, int n, int L, hipStream_t s);
@@ -52,6 +57,12 @@ int vv_kv_import_launch(const void* k, const void* v, int src_bf16, void* kc, vo
 int vv_pcm16_launch(const float* x, short* out, int n, int samples, hipStream_t s);
 int vv_cvt_launch(const void* src, void* dst, int64_t n, int to_bf16, hipStream_t s);
 int vv_dw_transpose_launch(const float* src, float* dst, int C, hipStream_t s);
+int vv_pack_rows_launch(const float* x, int ldx, const float* nw, float eps, void* xp, int T, int K, hipStream_t s);
+int vv_unpack_rows_launch(const void* xp, float* x, int T, int K, hipStream_t s);
+int vv_gemm3_launch(const void* W, const void* W2, const void* Xp, float* Y, void* Yp, const float* bias, int T, int N, int K,
+                    int ldy, int epi, hipStream_t s);
+int vv_attn_prefill2_launch(int D, const float* q, const VVRow* rows, const void* kc, const void* vc, int R, int Hq, int Hkv,
+                            int64_t cache_stride, int64_t head_stride, float* out, hipStream_t s);
 int vv_block1d_supported(int C);
 int vv_gemv_ok(const VVGemm* a);
 int vv_tile_ok(const VVGemm* a, int xs);
@@ -151,6 +162,8 @@ struct vv_ctx {
     hipEvent_t ring_ev[RING] = {}; bool ring_used[RING] = {}; int ring_i = 0;
     float *h = nullptr, *qkv = nullptr, *qrot = nullptr, *attn = nullptr, *act = nullptr;
     float *h_parts = nullptr, *xh_parts = nullptr;     // K-split partial tensors of the residual streams (2 x [rows][H] each)
+    void *xp = nullptr, *actp = nullptr;               // prefill (prefill.hip): activations as packed bf16 MFMA fragments
+    bool tile3_ok = false, attn2_ok = false;
     bool ksplit_ok = true;
     float *pm = nullptr, *pl = nullptr, *po = nullptr;
     // head
@@ -351,7 +364,10 @@ static int build_codec(vv_ctx* ctx, CodecNet& net, const std::string& pfx, bool 
             s.xs = (float*)dalloc(ctx, xbytes);
             s.blocks = sw[i].blocks;
             s.fused = vv_block1d_supported(C[i]) && Tpf[i] >= 8 && !s.blocks.empty() && !getenv("VVHIP_NO_FUSED_BLOCK");
-            s.pp = !s.fused && !s.blocks.empty() && vv_normdw_sliced_ok(Tpf[i], C[i]) && !getenv("VVHIP_NO_SLICED_NORMDW");
+            // unfused stages ping-pong between xs and xs2 when a one-launch norm + depthwise-conv kernel exists for them:
+            // channel-sliced (T <= 8, C = 1024 / 2048) or row-tiled (middle stages, any T)
+            s.pp = !s.fused && !s.blocks.empty() && !getenv("VVHIP_NO_SLICED_NORMDW") &&
+                   (vv_normdw_sliced_ok(Tpf[i], C[i]) || (vv_normdw_rows_ok(Tpf[i], C[i]) && !getenv("VVHIP_NO_ROWS_NORMDW")));
             s.xs2 = (s.fused || s.pp) ? (float*)dalloc(ctx, xbytes) : nullptr;
             s.xfinal = ((s.fused || s.pp) && (s.blocks.size() & 1)) ? s.xs2 : s.xs;
             for (auto& b : s.blocks) {
@@ -469,9 +485,14 @@ static int run_codec(vv_ctx* ctx, CodecNet& net, int sl, int F, float* out, hipS
             const ConvG& cg = s.in;
             const float* X = (i == 0) ? net.in_buf[sl] : stages[i - 1].xfinal;
             const int Trows = cg.rows_per_frame * F;
-            VVGemm g = mk_gemm(cg.w, X, x, Trows, cg.N, cg.K, cg.ldx, cg.N);
-            g.epi = VV_EPI_BIAS; g.bias = cg.bias; g.nt = stream_w && Trows <= 16;
-            GEMM(g);
+            if (i == 0 && cg.K == 7 && cg.ldx == 1 && !getenv("VVHIP_NO_CONV_KERNELS")) {
+                ctx->launches++;                 // encoder stem: mono input, k = 7 (not an MFMA shape)
+                VVCHK(vv_stem_conv_launch(X, cg.w, cg.bias, x, Trows, cg.N, st));
+            } else {
+                VVGemm g = mk_gemm(cg.w, X, x, Trows, cg.N, cg.K, cg.ldx, cg.N);
+                g.epi = VV_EPI_BIAS; g.bias = cg.bias; g.nt = stream_w && Trows <= 16;
+                GEMM(g);
+            }
         }
         if (s.fused) {
             float* cur = s.xs;
@@ -490,6 +511,9 @@ static int run_codec(vv_ctx* ctx, CodecNet& net, int sl, int F, float* out, hipS
             if (s.pp && vv_normdw_sliced_ok(T, s.C)) {
                 ctx->launches += 1;
                 VVCHK(vv_normdw_sliced_launch(x, xo, b.nb, b.norm_w, b.dw_w, b.dw_b, b.gamma, T, s.C, eps, st));
+            } else if (s.pp && vv_normdw_rows_ok(T, s.C)) {
+                ctx->launches += 1;
+                VVCHK(vv_normdw_rows_launch(x, xo, b.nb, b.norm_w, b.dw_w, b.dw_b, b.gamma, T, s.C, eps, st));
             } else if (!s.pp && (size_t)T * s.C <= 8192 && (s.C & 3) == 0) {     // one workgroup is only faster for tiny row sets
                 ctx->launches += 1;
                 VVCHK(vv_normdw_launch(x, b.nb, b.norm_w, b.dw_w, b.dw_b, b.gamma, T, s.C, eps, st));
@@ -511,9 +535,14 @@ static int run_codec(vv_ctx* ctx, CodecNet& net, int sl, int F, float* out, hipS
     {   // head conv
         const ConvG& cg = net.head;
         Stage& s = stages[ns - 1];
-        VVGemm g = mk_gemm(cg.w, s.xfinal, out, cg.rows_per_frame * F, cg.N, cg.K, cg.ldx, cg.N);
-        g.epi = VV_EPI_BIAS; g.bias = cg.bias;
-        GEMM(g);
+        if (cg.N == 1 && cg.K == 7 * cg.ldx && (cg.ldx & 3) == 0 && cg.ldx <= 1024 && !getenv("VVHIP_NO_CONV_KERNELS")) {
+            ctx->launches++;                     // decoder head: k = 7 conv to one channel
+            VVCHK(vv_head_conv1_launch(s.xfinal, cg.w, cg.bias, out, cg.rows_per_frame * F, cg.ldx, st));
+        } else {
+            VVGemm g = mk_gemm(cg.w, s.xfinal, out, cg.rows_per_frame * F, cg.N, cg.K, cg.ldx, cg.N);
+            g.epi = VV_EPI_BIAS; g.bias = cg.bias;
+            GEMM(g);
+        }
     }
     void* tab; int nt;
     if (codec_tables(ctx, net, sl, F, &tab, &nt)) return -1;
@@ -646,6 +675,13 @@ extern "C" int vv_create(const vv_config* cfg, vv_ctx** out) {
     ctx->qrot = (float*)dalloc(ctx, (size_t)R * Hq * D * 4);
     ctx->attn = (float*)dalloc(ctx, (size_t)R * Hq * D * 4);
     ctx->act = (float*)dalloc(ctx, (size_t)R * I * 4);
+    if (R >= 64 && (H % 8) == 0 && ((Hq * D) % 8) == 0 && (I % 8) == 0) {
+        // prompt prefill in bf16-activation mode: LDS-staged 128 x 128 MFMA GEMM over packed activations (prefill.hip)
+        ctx->xp = dalloc(ctx, (size_t)vv_packed_elems(R, std::max(H, Hq * D)) * 2);
+        ctx->actp = dalloc(ctx, (size_t)vv_packed_elems(R, I) * 2);
+        ctx->tile3_ok = c.xsplit == 1 && !getenv("VVHIP_NO_TILE3");
+    }
+    ctx->attn2_ok = c.xsplit == 1 && !getenv("VVHIP_NO_ATTN2");
     ctx->rope_tab = dalloc(ctx, (size_t)c.max_ctx * (D / 2) * 8, false);
     ctx->tickets = (unsigned*)dalloc(ctx, (size_t)R * Hkv * 4);
     ctx->fused_attn_ok = !getenv("VVHIP_NO_FUSED_ATTN");
@@ -860,6 +896,29 @@ static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float*
     HIPCHK(ctx, hipMemcpyAsync(ctx->h, x_in, (size_t)R * H * 4, hipMemcpyDeviceToDevice, st));
     int hp = 0;                                    // extra parts the residual stream h currently consists of
     const int hps = ctx->c.max_rows * H;
+    if (contiguous && ctx->tile3_ok && R >= 64) {
+        // ---- prompt prefill, bf16-activation mode: packed activations + LDS-staged MFMA GEMMs + 64-row prefill attention ----
+        for (int l = l0; l < l1; ++l) {
+            auto& L = ctx->layers[l];
+            char* kl = (char*)ctx->kc + (size_t)l * ctx->layer_stride * 2;
+            char* vl = (char*)ctx->vc + (size_t)l * ctx->layer_stride * 2;
+            ctx->launches += 9;
+            VVCHK(vv_pack_rows_launch(ctx->h, H, L.ln1, c.lm_eps, ctx->xp, R, H, st));
+            VVCHK(vv_gemm3_launch(L.wqkv, nullptr, ctx->xp, ctx->qkv, nullptr, L.bqkv, R, QKV, H, QKV, VV_EPI_BIAS, st));
+            VVCHK(vv_rope_append_launch(D, ctx->qkv, ctx->rows_dev, ctx->inv_freq, ctx->qrot, kl, vl,
+                                        R, Hq, Hkv, ctx->cache_stride, ctx->head_stride, st));
+            VVCHK(vv_attn_prefill2_launch(D, ctx->qrot, ctx->rows_dev, kl, vl, R, Hq, Hkv, ctx->cache_stride, ctx->head_stride, ctx->attn, st));
+            VVCHK(vv_pack_rows_launch(ctx->attn, Hq * D, nullptr, 0.f, ctx->xp, R, Hq * D, st));
+            VVCHK(vv_gemm3_launch(L.wo, nullptr, ctx->xp, ctx->h, nullptr, nullptr, R, H, Hq * D, H, VV_EPI_RESID, st));
+            VVCHK(vv_pack_rows_launch(ctx->h, H, L.ln2, c.lm_eps, ctx->xp, R, H, st));
+            VVCHK(vv_gemm3_launch(L.wg, L.wu, ctx->xp, nullptr, ctx->actp, nullptr, R, I, H, 0, VV_EPI_SWIGLU, st));
+            VVCHK(vv_gemm3_launch(L.wd, nullptr, ctx->actp, ctx->h, nullptr, nullptr, R, H, I, H, VV_EPI_RESID, st));
+        }
+        ctx->launches++;
+        if (final_norm) VVCHK(vv_rmsnorm_rows_launch(ctx->h, H, hidden_out, H, ctx->lm_norm, R, H, c.lm_eps, st));
+        else HIPCHK(ctx, hipMemcpyAsync(hidden_out, ctx->h, (size_t)R * H * 4, hipMemcpyDeviceToDevice, st));
+        return 0;
+    }
     for (int l = l0; l < l1; ++l) {
         auto& L = ctx->layers[l];
         VVGemm g = mk_gemm(L.wqkv, ctx->h, ctx->qkv, R, QKV, H, H, QKV);
@@ -878,7 +937,9 @@ static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float*
             ctx->launches += 3;
             VVCHK(vv_rope_append_launch(D, ctx->qkv, ctx->rows_dev, ctx->inv_freq, ctx->qrot, kl, vl,
                                         R, Hq, Hkv, ctx->cache_stride, ctx->head_stride, st));
-            if (contiguous)      // prompt chunk: 16 query rows share every K/V fragment
+            if (contiguous && ctx->attn2_ok)      // prompt chunk, bf16 mode: 64 query rows x all heads of the group share every K/V block
+                VVCHK(vv_attn_prefill2_launch(D, ctx->qrot, ctx->rows_dev, kl, vl, R, Hq, Hkv, ctx->cache_stride, ctx->head_stride, ctx->attn, st));
+            else if (contiguous)      // prompt chunk: 16 query rows share every K/V fragment
                 VVCHK(vv_attn_prefill_launch(D, c.xsplit, ctx->qrot, ctx->rows_dev, kl, vl, R, Hq, Hkv, ctx->cache_stride,
                                              ctx->head_stride, ctx->attn, st));
             else
@@ -1196,6 +1257,18 @@ extern "C" int vv_gemm_raw(void* stream, const void* w, const void* w2, const fl
     if (nontemporal > 1) g.dbg = reinterpret_cast<unsigned long long*>(const_cast<float*>(nscale));   // timing builds: nscale slot carries the stamp buffer
     if (g.dbg) g.nscale = nullptr;
     return vv_gemm_launch(g, xsplit, (hipStream_t)stream);
+}
+// tests: Y = f(X) . W^T through the prefill GEMM (prefill.hip): X fp32 [T][K] is packed (optionally RMS-normalised) into xp_scratch,
+// epi STORE/BIAS/RESID write fp32 Y [T][N]; epi SWIGLU (W = gate, W2 = up) writes packed bf16 into yp_scratch, unpacked to Y.
+extern "C" int vv_gemm3_raw(void* stream, const void* w, const void* w2, const float* x_dev, int T, int N, int K, int epi,
+                            const float* nw_dev, float eps, const float* bias_dev, float* y_dev, void* xp_scratch, void* yp_scratch) {
+    hipStream_t st = (hipStream_t)stream;
+    int r = vv_pack_rows_launch(x_dev, K, nw_dev, eps, xp_scratch, T, K, st);
+    if (r) return r;
+    r = vv_gemm3_launch(w, w2, xp_scratch, y_dev, yp_scratch, bias_dev, T, N, K, N, epi, st);
+    if (r) return r;
+    if (epi == VV_EPI_SWIGLU) r = vv_unpack_rows_launch(yp_scratch, y_dev, T, N, st);
+    return r;
 }
 extern "C" int vv_profile_begin(vv_ctx* ctx) {
     HIPCHK(ctx, hipDeviceSynchronize());

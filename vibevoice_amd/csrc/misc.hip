@@ -192,6 +192,106 @@ __global__ __launch_bounds__(256) void vv_normdw_sliced_kernel(const float* __re
     }
 }
 
+// Row-tiled form of the same fusion for the middle stages (C = 256 / 512, T = 40 .. 1000): one launch instead of
+// vv_rmsnorm_rows_kernel + vv_dwconv_res_kernel.  A workgroup owns RB output rows: it normalises rows t0-6 .. t0+RB-1 into
+// LDS (the six halo rows are re-derived from the input, or taken from the streaming history for t < 0), then applies the
+// depthwise conv + layer scale + residual.  Output goes to a DIFFERENT buffer (the stage ping-pongs): the neighbours are
+// still reading the halo rows of xin.  The owner of a row >= T-6 also writes its normed row into nb (the next frame's history).
+template <int RB>
+__global__ __launch_bounds__(256) void vv_normdw_rows_kernel(const float* __restrict__ xin, float* __restrict__ xout,
+                                                             float* __restrict__ nb, const float* __restrict__ nw,
+                                                             const float* __restrict__ w, const float* __restrict__ b,
+                                                             const float* __restrict__ gamma, int T, int C, float eps) {
+    extern __shared__ __attribute__((aligned(16))) float nrm_sh[];          // [RB + 6][C]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t0 = blockIdx.x * RB;
+    for (int rr = wave; rr < RB + 6; rr += 4) {
+        const int t = t0 - 6 + rr;
+        float* dst = nrm_sh + (size_t)rr * C;
+        if (t < 0) {
+            const float* hr = nb + (int64_t)(6 + t) * C;
+            for (int c = lane * 4; c < C; c += 256) *reinterpret_cast<float4*>(dst + c) = *reinterpret_cast<const float4*>(hr + c);
+        } else if (t < T) {
+            const float* xr = xin + (int64_t)t * C;
+            float s = 0.f;
+            for (int c = lane * 4; c < C; c += 256) {
+                const float4 v = *reinterpret_cast<const float4*>(xr + c);
+                s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            }
+            const float rs = rsqrtf(wave_sum(s) / (float)C + eps);
+            const bool keep = (rr >= 6) && (t >= T - 6);                    // this workgroup owns row t and it is part of the next history
+            for (int c = lane * 4; c < C; c += 256) {
+                const float4 v = *reinterpret_cast<const float4*>(xr + c);
+                const float4 ww = *reinterpret_cast<const float4*>(nw + c);
+                const float4 o = {v.x * rs * ww.x, v.y * rs * ww.y, v.z * rs * ww.z, v.w * rs * ww.w};
+                *reinterpret_cast<float4*>(dst + c) = o;
+                if (keep) *reinterpret_cast<float4*>(nb + (int64_t)(6 + t) * C + c) = o;
+            }
+        } else {
+            for (int c = lane * 4; c < C; c += 256) *reinterpret_cast<float4*>(dst + c) = float4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    __syncthreads();
+    const int C4 = C >> 2;
+    for (int e = tid; e < RB * C4; e += 256) {
+        const int r = e / C4, c = (e - r * C4) * 4;
+        const int t = t0 + r;
+        if (t >= T) break;
+        const float4 bb = *reinterpret_cast<const float4*>(b + c);
+        float4 acc = bb;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const float4 wj = *reinterpret_cast<const float4*>(w + (size_t)j * C + c);
+            const float4 nj = *reinterpret_cast<const float4*>(nrm_sh + (size_t)(r + j) * C + c);
+            acc.x += wj.x * nj.x; acc.y += wj.y * nj.y; acc.z += wj.z * nj.z; acc.w += wj.w * nj.w;
+        }
+        const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+        const float4 xv = *reinterpret_cast<const float4*>(xin + (int64_t)t * C + c);
+        *reinterpret_cast<float4*>(xout + (int64_t)t * C + c) = float4{xv.x + g.x * acc.x, xv.y + g.y * acc.y, xv.z + g.z * acc.z, xv.w + g.w * acc.w};
+    }
+}
+
+// element W[n][k] of a packed matrix (vv_common.h) with KT k-tiles
+__device__ __forceinline__ float packed_w(const __bf16* __restrict__ wp, int KT, int n, int k) {
+    return (float)wp[(((int64_t)(n >> 4) * KT + (k >> 5)) * 64 + (n & 15) + 16 * ((k & 31) >> 3)) * 8 + (k & 7)];
+}
+
+// Encoder stem: causal conv k = 7 over a MONO signal (Cin = 1): out[t][n] = b[n] + sum_j W[n][j] * in[t + j], `in` = the
+// time-major input buffer with its 6 history samples in front.  K = 7 is not an MFMA shape (the general GEMM kernel spent
+// 10 us on it); one output per thread, coalesced along n.  W packed [N][7].
+__global__ void vv_stem_conv_kernel(const float* __restrict__ in, const __bf16* __restrict__ wp, const float* __restrict__ bias,
+                                    float* __restrict__ out, int T, int N) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= T * N) return;
+    const int t = e / N, n = e - t * N;
+    float acc = bias[n];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) acc += packed_w(wp, 1, n, j) * in[t + j];
+    out[e] = acc;
+}
+
+// Decoder head: causal conv k = 7 from Cin channels to ONE output channel: out[t] = b + sum_{k < 7 Cin} W[0][k] * X[t * Cin + k]
+// (X = the last stage's buffer, 6 history rows in front: a window is 7 Cin contiguous floats).  Four lanes per output sample.
+__global__ __launch_bounds__(256) void vv_head_conv1_kernel(const float* __restrict__ x, const __bf16* __restrict__ wp,
+                                                            const float* __restrict__ bias, float* __restrict__ out, int T, int Cin) {
+    extern __shared__ float wsh[];                       // [7 * Cin]
+    const int K = 7 * Cin, KT = (K + 31) >> 5;
+    for (int k = threadIdx.x; k < K; k += 256) wsh[k] = packed_w(wp, KT, 0, k);
+    __syncthreads();
+    const int g = blockIdx.x * 64 + (threadIdx.x >> 2), part = threadIdx.x & 3;
+    float acc = 0.f;
+    if (g < T) {
+        const float* xr = x + (int64_t)g * Cin;
+        for (int k = part * 4; k < K; k += 16) {
+            const float4 v = *reinterpret_cast<const float4*>(xr + k);
+            acc += v.x * wsh[k] + v.y * wsh[k + 1] + v.z * wsh[k + 2] + v.w * wsh[k + 3];
+        }
+    }
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    if (g < T && part == 0) out[g] = acc + bias[0];
+}
+
 // Streaming state carry: for every stateful buffer move rows [T, T+hist) -> [0, hist).
 // One lane owns one column and walks rows in ascending order, so overlapping moves
 // (T < hist) are race-free.                        grid (n_entries, col_chunks), block 256
@@ -373,6 +473,24 @@ int vv_normdw_sliced_launch(const float* xin, float* xout, float* nb, const floa
     if (!vv_normdw_sliced_ok(T, C) || xin == xout) return -1;
     if (C == 1024) hipLaunchKernelGGL((vv_normdw_sliced_kernel<1>), dim3(C / 256), dim3(256), 0, s, xin, xout, nb, nw, w, b, gamma, T, C, eps);
     else hipLaunchKernelGGL((vv_normdw_sliced_kernel<2>), dim3(C / 256), dim3(256), 0, s, xin, xout, nb, nw, w, b, gamma, T, C, eps);
+    return okk();
+}
+int vv_normdw_rows_ok(int T, int C) { return T >= 1 && (C & 3) == 0 && C >= 64 && C <= 1024; }
+int vv_normdw_rows_launch(const float* xin, float* xout, float* nb, const float* nw, const float* w, const float* b,
+                          const float* gamma, int T, int C, float eps, hipStream_t s) {
+    if (!vv_normdw_rows_ok(T, C) || xin == xout) return -1;
+    constexpr int RB = 8;
+    const size_t smem = (size_t)(RB + 6) * C * 4;
+    hipLaunchKernelGGL((vv_normdw_rows_kernel<RB>), dim3((T + RB - 1) / RB), dim3(256), smem, s, xin, xout, nb, nw, w, b, gamma, T, C, eps);
+    return okk();
+}
+int vv_stem_conv_launch(const float* in, const void* wp, const float* bias, float* out, int T, int N, hipStream_t s) {
+    hipLaunchKernelGGL(vv_stem_conv_kernel, dim3((T * N + 255) / 256), dim3(256), 0, s, in, (const __bf16*)wp, bias, out, T, N);
+    return okk();
+}
+int vv_head_conv1_launch(const float* x, const void* wp, const float* bias, float* out, int T, int Cin, hipStream_t s) {
+    if ((Cin & 3) || (((uintptr_t)x) & 15) || 7 * Cin * 4 > 48 * 1024) return -1;
+    hipLaunchKernelGGL(vv_head_conv1_kernel, dim3((T + 63) / 64), dim3(256), (size_t)7 * Cin * 4, s, x, (const __bf16*)wp, bias, out, T, Cin);
     return okk();
 }
 int vv_shift_rows_launch(const void* tab, int n_entries, int maxC, hipStream_t s) {

@@ -1,0 +1,478 @@
+// prefill.hip -- the MFMA-bound half of the path: prompt prefill in the bf16-activation mode (xsplit = 1).
+//
+// The decode kernels (gemv.hip / attn.hip) are built around streaming weights once per token; a 10 K-token 7B prompt is
+// 190 TFLOP of dense work instead, and the round-1 prefill (tile.hip: 64 x 128 tiles, fp32 activations converted per
+// tile, weights straight from L2 into VGPRs; attention re-reading K/V for every head and every 16 query rows) sat at
+// ~0.4 PFLOP/s for the GEMMs with a third of the time in attention.  This file is the prefill path rebuilt around LDS:
+//
+//   vv_pack_rows_kernel     fp32 rows [T][K] (+ RMSNorm) -> bf16 MFMA fragments [T/16][K/32][64 lanes][8]: the activation
+//                           becomes a ready-made B operand, exactly like the packed weights are ready-made A operands
+//                           (vv_common.h), so a GEMM stage is a straight 1 KiB-per-wave-instruction copy into LDS.
+//   vv_gemm3_kernel         Y[t][n] (op)= sum_k X[t][k] W[n][k]: 128 rows x 128 features per workgroup, 4 waves of
+//                           64 x 64 (4 x 4 MFMA 16x16x32 accumulators), K stepped 64 at a time; both operands arrive in
+//                           LDS by global_load_lds_dwordx4 (no VGPR round trip, lane-linear = the fragment order, no bank
+//                           conflicts on the ds_read_b128 that follow); epilogues bias / residual / SwiGLU, the SwiGLU one
+//                           writing its result as packed bf16 fragments for the down projection.  Workgroup ids are mapped
+//                           so that one XCD (own L2) owns a contiguous range of feature blocks.
+//   vv_attn_prefill2_kernel causal attention for a chunk of consecutive positions: a workgroup owns 64 query rows x one kv
+//                           head, streams every 32-position K/V block ONCE through a double-buffered LDS stage
+//                           (global_load_lds) and each wave runs the online softmax of one query head over 4 row tiles
+//                           (K / V fragments read from LDS once per block and reused for the 4 tiles): K/V traffic per
+//                           query row drops 4 x (rows) x G (heads) against vv_attn_prefill_kernel.
+#include <cstdlib>
+#include "vv_common.h"
+
+namespace {
+
+typedef __attribute__((address_space(1))) const void gvoid_t;
+typedef __attribute__((address_space(3))) void lvoid_t;
+
+// one wave-instruction: 64 lanes x 16 B from per-lane global addresses into LDS at (wave-uniform) dst + lane * 16
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds((gvoid_t*)gsrc, (lvoid_t*)lds_dst, 16, 0, 0);
+}
+
+// every LDS-DMA copy this wave issued has landed, then the workgroup barrier: after it every wave's copies are visible
+__device__ __forceinline__ void stage_sync() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+__device__ __forceinline__ float p_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------ activation packing
+// grid = ceil(T / 16) workgroups x 256 threads.  Rows >= T and columns >= K are written as zeros.
+__global__ __launch_bounds__(256) void vv_pack_rows_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ nw,
+                                                           float eps, u32x4* __restrict__ xp, int T, int K) {
+    __shared__ float rs_sh[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t0 = blockIdx.x * 16;
+    const int KT = (K + 31) >> 5;
+    if (nw != nullptr) {            // RMSNorm: 1/rms per row; wave w owns rows 4w .. 4w+3
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int t = t0 + wave * 4 + r;
+            float s = 0.f;
+            if (t < T) {
+                const float* xr = x + (int64_t)t * ldx;
+                for (int k = lane * 4; k < K; k += 256) {
+                    const float4 v = *reinterpret_cast<const float4*>(xr + k);
+                    s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+                }
+            }
+            s = p_wave_sum(s);
+            if (lane == 0) rs_sh[wave * 4 + r] = rsqrtf(s / (float)K + eps);
+        }
+        __syncthreads();
+    }
+    const int row = lane & 15, kq = lane >> 4;
+    const int t = t0 + row;
+    const float rs = (nw != nullptr) ? rs_sh[row] : 1.0f;
+    const float* xr = x + (int64_t)(t < T ? t : 0) * ldx;
+    for (int kt = wave; kt < KT; kt += 4) {
+        const int k = kt * 32 + kq * 8;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        if (t < T && k < K) {       // K % 8 == 0 is a launch precondition
+            const float4 a = *reinterpret_cast<const float4*>(xr + k), b = *reinterpret_cast<const float4*>(xr + k + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+            if (nw != nullptr) {
+                const float4 wa = *reinterpret_cast<const float4*>(nw + k), wb = *reinterpret_cast<const float4*>(nw + k + 4);
+                const float w8[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = v[j] * rs * w8[j];
+            }
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (__bf16)v[j];
+        xp[((int64_t)blockIdx.x * KT + kt) * 64 + lane] = __builtin_bit_cast(u32x4, o);
+    }
+}
+
+// packed bf16 fragments -> fp32 rows (tests)
+__global__ void vv_unpack_rows_kernel(const __bf16* __restrict__ xp, float* __restrict__ x, int T, int K) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)T * K) return;
+    const int t = (int)(e / K), k = (int)(e - (int64_t)t * K);
+    const int KT = (K + 31) >> 5;
+    const int64_t tile = (int64_t)(t >> 4) * KT + (k >> 5);
+    const int lane = (t & 15) + 16 * ((k & 31) >> 3);
+    x[e] = (float)xp[(tile * 64 + lane) * 8 + (k & 7)];
+}
+
+// ------------------------------------------------------------------------------------------------ GEMM
+struct VVGemm3 {
+    const u32x4* W;        // packed [N][K]
+    const u32x4* W2;       // second matrix (SwiGLU "up"), same shape
+    const u32x4* Xp;       // packed activations [T][K]
+    float* Y;              // fp32 [T][ldy]            (STORE / BIAS / RESID)
+    u32x4* Yp;             // packed bf16 [T][N]       (SWIGLU)
+    const float* bias;     // [N] or null
+    int T, N, K, ldy;
+    int n_blocks, t_blocks;
+};
+
+__device__ __forceinline__ float g3_silu(float u) { return u / (1.0f + __expf(-u)); }
+
+template <int EPI>
+__global__ __launch_bounds__(256) void vv_gemm3_kernel(const VVGemm3 a) {
+    constexpr bool DUAL = (EPI == VV_EPI_SWIGLU);
+    constexpr int FT = DUAL ? 4 : 8;              // feature tiles (per matrix) per workgroup
+    // LDS stage: 16 A fragments then 16 B fragments of one 64-wide K step (2 k-tiles): [frag][64 lanes][16 B]
+    __shared__ __attribute__((aligned(16))) unsigned char stage[32 * 1024];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 15, fq = lane >> 4;
+    const int KT = (a.K + 31) >> 5;
+    const int n_tiles = (a.N + 15) >> 4, t_tiles = (a.T + 15) >> 4;
+    // ---- workgroup -> (feature block, row block).  Consecutive workgroup ids land on consecutive XCDs; give each XCD a
+    // contiguous range of feature blocks and walk the row blocks of one feature block back to back on the same XCD, so the
+    // block's weights are fetched into one L2 once and reused by its row blocks.  Bijective for any block count.
+    int nb, tb;
+    {
+        const int total = a.n_blocks * a.t_blocks;
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, idx = bid >> 3;
+        const int q = total >> 3, r = total & 7;
+        const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;     // position in XCD-major order
+        nb = lin / a.t_blocks;
+        tb = lin - nb * a.t_blocks;
+    }
+    const int ft0 = nb * FT;                       // first feature tile of this workgroup (in each matrix)
+    const int tt0 = tb * 8;                        // first row tile
+    const int wr = wave >> 1, wc = wave & 1;       // 2 x 2 waves: rows wr*64.., features wc*64..
+
+    // ---- stage loader: wave w copies fragments 8w .. 8w+7 of the 32 ----
+    // fragment f < 16: A, feature-tile slot f >> 1 (DUAL: slots 0-3 gate, 4-7 up), k-tile f & 1;  f >= 16: B, row tile (f-16) >> 1
+    const u32x4* src[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int f = wave * 8 + i;
+        if (f < 16) {
+            const int slot = f >> 1;
+            const u32x4* base = (DUAL && slot >= 4) ? a.W2 : a.W;
+            int ft = ft0 + (DUAL ? (slot & 3) : slot);
+            if (ft > n_tiles - 1) ft = n_tiles - 1;                   // clamped: legal address, masked at the store
+            src[i] = base + (int64_t)ft * KT * 64 + lane;
+        } else {
+            int tt = tt0 + ((f - 16) >> 1);
+            if (tt > t_tiles - 1) tt = t_tiles - 1;
+            src[i] = a.Xp + (int64_t)tt * KT * 64 + lane;
+        }
+    }
+    f32x4 acc[4][4];                               // [feature tile of this wave][row tile of this wave]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int n_steps = (KT + 1) >> 1;
+#pragma unroll 1
+    for (int s = 0; s < n_steps; ++s) {
+        const int kt0 = s * 2;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int f = wave * 8 + i;
+            int kt = kt0 + (f & 1);
+            if (kt > KT - 1) kt = KT - 1;                              // odd K tail: re-reads the last k-tile, MFMA skipped
+            glds16(src[i] + (int64_t)kt * 64, stage + f * 1024);
+        }
+        stage_sync();                                                 // the stage has landed for every wave
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            if (kt0 + kk < KT) {
+                bf16x8 af[4], bfr[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    // this wave's feature tiles: plain: slots wc*4+i;  DUAL: i < 2 gate slots wc*2+i, i >= 2 up slots 4+wc*2+(i-2)
+                    const int slot = DUAL ? ((i < 2) ? (wc * 2 + i) : (4 + wc * 2 + (i - 2))) : (wc * 4 + i);
+                    af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(stage + ((slot * 2 + kk) * 64 + lane) * 16));
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(stage + ((16 + (wr * 4 + j) * 2 + kk) * 64 + lane) * 16));
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                              // everyone is done reading before the next stage lands
+    }
+
+    // ---- epilogue: lane holds D[n = tile*16 + fq*4 + r][t = ttile*16 + frow] ----
+    if constexpr (DUAL) {
+        const int KTo = (a.N + 31) >> 5;                               // k-tiles of the OUTPUT operand (its K is our N)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ft = ft0 + wc * 2 + i;
+            if (ft >= n_tiles) continue;
+            const int n0 = ft * 16 + fq * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int tt = tt0 + wr * 4 + j;
+                if (tt >= t_tiles) continue;
+                typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool live = (n0 + r < a.N) && (tt * 16 + frow < a.T);
+                    o[r] = (__bf16)(live ? g3_silu(acc[i][j][r]) * acc[2 + i][j][r] : 0.f);
+                }
+                // element (t, n) of the packed output: tile (tt, n >> 5), lane (t & 15) + 16 * ((n & 31) >> 3), slot n & 7
+                const int64_t tile = (int64_t)tt * KTo + (n0 >> 5);
+                const int ol = frow + 16 * ((n0 & 31) >> 3);
+                unsigned char* dst = reinterpret_cast<unsigned char*>(a.Yp) + ((tile * 64 + ol) * 16 + (n0 & 7) * 2);
+                *reinterpret_cast<uint2*>(dst) = __builtin_bit_cast(uint2, o);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ft = ft0 + wc * 4 + i;
+            if (ft >= n_tiles) continue;
+            const int n0 = ft * 16 + fq * 4;
+            if (n0 >= a.N) continue;                                   // N % 4 == 0 is a launch precondition
+            float4 pb = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (EPI == VV_EPI_BIAS) {
+                if (a.bias) pb = *reinterpret_cast<const float4*>(a.bias + n0);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int t = (tt0 + wr * 4 + j) * 16 + frow;
+                if (t >= a.T) continue;
+                float* yp = a.Y + (int64_t)t * a.ldy + n0;
+                float4 o = {acc[i][j][0] + pb.x, acc[i][j][1] + pb.y, acc[i][j][2] + pb.z, acc[i][j][3] + pb.w};
+                if constexpr (EPI == VV_EPI_RESID) {
+                    const float4 py = *reinterpret_cast<const float4*>(yp);
+                    o.x += py.x; o.y += py.y; o.z += py.z; o.w += py.w;
+                }
+                *reinterpret_cast<float4*>(yp) = o;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ prefill attention
+// rows = consecutive positions of ONE cache (rows[0] first); q_rot (rotated, scaled by 1/sqrt(D)) and the chunk's own K/V
+// are already in place (vv_rope_append_kernel).  grid (ceil(R / 64), Hkv), 256 threads.  KV-cache layout: attn.hip header.
+template <int D>
+__global__ __launch_bounds__(256) void vv_attn_prefill2_kernel(
+    const float* __restrict__ q, const VVRow* __restrict__ rows, const __bf16* __restrict__ kc,
+    const __bf16* __restrict__ vc, int R, int Hq, int Hkv, int64_t cache_stride, int64_t head_stride,
+    float* __restrict__ out) {
+    constexpr int KT = D / 32, DT = D / 16;
+    constexpr int KF = 2 * KT;                       // K fragments of a 32-position block (2 position tiles x KT)
+    constexpr int NF = KF + DT;                      // + DT transposed-V fragments
+    constexpr int BUF = NF * 1024;
+    __shared__ __attribute__((aligned(16))) unsigned char kv[2 * BUF];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // longest workgroups first: the last query tile walks the whole prefix
+    const int qt = (int)gridDim.x - 1 - (int)blockIdx.x;
+    const int r0 = qt * 64, kvh = blockIdx.y;
+    const VVRow rw = rows[0];
+    const int G = Hq / Hkv;
+    const int col = lane & 15, qg = lane >> 4;
+    const int pend = rw.pos + min(r0 + 63, R - 1) + 1;              // positions this tile walks: [0, pend)
+    const int n_blk = (pend + 31) >> 5;
+    const int first_masked = (rw.pos + r0) >> 5;                      // blocks below this one are visible to every query row
+    const u32x4* kt_base = reinterpret_cast<const u32x4*>(kc + (int64_t)rw.cache * cache_stride + (int64_t)kvh * head_stride);
+    const u32x4* vt_base = reinterpret_cast<const u32x4*>(vc + (int64_t)rw.cache * cache_stride + (int64_t)kvh * head_stride);
+    constexpr float LOG2E = 1.4426950408889634f;
+
+    // fragments of block b: K tiles (b*2)*KT .. +KF (contiguous), V tiles b*DT .. +DT (contiguous); wave w copies every 4th
+    auto issue = [&](int b, unsigned char* buf) {
+        const u32x4* ks = kt_base + (int64_t)b * KF * 64 + lane;
+        const u32x4* vs = vt_base + (int64_t)b * DT * 64 + lane;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            if ((f & 3) == wave) {                                    // uniform per wave
+                if (f < KF) glds16(ks + f * 64, buf + f * 1024);
+                else glds16(vs + (f - KF) * 64, buf + f * 1024);
+            }
+        }
+    };
+
+    for (int g0 = 0; g0 < G; g0 += 4) {              // 4 query heads of the group per pass, one per wave
+        const int g = g0 + wave;
+        const bool act = g < G;
+        const int h = kvh * G + (act ? g : 0);
+        // ---- q fragments of the 4 row tiles, in the log2 domain (scores * log2 e: p = exp2(s - m)) ----
+        bf16x8 qf[4][KT];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            const int row = min(r0 + rt * 16 + col, R - 1);
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                const float* qp = q + ((int64_t)row * Hq + h) * D + kt * 32 + qg * 8;
+                const float4 a0 = *reinterpret_cast<const float4*>(qp), a1 = *reinterpret_cast<const float4*>(qp + 4);
+                const float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) qf[rt][kt][j] = (__bf16)(v[j] * LOG2E);
+            }
+        }
+        float m[4], lsum[4];
+        f32x4 o[4][DT];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            m[rt] = -INFINITY; lsum[rt] = 0.f;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) o[rt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();                              // the previous pass is done with both buffers
+        issue(0, kv);
+#pragma unroll 1
+        for (int b = 0; b < n_blk; ++b) {
+            unsigned char* cur = kv + (b & 1) * BUF;
+            stage_sync();                             // block b has landed (every wave drained its own copies first);
+                                                      // everyone has finished block b-1, whose buffer is refilled now
+            if (b + 1 < n_blk) issue(b + 1, kv + ((b + 1) & 1) * BUF);
+            if (!act) continue;
+            const int p0 = b * 32;
+            const bool masked = b >= first_masked;
+            // ---- S^T = K q^T for the 4 row tiles: every K fragment is read from LDS once ----
+            f32x4 s0[4], s1[4];
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) { s0[rt] = f32x4{0.f, 0.f, 0.f, 0.f}; s1[rt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                const bf16x8 ka = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(cur + (kt * 64 + lane) * 16));
+                const bf16x8 kb = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(cur + ((KT + kt) * 64 + lane) * 16));
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) {
+                    s0[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[rt][kt], s0[rt], 0, 0, 0);
+                    s1[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb, qf[rt][kt], s1[rt], 0, 0, 0);
+                }
+            }
+            // ---- online softmax per row tile -> P as the B operand of P.V ----
+            bf16x8 pb[4];
+            float al[4];
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                float sv[8];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) { sv[rr] = s0[rt][rr]; sv[4 + rr] = s1[rt][rr]; }
+                if (masked) {
+                    const int plim = rw.pos + min(r0 + rt * 16 + col, R - 1);     // last position this column's query may attend
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int pa = p0 + qg * 4 + rr;
+                        if (pa > plim) sv[rr] = -INFINITY;
+                        if (pa + 16 > plim) sv[4 + rr] = -INFINITY;
+                    }
+                }
+                float mx = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                const float mn = fmaxf(m[rt], mx);
+                // a column whose whole block is masked (query earlier than this block) keeps its state untouched
+                const bool dead = (mn == -INFINITY);
+                const float alpha = (m[rt] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m[rt] - mn);
+                float ps = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float p = (sv[j] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(sv[j] - mn);
+                    ps += p;
+                    pb[rt][j] = (__bf16)p;
+                }
+                if (!dead) { lsum[rt] = lsum[rt] * alpha + ps; m[rt] = mn; }
+                al[rt] = dead ? 1.f : alpha;
+            }
+            // ---- O += P . V: every V fragment is read from LDS once ----
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const bf16x8 vt = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(cur + ((KF + dt) * 64 + lane) * 16));
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) {
+                    o[rt][dt] *= al[rt];
+                    o[rt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, pb[rt], o[rt][dt], 0, 0, 0);
+                }
+            }
+        }
+        if (act) {
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                float l = lsum[rt];
+                l += __shfl_xor(l, 16);
+                l += __shfl_xor(l, 32);
+                const int row = r0 + rt * 16 + col;
+                if (row < R) {
+                    const float inv = 1.0f / l;
+                    float* orow = out + ((int64_t)row * Hq + h) * D + qg * 4;
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt)
+                        *reinterpret_cast<float4*>(orow + dt * 16) =
+                            float4{o[rt][dt][0] * inv, o[rt][dt][1] * inv, o[rt][dt][2] * inv, o[rt][dt][3] * inv};
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int vv_pack_rows_launch(const float* x, int ldx, const float* nw, float eps, void* xp, int T, int K, hipStream_t s) {
+    if ((K & 7) || (ldx & 3) || (((uintptr_t)x) & 15) || (((uintptr_t)xp) & 15) || (nw && (((uintptr_t)nw) & 15))) return -1;
+    hipLaunchKernelGGL(vv_pack_rows_kernel, dim3((T + 15) / 16), dim3(256), 0, s, x, ldx, nw, eps, (u32x4*)xp, T, K);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int vv_unpack_rows_launch(const void* xp, float* x, int T, int K, hipStream_t s) {
+    const int64_t n = (int64_t)T * K;
+    hipLaunchKernelGGL(vv_unpack_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const __bf16*)xp, x, T, K);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// Y (op)= Xp . W^T.  epi: VV_EPI_STORE / BIAS / RESID -> fp32 Y[T][ldy];  VV_EPI_SWIGLU -> packed bf16 Yp [T][N] (W = gate, W2 = up)
+int vv_gemm3_launch(const void* W, const void* W2, const void* Xp, float* Y, void* Yp, const float* bias, int T, int N, int K,
+                    int ldy, int epi, hipStream_t s) {
+    if (T < 1 || N < 1 || K < 32 || (N & 3)) return -1;
+    VVGemm3 a;
+    a.W = (const u32x4*)W; a.W2 = (const u32x4*)W2; a.Xp = (const u32x4*)Xp; a.Y = Y; a.Yp = (u32x4*)Yp; a.bias = bias;
+    a.T = T; a.N = N; a.K = K; a.ldy = ldy;
+    const int n_tiles = (N + 15) / 16;
+    const int ft = (epi == VV_EPI_SWIGLU) ? 4 : 8;
+    a.n_blocks = (n_tiles + ft - 1) / ft;
+    a.t_blocks = (T + 127) / 128;
+    const dim3 grid((unsigned)(a.n_blocks * a.t_blocks));
+    if (epi == VV_EPI_SWIGLU) {
+        if (!W2 || !Yp) return -1;
+        hipLaunchKernelGGL((vv_gemm3_kernel<VV_EPI_SWIGLU>), grid, dim3(256), 0, s, a);
+    } else if (epi == VV_EPI_RESID) {
+        if (!Y || (ldy & 3)) return -1;
+        hipLaunchKernelGGL((vv_gemm3_kernel<VV_EPI_RESID>), grid, dim3(256), 0, s, a);
+    } else if (epi == VV_EPI_BIAS || epi == VV_EPI_STORE) {
+        if (!Y || (ldy & 3)) return -1;
+        hipLaunchKernelGGL((vv_gemm3_kernel<VV_EPI_BIAS>), grid, dim3(256), 0, s, a);      // bias == null: plain store
+    } else {
+        return -3;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int vv_attn_prefill2_launch(int D, const float* q, const VVRow* rows, const void* kc, const void* vc, int R, int Hq, int Hkv,
+                            int64_t cache_stride, int64_t head_stride, float* out, hipStream_t s) {
+    if (Hq % Hkv != 0) return -1;
+    const dim3 grid((R + 63) / 64, Hkv);
+    if (D == 128)
+        hipLaunchKernelGGL((vv_attn_prefill2_kernel<128>), grid, dim3(256), 0, s, q, rows, (const __bf16*)kc, (const __bf16*)vc,
+                           R, Hq, Hkv, cache_stride, head_stride, out);
+    else if (D == 64)
+        hipLaunchKernelGGL((vv_attn_prefill2_kernel<64>), grid, dim3(256), 0, s, q, rows, (const __bf16*)kc, (const __bf16*)vc,
+                           R, Hq, Hkv, cache_stride, head_stride, out);
+    else
+        return -1;
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+}  // extern "C"

@@ -346,6 +346,18 @@ class Engine:
         self.sync()
         return out
 
+    def gemm3_raw(self, wp, x, y, N, K, epi=0, w2p=None, nw=None, eps=1e-6, bias=None):
+        """the prefill GEMM (prefill.hip) on fp32 rows x [T, K] -> y [T, N]"""
+        T = x.shape[0]
+        xp = torch.zeros(int(self.lib.vv_packed_bytes(T, K)), dtype=torch.uint8, device=self.device)
+        yp = torch.zeros(int(self.lib.vv_packed_bytes(T, N)), dtype=torch.uint8, device=self.device)
+        torch.cuda.synchronize(self.device)
+        rc = self.lib.vv_gemm3_raw(self._s, self._p(wp), self._p(w2p), self._p(x), T, N, K, epi, self._p(nw), float(eps),
+                                   self._p(bias), self._p(y), self._p(xp), self._p(yp))
+        if rc != 0:
+            raise EngineError(f"vv_gemm3_raw failed ({rc})")
+        self.sync()
+
     def gemm_raw(self, wp, x, y, N, K, T=None, ldx=None, ldy=None, pro=0, epi=0, w2p=None, nw=None, eps=1e-6,
                  bias=None, nscale=None, xsplit=None, ksplit=0, nontemporal=0):
         T = x.shape[0] if T is None else T
