@@ -40,7 +40,7 @@ typedef struct vv_config {
     /* runtime */
     int n_slots;       /* concurrent utterances: 2 KV caches (cond/uncond) + 2 conv states each */
     int max_ctx;       /* KV positions per cache (rounded up to 128) */
-    int max_rows;      /* max LM rows per launch (<=2048): decode uses 2 per utterance, prompt prefill fills it */
+    int max_rows;      /* max LM rows per launch (<=16384): decode uses 2 per utterance, prompt prefill fills it */
     int xsplit;        /* activation precision inside MFMA: 1 bf16, 2 ~fp24, 3 fp32-exact */
     int attn_splits;   /* flash-decoding splits along the sequence */
     int enc_frames;    /* frames per chunk of the voice-prompt encoder (>=1) */
@@ -84,7 +84,7 @@ typedef struct vv_row { int cache; int pos; } vv_row;
  * for the positive rows and :583-585 for the negative rows -- both in ONE pass
  * over the weights.  hidden_out = last_hidden_state (after the final RMSNorm).
  * Row sets: (a) every row a different cache (decode steps; one fused attention launch per layer), or (b) consecutive
- * positions of one cache (prompt prefill, up to max_rows rows; MFMA tile GEMM + prefill attention), or (c) any other
+ * positions of one cache (prompt prefill, up to max_rows rows; LDS-staged MFMA GEMM + 64-row prefill attention), or (c) any other
  * mix of at most 64 rows (3-launch attention: all appends land before any row attends). */
 int vv_lm_forward(vv_ctx* ctx, void* stream, int n_rows, const vv_row* rows,
                   const float* x_in_dev, float* hidden_out_dev);

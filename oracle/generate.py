@@ -22,9 +22,12 @@ Negative (CFG) branch, compact form of :379-386, :549-565, :576-624:
     negative step, which the processor's prompt guarantees: every prompt ends
     in <speech_start>, so step 0 emits <speech_diffusion> for every row.)
 
-PARITY UNPINNED for the orchestration itself (the reference generate() does
-not run under transformers 5.x); every arithmetic stage called from here is
-pinned by tests/golden.
+PARITY PINNED: the reference's own generate() runs in the build container under transformers 5.15 through the
+API shims of oracle/refshim.install_generate_shims(); tests/golden/make_golden.py::gen_generate recorded it on the
+tiny seeded model (generate_forced_b1 / _b2, generate_greedy_b1, generate_cap_b1, generate_ragged_voice_b1,
+generate_sampled_b1) and tests/test_oracle_golden.py holds this loop to those files (token sequences identical,
+waveform rel-L2 <= 1e-4).  Caveat: the pinned dependency is transformers==4.51.3 (pyproject.toml:22), the recording
+ran on 5.15 with its 4.51.3 behaviours restored by the shims.
 """
 from dataclasses import dataclass, field
 from typing import Callable, List, Optional

@@ -87,13 +87,13 @@ def test_one_layer_at_real_widths(tag, xs, tol):
         eng.sync()
         assert rel_err(hid, ref) <= tol, rel_err(hid, ref)
         oc2 = m.new_cache()
-        xs = g.normal((4, 2, H), 1.0, mat=False)
+        xdec = g.normal((4, 2, H), 1.0, mat=False)
         for i in range(4):
-            r1 = m.forward(xs[i, 0:1], oc)
-            r2 = m.forward(xs[i, 1:2], oc2)
+            r1 = m.forward(xdec[i, 0:1], oc)
+            r2 = m.forward(xdec[i, 1:2], oc2)
             out = eng.new(2, H)
             with torch.cuda.stream(eng.stream):
-                eng.lm_forward([(0, L0 + i), (1, i)], dev(xs[i], eng), out)
+                eng.lm_forward([(0, L0 + i), (1, i)], dev(xdec[i], eng), out)
             eng.sync()
             assert rel_err(out[0], r1[0]) <= tol, (i, rel_err(out[0], r1[0]))
             assert rel_err(out[1], r2[0]) <= tol, (i, rel_err(out[1], r2[0]))

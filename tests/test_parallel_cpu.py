@@ -105,3 +105,31 @@ def test_two_rank_packed_broadcast_and_sharded_generation():
         assert (alen is None) == (a is None)
         if a is not None:
             assert alen == a.shape[-1] and abs(asum - a.double().sum().item()) <= 1e-3 * max(1.0, abs(asum))
+
+
+def test_bench_gpus_flag_spawns_one_rank_per_gpu(monkeypatch):
+    """`python bench.py --gpus N` outside torchrun must start N ranks itself (the flag was parsed and ignored):
+    the command it runs is torch.distributed.run with one process per GPU and a 127.0.0.1 rendezvous, forwarding its own flags."""
+    import importlib.util
+    import os
+    import subprocess
+    import sys
+    import pytest
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 4)
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: (seen.update(cmd=cmd, env=env), 0)[1])
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7"])
+    monkeypatch.delenv("RANK", raising=False)
+    args = bench.parse_args(["--gpus", "4", "--steps", "7"])
+    assert bench.respawn_ranks(args) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "7"]
+    assert seen["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    with pytest.raises(SystemExit, match="only 1 GPU"):
+        bench.respawn_ranks(args)

@@ -1,0 +1,58 @@
+#!/usr/bin/env python
+"""Summarise a rocprofv3 output database (ROCm 7.2 writes a rocpd SQLite file, <prefix>_results.db) into the CSV files kept
+under profiles/:
+
+    python tools/rocprof_summary.py gpurun_out/prof/x_results.db profiles/r02_7b_northstar        # -> *_kernel_stats.csv
+    python tools/rocprof_summary.py gpurun_out/pmc/x_results.db profiles/r02_7b_pmc --pmc         # -> *_pmc_by_kernel.csv
+
+--kernel-trace runs: per kernel name: calls, total / average / min / max duration, share of GPU kernel time.
+--pmc runs: per kernel name and counter: dispatches, mean and sum of the counter, mean dispatch duration (counter collection
+serialises dispatches, so these durations are NOT the ones of the timed run).
+"""
+import csv
+import re
+import sqlite3
+import sys
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void ", "", name)
+    return name
+
+
+def kernel_stats(db, out):
+    cur = db.cursor()
+    rows = cur.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
+                       "from kernels group by name order by 3 desc").fetchall()
+    tot = sum(r[2] for r in rows) or 1
+    with open(out + "_kernel_stats.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "Percentage"])
+        for r in rows:
+            w.writerow([short(r[0]), r[1], int(r[2]), round(r[3], 1), int(r[4]), int(r[5]), round(100.0 * r[2] / tot, 3)])
+    return rows, tot
+
+
+def pmc_stats(db, out):
+    cur = db.cursor()
+    rows = cur.execute("select kernel_name, counter_name, count(*), avg(value), sum(value), avg(end-start) "
+                       "from counters_collection group by kernel_name, counter_name order by 5 desc").fetchall()
+    with open(out + "_pmc_by_kernel.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Kernel", "Counter", "Dispatches", "MeanValue", "SumValue", "MeanDispatchNs"])
+        for r in rows:
+            w.writerow([short(r[0]), r[1], r[2], round(r[3], 2), round(r[4], 1), round(r[5], 1)])
+    return rows
+
+
+if __name__ == "__main__":
+    db = sqlite3.connect(sys.argv[1])
+    if "--pmc" in sys.argv:
+        for r in pmc_stats(db, sys.argv[2])[:30]:
+            print(f"{short(r[0])[:90]:90s} {r[1]:32s} n={r[2]:6d} mean={r[3]:14.1f} dur={r[5] / 1e3:9.2f}us")
+    else:
+        rows, tot = kernel_stats(db, sys.argv[2])
+        print(f"total kernel time {tot / 1e6:.2f} ms")
+        for r in rows[:25]:
+            print(f"{short(r[0])[:100]:100s} {r[1]:7d} {r[2] / 1e6:9.2f} ms  avg {r[3] / 1e3:9.2f} us  {100 * r[2] / tot:5.1f}%")

@@ -22,9 +22,9 @@ namespace {
 
 // positions per split: at least 512 (below that one workgroup walking the sequence beats a cross-workgroup merge),
 // a multiple of 128 (4 waves x 32), and few enough splits to fit the grid
-__device__ __forceinline__ int attn_chunk(int len, int S) {
+__device__ __forceinline__ int attn_chunk(int len, int S, int gran = 128) {
     int chunk = (len + S - 1) / S;
-    chunk = (chunk + 127) & ~127;
+    chunk = (chunk + gran - 1) / gran * gran;          // a multiple of (waves x 32): gran is 128 or 256, 512 is a multiple of both
     return chunk < 512 ? 512 : chunk;
 }
 
@@ -238,8 +238,12 @@ __global__ void vv_rope_table_kernel(const float* __restrict__ inv_freq, float2*
 //   then -- if the sequence needed more than one chunk -- the LAST workgroup of a (row, kv head) to finish merges
 //   the partials: partial -> release fence -> ticket (device-scope atomic) -> acquire fence -> fixed-order merge.
 //   Replaces rope_append + split + merge (3 launches, 2 extra kernel boundaries per layer).
-template <int D, int XS>
-__global__ __launch_bounds__(256) void vv_attn_fused_kernel(
+// WAVES = waves per workgroup = 32-position blocks in flight per workgroup pass.  4 for short sequences (one workgroup, few
+// blocks); 8 for long ones: a wave keeps two K/V blocks (32 KiB) in flight, a CU streams at (bytes in flight) / (HBM
+// latency), so at 32K positions the 4-wave form ran at 1.7 TB/s -- twice the waves and twice the workgroups (see the
+// launcher: one split per 512 positions, up to attn_splits) put every CU on the KV stream.
+template <int D, int XS, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void vv_attn_fused_kernel(
     const float* __restrict__ qkv, const VVRow* __restrict__ rows, const float2* __restrict__ rope_tab,
     __bf16* __restrict__ kc, __bf16* __restrict__ vc, int Hq, int Hkv, int64_t cache_stride, int64_t head_stride,
     float q_scale, float* __restrict__ part_m, float* __restrict__ part_l, float* __restrict__ part_o,
@@ -253,7 +257,7 @@ __global__ __launch_bounds__(256) void vv_attn_fused_kernel(
     const int pos = rw.pos, len = pos + 1;
     const int G = Hq / Hkv;
     const int g = lane & 15, qg = lane >> 4;
-    const int chunk = attn_chunk(len, S);
+    const int chunk = attn_chunk(len, S, WAVES * 32);
     const int start = split * chunk;
     const int end = min(len, start + chunk);
     if (start >= len) return;
@@ -341,14 +345,14 @@ __global__ __launch_bounds__(256) void vv_attn_fused_kernel(
         for (int dt = 0; dt < DT; ++dt) nvt[dt] = vt_base[(vt0 + dt) * 64 + lane];
     };
     if (start + wave * 32 < end) kv_load(start + wave * 32);
-    for (int p0 = start + wave * 32; p0 < end; p0 += 128) {
+    for (int p0 = start + wave * 32; p0 < end; p0 += WAVES * 32) {
         f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
         u32x4 ka[KT], kb[KT], vt[DT];
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) { ka[kt] = nka[kt]; kb[kt] = nkb[kt]; }
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) vt[dt] = nvt[dt];
-        if (p0 + 128 < end) kv_load(p0 + 128);
+        if (p0 + WAVES * 32 < end) kv_load(p0 + WAVES * 32);
         if (owner && (pos >> 5) == (p0 >> 5)) {
             // the append above may not have landed: take the new token's row / column from LDS instead
             const int p = pos & 31;
@@ -415,62 +419,75 @@ __global__ __launch_bounds__(256) void vv_attn_fused_kernel(
     lsum += __shfl_xor(lsum, 16);
     lsum += __shfl_xor(lsum, 32);
 
-    // ---- combine the 4 waves (fixed order) ----
-    __shared__ float sm[4][16], sl[4][16];
-    __shared__ f32x4 so[4][DT][64];
+    // ---- combine the waves (fixed order) ----
+    __shared__ float sm[WAVES][16], sl[WAVES][16];
+    __shared__ f32x4 so[WAVES][DT][64];
     if (lane < 16) { sm[wave][lane] = m; sl[wave][lane] = lsum; }
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) so[wave][dt][lane] = o[dt];
     __syncthreads();
-    if (wave != 0) return;
-    float M = -INFINITY;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) M = fmaxf(M, sm[w][g]);
-    float L = 0.f;
-    f32x4 O[DT];
-#pragma unroll
-    for (int i = 0; i < DT; ++i) O[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        const float mw = sm[w][g];
-        const float f = (mw == -INFINITY) ? 0.f : expf(mw - M);
-        L += sl[w][g] * f;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) O[dt] += so[w][dt][lane] * f;
-    }
-    float* orow = out + ((int64_t)r * Hq + kvh * G + g) * D + qg * 4;
-    if (used == 1) {                          // short sequence: this workgroup saw everything
-        if (g < G) {
-            const float inv = 1.0f / L;
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-                *reinterpret_cast<float4*>(orow + dt * 16) = float4{O[dt][0] * inv, O[dt][1] * inv, O[dt][2] * inv, O[dt][3] * inv};
-        }
-        return;
-    }
+    __shared__ int last_sh;
     const int64_t gidx = (int64_t)r * Hkv + kvh;
-    const int64_t pidx = gidx * S + split;
-    if (lane < 16) { part_m[pidx * 16 + lane] = M; part_l[pidx * 16 + lane] = L; }
-    if (g < G) {
+    float* orow = out + ((int64_t)r * Hq + kvh * G + g) * D + qg * 4;
+    if (wave == 0) {
+        float M = -INFINITY;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-            *reinterpret_cast<float4*>(part_o + (pidx * 16 + g) * D + dt * 16 + qg * 4) = float4{O[dt][0], O[dt][1], O[dt][2], O[dt][3]};
+        for (int w = 0; w < WAVES; ++w) M = fmaxf(M, sm[w][g]);
+        float L = 0.f;
+        f32x4 O[DT];
+#pragma unroll
+        for (int i = 0; i < DT; ++i) O[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            const float mw = sm[w][g];
+            const float f = (mw == -INFINITY) ? 0.f : expf(mw - M);
+            L += sl[w][g] * f;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) O[dt] += so[w][dt][lane] * f;
+        }
+        if (used == 1) {                          // short sequence: this workgroup saw everything
+            if (g < G) {
+                const float inv = 1.0f / L;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+                    *reinterpret_cast<float4*>(orow + dt * 16) = float4{O[dt][0] * inv, O[dt][1] * inv, O[dt][2] * inv, O[dt][3] * inv};
+            }
+        } else {
+            const int64_t pidx = gidx * S + split;
+            if (lane < 16) { part_m[pidx * 16 + lane] = M; part_l[pidx * 16 + lane] = L; }
+            if (g < G) {
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+                    *reinterpret_cast<float4*>(part_o + (pidx * 16 + g) * D + dt * 16 + qg * 4) = float4{O[dt][0], O[dt][1], O[dt][2], O[dt][3]};
+            }
+            // publish, then take a ticket: the workgroup that draws the last one merges
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            if (lane == 0) {
+                const unsigned old = __hip_atomic_fetch_add(tickets + gidx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last_sh = (old == (unsigned)(used - 1)) ? 1 : 0;
+                if (last_sh) tickets[gidx] = 0u;          // next launch starts from zero (kernel boundary orders it)
+            }
+        }
     }
-    // publish, then take a ticket: the workgroup that draws the last one merges
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    unsigned old = 0;
-    if (lane == 0) old = __hip_atomic_fetch_add(tickets + gidx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    old = __builtin_amdgcn_readfirstlane(old);
-    if (old != (unsigned)(used - 1)) return;
+    if (used == 1) return;                        // uniform over the workgroup
+    __syncthreads();
+    if (!last_sh) return;
+    // ---- merge of the `used` partials by ALL waves of the last arriver: wave w takes splits w, w + WAVES, ... (their loads
+    // overlap instead of forming one serial chain of L2 round trips), then the per-wave sums are added in wave order.  Which
+    // workgroup merges does not matter: the split -> wave assignment and both summation orders are fixed. ----
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    if (lane == 0) tickets[gidx] = 0u;        // next launch starts from zero (kernel boundary orders it)
+    float mw_max = -INFINITY;
+    for (int s2 = wave; s2 < used; s2 += WAVES) mw_max = fmaxf(mw_max, part_m[(gidx * S + s2) * 16 + g]);
+    if (lane < 16) sm[wave][lane] = mw_max;
+    __syncthreads();
     float MM = -INFINITY;
-    for (int s2 = 0; s2 < used; ++s2) MM = fmaxf(MM, part_m[(gidx * S + s2) * 16 + g]);
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) MM = fmaxf(MM, sm[w][g]);
     float LL = 0.f;
     f32x4 OO[DT];
 #pragma unroll
     for (int i = 0; i < DT; ++i) OO[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int s2 = 0; s2 < used; ++s2) {       // fixed order: the result does not depend on who merges
+    for (int s2 = wave; s2 < used; s2 += WAVES) {
         const int64_t pi = gidx * S + s2;
         const float ms = part_m[pi * 16 + g];
         const float f = (ms == -INFINITY) ? 0.f : expf(ms - MM);
@@ -483,11 +500,27 @@ __global__ __launch_bounds__(256) void vv_attn_fused_kernel(
             }
         }
     }
+    __syncthreads();                              // everyone has read sm[][] of the max pass
+    if (lane < 16) sl[wave][lane] = LL;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) so[wave][dt][lane] = OO[dt];
+    __syncthreads();
+    if (wave != 0) return;
+    float Lt = 0.f;
+    f32x4 Ot[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i) Ot[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+        Lt += sl[w][g];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) Ot[dt] += so[w][dt][lane];
+    }
     if (g < G) {
-        const float inv = 1.0f / LL;
+        const float inv = 1.0f / Lt;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
-            *reinterpret_cast<float4*>(orow + dt * 16) = float4{OO[dt][0] * inv, OO[dt][1] * inv, OO[dt][2] * inv, OO[dt][3] * inv};
+            *reinterpret_cast<float4*>(orow + dt * 16) = float4{Ot[dt][0] * inv, Ot[dt][1] * inv, Ot[dt][2] * inv, Ot[dt][3] * inv};
     }
 }
 
@@ -667,17 +700,19 @@ extern "C" int vv_rope_table_launch(const float* inv_freq, void* tab, int n_pos,
 // Decode-step attention in one launch; requires every row to own a different cache (the new token of row r must not
 // be visible to -- or needed by -- another row of the same launch).
 extern "C" int vv_attn_fused_launch(int D, int xs, const float* qkv, const VVRow* rows, const void* rope_tab, void* kc, void* vc,
-                                    int R, int Hq, int Hkv, int64_t cache_stride, int64_t head_stride, int S,
+                                    int R, int Hq, int Hkv, int64_t cache_stride, int64_t head_stride, int S, int waves,
                                     float* pm, float* pl, float* po, unsigned* tickets, float* out, hipStream_t s) {
-    if (Hq % Hkv != 0 || Hq / Hkv > 16) return -1;
+    if (Hq % Hkv != 0 || Hq / Hkv > 16 || (waves != 4 && waves != 8)) return -1;
     const float scale = 1.0f / sqrtf((float)D);
-#define VV_F(D_, XS_)                                                                                         \
-    hipLaunchKernelGGL((vv_attn_fused_kernel<D_, XS_>), dim3(S, Hkv, R), dim3(256), 0, s, qkv, rows,          \
+#define VV_F(D_, XS_, W_)                                                                                     \
+    hipLaunchKernelGGL((vv_attn_fused_kernel<D_, XS_, W_>), dim3(S, Hkv, R), dim3(W_ * 64), 0, s, qkv, rows,  \
                        (const float2*)rope_tab, (__bf16*)kc, (__bf16*)vc, Hq, Hkv, cache_stride, head_stride, scale, \
                        pm, pl, po, tickets, out)
-    if (D == 128) { if (xs == 1) VV_F(128, 1); else if (xs == 2) VV_F(128, 2); else VV_F(128, 3); }
-    else if (D == 64) { if (xs == 1) VV_F(64, 1); else if (xs == 2) VV_F(64, 2); else VV_F(64, 3); }
+#define VV_FW(D_, XS_) do { if (waves == 8) VV_F(D_, XS_, 8); else VV_F(D_, XS_, 4); } while (0)
+    if (D == 128) { if (xs == 1) VV_FW(128, 1); else if (xs == 2) VV_FW(128, 2); else VV_FW(128, 3); }
+    else if (D == 64) { if (xs == 1) VV_FW(64, 1); else if (xs == 2) VV_FW(64, 2); else VV_FW(64, 3); }
     else return -1;
+#undef VV_FW
 #undef VV_F
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -25,7 +25,7 @@ int vv_attn_prefill_launch(int D, int xs, const float* q, const VVRow* rows, con
                            int Hq, int Hkv, int64_t cache_stride, int64_t head_stride, float* out, hipStream_t s);
 int vv_rope_table_launch(const float* inv_freq, void* tab, int n_pos, int half, hipStream_t s);
 int vv_attn_fused_launch(int D, int xs, const float* qkv, const VVRow* rows, const void* rope_tab, void* kc, void* vc,
-                         int R, int Hq, int Hkv, int64_t cache_stride, int64_t head_stride, int S,
+                         int R, int Hq, int Hkv, int64_t cache_stride, int64_t head_stride, int S, int waves,
                          float* pm, float* pl, float* po, unsigned* tickets, float* out, hipStream_t s);
 int vv_attn_launch(int D, int xs, const float* q, const VVRow* rows, const void* kc, const void* vc, int R, int Hq,
                    int Hkv, int64_t cache_stride, int64_t head_stride, int S, float* pm, float* pl, float* po,
@@ -154,7 +154,7 @@ struct vv_ctx {
     // LM runtime
     void *kc = nullptr, *vc = nullptr;
     int64_t cache_stride = 0, head_stride = 0, layer_stride = 0;
-    VVRow* rows_dev = nullptr; VVRow* rows_pin = nullptr;
+    VVRow* rows_dev = nullptr; VVRow* rows_pin = nullptr; int rows_cap = 2048;
     int* ids_dev = nullptr; int* ids_pin = nullptr;
     // pinned staging is a ring (slot reuse waits on that slot's own copy event, long since complete): a step's
     // launches can be enqueued while the previous step is still running, no host-side stream sync
@@ -606,7 +606,7 @@ extern "C" int vv_create(const vv_config* cfg, vv_ctx** out) {
     vv_ctx* ctx = new vv_ctx();
     ctx->c = *cfg; ctx->err[0] = 0;
     vv_config& c = ctx->c;
-    if (c.max_rows < 1 || c.max_rows > 2048) { delete ctx; return fail(nullptr, "max_rows must be in [1,2048]"); }
+    if (c.max_rows < 1 || c.max_rows > 16384) { delete ctx; return fail(nullptr, "max_rows must be in [1,16384]"); }
     if (c.lm_head_dim != 64 && c.lm_head_dim != 128) { delete ctx; return fail(nullptr, "head_dim must be 64 or 128"); }
     // the attention kernels put the query heads of a GQA group on the 16 MFMA columns (attn.hip)
     if (c.lm_kv_heads < 1 || c.lm_heads % c.lm_kv_heads != 0 || c.lm_heads / c.lm_kv_heads > 16) {
@@ -615,7 +615,7 @@ extern "C" int vv_create(const vv_config* cfg, vv_ctx** out) {
         return fail(nullptr, "lm_heads=%d / lm_kv_heads=%d: the GQA group size must be an integer <= 16", hq, hkv);
     }
     if (c.xsplit < 1 || c.xsplit > 3) c.xsplit = 2;
-    if (c.attn_splits < 1) c.attn_splits = 32;
+    if (c.attn_splits < 1) c.attn_splits = 128;
     if (c.enc_frames < 1) c.enc_frames = 1;
     if (getenv("VVHIP_GRAPH_CAP")) ctx->graph_cap = (size_t)std::max(4, atoi(getenv("VVHIP_GRAPH_CAP")));
     c.max_ctx = (c.max_ctx + 127) & ~127;
@@ -663,8 +663,9 @@ extern "C" int vv_create(const vv_config* cfg, vv_ctx** out) {
     ctx->cache_stride = ctx->layer_stride * c.lm_layers;
     ctx->kc = dalloc(ctx, (size_t)ctx->cache_stride * n_caches * 2);
     ctx->vc = dalloc(ctx, (size_t)ctx->cache_stride * n_caches * 2);
-    ctx->rows_dev = (VVRow*)dalloc(ctx, sizeof(VVRow) * 2048);
-    hipHostMalloc((void**)&ctx->rows_pin, sizeof(VVRow) * 2048 * vv_ctx::RING);
+    ctx->rows_cap = std::max(2048, c.max_rows);
+    ctx->rows_dev = (VVRow*)dalloc(ctx, sizeof(VVRow) * ctx->rows_cap);
+    hipHostMalloc((void**)&ctx->rows_pin, sizeof(VVRow) * (size_t)ctx->rows_cap * vv_ctx::RING);
     for (int i = 0; i < vv_ctx::RING; ++i) hipEventCreateWithFlags(&ctx->ring_ev[i], hipEventDisableTiming);
     ctx->ids_dev = (int*)dalloc(ctx, sizeof(int) * 64);
     hipHostMalloc((void**)&ctx->ids_pin, sizeof(int) * 64 * vv_ctx::RING);
@@ -890,7 +891,8 @@ extern "C" int vv_set_schedule(vv_ctx* ctx, int n_steps, const float* t, const f
     return 0;
 }
 
-static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float* hidden_out, int l0, int l1, int final_norm, bool fused_attn, bool contiguous) {
+static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float* hidden_out, int l0, int l1, int final_norm, bool fused_attn, bool contiguous,
+                   int attn_S, int attn_waves) {
     const vv_config& c = ctx->c;
     const int H = ctx->H, D = ctx->D, Hq = ctx->Hq, Hkv = ctx->Hkv, I = ctx->I, QKV = ctx->QKV;
     HIPCHK(ctx, hipMemcpyAsync(ctx->h, x_in, (size_t)R * H * 4, hipMemcpyDeviceToDevice, st));
@@ -931,7 +933,7 @@ static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float*
             // decode rows (one cache each): RoPE + KV append + split attention + last-arriver merge in ONE launch
             ctx->launches += 1;
             VVCHK(vv_attn_fused_launch(D, c.xsplit, ctx->qkv, ctx->rows_dev, ctx->rope_tab, kl, vl, R, Hq, Hkv, ctx->cache_stride,
-                                       ctx->head_stride, c.attn_splits, ctx->pm, ctx->pl, ctx->po, ctx->tickets, ctx->attn, st));
+                                       ctx->head_stride, attn_S, attn_waves, ctx->pm, ctx->pl, ctx->po, ctx->tickets, ctx->attn, st));
         } else {
             // rows of one launch share caches (prefill chunks): every append must land before any row attends
             ctx->launches += 3;
@@ -944,7 +946,7 @@ static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float*
                                              ctx->head_stride, ctx->attn, st));
             else
                 VVCHK(vv_attn_launch(D, c.xsplit, ctx->qrot, ctx->rows_dev, kl, vl, R, Hq, Hkv, ctx->cache_stride,
-                                     ctx->head_stride, c.attn_splits, ctx->pm, ctx->pl, ctx->po, ctx->attn, st));
+                                     ctx->head_stride, attn_S, ctx->pm, ctx->pl, ctx->po, ctx->attn, st));
         }
         VVGemm go = mk_gemm(L.wo, ctx->attn, ctx->h, R, H, Hq * D, Hq * D, H);
         go.epi = VV_EPI_RESID; go.nt = 1;
@@ -980,7 +982,7 @@ extern "C" int vv_lm_forward_range(vv_ctx* ctx, void* stream, int n_rows, const 
         if (rows[i].pos < 0 || rows[i].pos >= ctx->c.max_ctx) return fail(ctx, "row %d: position %d exceeds max_ctx %d", i, rows[i].pos, ctx->c.max_ctx);
     }
     const int slot = ring_acquire(ctx);
-    VVRow* pin = ctx->rows_pin + (size_t)slot * 2048;
+    VVRow* pin = ctx->rows_pin + (size_t)slot * ctx->rows_cap;
     for (int i = 0; i < n_rows; ++i) { pin[i].cache = rows[i].cache; pin[i].pos = rows[i].pos; }
     HIPCHK(ctx, hipMemcpyAsync(ctx->rows_dev, pin, sizeof(VVRow) * n_rows, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipEventRecord(ctx->ring_ev[slot], st));
@@ -997,9 +999,18 @@ extern "C" int vv_lm_forward_range(vv_ctx* ctx, void* stream, int n_rows, const 
         if (rows[i].cache != rows[0].cache || rows[i].pos != rows[0].pos + i) contiguous = false;
     if (!contiguous && n_rows > ctx->ws_rows)
         return fail(ctx, "a launch of %d rows must be consecutive positions of one cache (decode / ragged launches take <= %d rows)", n_rows, ctx->ws_rows);
-    char key[128]; snprintf(key, 128, "lm:%d:%p:%p:%d:%d:%d:%d", n_rows, (const void*)x_in_dev, (void*)hidden_out_dev, l0, l1, final_norm,
-                            fused ? 1 : (contiguous ? 2 : 0));
-    return graphed(ctx, key, st, [&]() { return lm_body(ctx, st, n_rows, x_in_dev, hidden_out_dev, l0, l1, final_norm, fused, contiguous); });
+    // decode attention geometry: one split (workgroup column) per 512 positions of the longest row, at most attn_splits; the
+    // 8-wave form once the KV stream dominates.  Both are grid / template choices, so they are part of the graph key: a
+    // growing context re-captures the step graph every 512 positions.
+    int max_len = 1;
+    for (int i = 0; i < n_rows; ++i) max_len = std::max(max_len, rows[i].pos + 1);
+    static const int long_ctx = getenv("VVHIP_ATTN_LONG") ? atoi(getenv("VVHIP_ATTN_LONG")) : 4096;
+    static const int split_pos = getenv("VVHIP_ATTN_SPLIT_POS") ? std::max(512, atoi(getenv("VVHIP_ATTN_SPLIT_POS"))) : 512;
+    const int attn_S = std::min(ctx->c.attn_splits, std::max(1, (max_len + split_pos - 1) / split_pos));
+    const int attn_waves = (max_len >= long_ctx) ? 8 : 4;
+    char key[160]; snprintf(key, 160, "lm:%d:%p:%p:%d:%d:%d:%d:%d:%d", n_rows, (const void*)x_in_dev, (void*)hidden_out_dev, l0, l1, final_norm,
+                            fused ? 1 : (contiguous ? 2 : 0), contiguous ? 0 : attn_S, fused ? attn_waves : 0);
+    return graphed(ctx, key, st, [&]() { return lm_body(ctx, st, n_rows, x_in_dev, hidden_out_dev, l0, l1, final_norm, fused, contiguous, attn_S, attn_waves); });
 }
 
 extern "C" int vv_kv_import_at(vv_ctx* ctx, void* stream, int cache, int layer, int pos0, int n_pos, const void* k_dev, const void* v_dev, int src_dtype) {

@@ -197,57 +197,77 @@ __global__ __launch_bounds__(256) void vv_normdw_sliced_kernel(const float* __re
 // LDS (the six halo rows are re-derived from the input, or taken from the streaming history for t < 0), then applies the
 // depthwise conv + layer scale + residual.  Output goes to a DIFFERENT buffer (the stage ping-pongs): the neighbours are
 // still reading the halo rows of xin.  The owner of a row >= T-6 also writes its normed row into nb (the next frame's history).
-template <int RB>
+template <int RB, int NCH>          // NCH = C / 256 float4 chunks per lane and row
 __global__ __launch_bounds__(256) void vv_normdw_rows_kernel(const float* __restrict__ xin, float* __restrict__ xout,
                                                              float* __restrict__ nb, const float* __restrict__ nw,
                                                              const float* __restrict__ w, const float* __restrict__ b,
                                                              const float* __restrict__ gamma, int T, int C, float eps) {
-    extern __shared__ __attribute__((aligned(16))) float nrm_sh[];          // [RB + 6][C]
+    extern __shared__ __attribute__((aligned(16))) float nrm_sh[];          // [RB + 6][C] normed rows, then [RB][C] raw rows
+    float* raw_sh = nrm_sh + (size_t)(RB + 6) * C;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t0 = blockIdx.x * RB;
-    for (int rr = wave; rr < RB + 6; rr += 4) {
-        const int t = t0 - 6 + rr;
-        float* dst = nrm_sh + (size_t)rr * C;
-        if (t < 0) {
-            const float* hr = nb + (int64_t)(6 + t) * C;
-            for (int c = lane * 4; c < C; c += 256) *reinterpret_cast<float4*>(dst + c) = *reinterpret_cast<const float4*>(hr + c);
-        } else if (t < T) {
-            const float* xr = xin + (int64_t)t * C;
+    // ---- every global load of phase 1 is issued before the first wait: wave w owns rows rr = 4w .. 4w+3 of the RB + 6 ----
+    constexpr int RPW = (RB + 6 + 3) / 4;
+    float4 v[RPW][NCH], nwv[NCH];
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) nwv[q] = *reinterpret_cast<const float4*>(nw + (q * 64 + lane) * 4);
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int rr = wave * RPW + i, t = t0 - 6 + rr;
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            const int c = (q * 64 + lane) * 4;
+            float4 x4 = {0.f, 0.f, 0.f, 0.f};
+            if (rr < RB + 6) {
+                if (t < 0) x4 = *reinterpret_cast<const float4*>(nb + (int64_t)(6 + t) * C + c);          // history: already normed
+                else if (t < T) x4 = *reinterpret_cast<const float4*>(xin + (int64_t)t * C + c);
+            }
+            v[i][q] = x4;
+        }
+    }
+    // phase-2 operands of this thread's channel group (C/4 divides 256: the group is fixed per thread)
+    const int C4 = C >> 2;
+    const int c4 = (tid % C4) * 4;
+    float4 wj[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) wj[j] = *reinterpret_cast<const float4*>(w + (size_t)j * C + c4);
+    const float4 bb = *reinterpret_cast<const float4*>(b + c4), gg = *reinterpret_cast<const float4*>(gamma + c4);
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int rr = wave * RPW + i, t = t0 - 6 + rr;
+        if (rr >= RB + 6) break;
+        float rs = 1.0f;
+        const bool cur = (t >= 0 && t < T);
+        if (cur) {
             float s = 0.f;
-            for (int c = lane * 4; c < C; c += 256) {
-                const float4 v = *reinterpret_cast<const float4*>(xr + c);
-                s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-            }
-            const float rs = rsqrtf(wave_sum(s) / (float)C + eps);
-            const bool keep = (rr >= 6) && (t >= T - 6);                    // this workgroup owns row t and it is part of the next history
-            for (int c = lane * 4; c < C; c += 256) {
-                const float4 v = *reinterpret_cast<const float4*>(xr + c);
-                const float4 ww = *reinterpret_cast<const float4*>(nw + c);
-                const float4 o = {v.x * rs * ww.x, v.y * rs * ww.y, v.z * rs * ww.z, v.w * rs * ww.w};
-                *reinterpret_cast<float4*>(dst + c) = o;
-                if (keep) *reinterpret_cast<float4*>(nb + (int64_t)(6 + t) * C + c) = o;
-            }
-        } else {
-            for (int c = lane * 4; c < C; c += 256) *reinterpret_cast<float4*>(dst + c) = float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < NCH; ++q) s += v[i][q].x * v[i][q].x + v[i][q].y * v[i][q].y + v[i][q].z * v[i][q].z + v[i][q].w * v[i][q].w;
+            rs = rsqrtf(wave_sum(s) / (float)C + eps);
+        }
+        const bool keep = cur && (rr >= 6) && (t >= T - 6);                 // owned row that belongs to the next frame's history
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            const int c = (q * 64 + lane) * 4;
+            float4 o = v[i][q];
+            if (cur) o = float4{o.x * rs * nwv[q].x, o.y * rs * nwv[q].y, o.z * rs * nwv[q].z, o.w * rs * nwv[q].w};
+            *reinterpret_cast<float4*>(nrm_sh + (size_t)rr * C + c) = o;
+            if (rr >= 6) *reinterpret_cast<float4*>(raw_sh + (size_t)(rr - 6) * C + c) = v[i][q];
+            if (keep) *reinterpret_cast<float4*>(nb + (int64_t)(6 + t) * C + c) = o;
         }
     }
     __syncthreads();
-    const int C4 = C >> 2;
     for (int e = tid; e < RB * C4; e += 256) {
-        const int r = e / C4, c = (e - r * C4) * 4;
+        const int r = e / C4;
         const int t = t0 + r;
         if (t >= T) break;
-        const float4 bb = *reinterpret_cast<const float4*>(b + c);
         float4 acc = bb;
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
-            const float4 wj = *reinterpret_cast<const float4*>(w + (size_t)j * C + c);
-            const float4 nj = *reinterpret_cast<const float4*>(nrm_sh + (size_t)(r + j) * C + c);
-            acc.x += wj.x * nj.x; acc.y += wj.y * nj.y; acc.z += wj.z * nj.z; acc.w += wj.w * nj.w;
+            const float4 nj = *reinterpret_cast<const float4*>(nrm_sh + (size_t)(r + j) * C + c4);
+            acc.x += wj[j].x * nj.x; acc.y += wj[j].y * nj.y; acc.z += wj[j].z * nj.z; acc.w += wj[j].w * nj.w;
         }
-        const float4 g = *reinterpret_cast<const float4*>(gamma + c);
-        const float4 xv = *reinterpret_cast<const float4*>(xin + (int64_t)t * C + c);
-        *reinterpret_cast<float4*>(xout + (int64_t)t * C + c) = float4{xv.x + g.x * acc.x, xv.y + g.y * acc.y, xv.z + g.z * acc.z, xv.w + g.w * acc.w};
+        const float4 xv = *reinterpret_cast<const float4*>(raw_sh + (size_t)r * C + c4);
+        *reinterpret_cast<float4*>(xout + (int64_t)t * C + c4) = float4{xv.x + gg.x * acc.x, xv.y + gg.y * acc.y, xv.z + gg.z * acc.z, xv.w + gg.w * acc.w};
     }
 }
 
@@ -475,13 +495,21 @@ int vv_normdw_sliced_launch(const float* xin, float* xout, float* nb, const floa
     else hipLaunchKernelGGL((vv_normdw_sliced_kernel<2>), dim3(C / 256), dim3(256), 0, s, xin, xout, nb, nw, w, b, gamma, T, C, eps);
     return okk();
 }
-int vv_normdw_rows_ok(int T, int C) { return T >= 1 && (C & 3) == 0 && C >= 64 && C <= 1024; }
+int vv_normdw_rows_ok(int T, int C) { return T >= 1 && (C == 256 || C == 512 || C == 1024); }
 int vv_normdw_rows_launch(const float* xin, float* xout, float* nb, const float* nw, const float* w, const float* b,
                           const float* gamma, int T, int C, float eps, hipStream_t s) {
     if (!vv_normdw_rows_ok(T, C) || xin == xout) return -1;
     constexpr int RB = 8;
-    const size_t smem = (size_t)(RB + 6) * C * 4;
-    hipLaunchKernelGGL((vv_normdw_rows_kernel<RB>), dim3((T + RB - 1) / RB), dim3(256), smem, s, xin, xout, nb, nw, w, b, gamma, T, C, eps);
+    const size_t smem = (size_t)(2 * RB + 6) * C * 4;
+    const dim3 grid((T + RB - 1) / RB);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_normdw_rows_kernel<RB, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    if (C == 256) hipLaunchKernelGGL((vv_normdw_rows_kernel<RB, 1>), grid, dim3(256), smem, s, xin, xout, nb, nw, w, b, gamma, T, C, eps);
+    else if (C == 512) hipLaunchKernelGGL((vv_normdw_rows_kernel<RB, 2>), grid, dim3(256), smem, s, xin, xout, nb, nw, w, b, gamma, T, C, eps);
+    else hipLaunchKernelGGL((vv_normdw_rows_kernel<RB, 4>), grid, dim3(256), smem, s, xin, xout, nb, nw, w, b, gamma, T, C, eps);
     return okk();
 }
 int vv_stem_conv_launch(const float* in, const void* wp, const float* bias, float* out, int T, int N, hipStream_t s) {

@@ -14,11 +14,11 @@
 //                           conflicts on the ds_read_b128 that follow); epilogues bias / residual / SwiGLU, the SwiGLU one
 //                           writing its result as packed bf16 fragments for the down projection.  Workgroup ids are mapped
 //                           so that one XCD (own L2) owns a contiguous range of feature blocks.
-//   vv_attn_prefill2_kernel causal attention for a chunk of consecutive positions: a workgroup owns 64 query rows x one kv
-//                           head, streams every 32-position K/V block ONCE through a double-buffered LDS stage
-//                           (global_load_lds) and each wave runs the online softmax of one query head over 4 row tiles
-//                           (K / V fragments read from LDS once per block and reused for the 4 tiles): K/V traffic per
-//                           query row drops 4 x (rows) x G (heads) against vv_attn_prefill_kernel.
+//   vv_attn_prefill2_kernel causal attention for a chunk of consecutive positions: a workgroup owns 64 query rows x 4 query
+//                           heads of one kv head, streams the causal prefix ONCE, 64 positions per stage, through a
+//                           double-buffered LDS stage (global_load_lds); each wave runs the online softmax of one query
+//                           head over 4 row tiles (K / V fragments read from LDS once per block, reused for the 4 tiles):
+//                           16 x fewer K/V reads per query row than vv_attn_prefill_kernel.
 #include <cstdlib>
 #include "vv_common.h"
 
@@ -262,7 +262,8 @@ __global__ __launch_bounds__(256) void vv_gemm3_kernel(const VVGemm3 a) {
 
 // ------------------------------------------------------------------------------------------------ prefill attention
 // rows = consecutive positions of ONE cache (rows[0] first); q_rot (rotated, scaled by 1/sqrt(D)) and the chunk's own K/V
-// are already in place (vv_rope_append_kernel).  grid (ceil(R / 64), Hkv), 256 threads.  KV-cache layout: attn.hip header.
+// are already in place (vv_rope_append_kernel).  grid (ceil(R / 64), Hkv, ceil(G / 4)), 256 threads: a workgroup owns 64
+// query rows x 4 query heads of one kv head (one head per wave).  KV-cache layout: attn.hip header.
 template <int D>
 __global__ __launch_bounds__(256) void vv_attn_prefill2_kernel(
     const float* __restrict__ q, const VVRow* __restrict__ rows, const __bf16* __restrict__ kc,
@@ -270,9 +271,9 @@ __global__ __launch_bounds__(256) void vv_attn_prefill2_kernel(
     float* __restrict__ out) {
     constexpr int KT = D / 32, DT = D / 16;
     constexpr int KF = 2 * KT;                       // K fragments of a 32-position block (2 position tiles x KT)
-    constexpr int NF = KF + DT;                      // + DT transposed-V fragments
-    constexpr int BUF = NF * 1024;
-    __shared__ __attribute__((aligned(16))) unsigned char kv[2 * BUF];
+    constexpr int SF = 2 * (KF + DT);                // fragments of one 64-position stage: K of 2 blocks, then V of 2 blocks
+    constexpr int BUF = SF * 1024;
+    extern __shared__ __attribute__((aligned(16))) unsigned char kv[];          // 2 stages
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // longest workgroups first: the last query tile walks the whole prefix
@@ -280,72 +281,76 @@ __global__ __launch_bounds__(256) void vv_attn_prefill2_kernel(
     const int r0 = qt * 64, kvh = blockIdx.y;
     const VVRow rw = rows[0];
     const int G = Hq / Hkv;
+    const int g = (int)blockIdx.z * 4 + wave;        // this wave's query head inside the group
+    const bool act = g < G;
+    const int h = kvh * G + (act ? g : 0);
     const int col = lane & 15, qg = lane >> 4;
     const int pend = rw.pos + min(r0 + 63, R - 1) + 1;              // positions this tile walks: [0, pend)
-    const int n_blk = (pend + 31) >> 5;
+    const int n_stg = (pend + 63) >> 6;
     const int first_masked = (rw.pos + r0) >> 5;                      // blocks below this one are visible to every query row
     const u32x4* kt_base = reinterpret_cast<const u32x4*>(kc + (int64_t)rw.cache * cache_stride + (int64_t)kvh * head_stride);
     const u32x4* vt_base = reinterpret_cast<const u32x4*>(vc + (int64_t)rw.cache * cache_stride + (int64_t)kvh * head_stride);
     constexpr float LOG2E = 1.4426950408889634f;
 
-    // fragments of block b: K tiles (b*2)*KT .. +KF (contiguous), V tiles b*DT .. +DT (contiguous); wave w copies every 4th
-    auto issue = [&](int b, unsigned char* buf) {
-        const u32x4* ks = kt_base + (int64_t)b * KF * 64 + lane;
-        const u32x4* vs = vt_base + (int64_t)b * DT * 64 + lane;
+    // stage s = blocks 2s, 2s+1: K tiles (2s)*KF .. +2KF and V tiles (2s)*DT .. +2DT are both contiguous; wave w copies every 4th
+    auto issue = [&](int st, unsigned char* buf) {
+        const u32x4* ks = kt_base + (int64_t)st * 2 * KF * 64 + lane;
+        const u32x4* vs = vt_base + (int64_t)st * 2 * DT * 64 + lane;
 #pragma unroll
-        for (int f = 0; f < NF; ++f) {
+        for (int f = 0; f < SF; ++f) {
             if ((f & 3) == wave) {                                    // uniform per wave
-                if (f < KF) glds16(ks + f * 64, buf + f * 1024);
-                else glds16(vs + (f - KF) * 64, buf + f * 1024);
+                if (f < 2 * KF) glds16(ks + f * 64, buf + f * 1024);
+                else glds16(vs + (f - 2 * KF) * 64, buf + f * 1024);
             }
         }
     };
+    issue(0, kv);
 
-    for (int g0 = 0; g0 < G; g0 += 4) {              // 4 query heads of the group per pass, one per wave
-        const int g = g0 + wave;
-        const bool act = g < G;
-        const int h = kvh * G + (act ? g : 0);
-        // ---- q fragments of the 4 row tiles, in the log2 domain (scores * log2 e: p = exp2(s - m)) ----
-        bf16x8 qf[4][KT];
+    // ---- q fragments of the 4 row tiles, in the log2 domain (scores * log2 e: p = exp2(s - m)) ----
+    bf16x8 qf[4][KT];
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) {
-            const int row = min(r0 + rt * 16 + col, R - 1);
+    for (int rt = 0; rt < 4; ++rt) {
+        const int row = min(r0 + rt * 16 + col, R - 1);
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) {
-                const float* qp = q + ((int64_t)row * Hq + h) * D + kt * 32 + qg * 8;
-                const float4 a0 = *reinterpret_cast<const float4*>(qp), a1 = *reinterpret_cast<const float4*>(qp + 4);
-                const float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        for (int kt = 0; kt < KT; ++kt) {
+            const float* qp = q + ((int64_t)row * Hq + h) * D + kt * 32 + qg * 8;
+            const float4 a0 = *reinterpret_cast<const float4*>(qp), a1 = *reinterpret_cast<const float4*>(qp + 4);
+            const float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
-                for (int j = 0; j < 8; ++j) qf[rt][kt][j] = (__bf16)(v[j] * LOG2E);
-            }
+            for (int j = 0; j < 8; ++j) qf[rt][kt][j] = (__bf16)(v[j] * LOG2E);
         }
-        float m[4], lsum[4];
-        f32x4 o[4][DT];
+    }
+    float m[4], lsum[4];
+    f32x4 o[4][DT];
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) {
-            m[rt] = -INFINITY; lsum[rt] = 0.f;
+    for (int rt = 0; rt < 4; ++rt) {
+        m[rt] = -INFINITY; lsum[rt] = 0.f;
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) o[rt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        __syncthreads();                              // the previous pass is done with both buffers
-        issue(0, kv);
+        for (int dt = 0; dt < DT; ++dt) o[rt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll 1
-        for (int b = 0; b < n_blk; ++b) {
-            unsigned char* cur = kv + (b & 1) * BUF;
-            stage_sync();                             // block b has landed (every wave drained its own copies first);
-                                                      // everyone has finished block b-1, whose buffer is refilled now
-            if (b + 1 < n_blk) issue(b + 1, kv + ((b + 1) & 1) * BUF);
-            if (!act) continue;
+    for (int st = 0; st < n_stg; ++st) {
+        unsigned char* cur = kv + (st & 1) * BUF;
+        stage_sync();                             // stage st has landed (every wave drained its own copies first);
+                                                  // everyone has finished stage st-1, whose buffer is refilled now
+        if (st + 1 < n_stg) issue(st + 1, kv + ((st + 1) & 1) * BUF);
+        if (!act) continue;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int b = st * 2 + sub;
             const int p0 = b * 32;
+            if (p0 >= pend) break;                // uniform
             const bool masked = b >= first_masked;
+            const unsigned char* kb_ = cur + sub * KF * 1024;
+            const unsigned char* vb_ = cur + (2 * KF + sub * DT) * 1024;
             // ---- S^T = K q^T for the 4 row tiles: every K fragment is read from LDS once ----
             f32x4 s0[4], s1[4];
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt) { s0[rt] = f32x4{0.f, 0.f, 0.f, 0.f}; s1[rt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) {
-                const bf16x8 ka = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(cur + (kt * 64 + lane) * 16));
-                const bf16x8 kb = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(cur + ((KT + kt) * 64 + lane) * 16));
+                const bf16x8 ka = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(kb_ + (kt * 64 + lane) * 16));
+                const bf16x8 kb = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(kb_ + ((KT + kt) * 64 + lane) * 16));
 #pragma unroll
                 for (int rt = 0; rt < 4; ++rt) {
                     s0[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[rt][kt], s0[rt], 0, 0, 0);
@@ -389,7 +394,7 @@ __global__ __launch_bounds__(256) void vv_attn_prefill2_kernel(
             // ---- O += P . V: every V fragment is read from LDS once ----
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                const bf16x8 vt = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(cur + ((KF + dt) * 64 + lane) * 16));
+                const bf16x8 vt = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(vb_ + (dt * 64 + lane) * 16));
 #pragma unroll
                 for (int rt = 0; rt < 4; ++rt) {
                     o[rt][dt] *= al[rt];
@@ -397,21 +402,21 @@ __global__ __launch_bounds__(256) void vv_attn_prefill2_kernel(
                 }
             }
         }
-        if (act) {
+    }
+    if (act) {
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) {
-                float l = lsum[rt];
-                l += __shfl_xor(l, 16);
-                l += __shfl_xor(l, 32);
-                const int row = r0 + rt * 16 + col;
-                if (row < R) {
-                    const float inv = 1.0f / l;
-                    float* orow = out + ((int64_t)row * Hq + h) * D + qg * 4;
+        for (int rt = 0; rt < 4; ++rt) {
+            float l = lsum[rt];
+            l += __shfl_xor(l, 16);
+            l += __shfl_xor(l, 32);
+            const int row = r0 + rt * 16 + col;
+            if (row < R) {
+                const float inv = 1.0f / l;
+                float* orow = out + ((int64_t)row * Hq + h) * D + qg * 4;
 #pragma unroll
-                    for (int dt = 0; dt < DT; ++dt)
-                        *reinterpret_cast<float4*>(orow + dt * 16) =
-                            float4{o[rt][dt][0] * inv, o[rt][dt][1] * inv, o[rt][dt][2] * inv, o[rt][dt][3] * inv};
-                }
+                for (int dt = 0; dt < DT; ++dt)
+                    *reinterpret_cast<float4*>(orow + dt * 16) =
+                        float4{o[rt][dt][0] * inv, o[rt][dt][1] * inv, o[rt][dt][2] * inv, o[rt][dt][3] * inv};
             }
         }
     }
@@ -463,13 +468,20 @@ int vv_gemm3_launch(const void* W, const void* W2, const void* Xp, float* Y, voi
 int vv_attn_prefill2_launch(int D, const float* q, const VVRow* rows, const void* kc, const void* vc, int R, int Hq, int Hkv,
                             int64_t cache_stride, int64_t head_stride, float* out, hipStream_t s) {
     if (Hq % Hkv != 0) return -1;
-    const dim3 grid((R + 63) / 64, Hkv);
+    const int G = Hq / Hkv;
+    const dim3 grid((R + 63) / 64, Hkv, (G + 3) / 4);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_attn_prefill2_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_attn_prefill2_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
     if (D == 128)
-        hipLaunchKernelGGL((vv_attn_prefill2_kernel<128>), grid, dim3(256), 0, s, q, rows, (const __bf16*)kc, (const __bf16*)vc,
-                           R, Hq, Hkv, cache_stride, head_stride, out);
+        hipLaunchKernelGGL((vv_attn_prefill2_kernel<128>), grid, dim3(256), 2 * 2 * (2 * 4 + 8) * 1024, s, q, rows, (const __bf16*)kc,
+                           (const __bf16*)vc, R, Hq, Hkv, cache_stride, head_stride, out);
     else if (D == 64)
-        hipLaunchKernelGGL((vv_attn_prefill2_kernel<64>), grid, dim3(256), 0, s, q, rows, (const __bf16*)kc, (const __bf16*)vc,
-                           R, Hq, Hkv, cache_stride, head_stride, out);
+        hipLaunchKernelGGL((vv_attn_prefill2_kernel<64>), grid, dim3(256), 2 * 2 * (2 * 2 + 4) * 1024, s, q, rows, (const __bf16*)kc,
+                           (const __bf16*)vc, R, Hq, Hkv, cache_stride, head_stride, out);
     else
         return -1;
     return hipGetLastError() == hipSuccess ? 0 : -2;

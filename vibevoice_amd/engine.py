@@ -45,7 +45,7 @@ class EngineConfig:
     max_ctx: int = 4096
     max_rows: int = 16
     xsplit: int = 2
-    attn_splits: int = 32
+    attn_splits: int = 128      # upper bound on flash-decoding splits; a launch uses one per 512 positions of its longest row
     enc_frames: int = 4
     use_graph: bool = True
     tts_layers: int = 0          # Streaming-0.5B: the last tts_layers of lm_layers form the TTS LM
