@@ -31,6 +31,14 @@ def kernel_stats(db, out):
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "Percentage"])
         for r in rows:
             w.writerow([short(r[0]), r[1], int(r[2]), round(r[3], 1), int(r[4]), int(r[5]), round(100.0 * r[2] / tot, 3)])
+    # the same, split by launch geometry (one line per kernel name x grid): separates the shapes a kernel runs at
+    shp = cur.execute("select name, grid_x, grid_y, grid_z, workgroup_x, count(*), sum(end-start), avg(end-start) "
+                      "from kernels group by name, grid_x, grid_y, grid_z, workgroup_x order by 7 desc").fetchall()
+    with open(out + "_kernel_shapes.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "GridX", "GridY", "GridZ", "WorkgroupX", "Calls", "TotalDurationNs", "AverageNs"])
+        for r in shp[:400]:
+            w.writerow([short(r[0])[:80], r[1], r[2], r[3], r[4], r[5], int(r[6]), round(r[7], 1)])
     return rows, tot
 
 

@@ -16,6 +16,7 @@
 // blocks with an online softmax per query head (query heads of the GQA group are
 // the 16 MFMA columns, so K/V are read once per group); partial (m, l, O) go to a
 // workspace and a second tiny kernel merges the splits.
+#include <cstdlib>
 #include "vv_common.h"
 
 namespace {
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(WAVES * 64) void vv_attn_fused_kernel(
     const float* __restrict__ qkv, const VVRow* __restrict__ rows, const float2* __restrict__ rope_tab,
     __bf16* __restrict__ kc, __bf16* __restrict__ vc, int Hq, int Hkv, int64_t cache_stride, int64_t head_stride,
     float q_scale, float* __restrict__ part_m, float* __restrict__ part_l, float* __restrict__ part_o,
-    unsigned* __restrict__ tickets, float* __restrict__ out) {
+    unsigned* __restrict__ tickets, float* __restrict__ out, int cyclic) {
     constexpr int KT = D / 32, DT = D / 16, HALF = D / 2;
     const int S = gridDim.x;
     const int split = blockIdx.x, kvh = blockIdx.y, r = blockIdx.z;
@@ -257,17 +258,58 @@ __global__ __launch_bounds__(WAVES * 64) void vv_attn_fused_kernel(
     const int pos = rw.pos, len = pos + 1;
     const int G = Hq / Hkv;
     const int g = lane & 15, qg = lane >> 4;
-    const int chunk = attn_chunk(len, S, WAVES * 32);
-    const int start = split * chunk;
-    const int end = min(len, start + chunk);
-    if (start >= len) return;
-    const int used = (len + chunk - 1) / chunk;
-    const bool owner = (split == used - 1);            // this chunk ends at the new token
+    // Two ways to cut the sequence into `S` pieces.  contiguous: split s owns positions [s*chunk, (s+1)*chunk).  cyclic:
+    // split s owns the 32-position blocks b = s, s + S, s + 2S, ... -- at any moment the workgroups of a launch read one
+    // compact region of the cache, i.e. the concurrent requests spread over every HBM channel instead of marching through
+    // S far-apart regions in lockstep.  The online softmax does not care about the order.
+    int end, used, p_first, p_step;
+    bool owner;
+    if (cyclic) {
+        const int n_blocks = (len + 31) >> 5;
+        used = min(S, n_blocks);
+        if (split >= used) return;
+        owner = (split == ((pos >> 5) % S));             // the block holding the new token
+        end = len;
+        p_first = (split + S * wave) * 32;
+        p_step = S * WAVES * 32;
+    } else {
+        const int chunk = attn_chunk(len, S, WAVES * 32);
+        const int start = split * chunk;
+        end = min(len, start + chunk);
+        if (start >= len) return;
+        used = (len + chunk - 1) / chunk;
+        owner = (split == used - 1);                     // this chunk ends at the new token
+        p_first = start + wave * 32;
+        p_step = WAVES * 32;
+    }
     const int QW = (Hq + 2 * Hkv) * D;
     const float* qrow = qkv + (int64_t)r * QW;
     const float2* tp = rope_tab + (int64_t)pos * HALF;
     __bf16* kbase = kc + (int64_t)rw.cache * cache_stride + (int64_t)kvh * head_stride;
     __bf16* vbase = vc + (int64_t)rw.cache * cache_stride + (int64_t)kvh * head_stride;
+
+    const u32x4* kt_base = reinterpret_cast<const u32x4*>(kbase);
+    const u32x4* vt_base = reinterpret_cast<const u32x4*>(vbase);
+    float m = -INFINITY, lsum = 0.f;
+    f32x4 o[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // K/V fragments of the next 32-position block are requested before the current one is consumed; the FIRST block's loads go
+    // out here, before the q / RoPE work: they depend on nothing but the row table
+    u32x4 nka[KT], nkb[KT], nvt[DT];
+    auto kv_load = [&](int p0) {
+        const int64_t t0 = (int64_t)(p0 >> 4) * KT;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            nka[kt] = kt_base[(t0 + kt) * 64 + lane];
+            nkb[kt] = kt_base[(t0 + KT + kt) * 64 + lane];
+        }
+        const int64_t vt0 = (int64_t)(p0 >> 5) * DT;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) nvt[dt] = vt_base[(vt0 + dt) * 64 + lane];
+    };
+    if (p_first < end) kv_load(p_first);
 
     // ---- new token's K (rotated) / V: LDS copy for the patch below + the cache append (fire and forget) ----
     __shared__ __attribute__((aligned(16))) __bf16 knew[D];
@@ -324,35 +366,14 @@ __global__ __launch_bounds__(WAVES * 64) void vv_attn_fused_kernel(
     }
     __syncthreads();                         // knew / vnew visible to the wave that meets the new token
 
-    const u32x4* kt_base = reinterpret_cast<const u32x4*>(kbase);
-    const u32x4* vt_base = reinterpret_cast<const u32x4*>(vbase);
-    float m = -INFINITY, lsum = 0.f;
-    f32x4 o[DT];
-#pragma unroll
-    for (int i = 0; i < DT; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // K/V fragments of the next 32-position block are requested before the current one is consumed
-    u32x4 nka[KT], nkb[KT], nvt[DT];
-    auto kv_load = [&](int p0) {
-        const int64_t t0 = (int64_t)(p0 >> 4) * KT;
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-            nka[kt] = kt_base[(t0 + kt) * 64 + lane];
-            nkb[kt] = kt_base[(t0 + KT + kt) * 64 + lane];
-        }
-        const int64_t vt0 = (int64_t)(p0 >> 5) * DT;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) nvt[dt] = vt_base[(vt0 + dt) * 64 + lane];
-    };
-    if (start + wave * 32 < end) kv_load(start + wave * 32);
-    for (int p0 = start + wave * 32; p0 < end; p0 += WAVES * 32) {
+    for (int p0 = p_first; p0 < end; p0 += p_step) {
         f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
         u32x4 ka[KT], kb[KT], vt[DT];
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) { ka[kt] = nka[kt]; kb[kt] = nkb[kt]; }
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) vt[dt] = nvt[dt];
-        if (p0 + WAVES * 32 < end) kv_load(p0 + WAVES * 32);
+        if (p0 + p_step < end) kv_load(p0 + p_step);
         if (owner && (pos >> 5) == (p0 >> 5)) {
             // the append above may not have landed: take the new token's row / column from LDS instead
             const int p = pos & 31;
@@ -476,8 +497,20 @@ __global__ __launch_bounds__(WAVES * 64) void vv_attn_fused_kernel(
     // overlap instead of forming one serial chain of L2 round trips), then the per-wave sums are added in wave order.  Which
     // workgroup merges does not matter: the split -> wave assignment and both summation orders are fixed. ----
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // Loads are issued in batches of MB independent requests (clamped addresses, masked use): a plain `for` over the splits
+    // compiles to one L2 round trip per split -- 8 .. 16 us of pure latency per layer at 32 .. 64 splits.
+    constexpr int MB = 4;
     float mw_max = -INFINITY;
-    for (int s2 = wave; s2 < used; s2 += WAVES) mw_max = fmaxf(mw_max, part_m[(gidx * S + s2) * 16 + g]);
+    for (int base = wave; base < used; base += WAVES * 2 * MB) {
+        float mv[2 * MB];
+#pragma unroll
+        for (int u = 0; u < 2 * MB; ++u) {
+            const int s2 = base + u * WAVES;
+            mv[u] = part_m[(gidx * S + (s2 < used ? s2 : base)) * 16 + g];
+        }
+#pragma unroll
+        for (int u = 0; u < 2 * MB; ++u) mw_max = fmaxf(mw_max, mv[u]);           // a clamped duplicate does not change a max
+    }
     if (lane < 16) sm[wave][lane] = mw_max;
     __syncthreads();
     float MM = -INFINITY;
@@ -487,16 +520,27 @@ __global__ __launch_bounds__(WAVES * 64) void vv_attn_fused_kernel(
     f32x4 OO[DT];
 #pragma unroll
     for (int i = 0; i < DT; ++i) OO[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int s2 = wave; s2 < used; s2 += WAVES) {
-        const int64_t pi = gidx * S + s2;
-        const float ms = part_m[pi * 16 + g];
-        const float f = (ms == -INFINITY) ? 0.f : expf(ms - MM);
-        LL += part_l[pi * 16 + g] * f;
-        if (g < G) {
+    const int gc = g < G ? g : 0;                 // columns >= G carry nothing: read column 0, never stored
+    for (int base = wave; base < used; base += WAVES * MB) {
+        float ms[MB], ls[MB];
+        float4 pv[MB][DT];
+#pragma unroll
+        for (int u = 0; u < MB; ++u) {
+            const int s2 = base + u * WAVES;
+            const int64_t pi = gidx * S + (s2 < used ? s2 : base);
+            ms[u] = part_m[pi * 16 + g];
+            ls[u] = part_l[pi * 16 + g];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) pv[u][dt] = *reinterpret_cast<const float4*>(part_o + (pi * 16 + gc) * D + dt * 16 + qg * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < MB; ++u) {            // fixed order inside a wave: u ascending = split ascending
+            const bool live = base + u * WAVES < used;
+            const float f = (!live || ms[u] == -INFINITY) ? 0.f : expf(ms[u] - MM);
+            LL += ls[u] * f;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                const float4 po = *reinterpret_cast<const float4*>(part_o + (pi * 16 + g) * D + dt * 16 + qg * 4);
-                OO[dt][0] += po.x * f; OO[dt][1] += po.y * f; OO[dt][2] += po.z * f; OO[dt][3] += po.w * f;
+                OO[dt][0] += pv[u][dt].x * f; OO[dt][1] += pv[u][dt].y * f; OO[dt][2] += pv[u][dt].z * f; OO[dt][3] += pv[u][dt].w * f;
             }
         }
     }
@@ -704,10 +748,11 @@ extern "C" int vv_attn_fused_launch(int D, int xs, const float* qkv, const VVRow
                                     float* pm, float* pl, float* po, unsigned* tickets, float* out, hipStream_t s) {
     if (Hq % Hkv != 0 || Hq / Hkv > 16 || (waves != 4 && waves != 8)) return -1;
     const float scale = 1.0f / sqrtf((float)D);
+    static const int cyclic = getenv("VVHIP_ATTN_CONTIGUOUS") ? 0 : 1;
 #define VV_F(D_, XS_, W_)                                                                                     \
     hipLaunchKernelGGL((vv_attn_fused_kernel<D_, XS_, W_>), dim3(S, Hkv, R), dim3(W_ * 64), 0, s, qkv, rows,  \
                        (const float2*)rope_tab, (__bf16*)kc, (__bf16*)vc, Hq, Hkv, cache_stride, head_stride, scale, \
-                       pm, pl, po, tickets, out)
+                       pm, pl, po, tickets, out, cyclic)
 #define VV_FW(D_, XS_) do { if (waves == 8) VV_F(D_, XS_, 8); else VV_F(D_, XS_, 4); } while (0)
     if (D == 128) { if (xs == 1) VV_FW(128, 1); else if (xs == 2) VV_FW(128, 2); else VV_FW(128, 3); }
     else if (D == 64) { if (xs == 1) VV_FW(64, 1); else if (xs == 2) VV_FW(64, 2); else VV_FW(64, 3); }

@@ -360,6 +360,7 @@ __global__ __launch_bounds__(256) void vv_attn_prefill2_kernel(
             // ---- online softmax per row tile -> P as the B operand of P.V ----
             bf16x8 pb[4];
             float al[4];
+            bool resc[4];                         // wave-uniform: some column of this row tile moved its running max
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt) {
                 float sv[8];
@@ -390,6 +391,8 @@ __global__ __launch_bounds__(256) void vv_attn_prefill2_kernel(
                 }
                 if (!dead) { lsum[rt] = lsum[rt] * alpha + ps; m[rt] = mn; }
                 al[rt] = dead ? 1.f : alpha;
+                // once the running maxima have settled (alpha == 1 in every lane) the 32 accumulator multiplies are skipped
+                resc[rt] = __builtin_amdgcn_ballot_w64(al[rt] != 1.0f) != 0;
             }
             // ---- O += P . V: every V fragment is read from LDS once ----
 #pragma unroll
@@ -397,7 +400,7 @@ __global__ __launch_bounds__(256) void vv_attn_prefill2_kernel(
                 const bf16x8 vt = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(vb_ + (dt * 64 + lane) * 16));
 #pragma unroll
                 for (int rt = 0; rt < 4; ++rt) {
-                    o[rt][dt] *= al[rt];
+                    if (resc[rt]) o[rt][dt] *= al[rt];
                     o[rt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, pb[rt], o[rt][dt], 0, 0, 0);
                 }
             }
