@@ -116,8 +116,8 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const u32x4* __restri
     const unsigned tile = blockIdx.x;
     const unsigned k_tiles = (unsigned)(pK + 31) >> 5;
     // K range of this workgroup (grid.y splits K for few-tile x long-K shapes so that all CUs stream), then of this wave
-    const unsigned KSB = (MR == 4) ? gridDim.y : 1u;
-    const unsigned ksb = (MR == 4) ? blockIdx.y : 0u;
+    const unsigned KSB = (MR <= 4) ? gridDim.y : 1u;
+    const unsigned ksb = (MR <= 4) ? blockIdx.y : 0u;
     const unsigned kchunk = (k_tiles + KSB - 1) / KSB;
     const unsigned kb0 = min(k_tiles, ksb * kchunk), kb1 = min(k_tiles, kb0 + kchunk);
     const unsigned kper = (kb1 - kb0 + WPB - 1) / WPB;
@@ -495,6 +495,14 @@ extern "C" int vv_gemv_launch(VVGemm a, int xs, hipStream_t s) {
     if (a.kgrid > 1) grid.y = a.kgrid;
     if (xs == 1 && !wpb8_only && a.kgrid <= 1) {
         if (n_tiles > 256) {
+            // one utterance = two rows (cond + uncond): the 2-row form halves the activation registers and the staging tile, so
+            // one more workgroup fits per SIMD (RMS_MOD + SwiGLU: 160 -> <= 128 VGPRs) and a 672-tile launch is resident at once
+            static const bool no_mr2 = getenv("VVHIP_NO_MR2") != nullptr;
+            if (a.T <= 2 && !no_mr2) {
+#define X(P, E) if (a.pro == P && a.epi == E) VV_GO(1, P, E, 2, 4);
+                VV_GEMV_W4(X)
+#undef X
+            }
 #define X(P, E) if (a.pro == P && a.epi == E) VV_GO(1, P, E, 4, 4);
             VV_GEMV_W4(X)
 #undef X

@@ -264,8 +264,8 @@ __global__ __launch_bounds__(256) void vv_gemm3_kernel(const VVGemm3 a) {
 // rows = consecutive positions of ONE cache (rows[0] first); q_rot (rotated, scaled by 1/sqrt(D)) and the chunk's own K/V
 // are already in place (vv_rope_append_kernel).  grid (ceil(R / 64), Hkv, ceil(G / 4)), 256 threads: a workgroup owns 64
 // query rows x 4 query heads of one kv head (one head per wave).  KV-cache layout: attn.hip header.
-template <int D>
-__global__ __launch_bounds__(256) void vv_attn_prefill2_kernel(
+template <int D, int RT>
+__global__ __launch_bounds__(64 * 4 * (4 / RT)) void vv_attn_prefill2_kernel(
     const float* __restrict__ q, const VVRow* __restrict__ rows, const __bf16* __restrict__ kc,
     const __bf16* __restrict__ vc, int R, int Hq, int Hkv, int64_t cache_stride, int64_t head_stride,
     float* __restrict__ out) {
@@ -274,14 +274,19 @@ __global__ __launch_bounds__(256) void vv_attn_prefill2_kernel(
     constexpr int SF = 2 * (KF + DT);                // fragments of one 64-position stage: K of 2 blocks, then V of 2 blocks
     constexpr int BUF = SF * 1024;
     extern __shared__ __attribute__((aligned(16))) unsigned char kv[];          // 2 stages
+    // RT = row tiles (16 query rows each) per wave.  RT = 4: 4 waves, one per SIMD, 389 registers -- softmax VALU work and
+    // MFMAs of a wave cannot overlap.  RT = 2: 8 waves (4 heads x 2 row halves), two per SIMD at <= 256 registers: one wave's
+    // exp / max / convert work runs under the other's MFMAs, at the price of every K/V fragment being read from LDS twice.
+    constexpr int NW = 4 * (4 / RT);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // longest workgroups first: the last query tile walks the whole prefix
     const int qt = (int)gridDim.x - 1 - (int)blockIdx.x;
     const int r0 = qt * 64, kvh = blockIdx.y;
+    const int rw0 = r0 + (wave >> 2) * (RT * 16);    // first query row of this wave
     const VVRow rw = rows[0];
     const int G = Hq / Hkv;
-    const int g = (int)blockIdx.z * 4 + wave;        // this wave's query head inside the group
+    const int g = (int)blockIdx.z * 4 + (wave & 3);  // this wave's query head inside the group
     const bool act = g < G;
     const int h = kvh * G + (act ? g : 0);
     const int col = lane & 15, qg = lane >> 4;
@@ -298,7 +303,7 @@ __global__ __launch_bounds__(256) void vv_attn_prefill2_kernel(
         const u32x4* vs = vt_base + (int64_t)st * 2 * DT * 64 + lane;
 #pragma unroll
         for (int f = 0; f < SF; ++f) {
-            if ((f & 3) == wave) {                                    // uniform per wave
+            if ((f % NW) == wave) {                                   // uniform per wave
                 if (f < 2 * KF) glds16(ks + f * 64, buf + f * 1024);
                 else glds16(vs + (f - 2 * KF) * 64, buf + f * 1024);
             }
@@ -307,10 +312,10 @@ __global__ __launch_bounds__(256) void vv_attn_prefill2_kernel(
     issue(0, kv);
 
     // ---- q fragments of the 4 row tiles, in the log2 domain (scores * log2 e: p = exp2(s - m)) ----
-    bf16x8 qf[4][KT];
+    bf16x8 qf[RT][KT];
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
-        const int row = min(r0 + rt * 16 + col, R - 1);
+    for (int rt = 0; rt < RT; ++rt) {
+        const int row = min(rw0 + rt * 16 + col, R - 1);
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
             const float* qp = q + ((int64_t)row * Hq + h) * D + kt * 32 + qg * 8;
@@ -320,10 +325,10 @@ __global__ __launch_bounds__(256) void vv_attn_prefill2_kernel(
             for (int j = 0; j < 8; ++j) qf[rt][kt][j] = (__bf16)(v[j] * LOG2E);
         }
     }
-    float m[4], lsum[4];
-    f32x4 o[4][DT];
+    float m[RT], lsum[RT];
+    f32x4 o[RT][DT];
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
         m[rt] = -INFINITY; lsum[rt] = 0.f;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) o[rt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -344,30 +349,30 @@ __global__ __launch_bounds__(256) void vv_attn_prefill2_kernel(
             const unsigned char* kb_ = cur + sub * KF * 1024;
             const unsigned char* vb_ = cur + (2 * KF + sub * DT) * 1024;
             // ---- S^T = K q^T for the 4 row tiles: every K fragment is read from LDS once ----
-            f32x4 s0[4], s1[4];
+            f32x4 s0[RT], s1[RT];
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) { s0[rt] = f32x4{0.f, 0.f, 0.f, 0.f}; s1[rt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            for (int rt = 0; rt < RT; ++rt) { s0[rt] = f32x4{0.f, 0.f, 0.f, 0.f}; s1[rt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) {
                 const bf16x8 ka = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(kb_ + (kt * 64 + lane) * 16));
                 const bf16x8 kb = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(kb_ + ((KT + kt) * 64 + lane) * 16));
 #pragma unroll
-                for (int rt = 0; rt < 4; ++rt) {
+                for (int rt = 0; rt < RT; ++rt) {
                     s0[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[rt][kt], s0[rt], 0, 0, 0);
                     s1[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb, qf[rt][kt], s1[rt], 0, 0, 0);
                 }
             }
             // ---- online softmax per row tile -> P as the B operand of P.V ----
-            bf16x8 pb[4];
-            float al[4];
-            bool resc[4];                         // wave-uniform: some column of this row tile moved its running max
+            bf16x8 pb[RT];
+            float al[RT];
+            bool resc[RT];                        // wave-uniform: some column of this row tile moved its running max
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) {
+            for (int rt = 0; rt < RT; ++rt) {
                 float sv[8];
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) { sv[rr] = s0[rt][rr]; sv[4 + rr] = s1[rt][rr]; }
                 if (masked) {
-                    const int plim = rw.pos + min(r0 + rt * 16 + col, R - 1);     // last position this column's query may attend
+                    const int plim = rw.pos + min(rw0 + rt * 16 + col, R - 1);    // last position this column's query may attend
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) {
                         const int pa = p0 + qg * 4 + rr;
@@ -399,7 +404,7 @@ __global__ __launch_bounds__(256) void vv_attn_prefill2_kernel(
             for (int dt = 0; dt < DT; ++dt) {
                 const bf16x8 vt = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(vb_ + (dt * 64 + lane) * 16));
 #pragma unroll
-                for (int rt = 0; rt < 4; ++rt) {
+                for (int rt = 0; rt < RT; ++rt) {
                     if (resc[rt]) o[rt][dt] *= al[rt];
                     o[rt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, pb[rt], o[rt][dt], 0, 0, 0);
                 }
@@ -408,11 +413,11 @@ __global__ __launch_bounds__(256) void vv_attn_prefill2_kernel(
     }
     if (act) {
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) {
+        for (int rt = 0; rt < RT; ++rt) {
             float l = lsum[rt];
             l += __shfl_xor(l, 16);
             l += __shfl_xor(l, 32);
-            const int row = r0 + rt * 16 + col;
+            const int row = rw0 + rt * 16 + col;
             if (row < R) {
                 const float inv = 1.0f / l;
                 float* orow = out + ((int64_t)row * Hq + h) * D + qg * 4;
@@ -473,20 +478,22 @@ int vv_attn_prefill2_launch(int D, const float* q, const VVRow* rows, const void
     if (Hq % Hkv != 0) return -1;
     const int G = Hq / Hkv;
     const dim3 grid((R + 63) / 64, Hkv, (G + 3) / 4);
+    static const bool rt4 = getenv("VVHIP_ATTN2_RT4") != nullptr;          // A/B: 4 waves x 4 row tiles (one wave per SIMD)
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_attn_prefill2_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_attn_prefill2_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_attn_prefill2_kernel<128, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_attn_prefill2_kernel<64, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_attn_prefill2_kernel<128, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_attn_prefill2_kernel<64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    if (D == 128)
-        hipLaunchKernelGGL((vv_attn_prefill2_kernel<128>), grid, dim3(256), 2 * 2 * (2 * 4 + 8) * 1024, s, q, rows, (const __bf16*)kc,
-                           (const __bf16*)vc, R, Hq, Hkv, cache_stride, head_stride, out);
-    else if (D == 64)
-        hipLaunchKernelGGL((vv_attn_prefill2_kernel<64>), grid, dim3(256), 2 * 2 * (2 * 2 + 4) * 1024, s, q, rows, (const __bf16*)kc,
-                           (const __bf16*)vc, R, Hq, Hkv, cache_stride, head_stride, out);
-    else
-        return -1;
+#define VV_A2(D_, RT_, SM_)                                                                                         \
+    hipLaunchKernelGGL((vv_attn_prefill2_kernel<D_, RT_>), grid, dim3(64 * 4 * (4 / RT_)), SM_, s, q, rows, (const __bf16*)kc, \
+                       (const __bf16*)vc, R, Hq, Hkv, cache_stride, head_stride, out)
+    if (D == 128) { if (rt4) VV_A2(128, 4, 2 * 2 * (2 * 4 + 8) * 1024); else VV_A2(128, 2, 2 * 2 * (2 * 4 + 8) * 1024); }
+    else if (D == 64) { if (rt4) VV_A2(64, 4, 2 * 2 * (2 * 2 + 4) * 1024); else VV_A2(64, 2, 2 * 2 * (2 * 2 + 4) * 1024); }
+    else return -1;
+#undef VV_A2
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
