@@ -120,12 +120,16 @@ struct VVGemm3 {
 
 __device__ __forceinline__ float g3_silu(float u) { return u / (1.0f + __expf(-u)); }
 
-template <int EPI>
-__global__ __launch_bounds__(256) void vv_gemm3_kernel(const VVGemm3 a) {
+// TR = row tiles (16 rows each) per wave: the workgroup covers 128 features x 32*TR rows.  TR = 8 (256 rows) doubles the
+// MFMAs per staged byte and per barrier: three such workgroups per CU carry enough arithmetic to cover a stage's load latency.
+template <int EPI, int TR>
+__global__ __launch_bounds__(256, TR == 8 ? 2 : 4) void vv_gemm3_kernel(const VVGemm3 a) {
     constexpr bool DUAL = (EPI == VV_EPI_SWIGLU);
     constexpr int FT = DUAL ? 4 : 8;              // feature tiles (per matrix) per workgroup
-    // LDS stage: 16 A fragments then 16 B fragments of one 64-wide K step (2 k-tiles): [frag][64 lanes][16 B]
-    __shared__ __attribute__((aligned(16))) unsigned char stage[32 * 1024];
+    // LDS stage: 16 A fragments then 4*TR B fragments of one 64-wide K step (2 k-tiles): [frag][64 lanes][16 B]
+    constexpr int NFR = 16 + 4 * TR;               // fragments per stage
+    constexpr int FPW = NFR / 4;                   // copied by each wave
+    __shared__ __attribute__((aligned(16))) unsigned char stage[NFR * 1024];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 15, fq = lane >> 4;
@@ -145,15 +149,15 @@ __global__ __launch_bounds__(256) void vv_gemm3_kernel(const VVGemm3 a) {
         tb = lin - nb * a.t_blocks;
     }
     const int ft0 = nb * FT;                       // first feature tile of this workgroup (in each matrix)
-    const int tt0 = tb * 8;                        // first row tile
-    const int wr = wave >> 1, wc = wave & 1;       // 2 x 2 waves: rows wr*64.., features wc*64..
+    const int tt0 = tb * 2 * TR;                   // first row tile
+    const int wr = wave >> 1, wc = wave & 1;       // 2 x 2 waves: rows wr*16*TR.., features wc*64..
 
-    // ---- stage loader: wave w copies fragments 8w .. 8w+7 of the 32 ----
+    // ---- stage loader: wave w copies fragments FPW*w .. FPW*w + FPW-1 of the NFR ----
     // fragment f < 16: A, feature-tile slot f >> 1 (DUAL: slots 0-3 gate, 4-7 up), k-tile f & 1;  f >= 16: B, row tile (f-16) >> 1
-    const u32x4* src[8];
+    const u32x4* src[FPW];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int f = wave * 8 + i;
+    for (int i = 0; i < FPW; ++i) {
+        const int f = wave * FPW + i;
         if (f < 16) {
             const int slot = f >> 1;
             const u32x4* base = (DUAL && slot >= 4) ? a.W2 : a.W;
@@ -166,19 +170,19 @@ __global__ __launch_bounds__(256) void vv_gemm3_kernel(const VVGemm3 a) {
             src[i] = a.Xp + (int64_t)tt * KT * 64 + lane;
         }
     }
-    f32x4 acc[4][4];                               // [feature tile of this wave][row tile of this wave]
+    f32x4 acc[4][TR];                              // [feature tile of this wave][row tile of this wave]
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TR; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int n_steps = (KT + 1) >> 1;
 #pragma unroll 1
     for (int s = 0; s < n_steps; ++s) {
         const int kt0 = s * 2;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int f = wave * 8 + i;
+        for (int i = 0; i < FPW; ++i) {
+            const int f = wave * FPW + i;
             int kt = kt0 + (f & 1);
             if (kt > KT - 1) kt = KT - 1;                              // odd K tail: re-reads the last k-tile, MFMA skipped
             glds16(src[i] + (int64_t)kt * 64, stage + f * 1024);
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(256) void vv_gemm3_kernel(const VVGemm3 a) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             if (kt0 + kk < KT) {
-                bf16x8 af[4], bfr[4];
+                bf16x8 af[4], bfr[TR];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     // this wave's feature tiles: plain: slots wc*4+i;  DUAL: i < 2 gate slots wc*2+i, i >= 2 up slots 4+wc*2+(i-2)
@@ -195,12 +199,12 @@ __global__ __launch_bounds__(256) void vv_gemm3_kernel(const VVGemm3 a) {
                     af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(stage + ((slot * 2 + kk) * 64 + lane) * 16));
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(stage + ((16 + (wr * 4 + j) * 2 + kk) * 64 + lane) * 16));
+                for (int j = 0; j < TR; ++j)
+                    bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(stage + ((16 + (wr * TR + j) * 2 + kk) * 64 + lane) * 16));
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < TR; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
             }
         }
@@ -216,8 +220,8 @@ __global__ __launch_bounds__(256) void vv_gemm3_kernel(const VVGemm3 a) {
             if (ft >= n_tiles) continue;
             const int n0 = ft * 16 + fq * 4;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int tt = tt0 + wr * 4 + j;
+            for (int j = 0; j < TR; ++j) {
+                const int tt = tt0 + wr * TR + j;
                 if (tt >= t_tiles) continue;
                 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
                 bf16x4 o;
@@ -245,8 +249,8 @@ __global__ __launch_bounds__(256) void vv_gemm3_kernel(const VVGemm3 a) {
                 if (a.bias) pb = *reinterpret_cast<const float4*>(a.bias + n0);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int t = (tt0 + wr * 4 + j) * 16 + frow;
+            for (int j = 0; j < TR; ++j) {
+                const int t = (tt0 + wr * TR + j) * 16 + frow;
                 if (t >= a.T) continue;
                 float* yp = a.Y + (int64_t)t * a.ldy + n0;
                 float4 o = {acc[i][j][0] + pb.x, acc[i][j][1] + pb.y, acc[i][j][2] + pb.z, acc[i][j][3] + pb.w};
@@ -456,20 +460,26 @@ int vv_gemm3_launch(const void* W, const void* W2, const void* Xp, float* Y, voi
     const int n_tiles = (N + 15) / 16;
     const int ft = (epi == VV_EPI_SWIGLU) ? 4 : 8;
     a.n_blocks = (n_tiles + ft - 1) / ft;
-    a.t_blocks = (T + 127) / 128;
+    // 256-row workgroups once the problem is tall enough to fill the chip with them
+    static const int tr_env = getenv("VVHIP_GEMM3_TR") ? atoi(getenv("VVHIP_GEMM3_TR")) : 0;
+    const int tr = tr_env == 4 || tr_env == 8 ? tr_env : ((int64_t)a.n_blocks * ((T + 255) / 256) >= 768 ? 8 : 4);
+    a.t_blocks = (T + 32 * tr - 1) / (32 * tr);
     const dim3 grid((unsigned)(a.n_blocks * a.t_blocks));
+#define VV_G3(E_) do { if (tr == 8) hipLaunchKernelGGL((vv_gemm3_kernel<E_, 8>), grid, dim3(256), 0, s, a); \
+                       else hipLaunchKernelGGL((vv_gemm3_kernel<E_, 4>), grid, dim3(256), 0, s, a); } while (0)
     if (epi == VV_EPI_SWIGLU) {
         if (!W2 || !Yp) return -1;
-        hipLaunchKernelGGL((vv_gemm3_kernel<VV_EPI_SWIGLU>), grid, dim3(256), 0, s, a);
+        VV_G3(VV_EPI_SWIGLU);
     } else if (epi == VV_EPI_RESID) {
         if (!Y || (ldy & 3)) return -1;
-        hipLaunchKernelGGL((vv_gemm3_kernel<VV_EPI_RESID>), grid, dim3(256), 0, s, a);
+        VV_G3(VV_EPI_RESID);
     } else if (epi == VV_EPI_BIAS || epi == VV_EPI_STORE) {
         if (!Y || (ldy & 3)) return -1;
-        hipLaunchKernelGGL((vv_gemm3_kernel<VV_EPI_BIAS>), grid, dim3(256), 0, s, a);      // bias == null: plain store
+        VV_G3(VV_EPI_BIAS);                        // bias == null: plain store
     } else {
         return -3;
     }
+#undef VV_G3
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
