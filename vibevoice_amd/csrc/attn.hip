@@ -298,17 +298,23 @@ __global__ __launch_bounds__(WAVES * 64) void vv_attn_fused_kernel(
     // K/V fragments of the next 32-position block are requested before the current one is consumed; the FIRST block's loads go
     // out here, before the q / RoPE work: they depend on nothing but the row table
     u32x4 nka[KT], nkb[KT], nvt[DT];
+#ifdef VV_ATTN_NT
+#define VV_KVLD(p) __builtin_nontemporal_load(p)
+#else
+#define VV_KVLD(p) (*(p))
+#endif
     auto kv_load = [&](int p0) {
         const int64_t t0 = (int64_t)(p0 >> 4) * KT;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
-            nka[kt] = kt_base[(t0 + kt) * 64 + lane];
-            nkb[kt] = kt_base[(t0 + KT + kt) * 64 + lane];
+            nka[kt] = VV_KVLD(kt_base + (t0 + kt) * 64 + lane);
+            nkb[kt] = VV_KVLD(kt_base + (t0 + KT + kt) * 64 + lane);
         }
         const int64_t vt0 = (int64_t)(p0 >> 5) * DT;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) nvt[dt] = vt_base[(vt0 + dt) * 64 + lane];
+        for (int dt = 0; dt < DT; ++dt) nvt[dt] = VV_KVLD(vt_base + (vt0 + dt) * 64 + lane);
     };
+#undef VV_KVLD
     if (p_first < end) kv_load(p_first);
 
     // ---- new token's K (rotated) / V: LDS copy for the patch below + the cache append (fire and forget) ----
