@@ -248,7 +248,7 @@ __global__ __launch_bounds__(WAVES * 64) void vv_attn_fused_kernel(
     const float* __restrict__ qkv, const VVRow* __restrict__ rows, const float2* __restrict__ rope_tab,
     __bf16* __restrict__ kc, __bf16* __restrict__ vc, int Hq, int Hkv, int64_t cache_stride, int64_t head_stride,
     float q_scale, float* __restrict__ part_m, float* __restrict__ part_l, float* __restrict__ part_o,
-    unsigned* __restrict__ tickets, float* __restrict__ out, int cyclic) {
+    unsigned* __restrict__ tickets, float* __restrict__ out, int cyclic, int defer_merge) {
     constexpr int KT = D / 32, DT = D / 16, HALF = D / 2;
     const int S = gridDim.x;
     const int split = blockIdx.x, kvh = blockIdx.y, r = blockIdx.z;
@@ -487,16 +487,17 @@ __global__ __launch_bounds__(WAVES * 64) void vv_attn_fused_kernel(
                 for (int dt = 0; dt < DT; ++dt)
                     *reinterpret_cast<float4*>(part_o + (pidx * 16 + g) * D + dt * 16 + qg * 4) = float4{O[dt][0], O[dt][1], O[dt][2], O[dt][3]};
             }
+            // deferred merge (long contexts): a separate, wide merge kernel follows in the stream -- no fence, no ticket
             // publish, then take a ticket: the workgroup that draws the last one merges
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            if (lane == 0) {
+            if (!defer_merge) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            if (!defer_merge && lane == 0) {
                 const unsigned old = __hip_atomic_fetch_add(tickets + gidx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 last_sh = (old == (unsigned)(used - 1)) ? 1 : 0;
                 if (last_sh) tickets[gidx] = 0u;          // next launch starts from zero (kernel boundary orders it)
             }
         }
     }
-    if (used == 1) return;                        // uniform over the workgroup
+    if (used == 1 || defer_merge) return;         // uniform over the workgroup
     __syncthreads();
     if (!last_sh) return;
     // ---- merge of the `used` partials by ALL waves of the last arriver: wave w takes splits w, w + WAVES, ... (their loads
@@ -702,6 +703,70 @@ __global__ void vv_attn_merge_kernel(const float* __restrict__ part_m, const flo
     out[((int64_t)r * Hq + h) * D + d] = acc / L;
 }
 
+// Merge of the split partials written by vv_attn_fused_kernel in deferred mode: grid (R, Hq), 512 threads = D output
+// dimensions x 512/D split groups.  Group j takes splits j, j + NG, ...: eight (m, l, o) triples are requested at once, so a
+// 32-way merge is ONE round trip per thread instead of a chain of them inside the last attention workgroup (which also paid a
+// release fence + device-scope ticket per split: 0.33 us per split at 32K positions).  Rows that needed one split were
+// finished by the attention kernel itself and are skipped.  Fixed assignment and summation order: deterministic.
+template <int D>
+__global__ __launch_bounds__(512) void vv_attn_merge2_kernel(const float* __restrict__ part_m, const float* __restrict__ part_l,
+                                                             const float* __restrict__ part_o, const VVRow* __restrict__ rows,
+                                                             float* __restrict__ out, int Hq, int Hkv, int S, int cyclic, int gran) {
+    constexpr int NG = 512 / D, MB = 8;
+    __shared__ float sm[NG][D], sl[NG][D], sa[NG][D];
+    const int r = blockIdx.x, h = blockIdx.y;
+    const int d = threadIdx.x % D, grp = threadIdx.x / D;
+    const int G = Hq / Hkv;
+    const int kvh = h / G, g = h - kvh * G;
+    const int len = rows[r].pos + 1;
+    int used;
+    if (cyclic) used = min(S, (len + 31) >> 5);
+    else { const int chunk = attn_chunk(len, S, gran); used = (len + chunk - 1) / chunk; }
+    if (used <= 1) return;
+    const int64_t base = ((int64_t)r * Hkv + kvh) * S;
+    float mrun = -INFINITY, lrun = 0.f, arun = 0.f;
+    for (int b0 = grp; b0 < used; b0 += NG * MB) {
+        float mv[MB], lv[MB], ov[MB];
+#pragma unroll
+        for (int u = 0; u < MB; ++u) {
+            const int s2 = b0 + u * NG;
+            const int64_t pi = base + (s2 < used ? s2 : b0);
+            mv[u] = part_m[pi * 16 + g];
+            lv[u] = part_l[pi * 16 + g];
+            ov[u] = part_o[(pi * 16 + g) * D + d];
+        }
+        float mb = mrun;
+#pragma unroll
+        for (int u = 0; u < MB; ++u) if (b0 + u * NG < used) mb = fmaxf(mb, mv[u]);
+        if (mb != -INFINITY) {
+            const float fs = (mrun == -INFINITY) ? 0.f : expf(mrun - mb);
+            lrun *= fs; arun *= fs;
+#pragma unroll
+            for (int u = 0; u < MB; ++u) {
+                const bool live = (b0 + u * NG < used) && mv[u] != -INFINITY;
+                const float f = live ? expf(mv[u] - mb) : 0.f;
+                lrun += lv[u] * f;
+                arun += ov[u] * f;
+            }
+            mrun = mb;
+        }
+    }
+    sm[grp][d] = mrun; sl[grp][d] = lrun; sa[grp][d] = arun;
+    __syncthreads();
+    if (grp != 0) return;
+    float M = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NG; ++j) M = fmaxf(M, sm[j][d]);
+    float L = 0.f, A = 0.f;
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        const float f = (sm[j][d] == -INFINITY) ? 0.f : expf(sm[j][d] - M);
+        L += sl[j][d] * f;
+        A += sa[j][d] * f;
+    }
+    out[((int64_t)r * Hq + h) * D + d] = A / L;
+}
+
 }  // namespace
 
 extern "C" int vv_rope_append_launch(int D, const float* qkv, const VVRow* rows, const float* inv_freq, float* q_out,
@@ -755,16 +820,23 @@ extern "C" int vv_attn_fused_launch(int D, int xs, const float* qkv, const VVRow
     if (Hq % Hkv != 0 || Hq / Hkv > 16 || (waves != 4 && waves != 8)) return -1;
     const float scale = 1.0f / sqrtf((float)D);
     static const int cyclic = getenv("VVHIP_ATTN_CONTIGUOUS") ? 0 : 1;
+    // several splits: the partials are merged by a separate wide kernel (no per-split fence / ticket inside the attention kernel)
+    static const int defer_ok = getenv("VVHIP_ATTN_TICKET_MERGE") ? 0 : 1;
+    const int defer = (S > 1 && defer_ok) ? 1 : 0;
 #define VV_F(D_, XS_, W_)                                                                                     \
     hipLaunchKernelGGL((vv_attn_fused_kernel<D_, XS_, W_>), dim3(S, Hkv, R), dim3(W_ * 64), 0, s, qkv, rows,  \
                        (const float2*)rope_tab, (__bf16*)kc, (__bf16*)vc, Hq, Hkv, cache_stride, head_stride, scale, \
-                       pm, pl, po, tickets, out, cyclic)
+                       pm, pl, po, tickets, out, cyclic, defer)
 #define VV_FW(D_, XS_) do { if (waves == 8) VV_F(D_, XS_, 8); else VV_F(D_, XS_, 4); } while (0)
     if (D == 128) { if (xs == 1) VV_FW(128, 1); else if (xs == 2) VV_FW(128, 2); else VV_FW(128, 3); }
     else if (D == 64) { if (xs == 1) VV_FW(64, 1); else if (xs == 2) VV_FW(64, 2); else VV_FW(64, 3); }
     else return -1;
 #undef VV_FW
 #undef VV_F
+    if (defer) {
+        if (D == 128) hipLaunchKernelGGL((vv_attn_merge2_kernel<128>), dim3(R, Hq), dim3(512), 0, s, pm, pl, po, rows, out, Hq, Hkv, S, cyclic, waves * 32);
+        else hipLaunchKernelGGL((vv_attn_merge2_kernel<64>), dim3(R, Hq), dim3(512), 0, s, pm, pl, po, rows, out, Hq, Hkv, S, cyclic, waves * 32);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

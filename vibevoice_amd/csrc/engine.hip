@@ -1008,7 +1008,13 @@ extern "C" int vv_lm_forward_range(vv_ctx* ctx, void* stream, int n_rows, const 
     // wave count); the form stays reachable for experiments
     static const int long_ctx = getenv("VVHIP_ATTN_LONG") ? atoi(getenv("VVHIP_ATTN_LONG")) : (1 << 30);
     static const int split_pos = getenv("VVHIP_ATTN_SPLIT_POS") ? std::max(256, atoi(getenv("VVHIP_ATTN_SPLIT_POS"))) : 1024;
-    const int attn_S = std::min(ctx->c.attn_splits, std::max(1, (max_len + split_pos - 1) / split_pos));
+    // ... and no more splits than it takes to put ~256 workgroups on the chip: with eight 32K-context utterances in flight the
+    // rows themselves are the parallelism (8 splits of 4096 positions: 122 us per layer against 162 us with 32 splits)
+    static const int target_wgs = getenv("VVHIP_ATTN_TARGET_WGS") ? std::max(1, atoi(getenv("VVHIP_ATTN_TARGET_WGS"))) : 256;
+    int n_long = 0;
+    for (int i = 0; i < n_rows; ++i) if (rows[i].pos + 1 > split_pos) ++n_long;
+    const int by_wgs = std::max(1, (target_wgs + std::max(1, n_long) * ctx->Hkv - 1) / (std::max(1, n_long) * ctx->Hkv));
+    const int attn_S = std::min(std::min(ctx->c.attn_splits, by_wgs), std::max(1, (max_len + split_pos - 1) / split_pos));
     const int attn_waves = (max_len >= long_ctx) ? 8 : 4;
     char key[160]; snprintf(key, 160, "lm:%d:%p:%p:%d:%d:%d:%d:%d:%d", n_rows, (const void*)x_in_dev, (void*)hidden_out_dev, l0, l1, final_norm,
                             fused ? 1 : (contiguous ? 2 : 0), contiguous ? 0 : attn_S, fused ? attn_waves : 0);
