@@ -457,7 +457,11 @@ extern "C" int vv_gemv_launch(VVGemm a, int xs, hipStream_t s) {
     if (a.T > 4) {
         if (xs > 2) return -3;       // 16-row staging tiles of the exact mode exceed the LDS: general kernel
         grid.y = (a.T + 15) / 16;
-        if (xs == 1 && (int64_t)n_tiles * grid.y > 512) {       // more workgroups than 2 per CU: the 4-wave form keeps them all resident
+        static const int wide4_wgs = getenv("VVHIP_WIDE4_WGS") ? atoi(getenv("VVHIP_WIDE4_WGS")) : 128;
+        // The 16-row tiles are used by the codec (T = 5..16 rows): above ~half a workgroup per CU the 4-wave form
+        // (2x the resident workgroups per CU) wins; measured 3.117 -> 3.053 ms/frame on the 1.5B config for
+        // thresholds 64..128 vs 512 (DESIGN.md section 8 lists the sweep).
+        if (xs == 1 && (int64_t)n_tiles * grid.y > wide4_wgs) {
 #define X(P, E) if (a.pro == P && a.epi == E) VV_GO(1, P, E, 16, 4);
             VV_GEMV_WIDE4(X)
 #undef X
