@@ -128,6 +128,15 @@ int vv_codec_decode(vv_ctx* ctx, void* stream, int slot, int frames, const float
 /* semantic_tokenizer.encode(audio, cache, use_cache=True).mean (:658-664) */
 int vv_semantic_encode(vv_ctx* ctx, void* stream, int slot, int frames, const float* audio_dev,
                        float* sem_out_dev);
+/* One frame of n utterances (1..8) through both tokenizers in one call: the reference decodes / re-encodes the whole set of
+ * diffusion rows of a step as ONE batch -- acoustic_tokenizer.decode(scaled_latent, cache=acoustic_cache,
+ * sample_indices=diffusion_indices) then semantic_tokenizer.encode(audio_chunk, cache=semantic_cache, sample_indices=...)
+ * (modeling_vibevoice_inference.py:636-672; per-sample cache rows: modular_vibevoice_tokenizer.py:76-126).  Row j of
+ * latent_dev [n][latent] / audio_out_dev [n][hop] / sem_out_dev [n][sem_dim] belongs to streaming slot slots[j] (distinct).
+ * sem_out_dev = NULL: decode only.  Same results as n vv_codec_decode + vv_semantic_encode calls up to bf16 summation order;
+ * the weight-heavy stages of both nets read their weights once for the whole batch. */
+int vv_codec_chain_batch(vv_ctx* ctx, void* stream, int n, const int* slots, const float* latent_dev,
+                         float* audio_out_dev, float* sem_out_dev, int apply_speech_factors);
 /* acoustic_tokenizer.encode(wav).mean, non-streaming (:154; modular_vibevoice_tokenizer.py:1081-1085):
  * wav_dev [frames*hop] -> mean_out_dev [frames][latent] */
 int vv_acoustic_encode(vv_ctx* ctx, void* stream, int frames, const float* wav_dev, float* mean_out_dev);

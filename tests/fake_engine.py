@@ -107,6 +107,12 @@ class FakeEngine:
         sem = codec.encoder_forward(om.sem_w, audio[None, None, :], om.ratios, om.sem_depths, state=self.sem_state[slot], eps=om.codec_eps)
         sem_out.copy_(sem[0, :, 0])
 
+    def codec_chain_batch(self, slots, latent, audio_out, sem_out=None, apply_speech_factors=True):
+        for j, sl in enumerate(slots):
+            self.codec_decode(sl, latent[j:j + 1], audio_out[j], apply_speech_factors)
+            if sem_out is not None:
+                self.semantic_encode(sl, audio_out[j], sem_out[j])
+
     def acoustic_encode(self, frames, wav, mean_out):
         om = self.om
         lat = codec.encoder_forward(om.ac_w, wav[None, None, :], om.ratios, om.enc_depths, state=None, eps=om.codec_eps)

@@ -106,3 +106,74 @@ def test_generate_at_1p5b_layer_shapes():
         model.engine.close()
         if model_bf16 is not None:
             model_bf16.engine.close()
+
+
+def test_codec_chain_batch_at_real_widths():
+    """vv_codec_chain_batch (several utterances' tokenizer chains in one call, the weight-heavy stages slot-batched) at the
+    real tokenizer widths, bf16 mode + hipGraph: against the CPU oracle's streaming decoder / encoder per slot, and against
+    the engine's own one-utterance path run on a spare slot with the same inputs.  Covers a mid-stream reset of one slot,
+    a changing slot set, and a slot that alternates between the batched and the single path."""
+    from oracle import codec
+    from vibevoice_amd import synthetic
+    from vibevoice_amd.configs import CONFIGS
+    from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference
+    cfg = copy.deepcopy(CONFIGS["1.5b"])
+    cfg["decoder_config"]["num_hidden_layers"] = 1
+    cfg["decoder_config"]["vocab_size"] = 2048
+    cfg["decoder_config"]["max_position_embeddings"] = 64
+    gen = torch.Generator().manual_seed(3)
+    sd = {k: synthetic.random_tensor(k, shp, gen, "cpu", torch.bfloat16) for k, shp in synthetic.param_shapes(cfg).items()}
+    model = VibeVoiceForConditionalGenerationInference.from_state_dict(cfg, sd, torch.float32, None, n_slots=5, max_ctx=64,
+                                                                       xsplit=1, use_graph=True, enc_frames=1)
+    scaling, bias = 0.2, -0.05
+    model.set_speech_factors(scaling, bias)
+    eng = model.engine
+    try:
+        ac_w = {k[len("model.acoustic_tokenizer."):]: v.float() for k, v in sd.items() if k.startswith("model.acoustic_tokenizer.")}
+        sem_w = {k[len("model.semantic_tokenizer."):]: v.float() for k, v in sd.items() if k.startswith("model.semantic_tokenizer.")}
+        depths = [3, 3, 3, 3, 3, 3, 8]
+        ratios = [8, 5, 5, 4, 2, 2]
+        st_dec = {s: {} for s in range(5)}
+        st_sem = {s: {} for s in range(5)}
+        g = torch.Generator().manual_seed(4)
+        # (slot set of the batched call, slots run through the one-utterance path) per frame; slot 1 mirrors slot 0's inputs
+        plan = [([0, 2, 3], [1]), ([0, 2, 3], [1]), ([3, 0], [1, 2]), ([0, 2, 3, 4], [1]), ([4, 3, 2, 0], [1]), ([0, 2], [1])]
+        lat_of = {}
+        worst_a = worst_s = worst_pair = 0.0
+        for t, (batch, single) in enumerate(plan):
+            if t == 2:                       # slot 3 restarts mid-stream (speech_end -> the caches are zeroed)
+                with torch.cuda.stream(eng.stream):
+                    eng.codec_reset(3)
+                codec.zero_state(st_dec[3]); codec.zero_state(st_sem[3])
+            for s in set(batch + single):
+                lat_of[s] = torch.randn(64, generator=g) * 0.7
+            lat_of[1] = lat_of[0].clone()
+            n = len(batch)
+            lat = torch.stack([lat_of[s] for s in batch]).to(eng.device)
+            audio = eng.new(n, 3200)
+            sem = eng.new(n, 128)
+            with torch.cuda.stream(eng.stream):
+                eng.codec_chain_batch(batch, lat, audio, sem)
+                outs = {}
+                for s in single:
+                    a1, s1 = eng.new(3200), eng.new(128)
+                    eng.codec_decode(s, lat_of[s][None].to(eng.device), a1)
+                    eng.semantic_encode(s, a1, s1)
+                    outs[s] = (a1, s1)
+            eng.sync()
+            for j, s in enumerate(batch):
+                outs[s] = (audio[j], sem[j])
+            for s, (a, se) in outs.items():
+                x = lat_of[s] / scaling - bias
+                ra = codec.decoder_forward(ac_w, x[None, :, None], ratios, list(reversed(depths)), st_dec[s], 1e-5)[0, 0]
+                rs = codec.encoder_forward(sem_w, ra[None, None], ratios, depths, st_sem[s], 1e-5)[0, :, 0]
+                worst_a = max(worst_a, rel_err(a, ra)); worst_s = max(worst_s, rel_err(se, rs))
+                assert rel_err(a, ra) <= 5e-2, (t, s, rel_err(a, ra))
+                assert rel_err(se, rs) <= 5e-2, (t, s, rel_err(se, rs))
+            # the batched path (slot 0) and the one-utterance path (slot 1) saw identical inputs from the start
+            pa, ps = rel_err(outs[0][0], outs[1][0].cpu()), rel_err(outs[0][1], outs[1][1].cpu())
+            worst_pair = max(worst_pair, pa, ps)
+            assert pa <= 1e-2 and ps <= 1e-2, (t, pa, ps)
+        print(f"codec_chain_batch: audio vs oracle {worst_a:.2e}, semantic vs oracle {worst_s:.2e}, batched vs single {worst_pair:.2e}")
+    finally:
+        eng.close()

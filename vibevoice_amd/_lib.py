@@ -47,6 +47,7 @@ _SIGS = {
     "vv_head_forward": (C.c_int, [_P, _P, C.c_int, _P, C.POINTER(C.c_float), _P, _P]),
     "vv_codec_decode": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, C.c_int]),
     "vv_semantic_encode": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
+    "vv_codec_chain_batch": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, C.c_int]),
     "vv_acoustic_encode": (C.c_int, [_P, _P, C.c_int, _P, _P]),
     "vv_audio_to_pcm16": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     "vv_codec_reset": (C.c_int, [_P, _P, C.c_int]),

@@ -36,6 +36,10 @@ int vv_dwconv_res_launch(const float* nb, const float* x, float* xo, const float
 int vv_normdw_sliced_ok(int T, int C);
 int vv_normdw_sliced_launch(const float* xin, float* xout, float* nb, const float* nw, const float* w, const float* b,
                             const float* gamma, int T, int C, float eps, hipStream_t s);
+int vv_normdw_sliced_slots_launch(const float* xin, float* xout, float* nb, const float* nw, const float* w, const float* b,
+                                  const float* gamma, int T, int C, float eps, const int* ids, int n, int64_t sx, int64_t snb,
+                                  hipStream_t s);
+int vv_affine_slots_launch(const float* x, float* y, float mul, float add, int L, const int* ids, int n, int64_t stride, hipStream_t s);
 int vv_normdw_launch(float* x, float* nb, const float* nw, const float* w, const float* b, const float* gamma, int T, int C,
                      float eps, hipStream_t s);
 int vv_normdw_rows_ok(int T, int C);
@@ -98,6 +102,7 @@ struct Block {
     void *w1, *w2;
     float* nb;                  // unfused path: [6 + Tmax][C] normed buffer with history
     float* nst;                 // fused path: [12][C] normed history (rows 0..5) + next state (rows 6..11)
+    int64_t nb_stride;          // floats between the nb (nst) buffers of consecutive utterance slots
 };
 
 struct ConvG {                  // conv / transposed conv as a GEMM over a time-major buffer
@@ -114,6 +119,7 @@ struct Stage {
     float* xfinal;              // buffer holding the stage output (and its history rows)
     bool fused;                 // blocks run as one vv_block1d_kernel each
     bool pp;                    // unfused T <= 8 stage: channel-sliced norm+conv, blocks ping-pong between xs and xs2
+    int64_t sl_stride;          // floats between the xs (xs2) buffers of consecutive utterance slots
     std::vector<Block> blocks;
     ConvG in;                   // produces this stage's rows from the previous buffer
 };
@@ -129,6 +135,11 @@ struct CodecNet {
     std::vector<int> shift_n;
     std::vector<void*> zero_tab;
     int maxC = 1;
+    // slot-batched stages (several utterances' rows in ONE weight pass, run_codec_batch): the leading `kd` stages of a decoder,
+    // the stages from `ke` on of an encoder -- the T <= 8, C >= 1024 stages that hold ~95 % of a tokenizer's weight bytes
+    int kd = 0, ke = 1 << 30;
+    int64_t in_stride = 0, u_stride = 0;     // floats between the in_buf / u buffers of consecutive slots
+    std::map<uint64_t, std::pair<void*, int>> shift_multi; // slot bit mask -> merged history-shift table
 };
 
 struct GraphEntry { hipGraphExec_t exec; uint64_t last_use; };
@@ -182,6 +193,8 @@ struct vv_ctx {
     float *ct1 = nullptr;
     // codecs
     CodecNet dec, aenc, senc;
+    // vv_codec_chain_batch: the per-utterance parts of a batch's tokenizer chains fork onto these streams (graph branches)
+    hipStream_t side[8] = {}; hipEvent_t ev_fork = nullptr, ev_join[8] = {}; bool side_ready = false;
     float scaling = 1.f, bias = 0.f;
     int hop = 3200;
     // staging
@@ -347,44 +360,67 @@ static int build_codec(vv_ctx* ctx, CodecNet& net, const std::string& pfx, bool 
         add_mat(ctx, pfx + "head.conv.conv.weight", g.N, g.K, g.w, 0, 1, Cin, g.N, 7, 1);
         g.bias = add_vec(ctx, pfx + "head.conv.conv.bias", g.N);
     }
+    // ---- per-slot buffers + shift tables.  Every kind of buffer is ONE allocation with a uniform slot stride (a multiple of
+    // 64 floats), so a slot-batched launch reaches utterance k's copy at base + k * stride ----
+    auto pad64 = [](size_t n) { return (n + 63) / 64 * 64; };
     net.u.resize(n_slots);
-    for (int sl = 0; sl < n_slots; ++sl) net.u[sl] = (float*)dalloc(ctx, umax, false);
-    // ---- per-slot buffers + shift tables ----
+    net.u_stride = (int64_t)pad64(umax / 4 + 1);
+    float* u_all = (float*)dalloc(ctx, (size_t)n_slots * net.u_stride * 4, false);
     net.in_buf.resize(n_slots); net.st.resize(n_slots); net.shift_tab.resize(n_slots); net.zero_tab.resize(n_slots);
     net.shift_n.resize(n_slots);
+    net.in_stride = (int64_t)pad64((size_t)(6 + net.in_Tpf * Fmax) * net.in_dim);
+    float* in_all = (float*)dalloc(ctx, (size_t)n_slots * net.in_stride * 4);
+    if (!u_all || !in_all) return -1;
     for (int sl = 0; sl < n_slots; ++sl) {
-        net.in_buf[sl] = (float*)dalloc(ctx, (size_t)(6 + net.in_Tpf * Fmax) * net.in_dim * 4);
+        net.u[sl] = u_all + (size_t)sl * net.u_stride;
+        net.in_buf[sl] = in_all + (size_t)sl * net.in_stride;
         net.st[sl].resize(ns);
-        for (int i = 0; i < ns; ++i) {
+        net.zero_tab[sl] = nullptr;
+    }
+    for (int i = 0; i < ns; ++i) {
+        const int hist = (i == ns - 1) ? 6 : (decoder ? 1 : ratios[i]);
+        const bool fused = vv_block1d_supported(C[i]) && Tpf[i] >= 8 && !sw[i].blocks.empty() && !getenv("VVHIP_NO_FUSED_BLOCK");
+        // unfused stages ping-pong between xs and xs2 when a one-launch norm + depthwise-conv kernel exists for them:
+        // channel-sliced (T <= 8, C = 1024 / 2048) or row-tiled (middle stages, any T)
+        const bool pp = !fused && !sw[i].blocks.empty() && !getenv("VVHIP_NO_SLICED_NORMDW") &&
+                        (vv_normdw_sliced_ok(Tpf[i], C[i]) || (vv_normdw_rows_ok(Tpf[i], C[i]) && !getenv("VVHIP_NO_ROWS_NORMDW")));
+        const int64_t xstride = (int64_t)pad64((size_t)(hist + (size_t)Tpf[i] * Fmax) * C[i]);
+        float* xs_all = (float*)dalloc(ctx, (size_t)n_slots * xstride * 4);
+        float* xs2_all = (fused || pp) ? (float*)dalloc(ctx, (size_t)n_slots * xstride * 4) : nullptr;
+        if (!xs_all || ((fused || pp) && !xs2_all)) return -1;
+        const int64_t nbstride = (int64_t)pad64(fused ? (size_t)12 * C[i] : (size_t)(6 + (size_t)Tpf[i] * Fmax) * C[i]);
+        std::vector<float*> nb_all(sw[i].blocks.size());
+        for (auto& p : nb_all) { p = (float*)dalloc(ctx, (size_t)n_slots * nbstride * 4); if (!p) return -1; }
+        for (int sl = 0; sl < n_slots; ++sl) {
             Stage& s = net.st[sl][i];
-            s.C = C[i]; s.Tpf = Tpf[i]; s.in = sw[i].in;
-            if (i == ns - 1) s.hist = 6;
-            else s.hist = decoder ? 1 : ratios[i];
-            const size_t xbytes = (size_t)(s.hist + (size_t)Tpf[i] * Fmax) * C[i] * 4;
-            s.xs = (float*)dalloc(ctx, xbytes);
+            s.C = C[i]; s.Tpf = Tpf[i]; s.in = sw[i].in; s.hist = hist; s.fused = fused; s.pp = pp; s.sl_stride = xstride;
+            s.xs = xs_all + (size_t)sl * xstride;
+            s.xs2 = xs2_all ? xs2_all + (size_t)sl * xstride : nullptr;
             s.blocks = sw[i].blocks;
-            s.fused = vv_block1d_supported(C[i]) && Tpf[i] >= 8 && !s.blocks.empty() && !getenv("VVHIP_NO_FUSED_BLOCK");
-            // unfused stages ping-pong between xs and xs2 when a one-launch norm + depthwise-conv kernel exists for them:
-            // channel-sliced (T <= 8, C = 1024 / 2048) or row-tiled (middle stages, any T)
-            s.pp = !s.fused && !s.blocks.empty() && !getenv("VVHIP_NO_SLICED_NORMDW") &&
-                   (vv_normdw_sliced_ok(Tpf[i], C[i]) || (vv_normdw_rows_ok(Tpf[i], C[i]) && !getenv("VVHIP_NO_ROWS_NORMDW")));
-            s.xs2 = (s.fused || s.pp) ? (float*)dalloc(ctx, xbytes) : nullptr;
             s.xfinal = ((s.fused || s.pp) && (s.blocks.size() & 1)) ? s.xs2 : s.xs;
-            for (auto& b : s.blocks) {
-                b.nb = nullptr; b.nst = nullptr;
-                if (s.fused) b.nst = (float*)dalloc(ctx, (size_t)12 * C[i] * 4);
-                else b.nb = (float*)dalloc(ctx, (size_t)(6 + (size_t)Tpf[i] * Fmax) * C[i] * 4);
+            for (size_t j = 0; j < s.blocks.size(); ++j) {
+                Block& b = s.blocks[j];
+                b.nb = nullptr; b.nst = nullptr; b.nb_stride = nbstride;
+                if (s.fused) b.nst = nb_all[j] + (size_t)sl * nbstride;
+                else b.nb = nb_all[j] + (size_t)sl * nbstride;
             }
         }
-        net.zero_tab[sl] = nullptr;
+    }
+    // which stages can run slot-batched: channel-sliced norm+conv stages (T <= 8 rows per frame, C = 1024 / 2048), bf16 modes
+    {
+        auto ok = [&](int i) {
+            const Stage& s = net.st[0][i];
+            return !s.fused && s.pp && vv_normdw_sliced_ok(s.Tpf, s.C) && ctx->c.xsplit <= 2 && n_slots > 1 && Fmax == 1 &&
+                   !getenv("VVHIP_NO_BATCH_CODEC");
+        };
+        net.kd = 0; net.ke = ns;
+        if (decoder) { while (net.kd < ns && ok(net.kd)) net.kd++; }
+        else { while (net.ke > 0 && ok(net.ke - 1)) net.ke--; }
     }
     return 0;
 }
 
-static int codec_tables(vv_ctx* ctx, CodecNet& net, int sl, int F, void** tab_out, int* n_out) {
-    auto it = net.shift_tab[sl].find(F);
-    if (it != net.shift_tab[sl].end()) { *tab_out = it->second; *n_out = net.shift_n[sl]; return 0; }
-    std::vector<VVShiftH> t;
+static void codec_table_entries(CodecNet& net, int sl, int F, std::vector<VVShiftH>& t) {
     t.push_back({net.in_buf[sl], net.in_Tpf * F, 6, net.in_dim});
     for (auto& s : net.st[sl]) {
         t.push_back({s.xfinal, s.Tpf * F, s.hist, s.C});
@@ -393,6 +429,27 @@ static int codec_tables(vv_ctx* ctx, CodecNet& net, int sl, int F, void** tab_ou
             else t.push_back({b.nb, s.Tpf * F, 6, s.C});
         }
     }
+}
+// one history-shift table for a set of slots (one launch after a slot-batched pass), F = 1
+static int codec_tables_multi(vv_ctx* ctx, CodecNet& net, const int* ids, int n, void** tab_out, int* n_out) {
+    uint64_t mask = 0;
+    for (int j = 0; j < n; ++j) mask |= 1ull << ids[j];
+    auto it = net.shift_multi.find(mask);
+    if (it != net.shift_multi.end()) { *tab_out = it->second.first; *n_out = it->second.second; return 0; }
+    std::vector<VVShiftH> t;
+    for (int j = 0; j < n; ++j) codec_table_entries(net, ids[j], 1, t);
+    void* d = dalloc(ctx, t.size() * sizeof(VVShiftH), false);
+    if (!d) return -1;
+    HIPCHK(ctx, hipMemcpy(d, t.data(), t.size() * sizeof(VVShiftH), hipMemcpyHostToDevice));
+    net.shift_multi[mask] = {d, (int)t.size()};
+    *tab_out = d; *n_out = (int)t.size();
+    return 0;
+}
+static int codec_tables(vv_ctx* ctx, CodecNet& net, int sl, int F, void** tab_out, int* n_out) {
+    auto it = net.shift_tab[sl].find(F);
+    if (it != net.shift_tab[sl].end()) { *tab_out = it->second; *n_out = net.shift_n[sl]; return 0; }
+    std::vector<VVShiftH> t;
+    codec_table_entries(net, sl, F, t);
     void* d = dalloc(ctx, t.size() * sizeof(VVShiftH), false);
     if (!d) return -1;
     HIPCHK(ctx, hipMemcpy(d, t.data(), t.size() * sizeof(VVShiftH), hipMemcpyHostToDevice));
@@ -472,12 +529,16 @@ extern "C" int vv_timeline_dump(vv_ctx* ctx, unsigned long long* out_host, int* 
 
 // Runs one codec net over F frames for slot `sl`.  The caller has already written the
 // input rows into net.in_buf[sl] + 6*in_dim.
-static int run_codec(vv_ctx* ctx, CodecNet& net, int sl, int F, float* out, hipStream_t st) {
+// Stages [i0, i1) only (i1 < 0: to the end); `head` / `shift`: run the head conv / the history shift at the end.  The split
+// forms serve vv_codec_chain_batch, where part of the net runs slot-batched (run_codec_batch) and the rest per utterance.
+static int run_codec(vv_ctx* ctx, CodecNet& net, int sl, int F, float* out, hipStream_t st, int i0 = 0, int i1 = -1,
+                     bool head = true, bool shift = true) {
     const float eps = ctx->c.codec_eps;
     const bool stream_w = (F == 1);      // T=1 stages stream their weights exactly once
     auto& stages = net.st[sl];
     const int ns = (int)stages.size();
-    for (int i = 0; i < ns; ++i) {
+    if (i1 < 0) i1 = ns;
+    for (int i = i0; i < i1; ++i) {
         Stage& s = stages[i];
         const int T = s.Tpf * F;
         float* x = s.xs + (size_t)s.hist * s.C;
@@ -532,7 +593,7 @@ static int run_codec(vv_ctx* ctx, CodecNet& net, int sl, int F, float* out, hipS
             if (s.pp) std::swap(x, xo);
         }
     }
-    {   // head conv
+    if (head) {   // head conv
         const ConvG& cg = net.head;
         Stage& s = stages[ns - 1];
         if (cg.N == 1 && cg.K == 7 * cg.ldx && (cg.ldx & 3) == 0 && cg.ldx <= 1024 && !getenv("VVHIP_NO_CONV_KERNELS")) {
@@ -544,10 +605,62 @@ static int run_codec(vv_ctx* ctx, CodecNet& net, int sl, int F, float* out, hipS
             GEMM(g);
         }
     }
+    if (!shift) return 0;
     void* tab; int nt;
     if (codec_tables(ctx, net, sl, F, &tab, &nt)) return -1;
     ctx->launches++;
     VVCHK(vv_shift_rows_launch(tab, nt, net.maxC, st));
+    return 0;
+}
+
+// Stages [i0, i1) of `n` utterance slots (ids ascending, one frame each) in ONE pass over the weights: every GEMM carries the
+// rows of all n slots (VVGemm::sl_*: gathered from / scattered to the per-slot streaming buffers, which sit at uniform
+// strides), the norm + depthwise-conv kernel takes the slot from blockIdx.y.  Only stages net.kd / net.ke admit (channel-
+// sliced norm+conv stages, T <= 8 rows per frame).  `out`: dense [n][out_dim] rows of the head conv (head = true).
+static int run_codec_batch(vv_ctx* ctx, CodecNet& net, const int* ids, int n, int i0, int i1, float* out, bool head, hipStream_t st) {
+    const float eps = ctx->c.codec_eps;
+    auto& st0 = net.st[0];                       // slot 0's descriptors: base pointers of every buffer kind
+    const int ns = (int)st0.size();
+    auto slots = [&](VVGemm& g, int T, int64_t sx, int64_t sy) {
+        g.sl_n = n; g.sl_T = T; g.sl_x = (int)sx; g.sl_y = (int)sy; g.T = n * T;
+        for (int j = 0; j < 8; ++j) g.sl_id[j] = j < n ? ids[j] : 0;
+    };
+    for (int i = i0; i < i1; ++i) {
+        Stage& s = st0[i];
+        const int T = s.Tpf;
+        float* x = s.xs + (size_t)s.hist * s.C;
+        {   // incoming conv: per-slot window rows in, per-slot stage rows out
+            const ConvG& cg = s.in;
+            const float* X = (i == 0) ? net.in_buf[0] : st0[i - 1].xfinal;
+            const int64_t sx = (i == 0) ? net.in_stride : st0[i - 1].sl_stride;
+            VVGemm g = mk_gemm(cg.w, X, x, cg.rows_per_frame, cg.N, cg.K, cg.ldx, cg.N);
+            g.epi = VV_EPI_BIAS; g.bias = cg.bias; g.nt = 1;
+            slots(g, cg.rows_per_frame, sx, s.sl_stride);
+            GEMM(g);
+        }
+        float* xo = s.xs2 + (size_t)s.hist * s.C;
+        for (auto& b : s.blocks) {
+            ctx->launches += 1;
+            VVCHK(vv_normdw_sliced_slots_launch(x, xo, b.nb, b.norm_w, b.dw_w, b.dw_b, b.gamma, T, s.C, eps, ids, n, s.sl_stride, b.nb_stride, st));
+            VVGemm g1 = mk_gemm(b.w1, xo, net.u[0], T, 4 * s.C, s.C, s.C, 4 * s.C);          // u: dense [n * T][4C] scratch
+            g1.pro = VV_PRO_RMS; g1.nw = b.ffn_norm_w; g1.eps = eps; g1.epi = VV_EPI_BIAS_GELU; g1.bias = b.b1; g1.nt = 1;
+            slots(g1, T, s.sl_stride, 0);
+            GEMM(g1);
+            VVGemm g2 = mk_gemm(b.w2, net.u[0], xo, T, s.C, 4 * s.C, 4 * s.C, s.C);
+            g2.epi = VV_EPI_RESID; g2.bias = b.b2; g2.nscale = b.ffn_gamma; g2.nt = 1;
+            slots(g2, T, 0, s.sl_stride);
+            GEMM(g2);
+            std::swap(x, xo);
+        }
+    }
+    if (head) {
+        const ConvG& cg = net.head;
+        Stage& s = st0[ns - 1];
+        VVGemm g = mk_gemm(cg.w, s.xfinal, out, cg.rows_per_frame, cg.N, cg.K, cg.ldx, cg.N);
+        g.epi = VV_EPI_BIAS; g.bias = cg.bias;
+        slots(g, cg.rows_per_frame, s.sl_stride, 0);
+        GEMM(g);
+    }
     return 0;
 }
 
@@ -745,6 +858,10 @@ extern "C" void vv_destroy(vv_ctx* ctx) {
     if (!ctx) return;
     hipDeviceSynchronize();
     for (auto& g : ctx->graphs) hipGraphExecDestroy(g.second.exec);
+    if (ctx->side_ready) {
+        for (int j = 0; j < 8; ++j) { hipStreamDestroy(ctx->side[j]); hipEventDestroy(ctx->ev_join[j]); }
+        hipEventDestroy(ctx->ev_fork);
+    }
     for (void* p : ctx->allocs) hipFree(p);          // weights, KV caches, state and scratch buffers
     ctx->allocs.clear();
     if (ctx->stage) hipFree(ctx->stage);
@@ -1216,6 +1333,78 @@ extern "C" int vv_semantic_encode(vv_ctx* ctx, void* stream, int slot, int frame
     return graphed(ctx, key, st, [&]() {
         HIPCHK(ctx, hipMemcpyAsync(net.in_buf[slot] + 6, audio_dev, (size_t)frames * ctx->hop * 4, hipMemcpyDeviceToDevice, st));
         return run_codec(ctx, net, slot, frames, sem_out_dev, st);
+    });
+}
+
+// One frame of n utterances through the acoustic decoder and (sem_out_dev != null) the semantic encoder -- the batched
+// `acoustic_tokenizer.decode(..., sample_indices=diffusion_indices)` + `semantic_tokenizer.encode(...)` pair of the reference's
+// loop (modeling_vibevoice_inference.py:636-672).  Row j of latent / audio / sem belongs to slot slots[j].  The stages that
+// hold the weight bytes (decoder stages [0, kd), encoder stages [ke, end) + head) run slot-batched: one pass over the weights
+// for the whole batch; the many-row, few-channel stages in between run per utterance on forked streams.
+extern "C" int vv_codec_chain_batch(vv_ctx* ctx, void* stream, int n, const int* slots, const float* latent_dev,
+                                    float* audio_out_dev, float* sem_out_dev, int apply) {
+    hipStream_t st = (hipStream_t)stream;
+    if (n < 1 || n > 8) return fail(ctx, "vv_codec_chain_batch: n = %d, must be 1..8", n);
+    uint64_t mask = 0;
+    for (int j = 0; j < n; ++j) {
+        if (slots[j] < 0 || slots[j] >= ctx->c.n_slots || slots[j] >= 64) return fail(ctx, "slot %d out of range", slots[j]);
+        if (mask & (1ull << slots[j])) return fail(ctx, "vv_codec_chain_batch: slot %d listed twice", slots[j]);
+        mask |= 1ull << slots[j];
+    }
+    const bool sem = sem_out_dev != nullptr;
+    if (sem && ctx->c.sem_dim <= 0) return fail(ctx, "no semantic tokenizer configured");
+    if (!ctx->side_ready) {
+        for (int j = 0; j < 8; ++j) {
+            HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->side[j], hipStreamNonBlocking));
+            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join[j], hipEventDisableTiming));
+        }
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        ctx->side_ready = true;
+    }
+    ctx->launches = 0;
+    std::string key = "chain:";
+    for (int j = 0; j < n; ++j) key += std::to_string(slots[j]) + ",";
+    char kp[128]; snprintf(kp, 128, ":%p:%p:%p:%d", (const void*)latent_dev, (void*)audio_out_dev, (void*)sem_out_dev, apply);
+    key += kp;
+    std::vector<int> ids(slots, slots + n);
+    return graphed(ctx, key, st, [&]() {
+        CodecNet& dec = ctx->dec; CodecNet& senc = ctx->senc;
+        const int L = ctx->c.latent_dim, S = ctx->c.sem_dim, hop = ctx->hop;
+        const float mul = apply ? 1.0f / ctx->scaling : 1.0f, add = apply ? -ctx->bias : 0.0f;
+        const int ns_d = (int)dec.st[0].size(), ns_e = sem ? (int)senc.st[0].size() : 0;
+        const bool bd = n > 1 && dec.kd > 0, be = sem && n > 1 && senc.ke < ns_e;
+        if (bd) {
+            ctx->launches++;
+            VVCHK(vv_affine_slots_launch(latent_dev, dec.in_buf[0] + 6 * L, mul, add, L, ids.data(), n, dec.in_stride, st));
+            if (run_codec_batch(ctx, dec, ids.data(), n, 0, dec.kd, nullptr, false, st)) return -1;
+        }
+        const bool fork = n > 1;
+        if (fork) HIPCHK(ctx, hipEventRecord(ctx->ev_fork, st));
+        for (int j = 0; j < n; ++j) {
+            hipStream_t ss = fork ? ctx->side[j] : st;
+            const int sl = ids[j];
+            if (fork) HIPCHK(ctx, hipStreamWaitEvent(ss, ctx->ev_fork, 0));
+            if (!bd) {
+                ctx->launches++;
+                VVCHK(vv_affine_launch(latent_dev + (size_t)j * L, dec.in_buf[sl] + 6 * L, mul, add, L, ss));
+            }
+            float* audio = audio_out_dev + (size_t)j * hop;
+            if (run_codec(ctx, dec, sl, 1, audio, ss, bd ? dec.kd : 0, ns_d, true, true)) return -1;
+            if (sem) {
+                HIPCHK(ctx, hipMemcpyAsync(senc.in_buf[sl] + 6, audio, (size_t)hop * 4, hipMemcpyDeviceToDevice, ss));
+                if (run_codec(ctx, senc, sl, 1, sem_out_dev + (size_t)j * S, ss, 0, be ? senc.ke : ns_e, !be, !be)) return -1;
+            }
+            if (fork) HIPCHK(ctx, hipEventRecord(ctx->ev_join[j], ss));
+        }
+        if (fork) for (int j = 0; j < n; ++j) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join[j], 0));
+        if (be) {
+            if (run_codec_batch(ctx, senc, ids.data(), n, senc.ke, ns_e, sem_out_dev, true, st)) return -1;
+            void* tab; int nt;
+            if (codec_tables_multi(ctx, senc, ids.data(), n, &tab, &nt)) return -1;
+            ctx->launches++;
+            VVCHK(vv_shift_rows_launch(tab, nt, senc.maxC, st));
+        }
+        return 0;
     });
 }
 

@@ -80,7 +80,9 @@ constexpr int U = 8;       // k-steps per batch (256 k = one float4 per lane per
 // 16 for few tiles x long K (the streaming rate of a CU is set by its waves' loads in flight), 8 otherwise.
 // PARTS: the activation (prologue side) or residual (epilogue side) tensor arrives as base + 2 part tensors (the producer
 // split K over 3 workgroup columns): the three loads are issued together and summed in a fixed order.
-template <int XS, int PRO, int EPI, int MR, int WPB, int PARTS = 0>      // PARTS: 0 none, 1 activation side, 2 residual side
+// SL: slot-batched rows (VVGemm::sl_*): the rows of one launch are gathered from / scattered to the streaming buffers of up
+// to 8 utterances -- one weight pass for the tokenizer stages of a whole batch.  16-row form only.
+template <int XS, int PRO, int EPI, int MR, int WPB, int PARTS = 0, int SL = 0>      // PARTS: 0 none, 1 activation side, 2 residual side
 // The operands every wave needs before its first load (weight / activation bases, shape, strides) are separate leading
 // scalar parameters: with -mllvm -amdgpu-kernarg-preload-count=16 the dispatcher delivers them in SGPRs at wave launch,
 // so the first addresses do not wait for a scalar-cache round trip; the rest of VVGemm is fetched by one s_load batch.
@@ -132,6 +134,16 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const u32x4* __restri
     const u32x4* wbase = pW + (size_t)tile * k_tiles * 64 + lane;
     const u32x4* wbase2 = DUAL ? pW2 + (size_t)tile * k_tiles * 64 + lane : nullptr;
 
+    // slot-batched rows: per-row activation offsets (wave-uniform), computed once
+    unsigned xoff_sl[SL ? MR : 1];
+    if constexpr (SL) {
+#pragma unroll
+        for (int r = 0; r < MR; ++r) {
+            const int rg = t_base + r;
+            const int j = rg / a.sl_T, tt = rg - j * a.sl_T;
+            xoff_sl[r] = (r < T) ? (a.sl_x ? (unsigned)(vv_slot_id(a.sl_id, j) * a.sl_x + tt * pldx) : (unsigned)(rg * pldx)) : 0u;
+        }
+    }
     constexpr int MODR = (PRO == VV_PRO_RMS_MOD) ? MR : 1;
     constexpr int ADDR = (PRO == VV_PRO_ADD_SILU) ? MR : 1;
     constexpr int PR = (PARTS == 1) ? MR : 1;
@@ -146,7 +158,8 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const u32x4* __restri
             if (r < T) {
                 const int rg = t_base + r;
                 const int xr_idx = a.x_row_mod > 0 ? rg % a.x_row_mod : rg;
-                R.x[r] = *reinterpret_cast<const float4*>(pX + (unsigned)(xr_idx * pldx) + k);
+                if constexpr (SL) R.x[r] = *reinterpret_cast<const float4*>(pX + xoff_sl[r] + k);
+                else R.x[r] = *reinterpret_cast<const float4*>(pX + (unsigned)(xr_idx * pldx) + k);
                 if constexpr (PARTS == 1) {
                     R.p0[r] = *reinterpret_cast<const float4*>(a.xa + (unsigned)(xr_idx * pldx) + k);
                     R.p1[r] = *reinterpret_cast<const float4*>(a.xa + (unsigned)(a.part_stride + xr_idx * pldx) + k);
@@ -182,12 +195,18 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const u32x4* __restri
     const bool epi_lane = (wave == 0) && frow < T && n0 < pN;
     float4 pre_y = {0.f, 0.f, 0.f, 0.f}, pre_b = {0.f, 0.f, 0.f, 0.f}, pre_g = {1.f, 1.f, 1.f, 1.f};
     float4 pre_y0 = {0.f, 0.f, 0.f, 0.f}, pre_y1 = {0.f, 0.f, 0.f, 0.f};
+    unsigned yrow_off = (unsigned)((t_base + frow) * pldy);
+    if constexpr (SL) {
+        const int rg = min(t_base + frow, pT - 1);
+        const int j = rg / a.sl_T, tt = rg - j * a.sl_T;
+        yrow_off = a.sl_y ? (unsigned)(vv_slot_id(a.sl_id, j) * a.sl_y + tt * pldy) : (unsigned)(rg * pldy);
+    }
     if (epi_lane) {            // N % 4 == 0 and 16-B aligned operands are launch preconditions (vv_gemv_ok)
         if constexpr (EPI == VV_EPI_BIAS || EPI == VV_EPI_BIAS_GELU || EPI == VV_EPI_RESID) {
             if (a.bias) pre_b = *reinterpret_cast<const float4*>(a.bias + n0);
         }
         if constexpr (EPI == VV_EPI_RESID || EPI == VV_EPI_GATED_RESID) {
-            pre_y = *reinterpret_cast<const float4*>(pY + (unsigned)((t_base + frow) * pldy + n0));
+            pre_y = *reinterpret_cast<const float4*>(pY + (yrow_off + (unsigned)n0));
             if constexpr (PARTS == 2) {
                 const float* yp0 = a.ya + (unsigned)((t_base + frow) * pldy + n0);
                 pre_y0 = *reinterpret_cast<const float4*>(yp0);
@@ -369,7 +388,7 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const u32x4* __restri
         }
         return;
     }
-    float* yp = (ksb == 0 ? pY : a.yparts + (unsigned)((ksb - 1) * a.part_stride)) + (unsigned)((t_base + frow) * pldy + n0);
+    float* yp = (ksb == 0 ? pY : a.yparts + (unsigned)((ksb - 1) * a.part_stride)) + (yrow_off + (unsigned)n0);
     *reinterpret_cast<float4*>(yp) = float4{o[0], o[1], o[2], o[3]};
     VV_STAMP(6);
     VV_BSTAMP(1);
@@ -378,11 +397,25 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const u32x4* __restri
 }  // namespace
 
 static bool gemv_combo_ok(int pro, int epi, bool wide);
+// pairs with a slot-batched form: strided conv / transposed conv (bias), FFN1 (RMSNorm + bias + GELU), FFN2 (layer scale + residual)
+#define VV_GEMV_SL(X) X(VV_PRO_NONE, VV_EPI_BIAS) X(VV_PRO_NONE, VV_EPI_RESID) X(VV_PRO_RMS, VV_EPI_BIAS_GELU)
 static bool gemv_parts_ok(int pro, int epi, bool xside);
 // Eligibility: decode rows, aligned operands, 32-bit offsets, a specialised (prologue, epilogue) pair.
 extern "C" int vv_gemv_ok(const VVGemm* a) {
     if (a->T < 1) return 0;
-    if (!gemv_combo_ok(a->pro, a->epi, a->T > 4)) return 0;
+    if (!gemv_combo_ok(a->pro, a->epi, a->T > 4 || a->sl_n > 0)) return 0;
+    if (a->sl_n > 0) {      // slot-batched rows: the three tokenizer pairs, plain operands, 32-bit offsets inside every slot buffer
+        if (a->sl_n > 8 || a->sl_T < 1 || a->T != a->sl_n * a->sl_T || a->sl_x < 0 || a->sl_y < 0 || (a->sl_x & 3) || (a->sl_y & 3)) return 0;
+        if (a->kgrid > 1 || a->n_xa || a->n_ya || a->x_row_mod > 0 || a->add_rows_per_vec > 0) return 0;
+        bool pair = false;
+#define X(P, E) if (a->pro == P && a->epi == E) pair = true;
+        VV_GEMV_SL(X)
+#undef X
+        if (!pair) return 0;
+        for (int j = 0; j < a->sl_n; ++j)
+            if (a->sl_id[j] < 0 || (int64_t)a->sl_id[j] * a->sl_x + (int64_t)a->sl_T * a->ldx >= (1LL << 30) ||
+                (int64_t)a->sl_id[j] * a->sl_y + (int64_t)a->sl_T * a->ldy >= (1LL << 30)) return 0;
+    }
     if ((a->x_row_mod > 0 || a->add_rows_per_vec > 0) && a->pro != VV_PRO_ADD_SILU) return 0;
     if ((a->K & 3) || (a->ldx & 3) || (((uintptr_t)a->X) & 15)) return 0;
     if (a->pro == VV_PRO_RMS_MOD && (a->ld_mod & 3)) return 0;
@@ -454,13 +487,23 @@ extern "C" int vv_gemv_launch(VVGemm a, int xs, hipStream_t s) {
 #define VV_GO(XS_, P, E, MR_, WP_)                                                                      \
     do { hipLaunchKernelGGL((vv_gemv_kernel<XS_, P, E, MR_, WP_>), grid, dim3(WP_ * 64), 0, s, a.W, a.W2, a.X, a.Y, a.nw, a.T, a.N, a.K, a.ldx, a.ldy, a);       \
          return hipGetLastError() == hipSuccess ? 0 : -2; } while (0)
-    if (a.T > 4) {
+    if (a.T > 4 || a.sl_n > 0) {
         if (xs > 2) return -3;       // 16-row staging tiles of the exact mode exceed the LDS: general kernel
         grid.y = (a.T + 15) / 16;
         static const int wide4_wgs = getenv("VVHIP_WIDE4_WGS") ? atoi(getenv("VVHIP_WIDE4_WGS")) : 128;
         // The 16-row tiles are used by the codec (T = 5..16 rows): above ~half a workgroup per CU the 4-wave form
         // (2x the resident workgroups per CU) wins; measured 3.117 -> 3.053 ms/frame on the 1.5B config for
         // thresholds 64..128 vs 512 (DESIGN.md section 8 lists the sweep).
+        if (a.sl_n > 0) {
+#define VV_GOSL(XS_, P, E, WP_)                                                                         \
+    do { hipLaunchKernelGGL((vv_gemv_kernel<XS_, P, E, 16, WP_, 0, 1>), grid, dim3(WP_ * 64), 0, s, a.W, a.W2, a.X, a.Y, a.nw, a.T, a.N, a.K, a.ldx, a.ldy, a);   \
+         return hipGetLastError() == hipSuccess ? 0 : -2; } while (0)
+#define X(P, E) if (a.pro == P && a.epi == E) { if (xs == 2) VV_GOSL(2, P, E, 8); else if ((int64_t)n_tiles * grid.y > wide4_wgs) VV_GOSL(1, P, E, 4); else VV_GOSL(1, P, E, 8); }
+            VV_GEMV_SL(X)
+#undef X
+#undef VV_GOSL
+            return -3;
+        }
         if (xs == 1 && (int64_t)n_tiles * grid.y > wide4_wgs) {
 #define X(P, E) if (a.pro == P && a.epi == E) VV_GO(1, P, E, 16, 4);
             VV_GEMV_WIDE4(X)

@@ -144,9 +144,14 @@ template <int NCH>      // NCH = C / 1024 float4 chunks per thread and row
 __global__ __launch_bounds__(256) void vv_normdw_sliced_kernel(const float* __restrict__ xin, float* __restrict__ xout,
                                                                float* __restrict__ nb, const float* __restrict__ nw,
                                                                const float* __restrict__ w, const float* __restrict__ b,
-                                                               const float* __restrict__ gamma, int T, int C, float eps) {
+                                                               const float* __restrict__ gamma, int T, int C, float eps,
+                                                               const VVSlotIds sl, int64_t sx, int64_t snb) {
     constexpr int TM = 8;
     __shared__ float red[4][TM];
+    if (sl.n > 0) {        // slot-batched launch: blockIdx.y picks the utterance, buffers are sx / snb floats apart
+        const int64_t id = vv_slot_id(sl.id, blockIdx.y);
+        xin += id * sx; xout += id * sx; nb += id * snb;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = blockIdx.x * 256 + tid;
     float4 full[TM][NCH];
@@ -491,8 +496,33 @@ int vv_normdw_sliced_ok(int T, int C) { return T >= 1 && T <= 8 && (C == 1024 ||
 int vv_normdw_sliced_launch(const float* xin, float* xout, float* nb, const float* nw, const float* w, const float* b,
                             const float* gamma, int T, int C, float eps, hipStream_t s) {
     if (!vv_normdw_sliced_ok(T, C) || xin == xout) return -1;
-    if (C == 1024) hipLaunchKernelGGL((vv_normdw_sliced_kernel<1>), dim3(C / 256), dim3(256), 0, s, xin, xout, nb, nw, w, b, gamma, T, C, eps);
-    else hipLaunchKernelGGL((vv_normdw_sliced_kernel<2>), dim3(C / 256), dim3(256), 0, s, xin, xout, nb, nw, w, b, gamma, T, C, eps);
+    VVSlotIds none; none.n = 0;
+    if (C == 1024) hipLaunchKernelGGL((vv_normdw_sliced_kernel<1>), dim3(C / 256), dim3(256), 0, s, xin, xout, nb, nw, w, b, gamma, T, C, eps, none, (int64_t)0, (int64_t)0);
+    else hipLaunchKernelGGL((vv_normdw_sliced_kernel<2>), dim3(C / 256), dim3(256), 0, s, xin, xout, nb, nw, w, b, gamma, T, C, eps, none, (int64_t)0, (int64_t)0);
+    return okk();
+}
+// the same kernel over n utterance slots: xin / xout / nb are slot 0's buffers, slot k's are sx / snb floats further
+int vv_normdw_sliced_slots_launch(const float* xin, float* xout, float* nb, const float* nw, const float* w, const float* b,
+                                  const float* gamma, int T, int C, float eps, const int* ids, int n, int64_t sx, int64_t snb,
+                                  hipStream_t s) {
+    if (!vv_normdw_sliced_ok(T, C) || xin == xout || n < 1 || n > 8) return -1;
+    VVSlotIds sl; sl.n = n;
+    for (int i = 0; i < 8; ++i) sl.id[i] = i < n ? ids[i] : 0;
+    if (C == 1024) hipLaunchKernelGGL((vv_normdw_sliced_kernel<1>), dim3(C / 256, n), dim3(256), 0, s, xin, xout, nb, nw, w, b, gamma, T, C, eps, sl, sx, snb);
+    else hipLaunchKernelGGL((vv_normdw_sliced_kernel<2>), dim3(C / 256, n), dim3(256), 0, s, xin, xout, nb, nw, w, b, gamma, T, C, eps, sl, sx, snb);
+    return okk();
+}
+// y[id[j] * stride + c] = x[j * L + c] * mul + add: the batch's latents into the per-utterance decoder input buffers
+__global__ void vv_affine_slots_kernel(const float* __restrict__ x, float* __restrict__ y, float mul, float add, int L,
+                                       const VVSlotIds sl, int64_t stride) {
+    const int j = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < L) y[(int64_t)vv_slot_id(sl.id, j) * stride + c] = x[(int64_t)j * L + c] * mul + add;
+}
+int vv_affine_slots_launch(const float* x, float* y, float mul, float add, int L, const int* ids, int n, int64_t stride, hipStream_t s) {
+    if (n < 1 || n > 8) return -1;
+    VVSlotIds sl; sl.n = n;
+    for (int i = 0; i < 8; ++i) sl.id[i] = i < n ? ids[i] : 0;
+    hipLaunchKernelGGL(vv_affine_slots_kernel, dim3((L + 255) / 256, n), dim3(256), 0, s, x, y, mul, add, L, sl, stride);
     return okk();
 }
 int vv_normdw_rows_ok(int T, int C) { return T >= 1 && (C == 256 || C == 512 || C == 1024); }

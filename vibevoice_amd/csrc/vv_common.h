@@ -71,5 +71,20 @@ struct VVGemm {
     const float* ya;       // n_ya part tensors laid out like Y
     int n_xa, n_ya;
     int part_stride;
+    // Slot-batched rows (tokenizer stages of several utterances in ONE weight pass, 16-row GEMV form only): the launch has
+    // sl_n * sl_T logical rows; row rg belongs to slot j = rg / sl_T, local row tt = rg % sl_T.  A side with a non-zero slot
+    // stride (sl_x / sl_y, floats) lives in per-utterance streaming buffers: row pointer = base + sl_id[j] * stride + tt * ld;
+    // a side with stride 0 is a dense [rows][ld] scratch tensor.  sl_n = 0: off.
+    int sl_n, sl_T, sl_x, sl_y;
+    int sl_id[8];
 };
+
+// up to 8 utterance slots of one launch (per-utterance kernels take the slot from blockIdx.y / .z)
+struct VVSlotIds { int n; int id[8]; };
+__device__ __forceinline__ int vv_slot_id(const int (&id)[8], int j) {     // select chain: no dynamic indexing of a by-value kernel argument
+    int r = id[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) r = (j == i) ? id[i] : r;
+    return r;
+}
 

@@ -299,6 +299,18 @@ class Engine:
         self._chk(self.lib.vv_semantic_encode(self._ctx, self._sp(stream), slot, 1, self._p(audio), self._p(sem_out)),
                   "vv_semantic_encode")
 
+    def codec_chain_batch(self, slots, latent: torch.Tensor, audio_out: torch.Tensor, sem_out=None, apply_speech_factors=True):
+        """One frame of len(slots) utterances through the acoustic decoder and (sem_out given) the semantic encoder: row j of
+        latent [n, latent] / audio_out [n, hop] / sem_out [n, sem_dim] belongs to streaming slot slots[j].  The reference
+        decodes / re-encodes the step's diffusion rows as one batch (modeling_vibevoice_inference.py:636-672); here the
+        weight-heavy stages of both nets read their weights once for the whole batch."""
+        n = len(slots)
+        assert latent.is_contiguous() and audio_out.is_contiguous() and (sem_out is None or sem_out.is_contiguous())
+        arr = (C.c_int * n)(*[int(s) for s in slots])
+        self._chk(self.lib.vv_codec_chain_batch(self._ctx, self._s, n, arr, self._p(latent), self._p(audio_out),
+                                                self._p(sem_out) if sem_out is not None else None, int(apply_speech_factors)),
+                  "vv_codec_chain_batch")
+
     def acoustic_encode(self, frames: int, wav: torch.Tensor, mean_out: torch.Tensor):
         self._chk(self.lib.vv_acoustic_encode(self._ctx, self._s, frames, self._p(wav), self._p(mean_out)),
                   "vv_acoustic_encode")

@@ -272,6 +272,8 @@ class VibeVoiceForConditionalGenerationInference:
         self._side_streams = [torch.cuda.Stream(device=self.device) for _ in range(min(NB, engine.cfg.n_slots))] if engine.cfg.n_slots > 1 else []
         self._audio_blocks = []                                       # output frames, 64 steps per block (no per-step allocation)
         self.concurrent_codecs = os.environ.get("VVHIP_SERIAL_CODECS") is None
+        # several utterances' tokenizer chains of a step as ONE engine call (vv_codec_chain_batch); off: one chain per utterance
+        self.batched_codecs = os.environ.get("VVHIP_NO_BATCH_CHAIN") is None and hasattr(engine, "codec_chain_batch")
         self.speculate_sampling = os.environ.get("VVHIP_NO_SPEC") is None
         self.last_stats = {}
 
@@ -646,7 +648,12 @@ class VibeVoiceForConditionalGenerationInference:
             e.diffusion_sample(n, self._cond, self._noise, cfg_scale, self._latent)
         if diff:
             # ---- codec decode, semantic encode, connectors (:636-672) ----
-            if len(diff) > 1 and self.concurrent_codecs and self._side_streams:
+            if len(diff) > 1 and self.batched_codecs:
+                # the reference decodes / re-encodes the step's diffusion rows as one batch (:636-672): one engine call, the
+                # weight-heavy tokenizer stages read their weights once for all rows
+                e.codec_chain_batch([u.slot for u in diff], self._latent[:n], self._audio[:n],
+                                    self._sem[:n] if e.cfg.sem_dim > 0 else None)
+            elif len(diff) > 1 and self.concurrent_codecs and self._side_streams:
                 # each utterance's tokenizer chain (decode -> semantic re-encode) is an independent, launch-latency
                 # bound graph: fork them onto side streams so they overlap, join before the connectors
                 self._fork_ev.record(e.stream)
