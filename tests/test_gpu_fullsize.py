@@ -108,12 +108,19 @@ def test_generate_at_1p5b_layer_shapes():
             model_bf16.engine.close()
 
 
-def test_codec_chain_batch_at_real_widths():
+@pytest.mark.parametrize("mode", ["full", "heavy"])
+def test_codec_chain_batch_at_real_widths(mode, monkeypatch):
     """vv_codec_chain_batch (several utterances' tokenizer chains in one call, the weight-heavy stages slot-batched) at the
     real tokenizer widths, bf16 mode + hipGraph: against the CPU oracle's streaming decoder / encoder per slot, and against
     the engine's own one-utterance path run on a spare slot with the same inputs.  Covers a mid-stream reset of one slot,
-    a changing slot set, and a slot that alternates between the batched and the single path."""
+    a changing slot set, and a slot that alternates between the batched and the single path.
+    mode "full": every stage of both nets slot-batched (the default); "heavy": only the T <= 8 stages, the rest per utterance
+    on forked graph branches (VVHIP_BATCH_CODEC=heavy)."""
     from oracle import codec
+    if mode == "heavy":
+        monkeypatch.setenv("VVHIP_BATCH_CODEC", "heavy")
+    else:
+        monkeypatch.delenv("VVHIP_BATCH_CODEC", raising=False)
     from vibevoice_amd import synthetic
     from vibevoice_amd.configs import CONFIGS
     from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference
@@ -174,6 +181,6 @@ def test_codec_chain_batch_at_real_widths():
             pa, ps = rel_err(outs[0][0], outs[1][0].cpu()), rel_err(outs[0][1], outs[1][1].cpu())
             worst_pair = max(worst_pair, pa, ps)
             assert pa <= 1e-2 and ps <= 1e-2, (t, pa, ps)
-        print(f"codec_chain_batch: audio vs oracle {worst_a:.2e}, semantic vs oracle {worst_s:.2e}, batched vs single {worst_pair:.2e}")
+        print(f"codec_chain_batch[{mode}]: audio vs oracle {worst_a:.2e}, semantic vs oracle {worst_s:.2e}, batched vs single {worst_pair:.2e}")
     finally:
         eng.close()

@@ -31,6 +31,9 @@ struct VVBlock {
     const u32x4 *w1, *w2;  // packed [4C][C], [C][4C]
     int T;
     float eps;
+    // slot-batched launch (sl.n > 0): blockIdx.y picks the utterance; its buffers sit sx (xin / xout) and snst floats further per slot id
+    VVSlotIds sl;
+    int64_t sx, snst;
 };
 
 template <int XS>
@@ -59,6 +62,11 @@ __global__ __launch_bounds__(256) void vv_block1d_kernel(const VVBlock a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int t0 = blockIdx.x * TT;
+    const float* xin = a.xin; float* xout = a.xout; float* nst = a.nst;
+    if (a.sl.n > 0) {
+        const int64_t id = vv_slot_id(a.sl.id, blockIdx.y);
+        xin += id * a.sx; xout += id * a.sx; nst += id * a.snst;
+    }
     // The packed weights do not depend on x: every fragment this wave will feed to the MFMA pipe is requested NOW
     // (FFN1: NT1/4 tiles x KT1, FFN2: NT2/4 tiles x KT2 -- at most 32 + 32 fragments for C = 128), so the L2 round
     // trips overlap the norm / conv phases instead of forming a chain of dependent loads inside the GEMM loops.
@@ -119,8 +127,8 @@ __global__ __launch_bounds__(256) void vv_block1d_kernel(const VVBlock a) {
             const int c = lane + q * 64;
             float v = 0.f;
             if (rr < TT + HALO && c < C) {
-                if (t < 0) v = a.nst[(HALO + t) * C + c];
-                else if (t < a.T) v = a.xin[(int64_t)t * C + c];
+                if (t < 0) v = nst[(HALO + t) * C + c];
+                else if (t < a.T) v = xin[(int64_t)t * C + c];
             }
             xv[i][q] = v;
         }
@@ -145,7 +153,7 @@ __global__ __launch_bounds__(256) void vv_block1d_kernel(const VVBlock a) {
                     const float n = xv[i][q] * r * nw_r[q];
                     nrm[rr * C + c] = n;
                     if (rr >= HALO) xs[(rr - HALO) * C + c] = xv[i][q];
-                    if (t >= a.T - HALO) a.nst[(HALO + t - (a.T - HALO)) * C + c] = n;     // next frame's history
+                    if (t >= a.T - HALO) nst[(HALO + t - (a.T - HALO)) * C + c] = n;     // next frame's history
                 }
             }
         } else {
@@ -232,7 +240,7 @@ __global__ __launch_bounds__(256) void vv_block1d_kernel(const VVBlock a) {
             o.y = xs[frow * C + c0 + 1] + fg_r[i2].y * (acc[1] + b2_r[i2].y);
             o.z = xs[frow * C + c0 + 2] + fg_r[i2].z * (acc[2] + b2_r[i2].z);
             o.w = xs[frow * C + c0 + 3] + fg_r[i2].w * (acc[3] + b2_r[i2].w);
-            *reinterpret_cast<float4*>(a.xout + (int64_t)t * C + c0) = o;
+            *reinterpret_cast<float4*>(xout + (int64_t)t * C + c0) = o;
         }
     }
 }
@@ -246,19 +254,38 @@ static void go(const VVBlock& a, hipStream_t s) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_block1d_kernel<C, XS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    hipLaunchKernelGGL((vv_block1d_kernel<C, XS>), dim3((a.T + TT - 1) / TT), dim3(256), smem, s, a);
+    hipLaunchKernelGGL((vv_block1d_kernel<C, XS>), dim3((a.T + TT - 1) / TT, a.sl.n > 0 ? a.sl.n : 1), dim3(256), smem, s, a);
 }
 
 }  // namespace
 
 extern "C" int vv_block1d_supported(int C) { return C == 32 || C == 64 || C == 128; }
+extern "C" int vv_block1d_slots_launch(int C, int xs, const float* xin, float* xout, float* nst, const float* norm_w,
+                                       const float* ffn_norm_w, const float* gamma, const float* ffn_gamma,
+                                       const float* dw_w, const float* dw_b, const float* b1, const float* b2,
+                                       const void* w1, const void* w2, int T, float eps, const int* ids, int n, int64_t sx,
+                                       int64_t snst, hipStream_t s);
 
 extern "C" int vv_block1d_launch(int C, int xs, const float* xin, float* xout, float* nst, const float* norm_w,
                                  const float* ffn_norm_w, const float* gamma, const float* ffn_gamma,
                                  const float* dw_w, const float* dw_b, const float* b1, const float* b2,
                                  const void* w1, const void* w2, int T, float eps, hipStream_t s) {
+    return vv_block1d_slots_launch(C, xs, xin, xout, nst, norm_w, ffn_norm_w, gamma, ffn_gamma, dw_w, dw_b, b1, b2, w1, w2, T, eps,
+                                   nullptr, 0, 0, 0, s);
+}
+
+// the same block over n utterance slots (ids != null): xin / xout / nst are slot 0's buffers
+extern "C" int vv_block1d_slots_launch(int C, int xs, const float* xin, float* xout, float* nst, const float* norm_w,
+                                       const float* ffn_norm_w, const float* gamma, const float* ffn_gamma,
+                                       const float* dw_w, const float* dw_b, const float* b1, const float* b2,
+                                       const void* w1, const void* w2, int T, float eps, const int* ids, int n, int64_t sx,
+                                       int64_t snst, hipStream_t s) {
+    if (n < 0 || n > 8) return -1;
     VVBlock a{xin, xout, nst, norm_w, ffn_norm_w, gamma, ffn_gamma, dw_w, dw_b, b1, b2,
               (const u32x4*)w1, (const u32x4*)w2, T, eps};
+    a.sl.n = ids ? n : 0;
+    for (int i = 0; i < 8; ++i) a.sl.id[i] = (ids && i < n) ? ids[i] : 0;
+    a.sx = sx; a.snst = snst;
 #define VV_B(C_)                                                     \
     do {                                                             \
         if (xs == 1) go<C_, 1>(a, s);                                \

@@ -39,6 +39,18 @@ int vv_normdw_sliced_launch(const float* xin, float* xout, float* nb, const floa
 int vv_normdw_sliced_slots_launch(const float* xin, float* xout, float* nb, const float* nw, const float* w, const float* b,
                                   const float* gamma, int T, int C, float eps, const int* ids, int n, int64_t sx, int64_t snb,
                                   hipStream_t s);
+int vv_normdw_rows_slots_launch(const float* xin, float* xout, float* nb, const float* nw, const float* w, const float* b,
+                                const float* gamma, int T, int C, float eps, const int* ids, int n, int64_t sx, int64_t snb,
+                                hipStream_t s);
+int vv_stem_conv_slots_launch(const float* in, const void* wp, const float* bias, float* out, int T, int N, const int* ids, int n,
+                              int64_t s_in, int64_t s_out, hipStream_t s);
+int vv_head_conv1_slots_launch(const float* x, const void* wp, const float* bias, float* out, int T, int Cin, const int* ids, int n,
+                               int64_t s_in, int64_t s_out, hipStream_t s);
+int vv_block1d_slots_launch(int C, int xs, const float* xin, float* xout, float* nst, const float* norm_w,
+                            const float* ffn_norm_w, const float* gamma, const float* ffn_gamma,
+                            const float* dw_w, const float* dw_b, const float* b1, const float* b2,
+                            const void* w1, const void* w2, int T, float eps, const int* ids, int n, int64_t sx,
+                            int64_t snst, hipStream_t s);
 int vv_affine_slots_launch(const float* x, float* y, float mul, float add, int L, const int* ids, int n, int64_t stride, hipStream_t s);
 int vv_normdw_launch(float* x, float* nb, const float* nw, const float* w, const float* b, const float* gamma, int T, int C,
                      float eps, hipStream_t s);
@@ -138,6 +150,7 @@ struct CodecNet {
     // slot-batched stages (several utterances' rows in ONE weight pass, run_codec_batch): the leading `kd` stages of a decoder,
     // the stages from `ke` on of an encoder -- the T <= 8, C >= 1024 stages that hold ~95 % of a tokenizer's weight bytes
     int kd = 0, ke = 1 << 30;
+    bool head_batch = false;                 // the head conv has a slot-batched form too
     int64_t in_stride = 0, u_stride = 0;     // floats between the in_buf / u buffers of consecutive slots
     std::map<uint64_t, std::pair<void*, int>> shift_multi; // slot bit mask -> merged history-shift table
 };
@@ -280,6 +293,7 @@ static float* add_vec(vv_ctx* ctx, const std::string& name, int64_t n, float* ds
 }
 
 // ------------------------------------------------------------------ codec nets
+static VVGemm mk_gemm(const void* W, const float* X, float* Y, int T, int N, int K, int ldx, int ldy);
 static int build_codec(vv_ctx* ctx, CodecNet& net, const std::string& pfx, bool decoder, int vae_dim, int Fmax, int n_slots) {
     const vv_config& c = ctx->c;
     const int ns = c.n_stages;
@@ -406,16 +420,35 @@ static int build_codec(vv_ctx* ctx, CodecNet& net, const std::string& pfx, bool 
             }
         }
     }
-    // which stages can run slot-batched: channel-sliced norm+conv stages (T <= 8 rows per frame, C = 1024 / 2048), bf16 modes
+    // which stages can run slot-batched (bf16 modes): the incoming conv as a slot-batched GEMV (or the stem kernel), the blocks
+    // as fused block kernels, or channel-sliced / row-tiled norm+conv + slot-batched FFN GEMVs.  VVHIP_BATCH_CODEC=heavy keeps
+    // only the weight-heavy T <= 8 stages batched (the rest per utterance on forked streams), =0 turns batching off.
     {
+        const char* mode = getenv("VVHIP_BATCH_CODEC");
+        const bool off = (mode && !strcmp(mode, "0")) || ctx->c.xsplit > 2 || n_slots < 2 || Fmax != 1;
+        const bool heavy_only = mode && !strcmp(mode, "heavy");
+        auto gemm_ok = [&](const ConvG& cg, int64_t sx, int64_t sy) {
+            VVGemm g = mk_gemm(cg.w, net.in_buf[0], net.u[0], 2 * cg.rows_per_frame, cg.N, cg.K, cg.ldx, cg.N);
+            g.epi = VV_EPI_BIAS; g.bias = cg.bias;
+            g.sl_n = 2; g.sl_T = cg.rows_per_frame; g.sl_x = (int)sx; g.sl_y = (int)sy; g.sl_id[0] = 0; g.sl_id[1] = n_slots - 1;
+            return vv_gemv_ok(&g) != 0;
+        };
         auto ok = [&](int i) {
             const Stage& s = net.st[0][i];
-            return !s.fused && s.pp && vv_normdw_sliced_ok(s.Tpf, s.C) && ctx->c.xsplit <= 2 && n_slots > 1 && Fmax == 1 &&
-                   !getenv("VVHIP_NO_BATCH_CODEC");
+            if (off || s.blocks.empty() || (s.C & 31)) return false;
+            const bool stem = (i == 0 && s.in.K == 7 && s.in.ldx == 1 && !getenv("VVHIP_NO_CONV_KERNELS"));
+            if (!stem && !gemm_ok(s.in, i == 0 ? net.in_stride : net.st[0][i - 1].sl_stride, s.sl_stride)) return false;
+            if (s.pp && vv_normdw_sliced_ok(s.Tpf, s.C)) return true;
+            if (heavy_only) return false;
+            return s.fused || (s.pp && vv_normdw_rows_ok(s.Tpf, s.C));
         };
         net.kd = 0; net.ke = ns;
         if (decoder) { while (net.kd < ns && ok(net.kd)) net.kd++; }
         else { while (net.ke > 0 && ok(net.ke - 1)) net.ke--; }
+        const ConvG& h = net.head;
+        const bool conv1 = h.N == 1 && h.K == 7 * h.ldx && (h.ldx & 3) == 0 && h.ldx <= 1024 && !getenv("VVHIP_NO_CONV_KERNELS");
+        net.head_batch = !off && !heavy_only && (conv1 || gemm_ok(h, net.st[0][ns - 1].sl_stride, 0));
+        if (!decoder && net.ke < ns && !(conv1 || gemm_ok(h, net.st[0][ns - 1].sl_stride, 0))) net.ke = ns;   // encoder tail needs its head batched
     }
     return 0;
 }
@@ -633,15 +666,32 @@ static int run_codec_batch(vv_ctx* ctx, CodecNet& net, const int* ids, int n, in
             const ConvG& cg = s.in;
             const float* X = (i == 0) ? net.in_buf[0] : st0[i - 1].xfinal;
             const int64_t sx = (i == 0) ? net.in_stride : st0[i - 1].sl_stride;
-            VVGemm g = mk_gemm(cg.w, X, x, cg.rows_per_frame, cg.N, cg.K, cg.ldx, cg.N);
-            g.epi = VV_EPI_BIAS; g.bias = cg.bias; g.nt = 1;
-            slots(g, cg.rows_per_frame, sx, s.sl_stride);
-            GEMM(g);
+            if (i == 0 && cg.K == 7 && cg.ldx == 1 && !getenv("VVHIP_NO_CONV_KERNELS")) {
+                ctx->launches++;
+                VVCHK(vv_stem_conv_slots_launch(X, cg.w, cg.bias, x, cg.rows_per_frame, cg.N, ids, n, sx, s.sl_stride, st));
+            } else {
+                VVGemm g = mk_gemm(cg.w, X, x, cg.rows_per_frame, cg.N, cg.K, cg.ldx, cg.N);
+                g.epi = VV_EPI_BIAS; g.bias = cg.bias; g.nt = 1;
+                slots(g, cg.rows_per_frame, sx, s.sl_stride);
+                GEMM(g);
+            }
         }
         float* xo = s.xs2 + (size_t)s.hist * s.C;
+        if (s.fused) {
+            for (auto& b : s.blocks) {
+                ctx->launches++;
+                VVCHK(vv_block1d_slots_launch(s.C, ctx->c.xsplit, x, xo, b.nst, b.norm_w, b.ffn_norm_w, b.gamma, b.ffn_gamma, b.dw_w, b.dw_b,
+                                              b.b1, b.b2, b.w1, b.w2, T, eps, ids, n, s.sl_stride, b.nb_stride, st));
+                std::swap(x, xo);
+            }
+            continue;
+        }
         for (auto& b : s.blocks) {
             ctx->launches += 1;
-            VVCHK(vv_normdw_sliced_slots_launch(x, xo, b.nb, b.norm_w, b.dw_w, b.dw_b, b.gamma, T, s.C, eps, ids, n, s.sl_stride, b.nb_stride, st));
+            if (vv_normdw_sliced_ok(T, s.C))
+                VVCHK(vv_normdw_sliced_slots_launch(x, xo, b.nb, b.norm_w, b.dw_w, b.dw_b, b.gamma, T, s.C, eps, ids, n, s.sl_stride, b.nb_stride, st));
+            else
+                VVCHK(vv_normdw_rows_slots_launch(x, xo, b.nb, b.norm_w, b.dw_w, b.dw_b, b.gamma, T, s.C, eps, ids, n, s.sl_stride, b.nb_stride, st));
             VVGemm g1 = mk_gemm(b.w1, xo, net.u[0], T, 4 * s.C, s.C, s.C, 4 * s.C);          // u: dense [n * T][4C] scratch
             g1.pro = VV_PRO_RMS; g1.nw = b.ffn_norm_w; g1.eps = eps; g1.epi = VV_EPI_BIAS_GELU; g1.bias = b.b1; g1.nt = 1;
             slots(g1, T, s.sl_stride, 0);
@@ -656,10 +706,15 @@ static int run_codec_batch(vv_ctx* ctx, CodecNet& net, const int* ids, int n, in
     if (head) {
         const ConvG& cg = net.head;
         Stage& s = st0[ns - 1];
-        VVGemm g = mk_gemm(cg.w, s.xfinal, out, cg.rows_per_frame, cg.N, cg.K, cg.ldx, cg.N);
-        g.epi = VV_EPI_BIAS; g.bias = cg.bias;
-        slots(g, cg.rows_per_frame, s.sl_stride, 0);
-        GEMM(g);
+        if (cg.N == 1 && cg.K == 7 * cg.ldx && (cg.ldx & 3) == 0 && cg.ldx <= 1024 && !getenv("VVHIP_NO_CONV_KERNELS")) {
+            ctx->launches++;                     // decoder head: k = 7 conv to one channel; dense [n][rows] output
+            VVCHK(vv_head_conv1_slots_launch(s.xfinal, cg.w, cg.bias, out, cg.rows_per_frame, cg.ldx, ids, n, s.sl_stride, cg.rows_per_frame, st));
+        } else {
+            VVGemm g = mk_gemm(cg.w, s.xfinal, out, cg.rows_per_frame, cg.N, cg.K, cg.ldx, cg.N);
+            g.epi = VV_EPI_BIAS; g.bias = cg.bias;
+            slots(g, cg.rows_per_frame, s.sl_stride, 0);
+            GEMM(g);
+        }
     }
     return 0;
 }
@@ -1373,30 +1428,45 @@ extern "C" int vv_codec_chain_batch(vv_ctx* ctx, void* stream, int n, const int*
         const float mul = apply ? 1.0f / ctx->scaling : 1.0f, add = apply ? -ctx->bias : 0.0f;
         const int ns_d = (int)dec.st[0].size(), ns_e = sem ? (int)senc.st[0].size() : 0;
         const bool bd = n > 1 && dec.kd > 0, be = sem && n > 1 && senc.ke < ns_e;
+        const bool dec_full = bd && dec.kd == ns_d && dec.head_batch;      // the whole decoder runs slot-batched
+        const bool enc_full = be && senc.ke == 0;
+        const bool fork = n > 1 && !(dec_full && (!sem || enc_full));      // some part still runs per utterance
         if (bd) {
             ctx->launches++;
             VVCHK(vv_affine_slots_launch(latent_dev, dec.in_buf[0] + 6 * L, mul, add, L, ids.data(), n, dec.in_stride, st));
-            if (run_codec_batch(ctx, dec, ids.data(), n, 0, dec.kd, nullptr, false, st)) return -1;
-        }
-        const bool fork = n > 1;
-        if (fork) HIPCHK(ctx, hipEventRecord(ctx->ev_fork, st));
-        for (int j = 0; j < n; ++j) {
-            hipStream_t ss = fork ? ctx->side[j] : st;
-            const int sl = ids[j];
-            if (fork) HIPCHK(ctx, hipStreamWaitEvent(ss, ctx->ev_fork, 0));
-            if (!bd) {
+            if (run_codec_batch(ctx, dec, ids.data(), n, 0, dec.kd, audio_out_dev, dec_full, st)) return -1;
+            if (dec_full) {
+                void* tab; int nt;
+                if (codec_tables_multi(ctx, dec, ids.data(), n, &tab, &nt)) return -1;
                 ctx->launches++;
-                VVCHK(vv_affine_launch(latent_dev + (size_t)j * L, dec.in_buf[sl] + 6 * L, mul, add, L, ss));
+                VVCHK(vv_shift_rows_launch(tab, nt, dec.maxC, st));
             }
-            float* audio = audio_out_dev + (size_t)j * hop;
-            if (run_codec(ctx, dec, sl, 1, audio, ss, bd ? dec.kd : 0, ns_d, true, true)) return -1;
-            if (sem) {
-                HIPCHK(ctx, hipMemcpyAsync(senc.in_buf[sl] + 6, audio, (size_t)hop * 4, hipMemcpyDeviceToDevice, ss));
-                if (run_codec(ctx, senc, sl, 1, sem_out_dev + (size_t)j * S, ss, 0, be ? senc.ke : ns_e, !be, !be)) return -1;
-            }
-            if (fork) HIPCHK(ctx, hipEventRecord(ctx->ev_join[j], ss));
         }
-        if (fork) for (int j = 0; j < n; ++j) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join[j], 0));
+        if (fork || n == 1) {
+            if (fork) HIPCHK(ctx, hipEventRecord(ctx->ev_fork, st));
+            for (int j = 0; j < n; ++j) {
+                hipStream_t ss = fork ? ctx->side[j] : st;
+                const int sl = ids[j];
+                if (fork) HIPCHK(ctx, hipStreamWaitEvent(ss, ctx->ev_fork, 0));
+                float* audio = audio_out_dev + (size_t)j * hop;
+                if (!dec_full) {
+                    if (!bd) {
+                        ctx->launches++;
+                        VVCHK(vv_affine_launch(latent_dev + (size_t)j * L, dec.in_buf[sl] + 6 * L, mul, add, L, ss));
+                    }
+                    if (run_codec(ctx, dec, sl, 1, audio, ss, bd ? dec.kd : 0, ns_d, true, true)) return -1;
+                }
+                if (sem) {
+                    HIPCHK(ctx, hipMemcpyAsync(senc.in_buf[sl] + 6, audio, (size_t)hop * 4, hipMemcpyDeviceToDevice, ss));
+                    if (run_codec(ctx, senc, sl, 1, sem_out_dev + (size_t)j * S, ss, 0, be ? senc.ke : ns_e, !be, !be)) return -1;
+                }
+                if (fork) HIPCHK(ctx, hipEventRecord(ctx->ev_join[j], ss));
+            }
+            if (fork) for (int j = 0; j < n; ++j) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join[j], 0));
+        } else if (sem) {
+            ctx->launches++;       // the batch's audio rows into the encoder's per-utterance input buffers
+            VVCHK(vv_affine_slots_launch(audio_out_dev, senc.in_buf[0] + 6, 1.0f, 0.0f, hop, ids.data(), n, senc.in_stride, st));
+        }
         if (be) {
             if (run_codec_batch(ctx, senc, ids.data(), n, senc.ke, ns_e, sem_out_dev, true, st)) return -1;
             void* tab; int nt;

@@ -206,8 +206,13 @@ template <int RB, int NCH>          // NCH = C / 256 float4 chunks per lane and 
 __global__ __launch_bounds__(256) void vv_normdw_rows_kernel(const float* __restrict__ xin, float* __restrict__ xout,
                                                              float* __restrict__ nb, const float* __restrict__ nw,
                                                              const float* __restrict__ w, const float* __restrict__ b,
-                                                             const float* __restrict__ gamma, int T, int C, float eps) {
+                                                             const float* __restrict__ gamma, int T, int C, float eps,
+                                                             const VVSlotIds sl, int64_t sx, int64_t snb) {
     extern __shared__ __attribute__((aligned(16))) float nrm_sh[];          // [RB + 6][C] normed rows, then [RB][C] raw rows
+    if (sl.n > 0) {        // slot-batched launch: blockIdx.y picks the utterance
+        const int64_t id = vv_slot_id(sl.id, blockIdx.y);
+        xin += id * sx; xout += id * sx; nb += id * snb;
+    }
     float* raw_sh = nrm_sh + (size_t)(RB + 6) * C;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t0 = blockIdx.x * RB;
@@ -285,9 +290,10 @@ __device__ __forceinline__ float packed_w(const __bf16* __restrict__ wp, int KT,
 // time-major input buffer with its 6 history samples in front.  K = 7 is not an MFMA shape (the general GEMM kernel spent
 // 10 us on it); one output per thread, coalesced along n.  W packed [N][7].
 __global__ void vv_stem_conv_kernel(const float* __restrict__ in, const __bf16* __restrict__ wp, const float* __restrict__ bias,
-                                    float* __restrict__ out, int T, int N) {
+                                    float* __restrict__ out, int T, int N, const VVSlotIds sl, int64_t s_in, int64_t s_out) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= T * N) return;
+    if (sl.n > 0) { const int64_t id = vv_slot_id(sl.id, blockIdx.y); in += id * s_in; out += id * s_out; }
     const int t = e / N, n = e - t * N;
     float acc = bias[n];
 #pragma unroll
@@ -298,8 +304,11 @@ __global__ void vv_stem_conv_kernel(const float* __restrict__ in, const __bf16* 
 // Decoder head: causal conv k = 7 from Cin channels to ONE output channel: out[t] = b + sum_{k < 7 Cin} W[0][k] * X[t * Cin + k]
 // (X = the last stage's buffer, 6 history rows in front: a window is 7 Cin contiguous floats).  Four lanes per output sample.
 __global__ __launch_bounds__(256) void vv_head_conv1_kernel(const float* __restrict__ x, const __bf16* __restrict__ wp,
-                                                            const float* __restrict__ bias, float* __restrict__ out, int T, int Cin) {
+                                                            const float* __restrict__ bias, float* __restrict__ out, int T, int Cin,
+                                                            const VVSlotIds sl, int64_t s_in, int64_t s_out) {
     extern __shared__ float wsh[];                       // [7 * Cin]
+    // slot-batched: input = utterance id's stage buffer, output = row blockIdx.y of a dense [n][s_out] tensor
+    if (sl.n > 0) { x += (int64_t)vv_slot_id(sl.id, blockIdx.y) * s_in; out += (int64_t)blockIdx.y * s_out; }
     const int K = 7 * Cin, KT = (K + 31) >> 5;
     for (int k = threadIdx.x; k < K; k += 256) wsh[k] = packed_w(wp, KT, 0, k);
     __syncthreads();
@@ -526,30 +535,54 @@ int vv_affine_slots_launch(const float* x, float* y, float mul, float add, int L
     return okk();
 }
 int vv_normdw_rows_ok(int T, int C) { return T >= 1 && (C == 256 || C == 512 || C == 1024); }
+int vv_normdw_rows_slots_launch(const float* xin, float* xout, float* nb, const float* nw, const float* w, const float* b,
+                                const float* gamma, int T, int C, float eps, const int* ids, int n, int64_t sx, int64_t snb,
+                                hipStream_t s);
 int vv_normdw_rows_launch(const float* xin, float* xout, float* nb, const float* nw, const float* w, const float* b,
                           const float* gamma, int T, int C, float eps, hipStream_t s) {
-    if (!vv_normdw_rows_ok(T, C) || xin == xout) return -1;
+    return vv_normdw_rows_slots_launch(xin, xout, nb, nw, w, b, gamma, T, C, eps, nullptr, 0, 0, 0, s);
+}
+// ids != null: the same kernel over n utterance slots (xin / xout / nb are slot 0's buffers, slot k's sx / snb floats further)
+int vv_normdw_rows_slots_launch(const float* xin, float* xout, float* nb, const float* nw, const float* w, const float* b,
+                                const float* gamma, int T, int C, float eps, const int* ids, int n, int64_t sx, int64_t snb,
+                                hipStream_t s) {
+    if (!vv_normdw_rows_ok(T, C) || xin == xout || n < 0 || n > 8) return -1;
     constexpr int RB = 8;
     const size_t smem = (size_t)(2 * RB + 6) * C * 4;
-    const dim3 grid((T + RB - 1) / RB);
+    VVSlotIds sl; sl.n = ids ? n : 0;
+    for (int i = 0; i < 8; ++i) sl.id[i] = (ids && i < n) ? ids[i] : 0;
+    const dim3 grid((T + RB - 1) / RB, sl.n > 0 ? sl.n : 1);
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_normdw_rows_kernel<RB, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    if (C == 256) hipLaunchKernelGGL((vv_normdw_rows_kernel<RB, 1>), grid, dim3(256), smem, s, xin, xout, nb, nw, w, b, gamma, T, C, eps);
-    else if (C == 512) hipLaunchKernelGGL((vv_normdw_rows_kernel<RB, 2>), grid, dim3(256), smem, s, xin, xout, nb, nw, w, b, gamma, T, C, eps);
-    else hipLaunchKernelGGL((vv_normdw_rows_kernel<RB, 4>), grid, dim3(256), smem, s, xin, xout, nb, nw, w, b, gamma, T, C, eps);
+    if (C == 256) hipLaunchKernelGGL((vv_normdw_rows_kernel<RB, 1>), grid, dim3(256), smem, s, xin, xout, nb, nw, w, b, gamma, T, C, eps, sl, sx, snb);
+    else if (C == 512) hipLaunchKernelGGL((vv_normdw_rows_kernel<RB, 2>), grid, dim3(256), smem, s, xin, xout, nb, nw, w, b, gamma, T, C, eps, sl, sx, snb);
+    else hipLaunchKernelGGL((vv_normdw_rows_kernel<RB, 4>), grid, dim3(256), smem, s, xin, xout, nb, nw, w, b, gamma, T, C, eps, sl, sx, snb);
+    return okk();
+}
+int vv_stem_conv_slots_launch(const float* in, const void* wp, const float* bias, float* out, int T, int N, const int* ids, int n,
+                              int64_t s_in, int64_t s_out, hipStream_t s) {
+    if (n < 0 || n > 8) return -1;
+    VVSlotIds sl; sl.n = ids ? n : 0;
+    for (int i = 0; i < 8; ++i) sl.id[i] = (ids && i < n) ? ids[i] : 0;
+    hipLaunchKernelGGL(vv_stem_conv_kernel, dim3((T * N + 255) / 256, sl.n > 0 ? sl.n : 1), dim3(256), 0, s, in, (const __bf16*)wp, bias, out, T, N, sl, s_in, s_out);
     return okk();
 }
 int vv_stem_conv_launch(const float* in, const void* wp, const float* bias, float* out, int T, int N, hipStream_t s) {
-    hipLaunchKernelGGL(vv_stem_conv_kernel, dim3((T * N + 255) / 256), dim3(256), 0, s, in, (const __bf16*)wp, bias, out, T, N);
+    return vv_stem_conv_slots_launch(in, wp, bias, out, T, N, nullptr, 0, 0, 0, s);
+}
+int vv_head_conv1_slots_launch(const float* x, const void* wp, const float* bias, float* out, int T, int Cin, const int* ids, int n,
+                               int64_t s_in, int64_t s_out, hipStream_t s) {
+    if ((Cin & 3) || (((uintptr_t)x) & 15) || 7 * Cin * 4 > 48 * 1024 || n < 0 || n > 8 || (s_in & 3)) return -1;
+    VVSlotIds sl; sl.n = ids ? n : 0;
+    for (int i = 0; i < 8; ++i) sl.id[i] = (ids && i < n) ? ids[i] : 0;
+    hipLaunchKernelGGL(vv_head_conv1_kernel, dim3((T + 63) / 64, sl.n > 0 ? sl.n : 1), dim3(256), (size_t)7 * Cin * 4, s, x, (const __bf16*)wp, bias, out, T, Cin, sl, s_in, s_out);
     return okk();
 }
 int vv_head_conv1_launch(const float* x, const void* wp, const float* bias, float* out, int T, int Cin, hipStream_t s) {
-    if ((Cin & 3) || (((uintptr_t)x) & 15) || 7 * Cin * 4 > 48 * 1024) return -1;
-    hipLaunchKernelGGL(vv_head_conv1_kernel, dim3((T + 63) / 64), dim3(256), (size_t)7 * Cin * 4, s, x, (const __bf16*)wp, bias, out, T, Cin);
-    return okk();
+    return vv_head_conv1_slots_launch(x, wp, bias, out, T, Cin, nullptr, 0, 0, 0, s);
 }
 int vv_shift_rows_launch(const void* tab, int n_entries, int maxC, hipStream_t s) {
     int cy = (maxC + 255) / 256; if (cy < 1) cy = 1; if (cy > 16) cy = 16;
