@@ -42,6 +42,52 @@ def kernel_stats(db, out):
     return rows, tot
 
 
+CATS = [("gemv", r"vv_gemv_kernel"), ("attention", r"vv_attn_"), ("tokenizer blocks / convs", r"vv_block1d|vv_normdw|vv_stem_conv|vv_head_conv|vv_shift|vv_dwconv|vv_rmsnorm_rows|vv_gemm_tile|vv_affine"),
+        ("prefill gemm", r"vv_gemm3|vv_pack_rows|vv_rope_append"), ("torch / copies", r"at::|rocclr|Cijk|elementwise")]
+
+
+def timeline(db, out):
+    """Decode-phase occupancy of the GPU timeline: the window from the end of the last prompt-prefill kernel (vv_gemm3) to the
+    last dispatch; busy = union of the kernel intervals inside it; gaps = the rest (launch boundaries, host latency)."""
+    cur = db.cursor()
+    rows = cur.execute("select name, start, end from kernels order by start").fetchall()
+    if not rows:
+        return
+    t0 = rows[0][1]
+    for name, st, en in rows:
+        if "vv_gemm3" in name or "vv_attn_prefill" in name:
+            t0 = max(t0, en)
+    win = [(n, s, e) for n, s, e in rows if s >= t0]
+    if len(win) < 10:
+        return
+    t1 = max(e for _, _, e in win)
+    busy, cur_s, cur_e = 0, None, None
+    for _, s, e in win:
+        if cur_e is None or s > cur_e:
+            if cur_e is not None:
+                busy += cur_e - cur_s
+            cur_s, cur_e = s, e
+        else:
+            cur_e = max(cur_e, e)
+    busy += cur_e - cur_s
+    span = t1 - t0
+    by = {c: [0, 0] for c, _ in CATS}
+    by["other"] = [0, 0]
+    for n, s, e in win:
+        for c, pat in CATS:
+            if re.search(pat, n):
+                by[c][0] += e - s; by[c][1] += 1
+                break
+        else:
+            by["other"][0] += e - s; by["other"][1] += 1
+    with open(out + "_timeline.txt", "w") as f:
+        f.write(f"decode-phase window {span / 1e6:.2f} ms, {len(win)} dispatches: GPU busy (union of kernel intervals) {busy / 1e6:.2f} ms = "
+                f"{100.0 * busy / span:.1f} %, gaps {100.0 * (span - busy) / span:.1f} %\n")
+        f.write("(rocprofv3 --kernel-trace serialises nothing but adds ~1 us per dispatch; sums per category may exceed the busy time where graph branches overlap)\n")
+        for c, (ns, k) in by.items():
+            f.write(f"  {c:28s} {k:8d} dispatches {ns / 1e6:10.2f} ms  {100.0 * ns / span:5.1f} % of the window\n")
+
+
 def pmc_stats(db, out):
     cur = db.cursor()
     rows = cur.execute("select kernel_name, counter_name, count(*), avg(value), sum(value), avg(end-start) "
@@ -61,6 +107,7 @@ if __name__ == "__main__":
             print(f"{short(r[0])[:90]:90s} {r[1]:32s} n={r[2]:6d} mean={r[3]:14.1f} dur={r[5] / 1e3:9.2f}us")
     else:
         rows, tot = kernel_stats(db, sys.argv[2])
+        timeline(db, sys.argv[2])
         print(f"total kernel time {tot / 1e6:.2f} ms")
         for r in rows[:25]:
             print(f"{short(r[0])[:100]:100s} {r[1]:7d} {r[2] / 1e6:9.2f} ms  avg {r[3] / 1e3:9.2f} us  {100 * r[2] / tot:5.1f}%")

@@ -75,6 +75,7 @@ int vv_cvt_launch(const void* src, void* dst, int64_t n, int to_bf16, hipStream_
 int vv_dw_transpose_launch(const float* src, float* dst, int C, hipStream_t s);
 int vv_pack_rows_launch(const float* x, int ldx, const float* nw, float eps, void* xp, int T, int K, hipStream_t s);
 int vv_unpack_rows_launch(const void* xp, float* x, int T, int K, hipStream_t s);
+int vv_ada_pack_launch(const float* cproj, const float* temb, void* xp, int rows, int n_steps, int H, hipStream_t s);
 int vv_gemm3_launch(const void* W, const void* W2, const void* Xp, float* Y, void* Yp, const float* bias, int T, int N, int K,
                     int ldy, int epi, hipStream_t s);
 int vv_attn_prefill2_launch(int D, const float* q, const VVRow* rows, const void* kc, const void* vc, int R, int Hq, int Hkv,
@@ -199,6 +200,7 @@ struct vv_ctx {
     float *temb = nullptr, *coef = nullptr, *tvals = nullptr;
     float* mod_all = nullptr; size_t mod_all_bytes = 0;
     float* ada_in = nullptr;
+    void* ada_p = nullptr;                 // the same rows as packed bf16 MFMA fragments (bf16 mode: one tile GEMM for all steps)
     float *cproj = nullptr, *mod = nullptr, *zz = nullptr, *x0p = nullptr, *xh = nullptr, *hact = nullptr, *eps = nullptr;
     float *tmp1 = nullptr, *tmp2 = nullptr;
     // connectors
@@ -1054,6 +1056,8 @@ extern "C" int vv_set_schedule(vv_ctx* ctx, int n_steps, const float* t, const f
             dfree(ctx, ctx->ada_in);
             ctx->mod_all = (float*)dalloc(ctx, need, false);
             ctx->ada_in = (float*)dalloc(ctx, (size_t)n_steps * 16 * ctx->H * 4, false);
+            dfree(ctx, ctx->ada_p);
+            ctx->ada_p = (ctx->c.xsplit == 1 && (ctx->H & 7) == 0) ? dalloc(ctx, (size_t)vv_packed_elems(n_steps * 16, ctx->H) * 2, false) : nullptr;
             ctx->mod_all_bytes = (ctx->mod_all && ctx->ada_in) ? need : 0;
         }
     }
@@ -1318,12 +1322,21 @@ static int sample_body(vv_ctx* ctx, hipStream_t st, int n, const float* cond, co
         // SiLU(cond + t) for all (step, row) pairs in one small launch: the GEMM workgroups (one per 16 output features,
         // > 1000 of them) then stage plain rows instead of each re-evaluating 16 x H SiLUs
         const int total = rows * ctx->n_steps;
+        // bf16 mode, three or more 16-row passes: ONE MFMA tile GEMM over all (step, row) pairs instead -- the modulation
+        // matrix (360 MB for the 7B head) is streamed once, not once per 16 rows (8 utterances x 20 steps: 20 passes)
+        static const bool ada_tile = !getenv("VVHIP_NO_ADA_GEMM3");
+        if (ada_tile && ctx->ada_p && total > 32 && (MODW & 3) == 0) {
+            ctx->launches += 2;
+            VVCHK(vv_ada_pack_launch(ctx->cproj, ctx->temb, ctx->ada_p, rows, ctx->n_steps, H, st));
+            VVCHK(vv_gemm3_launch(ctx->h_ada, nullptr, ctx->ada_p, ctx->mod_all, nullptr, nullptr, total, MODW, H, MODW, VV_EPI_STORE, st));
+        } else {
         VVCHK(vv_ada_in_launch(ctx->cproj, ctx->temb, ctx->ada_in, rows, ctx->n_steps, H, st));
         ctx->launches++;
         for (int t0 = 0; t0 < total; t0 += 16) {
             const int T = std::min(16, total - t0);
             VVGemm ga = mk_gemm(ctx->h_ada, ctx->ada_in + (size_t)t0 * H, ctx->mod_all + (size_t)t0 * MODW, T, MODW, H, H, MODW);
             GEMM(ga);
+        }
         }
     }
     for (int i = 0; i < ctx->n_steps; ++i) {

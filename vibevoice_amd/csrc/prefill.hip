@@ -95,6 +95,32 @@ __global__ __launch_bounds__(256) void vv_pack_rows_kernel(const float* __restri
     }
 }
 
+// adaLN input rows of every solver step, straight into MFMA fragments: logical row t = i * rows + r holds
+// SiLU(cond_proj[r] + t_emb[i]) (DiT adaLN_modulation's SiLU, modular_vibevoice_diffusion_head.py:198-205).
+// grid (ceil(T / 16), ceil(KT / 4)); wave w of a workgroup packs k-tile 4 * blockIdx.y + w of its 16-row tile.
+__global__ __launch_bounds__(256) void vv_ada_pack_kernel(const float* __restrict__ cproj, const float* __restrict__ temb,
+                                                          u32x4* __restrict__ xp, int rows, int n_steps, int H) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int KT = (H + 31) >> 5, T = rows * n_steps;
+    const int kt = blockIdx.y * 4 + wave;
+    if (kt >= KT) return;
+    const int t = blockIdx.x * 16 + (lane & 15), k = kt * 32 + (lane >> 4) * 8;
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (__bf16)0.f;
+    if (t < T && k < H) {               // H % 8 == 0 is a launch precondition
+        const int i = t / rows, r = t - i * rows;
+        const float* c = cproj + (int64_t)r * H + k;
+        const float* e = temb + (int64_t)i * H + k;
+        const float4 c0 = *reinterpret_cast<const float4*>(c), c1 = *reinterpret_cast<const float4*>(c + 4);
+        const float4 e0 = *reinterpret_cast<const float4*>(e), e1 = *reinterpret_cast<const float4*>(e + 4);
+        const float u[8] = {c0.x + e0.x, c0.y + e0.y, c0.z + e0.z, c0.w + e0.w, c1.x + e1.x, c1.y + e1.y, c1.z + e1.z, c1.w + e1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (__bf16)(u[j] / (1.0f + expf(-u[j])));
+    }
+    xp[((int64_t)blockIdx.x * KT + kt) * 64 + lane] = __builtin_bit_cast(u32x4, o);
+}
+
 // packed bf16 fragments -> fp32 rows (tests)
 __global__ void vv_unpack_rows_kernel(const __bf16* __restrict__ xp, float* __restrict__ x, int T, int K) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -451,6 +477,13 @@ int vv_unpack_rows_launch(const void* xp, float* x, int T, int K, hipStream_t s)
 }
 
 // Y (op)= Xp . W^T.  epi: VV_EPI_STORE / BIAS / RESID -> fp32 Y[T][ldy];  VV_EPI_SWIGLU -> packed bf16 Yp [T][N] (W = gate, W2 = up)
+int vv_ada_pack_launch(const float* cproj, const float* temb, void* xp, int rows, int n_steps, int H, hipStream_t s) {
+    if ((H & 7) || rows < 1 || n_steps < 1) return -1;
+    const int T = rows * n_steps, KT = (H + 31) >> 5;
+    hipLaunchKernelGGL(vv_ada_pack_kernel, dim3((T + 15) / 16, (KT + 3) / 4), dim3(256), 0, s, cproj, temb, (u32x4*)xp, rows, n_steps, H);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 int vv_gemm3_launch(const void* W, const void* W2, const void* Xp, float* Y, void* Yp, const float* bias, int T, int N, int K,
                     int ldy, int epi, hipStream_t s) {
     if (T < 1 || N < 1 || K < 32 || (N & 3)) return -1;
