@@ -116,3 +116,56 @@ def test_timed_mode_free_running(timed):
     first = rel_err(htr.latents[0], otr.latents[0])
     assert first <= 5e-2, first                                  # the first frame has no feedback yet
     print(f"[timed mode, free-running] first-frame latent rel-L2 {first:.3e}, worst frame RMS {r:.3f} dB, worst frame SNR {q:.1f} dB")
+
+
+def test_timed_mode_teacher_forced_batch8():
+    """8 desynchronised utterances in the timed mode: 16 LM rows and 16 diffusion-head rows per step run the packed-activation
+    batch kernels (gemv16p.hip: activations normalised + packed once per op, every projection streams weights against the
+    packed tile), the tokenizer chains go through vv_codec_chain_batch.  Same per-step bounds as B = 1, 2."""
+    from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference
+    s = build_small(synth.LMCfg(), xsplit=1, use_graph=True, n_slots=8, max_ctx=512, max_rows=16)
+    try:
+        B, L0 = 8, 14
+        g = synth.Gen(188)
+        ids = torch.full((B, L0), TOK.pad_token_id, dtype=torch.long)
+        mask = torch.zeros((B, L0), dtype=torch.long)
+        for b in range(B):
+            n = L0 - (b % 4)
+            row = torch.from_numpy(g.rng.integers(0, 300, (n,)))
+            row[-1] = S
+            ids[b, L0 - n:] = row
+            mask[b, L0 - n:] = 1
+        forced = [[D, D, D, D, E, S, D, D, X], [D, E, S, D, D, D, D, X], [D, D, D, X], [D, D, E, S, D, D, D, D, D, X],
+                  [D, X], [D, D, D, D, D, D, D, X], [D, D, D, E, S, D, X], [D, D, D, D, D, E, X]]
+        bank = {}
+
+        def noise_fn(step, n2):
+            return bank.setdefault((step, n2), synth.Gen(7000 + step * 17 + n2).normal((n2, 64), 1.0, mat=False))
+        om = s.oracle_model(kv_round_bf16=True)
+        om.t_cast_dtype = torch.bfloat16
+        otr = ogen.Trace()
+        oseq, oaud, omax = ogen.oracle_generate(om, TOK, ids, mask, cfg_scale=1.3, num_steps=5, noise_fn=noise_fn,
+                                                forced_tokens=forced, trace=otr)
+        cfgd = {"decoder_config": {"max_position_embeddings": s.lmcfg.max_pos}, "diffusion_head_config": {"ddpm_num_inference_steps": 5},
+                "acoustic_tokenizer_config": {"fix_std": 0.5, "std_dist_type": "gaussian"}}
+        m = VibeVoiceForConditionalGenerationInference(cfgd, s.eng, model_dtype=torch.bfloat16)
+        m.set_speech_factors(s.scaling, s.bias)
+        m.set_ddpm_inference_steps(5)
+        htr = ogen.Trace()
+        out = m.generate(input_ids=ids, attention_mask=mask, cfg_scale=1.3, tokenizer=TOKNS, generation_config={"do_sample": False},
+                         _forced_tokens=forced, _noise_fn=noise_fn, _trace=htr, show_progress_bar=False,
+                         _teacher_embeds=lambda step, rows: otr.next_embeds[step][rows])
+        assert torch.equal(out.sequences.cpu(), oseq)
+        assert len(htr.latents) == len(otr.latents) > 0
+        worst = 0.0
+        for a, b in zip(htr.latents, otr.latents):
+            worst = max(worst, rel_err(a, b))
+            assert rel_err(a, b) <= 5e-2, rel_err(a, b)
+        for a, b in zip(htr.neg_hidden, otr.neg_hidden):
+            assert rel_err(a, b) <= 5e-2, rel_err(a, b)
+        for a, b in zip(out.speech_outputs, oaud):
+            check_frames(a, b, rms_tol_db=0.5, snr_min_db=25.0)
+        print(f"[timed mode, teacher-forced, B=8] worst latent rel-L2 {worst:.3e}")
+        assert s.eng.stat(1) > 0
+    finally:
+        s.eng.close()

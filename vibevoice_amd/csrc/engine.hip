@@ -75,6 +75,10 @@ int vv_cvt_launch(const void* src, void* dst, int64_t n, int to_bf16, hipStream_
 int vv_dw_transpose_launch(const float* src, float* dst, int C, hipStream_t s);
 int vv_pack_rows_launch(const float* x, int ldx, const float* nw, float eps, void* xp, int T, int K, hipStream_t s);
 int vv_unpack_rows_launch(const void* xp, float* x, int T, int K, hipStream_t s);
+int vv_pack16_launch(const float* x, int ldx, int mode, const float* nw, float eps, const float* sc, const float* sh, int ld_mod,
+                     void* xp, int T, int K, hipStream_t s);
+int vv_gemv16p_launch(const void* W, const void* W2, const void* Xp, float* Y, void* Yp, const float* bias, const float* gate,
+                      int T, int N, int K, int ldy, int ld_gate, int epi, hipStream_t s);
 int vv_ada_pack_launch(const float* cproj, const float* temb, void* xp, int rows, int n_steps, int H, hipStream_t s);
 int vv_gemm3_launch(const void* W, const void* W2, const void* Xp, float* Y, void* Yp, const float* bias, int T, int N, int K,
                     int ldy, int epi, hipStream_t s);
@@ -189,6 +193,8 @@ struct vv_ctx {
     float *h_parts = nullptr, *xh_parts = nullptr;     // K-split partial tensors of the residual streams (2 x [rows][H] each)
     void *xp = nullptr, *actp = nullptr;               // prefill (prefill.hip): activations as packed bf16 MFMA fragments
     bool tile3_ok = false, attn2_ok = false;
+    // batch decode (5..16 rows, bf16 mode): activations packed once per op into one 16-row fragment tile (gemv16p.hip)
+    void *p16_x = nullptr, *p16_act = nullptr; bool p16_ok = false;
     bool ksplit_ok = true;
     float *pm = nullptr, *pl = nullptr, *po = nullptr;
     // head
@@ -853,6 +859,12 @@ extern "C" int vv_create(const vv_config* cfg, vv_ctx** out) {
         ctx->tile3_ok = c.xsplit == 1 && !getenv("VVHIP_NO_TILE3");
     }
     ctx->attn2_ok = c.xsplit == 1 && !getenv("VVHIP_NO_ATTN2");
+    if (c.xsplit == 1 && R > 4 && (H % 32) == 0 && ((Hq * D) % 32) == 0 && (I % 32) == 0 && !getenv("VVHIP_NO_P16")) {
+        const int kx = std::max(H, Hq * D), ka = std::max(I, c.head_ffn);
+        ctx->p16_x = dalloc(ctx, (size_t)vv_packed_elems(16, kx) * 2);
+        ctx->p16_act = dalloc(ctx, (size_t)vv_packed_elems(16, ka + 32) * 2);
+        ctx->p16_ok = ctx->p16_x && ctx->p16_act;
+    }
     ctx->rope_tab = dalloc(ctx, (size_t)c.max_ctx * (D / 2) * 8, false);
     ctx->tickets = (unsigned*)dalloc(ctx, (size_t)R * Hkv * 4);
     ctx->fused_attn_ok = !getenv("VVHIP_NO_FUSED_ATTN");
@@ -1097,12 +1109,19 @@ static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float*
         else HIPCHK(ctx, hipMemcpyAsync(hidden_out, ctx->h, (size_t)R * H * 4, hipMemcpyDeviceToDevice, st));
         return 0;
     }
+    const bool p16 = R > 4 && R <= 16 && ctx->p16_ok && fused_attn;      // batch decode rows: packed-activation projections
     for (int l = l0; l < l1; ++l) {
         auto& L = ctx->layers[l];
+        if (p16) {
+            ctx->launches += 2;
+            VVCHK(vv_pack16_launch(ctx->h, H, 1, L.ln1, c.lm_eps, nullptr, nullptr, 0, ctx->p16_x, R, H, st));
+            VVCHK(vv_gemv16p_launch(L.wqkv, nullptr, ctx->p16_x, ctx->qkv, nullptr, L.bqkv, nullptr, R, QKV, H, QKV, 0, VV_EPI_BIAS, st));
+        } else {
         VVGemm g = mk_gemm(L.wqkv, ctx->h, ctx->qkv, R, QKV, H, H, QKV);
         g.pro = VV_PRO_RMS; g.nw = L.ln1; g.eps = c.lm_eps; g.epi = VV_EPI_BIAS; g.bias = L.bqkv; g.nt = 1;
         g.xa = ctx->h_parts; g.n_xa = hp; g.part_stride = hps;
         GEMM(g);
+        }
         char* kl = (char*)ctx->kc + (size_t)l * ctx->layer_stride * 2;
         char* vl = (char*)ctx->vc + (size_t)l * ctx->layer_stride * 2;
         if (fused_attn) {
@@ -1123,6 +1142,23 @@ static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float*
             else
                 VVCHK(vv_attn_launch(D, c.xsplit, ctx->qrot, ctx->rows_dev, kl, vl, R, Hq, Hkv, ctx->cache_stride,
                                      ctx->head_stride, attn_S, ctx->pm, ctx->pl, ctx->po, ctx->attn, st));
+        }
+        if (p16) {
+            static const bool o_packed = !getenv("VVHIP_P16_NO_OPROJ");
+            if (o_packed) {
+                ctx->launches += 2;
+                VVCHK(vv_pack16_launch(ctx->attn, Hq * D, 0, nullptr, 0.f, nullptr, nullptr, 0, ctx->p16_x, R, Hq * D, st));
+                VVCHK(vv_gemv16p_launch(L.wo, nullptr, ctx->p16_x, ctx->h, nullptr, nullptr, nullptr, R, H, Hq * D, H, 0, VV_EPI_RESID, st));
+            } else {
+                VVGemm go = mk_gemm(L.wo, ctx->attn, ctx->h, R, H, Hq * D, Hq * D, H);
+                go.epi = VV_EPI_RESID; go.nt = 1;
+                GEMM(go);
+            }
+            ctx->launches += 3;
+            VVCHK(vv_pack16_launch(ctx->h, H, 1, L.ln2, c.lm_eps, nullptr, nullptr, 0, ctx->p16_x, R, H, st));
+            VVCHK(vv_gemv16p_launch(L.wg, L.wu, ctx->p16_x, nullptr, ctx->p16_act, nullptr, nullptr, R, I, H, 0, 0, VV_EPI_SWIGLU, st));
+            VVCHK(vv_gemv16p_launch(L.wd, nullptr, ctx->p16_act, ctx->h, nullptr, nullptr, nullptr, R, H, I, H, 0, VV_EPI_RESID, st));
+            continue;
         }
         VVGemm go = mk_gemm(L.wo, ctx->attn, ctx->h, R, H, Hq * D, Hq * D, H);
         go.epi = VV_EPI_RESID; go.nt = 1;
@@ -1278,6 +1314,14 @@ static int head_eval(vv_ctx* ctx, hipStream_t st, int rows, const float* zrows, 
     const int xps = 16 * H;
     for (int l = 0; l < HL; ++l) {
         const float* base = mod + (size_t)l * 3 * H;
+        if (rows > 4 && rows <= 16 && ctx->p16_ok && (HF % 32) == 0) {
+            // batch rows: normalise + modulate + pack ONCE, then both projections stream weights against packed fragments
+            ctx->launches += 3;
+            VVCHK(vv_pack16_launch(ctx->xh, H, 2, ctx->hl[l].norm, c.head_eps, base + H, base, MODW, ctx->p16_x, rows, H, st));
+            VVCHK(vv_gemv16p_launch(ctx->hl[l].wg, ctx->hl[l].wu, ctx->p16_x, nullptr, ctx->p16_act, nullptr, nullptr, rows, HF, H, 0, 0, VV_EPI_SWIGLU, st));
+            VVCHK(vv_gemv16p_launch(ctx->hl[l].wd, nullptr, ctx->p16_act, ctx->xh, nullptr, nullptr, base + 2 * H, rows, H, HF, H, MODW, VV_EPI_GATED_RESID, st));
+            continue;
+        }
         VVGemm g1 = mk_gemm(ctx->hl[l].wg, ctx->xh, ctx->hact, rows, HF, H, H, HF);
         g1.W2 = (const u32x4*)ctx->hl[l].wu; g1.pro = VV_PRO_RMS_MOD; g1.nw = ctx->hl[l].norm; g1.eps = c.head_eps;
         g1.mod_shift = base; g1.mod_scale = base + H; g1.ld_mod = MODW; g1.epi = VV_EPI_SWIGLU; g1.nt = 1;

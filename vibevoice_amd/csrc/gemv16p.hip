@@ -1,0 +1,243 @@
+// gemv16p.hip -- batch decode (5..16 activation rows, bf16 mode): weight-streaming GEMV over PRE-PACKED activations.
+//
+// The 16-row form of vv_gemv_kernel (gemv.hip) makes every workgroup (one per 16 output features, 200 .. 1200 of them)
+// load the launch's fp32 activation rows, normalise / modulate them and convert them to bf16 MFMA fragments in LDS.  With
+// 2 rows that work is noise; with 16 rows it is 16 x K x {4 B load, ~10 VALU ops} PER WORKGROUP -- for the diffusion head's
+// gate/up projection (K = 3584, 672 workgroups) three times the bytes of the weight slice the workgroup streams, and the
+// kernel turns VALU-bound: 56 us against 29 us for the same weights at 2 rows.  Here the activation is packed ONCE:
+//
+//   vv_pack16_kernel     one workgroup per row: RMSNorm (optionally adaLN-modulated: x^ = rs x nw (1 + scale) + shift) ->
+//                        bf16 MFMA B fragments [K/32][64 lanes][8] (the layout of vv_common.h, rows = fragment columns);
+//   vv_gemv16p_kernel    one workgroup per 16 features, waves split K: each k-step is one 1 KiB non-temporal weight load +
+//                        one 1 KiB fragment load of the packed activation (L2-resident, 2 B per element) -> MFMA.  No LDS
+//                        staging, no VALU work in the stream.  Epilogues: bias, residual, gated residual (fp32 rows out)
+//                        and SwiGLU, which writes its result straight as packed fragments for the down projection.
+#include <cstdlib>
+#include "vv_common.h"
+
+namespace {
+
+__device__ __forceinline__ float p16_silu(float u) { return u / (1.0f + expf(-u)); }
+
+__device__ __forceinline__ float p16_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// MODE 0: plain conversion;  MODE 1: RMSNorm with weight nw;  MODE 2: adaLN-modulated RMSNorm (scale / shift rows, stride ld_mod).
+// grid = 16 * ceil(T / 16) workgroups (rows >= T are written as zeros), 256 threads; K % 32 == 0, K <= 8192.
+template <int MODE>
+__global__ __launch_bounds__(256) void vv_pack16_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ nw, float eps,
+                                                        const float* __restrict__ sc, const float* __restrict__ sh, int ld_mod,
+                                                        unsigned char* __restrict__ xp, int T, int K) {
+    constexpr int MAXQ = 8;                              // float4 chunks per thread
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t = blockIdx.x;
+    const int KT = K >> 5, K4 = K >> 2;
+    float4 v[MAXQ];
+    float ssq = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXQ; ++i) {
+        const int q = tid + i * 256;
+        v[i] = (t < T && q < K4) ? *reinterpret_cast<const float4*>(x + (int64_t)t * ldx + q * 4) : float4{0.f, 0.f, 0.f, 0.f};
+        ssq += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+    }
+    ssq = p16_wave_sum(ssq);
+    if (lane == 0) red[wave] = ssq;
+    __syncthreads();
+    const float rs = (MODE == 0) ? 1.0f : rsqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)K + eps);
+#pragma unroll
+    for (int i = 0; i < MAXQ; ++i) {
+        const int q = tid + i * 256;
+        if (q >= K4) break;
+        const int k = q * 4;
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        if (t < T) {
+            const float4 w4 = (MODE != 0 && nw) ? *reinterpret_cast<const float4*>(nw + k) : float4{1.f, 1.f, 1.f, 1.f};
+            o[0] = v[i].x * rs * w4.x; o[1] = v[i].y * rs * w4.y; o[2] = v[i].z * rs * w4.z; o[3] = v[i].w * rs * w4.w;
+            if constexpr (MODE == 2) {
+                const float4 s4 = *reinterpret_cast<const float4*>(sc + (int64_t)t * ld_mod + k);
+                const float4 h4 = *reinterpret_cast<const float4*>(sh + (int64_t)t * ld_mod + k);
+                o[0] = o[0] * (1.f + s4.x) + h4.x; o[1] = o[1] * (1.f + s4.y) + h4.y;
+                o[2] = o[2] * (1.f + s4.z) + h4.z; o[3] = o[3] * (1.f + s4.w) + h4.w;
+            }
+        }
+        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+        bf16x4 b;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = (__bf16)o[j];
+        // element (t, k): tile (t >> 4) * KT + (k >> 5), lane (t & 15) + 16 * ((k & 31) >> 3), slot k & 7
+        const int64_t tile = (int64_t)(t >> 4) * KT + (k >> 5);
+        const int ol = (t & 15) + 16 * ((k & 31) >> 3);
+        *reinterpret_cast<uint2*>(xp + ((tile * 64 + ol) * 16 + (k & 7) * 2)) = __builtin_bit_cast(uint2, b);
+    }
+}
+
+struct VVGemv16p {
+    const u32x4* W;        // packed [N][K]
+    const u32x4* W2;       // SwiGLU "up" matrix, same shape
+    const u32x4* Xp;       // packed activations, ONE 16-row tile: [K/32][64][8]
+    float* Y;              // fp32 [T][ldy]  (bias / residual / gated residual)
+    unsigned char* Yp;     // packed bf16 [16][N]  (SwiGLU)
+    const float* bias;     // [N] or null
+    const float* gate;     // gated residual: per-row [T][ld_gate]
+    int T, N, K, ldy, ld_gate;
+};
+
+constexpr int PU = 8;      // k-steps per batch
+
+// EPI: VV_EPI_BIAS (bias may be null = store), VV_EPI_RESID (Y += acc (+ bias)), VV_EPI_GATED_RESID (Y += gate * acc),
+//      VV_EPI_SWIGLU (Yp = bf16(silu(gate_acc) * up_acc), packed).  WPB = waves per workgroup = K split.
+template <int EPI, int WPB>
+__global__ __launch_bounds__(WPB * 64) void vv_gemv16p_kernel(const VVGemv16p a) {
+    constexpr bool DUAL = (EPI == VV_EPI_SWIGLU);
+    constexpr int NM = DUAL ? 2 : 1;
+    __shared__ f32x4 red[WPB][NM][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned tile = blockIdx.x;
+    const unsigned k_tiles = (unsigned)(a.K + 31) >> 5;
+    const unsigned kper = (k_tiles + WPB - 1) / WPB;
+    const unsigned kt0 = wave * kper, kt1 = min(k_tiles, kt0 + kper);
+    const bool has_k = kt0 < kt1;
+    const int frow = lane & 15, fq = lane >> 4;
+    const u32x4* wbase = a.W + (size_t)tile * k_tiles * 64 + lane;
+    const u32x4* wbase2 = DUAL ? a.W2 + (size_t)tile * k_tiles * 64 + lane : nullptr;
+    const u32x4* xbase = a.Xp + lane;
+
+    auto load = [&](unsigned ktb, u32x4 (&w)[PU][NM], u32x4 (&xf)[PU]) {
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+            const unsigned kt = min(ktb + u, kt1 - 1);          // clamped: tail k-steps re-read the last tile, MFMA skipped
+            w[u][0] = __builtin_nontemporal_load(wbase + kt * 64);
+            if constexpr (DUAL) w[u][1] = __builtin_nontemporal_load(wbase2 + kt * 64);
+            xf[u] = xbase[kt * 64];
+        }
+    };
+    f32x4 acc[NM];
+#pragma unroll
+    for (int i = 0; i < NM; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto mma = [&](unsigned ktb, const u32x4 (&w)[PU][NM], const u32x4 (&xf)[PU]) {
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+            if (ktb + u < kt1) {
+                const bf16x8 xb = __builtin_bit_cast(bf16x8, xf[u]);
+#pragma unroll
+                for (int i = 0; i < NM; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[u][i]), xb, acc[i], 0, 0, 0);
+            }
+        }
+    };
+    u32x4 wA[PU][NM], xA[PU];
+    if (has_k) load(kt0, wA, xA);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- epilogue operands of wave 0: requested now, consumed one weight stream later ----
+    const int n0 = tile * 16 + fq * 4;
+    const bool epi_lane = (wave == 0) && frow < a.T && n0 < a.N;           // N % 4 == 0 is a launch precondition
+    float4 pre_y = {0.f, 0.f, 0.f, 0.f}, pre_b = {0.f, 0.f, 0.f, 0.f}, pre_g = {1.f, 1.f, 1.f, 1.f};
+    if (epi_lane) {
+        if constexpr (EPI == VV_EPI_BIAS || EPI == VV_EPI_RESID) {
+            if (a.bias) pre_b = *reinterpret_cast<const float4*>(a.bias + n0);
+        }
+        if constexpr (EPI == VV_EPI_RESID || EPI == VV_EPI_GATED_RESID)
+            pre_y = *reinterpret_cast<const float4*>(a.Y + (size_t)frow * a.ldy + n0);
+        if constexpr (EPI == VV_EPI_GATED_RESID)
+            pre_g = *reinterpret_cast<const float4*>(a.gate + (size_t)frow * a.ld_gate + n0);
+    }
+
+    if (has_k) {
+        if constexpr (DUAL) {
+            // two weight streams: a second buffer set would halve the resident workgroups; the other waves cover the latency
+#pragma unroll 1
+            for (unsigned ktb = kt0; ktb < kt1; ktb += PU) {
+                mma(ktb, wA, xA);
+                if (ktb + PU < kt1) load(ktb + PU, wA, xA);
+            }
+        } else {
+            u32x4 wB[PU][NM], xB[PU];
+#pragma unroll 1
+            for (unsigned ktb = kt0; ktb < kt1; ktb += 2 * PU) {
+                const bool n1 = ktb + PU < kt1, n2 = ktb + 2 * PU < kt1;
+                if (n1) load(ktb + PU, wB, xB);
+                mma(ktb, wA, xA);
+                if (n2) load(ktb + 2 * PU, wA, xA);
+                if (n1) mma(ktb + PU, wB, xB);
+            }
+        }
+    }
+    // ---- split-K partials -> LDS, one barrier, wave 0 finishes ----
+#pragma unroll
+    for (int i = 0; i < NM; ++i) red[wave][i][lane] = acc[i];
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 1; w < WPB; ++w)
+#pragma unroll
+        for (int i = 0; i < NM; ++i) acc[i] += red[w][i][lane];
+    if (!epi_lane) return;
+    if constexpr (DUAL) {
+        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (__bf16)(p16_silu(acc[0][r]) * acc[1][r]);
+        // element (t = frow, n) of the packed output: tile n >> 5, lane frow + 16 * ((n & 31) >> 3), slot n & 7
+        const int64_t otile = n0 >> 5;
+        const int ol = frow + 16 * ((n0 & 31) >> 3);
+        *reinterpret_cast<uint2*>(a.Yp + ((otile * 64 + ol) * 16 + (n0 & 7) * 2)) = __builtin_bit_cast(uint2, o);
+    } else {
+        float o[4] = {acc[0][0], acc[0][1], acc[0][2], acc[0][3]};
+        const float pb[4] = {pre_b.x, pre_b.y, pre_b.z, pre_b.w};
+        const float py[4] = {pre_y.x, pre_y.y, pre_y.z, pre_y.w};
+        const float pg[4] = {pre_g.x, pre_g.y, pre_g.z, pre_g.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if constexpr (EPI == VV_EPI_BIAS) o[r] += pb[r];
+            else if constexpr (EPI == VV_EPI_RESID) o[r] = py[r] + (o[r] + pb[r]);
+            else o[r] = py[r] + pg[r] * o[r];
+        }
+        *reinterpret_cast<float4*>(a.Y + (size_t)frow * a.ldy + n0) = float4{o[0], o[1], o[2], o[3]};
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// rows [T][K] fp32 (T <= 16) -> one packed 16-row tile.  mode 0: plain conversion; 1: RMSNorm (nw may be null: no affine);
+// 2: adaLN-modulated RMSNorm (sc / sh rows)
+int vv_pack16_launch(const float* x, int ldx, int mode, const float* nw, float eps, const float* sc, const float* sh, int ld_mod,
+                     void* xp, int T, int K, hipStream_t s) {
+    if (T < 1 || T > 16 || (K & 31) || K > 8192 || (ldx & 3) || (((uintptr_t)x) & 15) || mode < 0 || mode > 2 ||
+        (mode == 2 && ((ld_mod & 3) || !sc || !sh))) return -1;
+    if (mode == 2) hipLaunchKernelGGL((vv_pack16_kernel<2>), dim3(16), dim3(256), 0, s, x, ldx, nw, eps, sc, sh, ld_mod, (unsigned char*)xp, T, K);
+    else if (mode == 1) hipLaunchKernelGGL((vv_pack16_kernel<1>), dim3(16), dim3(256), 0, s, x, ldx, nw, eps, sc, sh, ld_mod, (unsigned char*)xp, T, K);
+    else hipLaunchKernelGGL((vv_pack16_kernel<0>), dim3(16), dim3(256), 0, s, x, ldx, nw, eps, sc, sh, ld_mod, (unsigned char*)xp, T, K);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// Y / Yp (op)= W . Xp for one packed 16-row activation tile.  Returns -3 when the shape has no instantiation.
+int vv_gemv16p_launch(const void* W, const void* W2, const void* Xp, float* Y, void* Yp, const float* bias, const float* gate,
+                      int T, int N, int K, int ldy, int ld_gate, int epi, hipStream_t s) {
+    if (T < 1 || T > 16 || (N & 3) || K < 32 || (K & 31)) return -3;
+    VVGemv16p a;
+    a.W = (const u32x4*)W; a.W2 = (const u32x4*)W2; a.Xp = (const u32x4*)Xp; a.Y = Y; a.Yp = (unsigned char*)Yp; a.bias = bias; a.gate = gate;
+    a.T = T; a.N = N; a.K = K; a.ldy = ldy; a.ld_gate = ld_gate;
+    const int n_tiles = (N + 15) / 16;
+    // waves per workgroup as in vv_gemv_launch: 4 once there are more tiles than CUs (every workgroup resident at once), else 8
+    static const int wide_tiles = getenv("VVHIP_P16_WIDE") ? atoi(getenv("VVHIP_P16_WIDE")) : 256;
+    const bool w4 = n_tiles > wide_tiles;
+#define VV_P(E_) do { if (w4) hipLaunchKernelGGL((vv_gemv16p_kernel<E_, 4>), dim3(n_tiles), dim3(256), 0, s, a); \
+                      else hipLaunchKernelGGL((vv_gemv16p_kernel<E_, 8>), dim3(n_tiles), dim3(512), 0, s, a); } while (0)
+    if (epi == VV_EPI_SWIGLU) { if (!W2 || !Yp || (N & 7)) return -3; VV_P(VV_EPI_SWIGLU); }
+    else if (epi == VV_EPI_BIAS || epi == VV_EPI_STORE) { if (!Y || (ldy & 3)) return -3; VV_P(VV_EPI_BIAS); }
+    else if (epi == VV_EPI_RESID) { if (!Y || (ldy & 3)) return -3; VV_P(VV_EPI_RESID); }
+    else if (epi == VV_EPI_GATED_RESID) { if (!Y || !gate || (ldy & 3) || (ld_gate & 3)) return -3; VV_P(VV_EPI_GATED_RESID); }
+    else return -3;
+#undef VV_P
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+}  // extern "C"
