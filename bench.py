@@ -275,6 +275,17 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline):
             marks["prefill_done"] = time.perf_counter()
 
     os.environ.setdefault("VVHIP_TIME_PREFILL", "1")        # sync + time the two prefill phases (outside the timed region)
+    if not args.continuous and not os.environ.get("VVHIP_COLD_PREFILL"):
+        # the reported prompt-prefill time is a warm engine's (a serving process): one throw-away pass of the same row count
+        # loads every prefill kernel's code object and pays the one-off launch-attribute calls; the real prefill overwrites the
+        # cache positions it touched
+        n_prompt = int(inputs["attention_mask"][0].sum())
+        wx = torch.zeros(min(n_prompt, eng.cfg.max_rows), d["hidden_size"], device=device)
+        wh = torch.empty_like(wx)
+        with torch.cuda.stream(eng.stream):
+            eng.lm_forward([(0, j) for j in range(wx.shape[0])], wx, wh)
+        eng.sync()
+        del wx, wh
     t_gen0 = time.perf_counter()
     if args.continuous:
         reqs = []

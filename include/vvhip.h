@@ -106,7 +106,7 @@ int vv_kv_import_at(vv_ctx* ctx, void* stream, int cache, int layer, int pos0, i
 int vv_add_type_embedding(vv_ctx* ctx, void* stream, int n, const float* x_dev, int type, float* out_dev);
 /* tts_eos_classifier: fc2(relu(fc1(h))) -> out_dev[n] logits (BinaryClassifier, modeling_vibevoice_streaming.py:42-53) */
 int vv_eos_logit(vv_ctx* ctx, void* stream, int n, const float* hidden_dev, float* out_dev);
-/* embed_tokens lookup (modeling_vibevoice_inference.py:218,569); ids on host */
+/* embed_tokens lookup (modeling_vibevoice_inference.py:218,569); ids on host, 1 <= n <= max(64, max_rows) per call */
 int vv_embed(vv_ctx* ctx, void* stream, int n, const int* ids, float* out_dev);
 /* logits restricted to the valid ids: replaces lm_head + constraint mask (:241-242,488-490).
  * logits_out_dev [n][n_valid] fp32 in the order given to vv_set_valid_tokens. */

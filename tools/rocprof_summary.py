@@ -47,33 +47,55 @@ CATS = [("gemv", r"vv_gemv_kernel"), ("attention", r"vv_attn_"), ("tokenizer blo
 
 
 def timeline(db, out):
-    """Decode-phase occupancy of the GPU timeline: the window from the end of the last prompt-prefill kernel (vv_gemm3) to the
-    last dispatch; busy = union of the kernel intervals inside it; gaps = the rest (launch boundaries, host latency)."""
+    """Decode-phase occupancy of the GPU timeline.  Dispatches after the last prompt-prefill kernel (vv_attn_prefill2 /
+    vv_gemm4 / vv_rope_append) are grouped into bursts (a pause of more than 300 us between dispatches = the host is between
+    bench phases, not inside a step); inside the bursts: busy = union of the kernel intervals, gaps = the rest (kernel
+    boundaries, launch latency)."""
     cur = db.cursor()
     rows = cur.execute("select name, start, end from kernels order by start").fetchall()
     if not rows:
         return
     t0 = rows[0][1]
     for name, st, en in rows:
-        if "vv_gemm3" in name or "vv_attn_prefill" in name:
+        if "vv_attn_prefill2" in name or "vv_gemm4" in name or "vv_rope_append" in name:
             t0 = max(t0, en)
     win = [(n, s, e) for n, s, e in rows if s >= t0]
     if len(win) < 10:
         return
-    t1 = max(e for _, _, e in win)
-    busy, cur_s, cur_e = 0, None, None
-    for _, s, e in win:
-        if cur_e is None or s > cur_e:
-            if cur_e is not None:
-                busy += cur_e - cur_s
-            cur_s, cur_e = s, e
-        else:
-            cur_e = max(cur_e, e)
-    busy += cur_e - cur_s
-    span = t1 - t0
+    span = busy = 0
+    n_bursts = 0
+    b_start = cur_s = cur_e = None
+    kept = []
+    burst = []
+
+    def close(burst):
+        nonlocal span, busy, n_bursts
+        if len(burst) < 50:          # a stray launch between phases
+            return
+        n_bursts += 1
+        kept.extend(burst)
+        span += max(e for _, _, e in burst) - burst[0][1]
+        cs, ce = burst[0][1], burst[0][2]
+        for _, s, e in burst[1:]:
+            if s > ce:
+                busy += ce - cs
+                cs, ce = s, e
+            else:
+                ce = max(ce, e)
+        busy += ce - cs
+    last_end = None
+    for rec in win:
+        if last_end is not None and rec[1] - last_end > 300000:
+            close(burst)
+            burst = []
+        burst.append(rec)
+        last_end = max(last_end or 0, rec[2])
+    close(burst)
+    if not span:
+        return
     by = {c: [0, 0] for c, _ in CATS}
     by["other"] = [0, 0]
-    for n, s, e in win:
+    for n, s, e in kept:
         for c, pat in CATS:
             if re.search(pat, n):
                 by[c][0] += e - s; by[c][1] += 1
@@ -81,11 +103,29 @@ def timeline(db, out):
         else:
             by["other"][0] += e - s; by["other"][1] += 1
     with open(out + "_timeline.txt", "w") as f:
-        f.write(f"decode-phase window {span / 1e6:.2f} ms, {len(win)} dispatches: GPU busy (union of kernel intervals) {busy / 1e6:.2f} ms = "
-                f"{100.0 * busy / span:.1f} %, gaps {100.0 * (span - busy) / span:.1f} %\n")
-        f.write("(rocprofv3 --kernel-trace serialises nothing but adds ~1 us per dispatch; sums per category may exceed the busy time where graph branches overlap)\n")
+        f.write(f"decode phase: {n_bursts} bursts, {span / 1e6:.2f} ms, {len(kept)} dispatches: GPU busy (union of kernel intervals) "
+                f"{busy / 1e6:.2f} ms = {100.0 * busy / span:.1f} %, gaps {100.0 * (span - busy) / span:.1f} %\n")
+        f.write("(rocprofv3 --kernel-trace adds ~1 us per dispatch; category sums may exceed the busy time where graph branches overlap)\n")
         for c, (ns, k) in by.items():
-            f.write(f"  {c:28s} {k:8d} dispatches {ns / 1e6:10.2f} ms  {100.0 * ns / span:5.1f} % of the window\n")
+            f.write(f"  {c:28s} {k:8d} dispatches {ns / 1e6:10.2f} ms  {100.0 * ns / span:5.1f} % of the bursts\n")
+
+
+def dump_around(db, out, pattern, occurrence, count=14):
+    """per-dispatch listing (start offset, duration, gap after the previous kernel's end) around the `occurrence`-th dispatch
+    whose name matches `pattern`: where the time between two kernels of a chain goes"""
+    cur = db.cursor()
+    rows = cur.execute("select name, start, end from kernels order by start").fetchall()
+    hits = [i for i, r in enumerate(rows) if re.search(pattern, r[0])]
+    if len(hits) <= occurrence:
+        return
+    i0 = max(0, hits[occurrence] - count // 2)
+    with open(out + "_dispatches.txt", "w") as f:
+        base = rows[i0][1]
+        prev_end = None
+        for n, s_, e in rows[i0:i0 + count]:
+            gap = (s_ - prev_end) / 1e3 if prev_end is not None else 0.0
+            f.write(f"{(s_ - base) / 1e3:10.1f} us  dur {(e - s_) / 1e3:9.1f} us  gap {gap:8.1f} us  {short(n)[:70]}\n")
+            prev_end = e
 
 
 def pmc_stats(db, out):
@@ -108,6 +148,9 @@ if __name__ == "__main__":
     else:
         rows, tot = kernel_stats(db, sys.argv[2])
         timeline(db, sys.argv[2])
+        if "--around" in sys.argv:
+            k = sys.argv.index("--around")
+            dump_around(db, sys.argv[2], sys.argv[k + 1], int(sys.argv[k + 2]))
         print(f"total kernel time {tot / 1e6:.2f} ms")
         for r in rows[:25]:
             print(f"{short(r[0])[:100]:100s} {r[1]:7d} {r[2] / 1e6:9.2f} ms  avg {r[3] / 1e3:9.2f} us  {100 * r[2] / tot:5.1f}%")

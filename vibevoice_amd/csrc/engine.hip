@@ -184,7 +184,7 @@ struct vv_ctx {
     void *kc = nullptr, *vc = nullptr;
     int64_t cache_stride = 0, head_stride = 0, layer_stride = 0;
     VVRow* rows_dev = nullptr; VVRow* rows_pin = nullptr; int rows_cap = 2048;
-    int* ids_dev = nullptr; int* ids_pin = nullptr;
+    int* ids_dev = nullptr; int* ids_pin = nullptr; int ids_cap = 64;      // token ids per vv_embed call: max(64, max_rows)
     // pinned staging is a ring (slot reuse waits on that slot's own copy event, long since complete): a step's
     // launches can be enqueued while the previous step is still running, no host-side stream sync
     static constexpr int RING = 32;
@@ -843,8 +843,9 @@ extern "C" int vv_create(const vv_config* cfg, vv_ctx** out) {
     ctx->rows_dev = (VVRow*)dalloc(ctx, sizeof(VVRow) * ctx->rows_cap);
     hipHostMalloc((void**)&ctx->rows_pin, sizeof(VVRow) * (size_t)ctx->rows_cap * vv_ctx::RING);
     for (int i = 0; i < vv_ctx::RING; ++i) hipEventCreateWithFlags(&ctx->ring_ev[i], hipEventDisableTiming);
-    ctx->ids_dev = (int*)dalloc(ctx, sizeof(int) * 64);
-    hipHostMalloc((void**)&ctx->ids_pin, sizeof(int) * 64 * vv_ctx::RING);
+    ctx->ids_cap = std::max(64, c.max_rows);
+    ctx->ids_dev = (int*)dalloc(ctx, sizeof(int) * ctx->ids_cap);
+    hipHostMalloc((void**)&ctx->ids_pin, sizeof(int) * (size_t)ctx->ids_cap * vv_ctx::RING);
     ctx->h = (float*)dalloc(ctx, (size_t)R * H * 4);
     ctx->h_parts = (float*)dalloc(ctx, (size_t)2 * R * H * 4);
     ctx->ksplit_ok = !getenv("VVHIP_NO_GEMV") && !getenv("VVHIP_NO_KSPLIT");
@@ -1277,10 +1278,10 @@ extern "C" int vv_eos_logit(vv_ctx* ctx, void* stream, int n, const float* hidde
 
 extern "C" int vv_embed(vv_ctx* ctx, void* stream, int n, const int* ids, float* out_dev) {
     hipStream_t st = (hipStream_t)stream;
-    if (n < 1 || n > 64) return fail(ctx, "vv_embed: n must be in [1,64]");
+    if (n < 1 || n > ctx->ids_cap) return fail(ctx, "vv_embed: n must be in [1,%d] (max(64, max_rows))", ctx->ids_cap);
     for (int i = 0; i < n; ++i) if (ids[i] < 0 || ids[i] >= ctx->c.lm_vocab) return fail(ctx, "token id %d out of range", ids[i]);
     const int slot = ring_acquire(ctx);
-    int* pin = ctx->ids_pin + (size_t)slot * 64;
+    int* pin = ctx->ids_pin + (size_t)slot * ctx->ids_cap;
     memcpy(pin, ids, sizeof(int) * n);
     HIPCHK(ctx, hipMemcpyAsync(ctx->ids_dev, pin, sizeof(int) * n, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipEventRecord(ctx->ring_ev[slot], st));

@@ -20,6 +20,7 @@
 //                           head over 4 row tiles (K / V fragments read from LDS once per block, reused for the 4 tiles):
 //                           16 x fewer K/V reads per query row than vv_attn_prefill_kernel.
 #include <cstdlib>
+#include <cstring>
 #include "vv_common.h"
 
 namespace {
@@ -290,6 +291,154 @@ __global__ __launch_bounds__(256, TR == 8 ? 2 : 4) void vv_gemm3_kernel(const VV
     }
 }
 
+// ------------------------------------------------------------------------------------------------ GEMM, 256 x 256 tile
+// The long-prompt form of vv_gemm3_kernel.  What bounds the 128-feature kernel above is not LDS bandwidth or the MFMA pipe but
+// the ~1.3 us a stage's LDS-DMA copies take to land: it waits for every stage in full and hides the wait only behind the other
+// one or three workgroups of its CU (MfmaUtil 45 % on gate/up).  Here a workgroup owns 256 features x 256 rows (8 waves as
+// 2 x 4, 128 x 64 each: 32 accumulators), a K step of 64 is a 64 KiB stage and carries 2048 MFMA cycles per SIMD -- more than
+// the copy latency -- and there are two stage buffers: stage s+1 is in flight while stage s is multiplied.  One barrier per
+// stage; every DMA has been waited for when the barrier is reached, so the plain __syncthreads() stays a bare s_barrier.
+// SwiGLU: the 256 weight rows are 128 gate + 128 up features, the workgroup emits 128 output features.
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void vv_gemm4_kernel(const VVGemm3 a) {
+    constexpr bool DUAL = (EPI == VV_EPI_SWIGLU);
+    constexpr int FT = DUAL ? 8 : 16;              // feature tiles (per matrix) per workgroup
+    constexpr int STAGE = 64 * 1024;               // 32 A fragments then 32 B fragments: [frag][64 lanes][16 B]
+    extern __shared__ __attribute__((aligned(16))) unsigned char ring[];      // 2 stages
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 15, fq = lane >> 4;
+    const int KT = (a.K + 31) >> 5;
+    const int n_tiles = (a.N + 15) >> 4, t_tiles = (a.T + 15) >> 4;
+    int nb, tb;
+    {   // XCD-major order over (feature block, row block): see vv_gemm3_kernel
+        const int total = a.n_blocks * a.t_blocks;
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, idx = bid >> 3;
+        const int q = total >> 3, r = total & 7;
+        const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        nb = lin / a.t_blocks;
+        tb = lin - nb * a.t_blocks;
+    }
+    const int ft0 = nb * FT, tt0 = tb * 16;
+    const int wf = wave & 1, wr = wave >> 1;       // features wf * 128 .. (DUAL: gate/up slots of half wf), rows wr * 64 ..
+    // loader: wave w copies fragments 8w .. 8w+7 of the 64.  f < 32: A slot f >> 1, k-tile f & 1; else B row tile (f - 32) >> 1
+    const u32x4* src[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int f = wave * 8 + i;
+        if (f < 32) {
+            const int slot = f >> 1;
+            const u32x4* base = (DUAL && slot >= 8) ? a.W2 : a.W;
+            int ft = ft0 + (DUAL ? (slot & 7) : slot);
+            if (ft > n_tiles - 1) ft = n_tiles - 1;
+            src[i] = base + (int64_t)ft * KT * 64 + lane;
+        } else {
+            int tt = tt0 + ((f - 32) >> 1);
+            if (tt > t_tiles - 1) tt = t_tiles - 1;
+            src[i] = a.Xp + (int64_t)tt * KT * 64 + lane;
+        }
+    }
+    auto issue = [&](int s, int b) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int f = wave * 8 + i;
+            int kt = s * 2 + (f & 1);
+            if (kt > KT - 1) kt = KT - 1;                              // odd K tail: re-reads the last k-tile, MFMA skipped
+            glds16(src[i] + (int64_t)kt * 64, ring + b * STAGE + f * 1024);
+        }
+    };
+    f32x4 acc[8][4];                               // [feature tile of this wave][row tile of this wave]
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int n_steps = (KT + 1) >> 1;
+    issue(0, 0);
+#pragma unroll 1
+    for (int s = 0; s < n_steps; ++s) {
+        stage_sync();                                                 // stage s has landed for every wave; stage s-1 is read out
+        if (s + 1 < n_steps) issue(s + 1, (s + 1) & 1);
+        const unsigned char* st = ring + (s & 1) * STAGE;
+        // both k-tiles' fragments are requested before the first MFMA (two register sets): the second tile's LDS reads run under
+        // the first tile's 32 MFMAs instead of one read -> wait -> 4 MFMAs chains on a single fragment register
+        bf16x8 af[2][8], bfr[2][4];
+        const bool two = s * 2 + 1 < KT;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            if (kk == 1 && !two) break;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int slot = DUAL ? ((i < 4) ? (wf * 4 + i) : (8 + wf * 4 + (i - 4))) : (wf * 8 + i);
+                af[kk][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(st + ((slot * 2 + kk) * 64 + lane) * 16));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                bfr[kk][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(st + ((32 + (wr * 4 + j) * 2 + kk) * 64 + lane) * 16));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            if (kk == 1 && !two) break;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][i], bfr[kk][j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // ---- epilogue: lane holds D[n = tile*16 + fq*4 + r][t = ttile*16 + frow] ----
+    if constexpr (DUAL) {
+        const int KTo = (a.N + 31) >> 5;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ft = ft0 + wf * 4 + i;
+            if (ft >= n_tiles) continue;
+            const int n0 = ft * 16 + fq * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int tt = tt0 + wr * 4 + j;
+                if (tt >= t_tiles) continue;
+                typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool live = (n0 + r < a.N) && (tt * 16 + frow < a.T);
+                    o[r] = (__bf16)(live ? g3_silu(acc[i][j][r]) * acc[4 + i][j][r] : 0.f);
+                }
+                const int64_t tile = (int64_t)tt * KTo + (n0 >> 5);
+                const int ol = frow + 16 * ((n0 & 31) >> 3);
+                unsigned char* dst = reinterpret_cast<unsigned char*>(a.Yp) + ((tile * 64 + ol) * 16 + (n0 & 7) * 2);
+                *reinterpret_cast<uint2*>(dst) = __builtin_bit_cast(uint2, o);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int ft = ft0 + wf * 8 + i;
+            if (ft >= n_tiles) continue;
+            const int n0 = ft * 16 + fq * 4;
+            if (n0 >= a.N) continue;
+            float4 pb = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (EPI == VV_EPI_BIAS) {
+                if (a.bias) pb = *reinterpret_cast<const float4*>(a.bias + n0);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int t = (tt0 + wr * 4 + j) * 16 + frow;
+                if (t >= a.T) continue;
+                float* yp = a.Y + (int64_t)t * a.ldy + n0;
+                float4 o = {acc[i][j][0] + pb.x, acc[i][j][1] + pb.y, acc[i][j][2] + pb.z, acc[i][j][3] + pb.w};
+                if constexpr (EPI == VV_EPI_RESID) {
+                    const float4 py = *reinterpret_cast<const float4*>(yp);
+                    o.x += py.x; o.y += py.y; o.z += py.z; o.w += py.w;
+                }
+                *reinterpret_cast<float4*>(yp) = o;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ prefill attention
 // rows = consecutive positions of ONE cache (rows[0] first); q_rot (rotated, scaled by 1/sqrt(D)) and the chunk's own K/V
 // are already in place (vv_rope_append_kernel).  grid (ceil(R / 64), Hkv, ceil(G / 4)), 256 threads: a workgroup owns 64
@@ -491,6 +640,33 @@ int vv_gemm3_launch(const void* W, const void* W2, const void* Xp, float* Y, voi
     a.W = (const u32x4*)W; a.W2 = (const u32x4*)W2; a.Xp = (const u32x4*)Xp; a.Y = Y; a.Yp = (u32x4*)Yp; a.bias = bias;
     a.T = T; a.N = N; a.K = K; a.ldy = ldy;
     const int n_tiles = (N + 15) / 16;
+    // long prompts: the 256 x 256 double-buffered kernel whenever its grid fills the chip at least once (VVHIP_GEMM4=0 off,
+    // =all regardless of the grid); smaller problems keep the 128-feature kernel, whose tiles quantise better.  Measured per
+    // launch at T = 10,922 (7B layer): gate/up 3188 -> 2460 us, down 1751 -> 1460, o 432 -> 343, qkv 518 -> 416.
+    static const char* g4 = getenv("VVHIP_GEMM4");
+    const bool g4_all = g4 && !strcmp(g4, "all"), g4_off = g4 && !strcmp(g4, "0");
+    const int64_t wgs4 = (int64_t)((n_tiles + ((epi == VV_EPI_SWIGLU) ? 8 : 16) - 1) / ((epi == VV_EPI_SWIGLU) ? 8 : 16)) * ((T + 255) / 256);
+    if (!g4_off && (g4_all || wgs4 >= 256) &&
+        (epi == VV_EPI_SWIGLU || epi == VV_EPI_RESID || epi == VV_EPI_BIAS || epi == VV_EPI_STORE)) {
+        const int ft4 = (epi == VV_EPI_SWIGLU) ? 8 : 16;
+        a.n_blocks = (n_tiles + ft4 - 1) / ft4;
+        a.t_blocks = (T + 255) / 256;
+        if (epi == VV_EPI_SWIGLU && (!W2 || !Yp)) return -1;
+        if (epi != VV_EPI_SWIGLU && (!Y || (ldy & 3))) return -1;
+        const dim3 grid4((unsigned)(a.n_blocks * a.t_blocks));
+        static bool attr4 = false;
+        if (!attr4) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_gemm4_kernel<VV_EPI_SWIGLU>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_gemm4_kernel<VV_EPI_RESID>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_gemm4_kernel<VV_EPI_BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr4 = true;
+        }
+        const size_t smem4 = 2 * 64 * 1024;
+        if (epi == VV_EPI_SWIGLU) hipLaunchKernelGGL((vv_gemm4_kernel<VV_EPI_SWIGLU>), grid4, dim3(512), smem4, s, a);
+        else if (epi == VV_EPI_RESID) hipLaunchKernelGGL((vv_gemm4_kernel<VV_EPI_RESID>), grid4, dim3(512), smem4, s, a);
+        else hipLaunchKernelGGL((vv_gemm4_kernel<VV_EPI_BIAS>), grid4, dim3(512), smem4, s, a);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     const int ft = (epi == VV_EPI_SWIGLU) ? 4 : 8;
     a.n_blocks = (n_tiles + ft - 1) / ft;
     // 256-row workgroups once the problem is tall enough to fill the chip with them

@@ -227,19 +227,28 @@ class Engine:
     def _p(t: Optional[torch.Tensor]):
         return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p()
 
+    @staticmethod
+    def _rows(rows):
+        """(cache, pos) pairs -> a VVRow array without a per-row Python loop (a 10,922-row prompt chunk is one call)"""
+        a = np.ascontiguousarray(np.asarray(rows, dtype=np.int32).reshape(-1, 2))
+        return (_lib.VVRow * a.shape[0]).from_buffer(a), a
+
     def lm_forward(self, rows: Sequence[tuple], x_in: torch.Tensor, hidden_out: torch.Tensor):
-        n = len(rows)
-        arr = (_lib.VVRow * n)()
-        for i, (cache, pos) in enumerate(rows):
-            arr[i].cache, arr[i].pos = int(cache), int(pos)
+        arr, keep = self._rows(rows)
+        self._chk(self.lib.vv_lm_forward(self._ctx, self._s, len(arr), arr, self._p(x_in), self._p(hidden_out)), "vv_lm_forward")
+
+    def lm_forward_span(self, cache: int, pos0: int, n: int, x_in: torch.Tensor, hidden_out: torch.Tensor):
+        """n consecutive positions pos0 .. pos0+n-1 of one cache (a prompt chunk)"""
+        a = np.empty((n, 2), dtype=np.int32)
+        a[:, 0] = cache
+        a[:, 1] = np.arange(pos0, pos0 + n, dtype=np.int32)
+        arr = (_lib.VVRow * n).from_buffer(a)
         self._chk(self.lib.vv_lm_forward(self._ctx, self._s, n, arr, self._p(x_in), self._p(hidden_out)), "vv_lm_forward")
 
     def lm_forward_range(self, rows: Sequence[tuple], x_in: torch.Tensor, hidden_out: torch.Tensor, l0: int, l1: int,
                          final_norm: bool):
-        n = len(rows)
-        arr = (_lib.VVRow * n)()
-        for i, (cache, pos) in enumerate(rows):
-            arr[i].cache, arr[i].pos = int(cache), int(pos)
+        arr, keep = self._rows(rows)
+        n = len(arr)
         self._chk(self.lib.vv_lm_forward_range(self._ctx, self._s, n, arr, self._p(x_in), self._p(hidden_out),
                                                int(l0), int(l1), int(final_norm)), "vv_lm_forward_range")
 
@@ -270,9 +279,15 @@ class Engine:
     def eos_logit(self, n: int, hidden: torch.Tensor, out: torch.Tensor):
         self._chk(self.lib.vv_eos_logit(self._ctx, self._s, n, self._p(hidden), self._p(out)), "vv_eos_logit")
 
+    @property
+    def embed_chunk(self) -> int:
+        """token ids one vv_embed call takes: max(64, max_rows)"""
+        return max(64, int(self.cfg.max_rows))
+
     def embed(self, ids: Sequence[int], out: torch.Tensor):
-        arr = (C.c_int * len(ids))(*[int(i) for i in ids])
-        self._chk(self.lib.vv_embed(self._ctx, self._s, len(ids), arr, self._p(out)), "vv_embed")
+        a = np.ascontiguousarray(np.asarray(ids, dtype=np.int32).reshape(-1))
+        arr = (C.c_int * a.shape[0]).from_buffer(a)
+        self._chk(self.lib.vv_embed(self._ctx, self._s, a.shape[0], arr, self._p(out)), "vv_embed")
 
     def lm_logits(self, n: int, hidden: torch.Tensor, logits_out: torch.Tensor):
         self._chk(self.lib.vv_lm_logits(self._ctx, self._s, n, self._p(hidden), self._p(logits_out)), "vv_lm_logits")
