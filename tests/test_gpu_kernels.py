@@ -106,13 +106,13 @@ def test_gemm_tile_prefill_shapes(sm, pro, epi, xs, tol):
 
 @pytest.mark.parametrize("epi", [0, 1, 4, 3])
 @pytest.mark.parametrize("T,N,K", [(333, 4112, 416), (128, 128, 64), (2048, 1024, 1536), (70, 200, 96), (500, 36, 3584),
-                                   (1030, 400, 8224), (1300, 4112, 416)])
+                                   (4100, 4112, 416), (4100, 4100, 2080)])
 def test_prefill_gemm3(sm, epi, T, N, K):
     """prefill.hip: activations packed to bf16 MFMA fragments (+ RMSNorm in the packing kernel for the BIAS case), 128 x 128
     LDS-staged MFMA GEMM with the store / bias / residual / SwiGLU epilogues; ragged T (not a multiple of 128 / 16), N not a
-    multiple of the 128-feature block, an odd number of 32-wide k-tiles (K = 416 -> 13), one-block problems.  T >= 1024 with
-    SwiGLU or K >= 8192 runs the 256 x 256 double-buffered kernel (vv_gemm4_kernel): ragged T / N and K = 8224 (257 k-tiles)
-    there too.  Against fp32
+    multiple of the 128-feature block, an odd number of 32-wide k-tiles (K = 416 -> 13), one-block problems.  The last two
+    shapes fill the chip with 256 x 256 workgroups and therefore run the double-buffered kernel (vv_gemm4_kernel): ragged T
+    (4100 = 16 row blocks + 4 rows), 257 feature tiles, odd k-tile counts (13, 65), every epilogue.  Against fp32
     torch on the same bf16-representable weights: bf16 activations inside the MFMA -> rel-L2 <= 2e-2."""
     eng = sm.eng
     g = synth.Gen(7000 + T + N + K + epi)
