@@ -76,7 +76,7 @@ class Qwen2Oracle:
         cos, sin = cos[:, None, :], sin[:, None, :]
         half = x.shape[-1] // 2
         rot = torch.cat([-x[..., half:], x[..., :half]], dim=-1)
-        return x * cos + rot * sin
+        return (x * cos + rot * sin).to(x.dtype)     # fp32: a no-op; bf16 weights (bench.py's eager-GPU leg): back to the model dtype
 
     def forward(self, embeds, cache, final_norm=True):
         """embeds [T, H] appended at positions cache.length .. +T-1 (causal)."""

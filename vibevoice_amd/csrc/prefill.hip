@@ -21,6 +21,7 @@
 //                           16 x fewer K/V reads per query row than vv_attn_prefill_kernel.
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include "vv_common.h"
 
 namespace {
@@ -609,6 +610,237 @@ __global__ __launch_bounds__(64 * 4 * (4 / RT)) void vv_attn_prefill2_kernel(
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ prefill attention, v3
+// Same data path as vv_attn_prefill2_kernel<D, 2> (8 waves = 4 query heads x 2 row halves, 64 positions per LDS stage), with
+// the softmax restructured after the rocprof / PMC pass on the 7B prompt (MFMA busy 18 %: per 32 positions a wave issued 32
+// MFMAs and ~200 VALU / LDS-permute instructions in one dependent chain):
+//   * ONE online-softmax update per 64-position stage instead of one per 32-position block: the row maximum, the running
+//     rescale factor, the exchange across the 4 lane rows and the rescale vote are paid once per 16 scores per lane, and the
+//     32 S^T MFMAs (then the 32 P.V MFMAs) of a stage issue back to back, so the partner wave on the SIMD has a full
+//     softmax's worth of matrix work to hide under;
+//   * the cross-row maximum by v_permlane16_swap / v_permlane32_swap (gfx950 VALU lane exchanges) instead of two
+//     ds_bpermute round trips through the LDS pipe, which the K / V fragment reads already keep busy;
+//   * stages wholly below the causal diagonal (all but the last one or two of a workgroup) take a path with no -inf
+//     compares / selects: every score is finite there, exp2(-inf - m) of the very first stage is the hardware's 0.
+template <bool PL>
+__device__ __forceinline__ float a3_xrow_max(float v) {
+    // max over the 4 lanes that share (lane & 15): rows of 16 lanes exchanged pairwise, then the two halves of the wave
+    if constexpr (!PL) {                 // A/B form (VVHIP_ATTN3_SHFL): the LDS-permute exchange of the v2 kernel
+        v = fmaxf(v, __shfl_xor(v, 16));
+        return fmaxf(v, __shfl_xor(v, 32));
+    }
+    unsigned x = __float_as_uint(v);
+    auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+    unsigned r0 = r[0], r1 = r[1];
+    v = fmaxf(__uint_as_float(r0), __uint_as_float(r1));
+    x = __float_as_uint(v);
+    auto t = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    unsigned t0 = t[0], t1 = t[1];
+    return fmaxf(__uint_as_float(t0), __uint_as_float(t1));
+}
+
+template <int D, bool PL>
+__global__ __launch_bounds__(512) void vv_attn_prefill3_kernel(
+    const float* __restrict__ q, const VVRow* __restrict__ rows, const __bf16* __restrict__ kc,
+    const __bf16* __restrict__ vc, int R, int Hq, int Hkv, int64_t cache_stride, int64_t head_stride,
+    float* __restrict__ out) {
+    constexpr int RT = 2;
+    constexpr int KT = D / 32, DT = D / 16;
+    constexpr int KF = 2 * KT;                       // K fragments of a 32-position block (2 position tiles x KT)
+    constexpr int SF = 2 * (KF + DT);                // fragments of one 64-position stage: K of 2 blocks, then V of 2 blocks
+    constexpr int BUF = SF * 1024;
+    constexpr int NW = 8;
+    static_assert((2 * KF) % NW == 0 && (2 * DT) % NW == 0, "every wave copies the same number of K and of V fragments");
+    extern __shared__ __attribute__((aligned(16))) unsigned char kv[];          // 2 stages
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int qt = (int)gridDim.x - 1 - (int)blockIdx.x;                        // longest workgroups first
+    const int r0 = qt * 64, kvh = blockIdx.y;
+    const int rw0 = r0 + (wave >> 2) * (RT * 16);    // first query row of this wave
+    const VVRow rw = rows[0];
+    const int G = Hq / Hkv;
+    const int g = (int)blockIdx.z * 4 + (wave & 3);  // this wave's query head inside the group
+    const bool act = g < G;
+    const int h = kvh * G + (act ? g : 0);
+    const int col = lane & 15, qg = lane >> 4;
+    const int pend = rw.pos + min(r0 + 63, R - 1) + 1;              // positions this tile walks: [0, pend)
+    const int n_stg = (pend + 63) >> 6;
+    const int first_masked = (rw.pos + r0) >> 6;                      // stages below this one are visible to every query row
+    const u32x4* kt_base = reinterpret_cast<const u32x4*>(kc + (int64_t)rw.cache * cache_stride + (int64_t)kvh * head_stride);
+    const u32x4* vt_base = reinterpret_cast<const u32x4*>(vc + (int64_t)rw.cache * cache_stride + (int64_t)kvh * head_stride);
+    constexpr float LOG2E = 1.4426950408889634f;
+
+    // stage copy: wave w moves K fragments w, w + 8, .. and V fragments w, w + 8, .. of the stage (no per-fragment branches)
+    const u32x4* ksrc = kt_base + wave * 64 + lane;
+    const u32x4* vsrc = vt_base + wave * 64 + lane;
+    auto issue = [&](int st, unsigned char* buf) {
+        const u32x4* ks = ksrc + (int64_t)st * (2 * KF * 64);
+        const u32x4* vs = vsrc + (int64_t)st * (2 * DT * 64);
+        unsigned char* kd = buf + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < (2 * KF) / NW; ++i) glds16(ks + i * (NW * 64), kd + i * (NW * 1024));
+#pragma unroll
+        for (int i = 0; i < (2 * DT) / NW; ++i) glds16(vs + i * (NW * 64), kd + (2 * KF + i * NW) * 1024);
+    };
+    issue(0, kv);
+
+    bf16x8 qf[RT][KT];
+    int plim[RT];                                    // last position this lane's query row (column of S^T) may attend
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int row = min(rw0 + rt * 16 + col, R - 1);
+        plim[rt] = rw.pos + row;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            const float* qp = q + ((int64_t)row * Hq + h) * D + kt * 32 + qg * 8;
+            const float4 a0 = *reinterpret_cast<const float4*>(qp), a1 = *reinterpret_cast<const float4*>(qp + 4);
+            const float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qf[rt][kt][j] = (__bf16)(v[j] * LOG2E);
+        }
+    }
+    float m[RT], lsum[RT];
+    f32x4 o[RT][DT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        m[rt] = -INFINITY; lsum[rt] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[rt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    // one stage = 64 positions (NB = 2 blocks) or, for the last stage of a ragged prefix, its first 32 (NB = 1); FAST: the
+    // whole stage lies below the causal diagonal of every query row of the workgroup
+    auto stage = [&](const unsigned char* cur, int p0, auto nb_c, auto fast_c) {
+        constexpr int NB = decltype(nb_c)::value;
+        constexpr bool FAST = decltype(fast_c)::value;
+        // ---- S^T = K q^T: sc[rt][2 blk + half] = positions p0 + 32 blk + 16 half + 4 qg + r, query row = lane & 15 ----
+        f32x4 sc[RT][2 * NB];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int i = 0; i < 2 * NB; ++i) sc[rt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) {
+            const unsigned char* kb_ = cur + blk * KF * 1024;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                const bf16x8 ka = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(kb_ + (kt * 64 + lane) * 16));
+                const bf16x8 kb = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(kb_ + ((KT + kt) * 64 + lane) * 16));
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    sc[rt][2 * blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[rt][kt], sc[rt][2 * blk], 0, 0, 0);
+                    sc[rt][2 * blk + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb, qf[rt][kt], sc[rt][2 * blk + 1], 0, 0, 0);
+                }
+            }
+        }
+        // ---- one online-softmax update per stage -> P as the B operands of P.V ----
+        bf16x8 pb[RT][NB];
+        float al[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            if constexpr (!FAST) {
+#pragma unroll
+                for (int i = 0; i < 2 * NB; ++i)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr)
+                        if (p0 + i * 16 + qg * 4 + rr > plim[rt]) sc[rt][i][rr] = -INFINITY;
+            }
+            float mx = sc[rt][0][0];
+#pragma unroll
+            for (int i = 0; i < 2 * NB; ++i)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) mx = fmaxf(mx, sc[rt][i][rr]);
+            mx = a3_xrow_max<PL>(mx);
+            const float mn = fmaxf(m[rt], mx);
+            float alpha, ps = 0.f;
+            if constexpr (FAST) {
+                // every score is finite; on the very first stage m = -inf and exp2(-inf) is the hardware's 0
+                alpha = __builtin_amdgcn_exp2f(m[rt] - mn);
+#pragma unroll
+                for (int i = 0; i < 2 * NB; ++i)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const float p = __builtin_amdgcn_exp2f(sc[rt][i][rr] - mn);
+                        ps += p;
+                        pb[rt][i >> 1][(i & 1) * 4 + rr] = (__bf16)p;
+                    }
+                lsum[rt] = lsum[rt] * alpha + ps;
+                m[rt] = mn;
+            } else {
+                // a column whose whole stage is masked (query row earlier than this stage) keeps its state untouched
+                const bool dead = (mn == -INFINITY);
+                const float msafe = dead ? 0.f : mn;                   // -inf - 0 = -inf -> p = 0, never -inf - -inf
+                alpha = dead ? 1.f : __builtin_amdgcn_exp2f(m[rt] - mn);     // m = -inf, mn finite: 0
+#pragma unroll
+                for (int i = 0; i < 2 * NB; ++i)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const float p = __builtin_amdgcn_exp2f(sc[rt][i][rr] - msafe);
+                        ps += p;
+                        pb[rt][i >> 1][(i & 1) * 4 + rr] = (__bf16)p;
+                    }
+                lsum[rt] = lsum[rt] * alpha + ps;                      // dead: alpha = 1, ps = 0
+                m[rt] = mn;                                            // dead: mn = m = -inf
+            }
+            al[rt] = alpha;
+        }
+        // once the running maxima have settled (alpha == 1 in every lane of both row tiles) the accumulator rescale is skipped:
+        // ONE wave-uniform branch per stage, then an unbroken run of MFMAs
+        if (__builtin_amdgcn_ballot_w64(al[0] != 1.0f || al[1] != 1.0f) != 0) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) o[rt][dt] *= al[rt];
+        }
+        // ---- O += P . V: NB k-steps per accumulator, every V fragment read from LDS once ----
+        const unsigned char* vb_ = cur + 2 * KF * 1024;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            bf16x8 vf[NB];
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk)
+                vf[blk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(vb_ + ((blk * DT + dt) * 64 + lane) * 16));
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int blk = 0; blk < NB; ++blk)
+                    o[rt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[blk], pb[rt][blk], o[rt][dt], 0, 0, 0);
+        }
+    };
+    using c1 = std::integral_constant<int, 1>;
+    using c2 = std::integral_constant<int, 2>;
+#pragma unroll 1
+    for (int st = 0; st < n_stg; ++st) {
+        unsigned char* cur = kv + (st & 1) * BUF;
+        stage_sync();                             // stage st has landed (every wave drained its own copies first);
+                                                  // everyone has finished stage st-1, whose buffer is refilled now
+        if (st + 1 < n_stg) issue(st + 1, kv + ((st + 1) & 1) * BUF);
+        if (!act) continue;
+        const int p0 = st * 64;
+        if (st < first_masked) stage(cur, p0, c2{}, std::true_type{});          // p0 + 63 < rw.pos + r0 <= every plim: 64 live positions
+        else if (p0 + 32 < pend) stage(cur, p0, c2{}, std::false_type{});
+        else stage(cur, p0, c1{}, std::false_type{});
+    }
+    if (act) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            float l = lsum[rt];
+            l += __shfl_xor(l, 16);
+            l += __shfl_xor(l, 32);
+            const int row = rw0 + rt * 16 + col;
+            if (row < R) {
+                const float inv = 1.0f / l;
+                float* orow = out + ((int64_t)row * Hq + h) * D + qg * 4;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+                    *reinterpret_cast<float4*>(orow + dt * 16) =
+                        float4{o[rt][dt][0] * inv, o[rt][dt][1] * inv, o[rt][dt][2] * inv, o[rt][dt][3] * inv};
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -698,8 +930,13 @@ int vv_attn_prefill2_launch(int D, const float* q, const VVRow* rows, const void
     const int G = Hq / Hkv;
     const dim3 grid((R + 63) / 64, Hkv, (G + 3) / 4);
     static const bool rt4 = getenv("VVHIP_ATTN2_RT4") != nullptr;          // A/B: 4 waves x 4 row tiles (one wave per SIMD)
+    static const bool v3 = !rt4 && !(getenv("VVHIP_ATTN3") && atoi(getenv("VVHIP_ATTN3")) == 0);   // VVHIP_ATTN3=0: the v2 kernel
     static bool attr = false;
     if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_attn_prefill3_kernel<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_attn_prefill3_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_attn_prefill3_kernel<128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_attn_prefill3_kernel<64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_attn_prefill2_kernel<128, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_attn_prefill2_kernel<64, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_attn_prefill2_kernel<128, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -709,6 +946,16 @@ int vv_attn_prefill2_launch(int D, const float* q, const VVRow* rows, const void
 #define VV_A2(D_, RT_, SM_)                                                                                         \
     hipLaunchKernelGGL((vv_attn_prefill2_kernel<D_, RT_>), grid, dim3(64 * 4 * (4 / RT_)), SM_, s, q, rows, (const __bf16*)kc, \
                        (const __bf16*)vc, R, Hq, Hkv, cache_stride, head_stride, out)
+    if (v3 && (D == 128 || D == 64)) {
+        static const bool shfl = getenv("VVHIP_ATTN3_SHFL") != nullptr;     // A/B: ds_bpermute row exchange instead of v_permlane*_swap
+        const int sm = 2 * 2 * (2 * (D / 32) + D / 16) * 1024;
+#define VV_A3(D_, PL_) hipLaunchKernelGGL((vv_attn_prefill3_kernel<D_, PL_>), grid, dim3(512), sm, s, q, rows, (const __bf16*)kc, \
+                                          (const __bf16*)vc, R, Hq, Hkv, cache_stride, head_stride, out)
+        if (D == 128) { if (shfl) VV_A3(128, false); else VV_A3(128, true); }
+        else { if (shfl) VV_A3(64, false); else VV_A3(64, true); }
+#undef VV_A3
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     if (D == 128) { if (rt4) VV_A2(128, 4, 2 * 2 * (2 * 4 + 8) * 1024); else VV_A2(128, 2, 2 * 2 * (2 * 4 + 8) * 1024); }
     else if (D == 64) { if (rt4) VV_A2(64, 4, 2 * 2 * (2 * 2 + 4) * 1024); else VV_A2(64, 2, 2 * 2 * (2 * 2 + 4) * 1024); }
     else return -1;

@@ -62,14 +62,15 @@ def aggregate_throughput(units_local: float, wall_local: float, device) -> Tuple
 
 
 def broadcast_packed(shapes: Iterable[Tuple[str, tuple]], make: Callable[[str, tuple], torch.Tensor], device,
-                     dtype=torch.bfloat16, src: int = 0, bucket_bytes: int = 48 << 30, stats: dict = None
+                     dtype=torch.bfloat16, src: int = 0, bucket_bytes: int = 2 << 30, stats: dict = None
                      ) -> Iterator[Tuple[str, torch.Tensor]]:
-    """The start-up collective of SURVEY 8(e): the whole parameter bundle travels as ONE packed blob per bucket (the 7B
-    bundle, 18.7 GB in bf16, is a single ncclBroadcast over the seven xGMI links of rank 0) instead of ~1000 per-tensor
-    collectives, each of which pays the RCCL launch + ring set-up latency.  Rank `src` writes make(name, shape) into its
-    slice of the blob; every rank then yields (name, view-into-the-blob).  A view is valid until the generator advances to
-    the next bucket (the engine's vv_upload re-packs it into its own storage at once).  `stats` receives bytes / seconds /
-    number of collectives.  bucket_bytes bounds the transient copy (default: one bucket for anything up to 48 GiB)."""
+    """The start-up collective of SURVEY 8(e): the parameter bundle travels as packed blobs (the 7B bundle, 18.7 GB in
+    bf16, is ten 2 GiB ncclBroadcasts over the xGMI links of rank 0) instead of ~1000 per-tensor collectives, each of which
+    pays the RCCL launch + ring set-up latency.  Rank `src` writes make(name, shape) into its slice of the blob; every rank
+    then yields (name, view-into-the-blob).  A view is valid until the generator advances to the next bucket (the engine's
+    vv_upload re-packs it into its own storage at once).  `stats` receives bytes / seconds / number of collectives.
+    bucket_bytes bounds the transient copy and keeps every collective's element count below 2^31 (default 2 GiB: 2^30 bf16
+    elements; a tensor larger than a bucket travels alone)."""
     import time
     rank, world = world_info()
     esz = torch.empty(0, dtype=dtype).element_size()
