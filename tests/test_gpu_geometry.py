@@ -189,3 +189,66 @@ def test_prefill_attention_over_4k_positions(xs, tol):
         assert rel_err(hid, ref) <= tol, rel_err(hid, ref)
     finally:
         eng.close()
+
+
+def _prefill_probe(L0, chunk, heads, kv_heads, hd):
+    """One bf16-mode layer over an L0-token prompt in `chunk`-row passes; returns the hidden states [L0, H] (CPU)."""
+    c = synth.LMCfg(hidden=heads * hd, layers=1, heads=heads, kv_heads=kv_heads, inter=512, vocab=64, max_pos=8192)
+    s = build_fast(c, xsplit=1, max_ctx=(L0 + 255) // 128 * 128, max_rows=chunk, head_layers=1)
+    eng = s.eng
+    try:
+        g = synth.Gen(L0 + chunk)
+        x = g.normal((L0, c.hidden), 1.0, mat=False)
+        hid = eng.new(L0, c.hidden)
+        xd = dev(x, eng)
+        with torch.cuda.stream(eng.stream):
+            for i0 in range(0, L0, chunk):
+                n = min(chunk, L0 - i0)
+                eng.lm_forward([(0, i0 + j) for j in range(n)], xd[i0:i0 + n], hid[i0:i0 + n])
+        eng.sync()
+        return hid.float().cpu(), s, x
+    finally:
+        eng.close()
+
+
+PROBE_SHAPES = [(4180, 512, 4, 2, 128), (1000, 1024, 7, 1, 128), (1555, 1024, 14, 2, 64), (90, 128, 4, 2, 128)]
+
+
+@pytest.mark.parametrize("L0,chunk,heads,kv_heads,hd", PROBE_SHAPES)
+def test_prefill_attention_v3_rowwise(L0, chunk, heads, kv_heads, hd):
+    """vv_attn_prefill3_kernel (one softmax update per 64-position stage, v_permlane*_swap row exchange, mask-free path below
+    the diagonal) held ROW BY ROW to (a) the same kernel with the LDS-permute exchange (VVHIP_ATTN3_SHFL: must be bit-identical
+    -- pins the permlane16 / permlane32 swap semantics), (b) the v2 kernel (VVHIP_ATTN3=0; per-row rel-L2 <= 5e-3: only the
+    granularity of the running maximum, i.e. the bf16 rounding of P, differs) and (c) the oracle's causal attention (per-row
+    rel-L2 within the bf16-mode bound).  A masking or tail-stage slip shows up as an O(1) error in single rows, which a
+    whole-tensor norm hides.  Shapes: ragged tails with 1..32 and 33..64 live positions in the last stage, passes that start
+    at a non-zero position, GQA groups 2 / 7 (one idle wave pair), both head widths.  The other kernels' outputs come from
+    subprocesses because the engine reads its A/B switches once per process."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    got, s, x = _prefill_probe(L0, chunk, heads, kv_heads, hd)
+    with tempfile.TemporaryDirectory() as td:
+        outs = {}
+        for tag, env in (("shfl", {"VVHIP_ATTN3_SHFL": "1"}), ("v2", {"VVHIP_ATTN3": "0"})):
+            path = os.path.join(td, tag + ".npy")
+            e = dict(os.environ, **env)
+            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            e["PYTHONPATH"] = os.pathsep.join([root, os.path.join(root, "tests")] + ([e["PYTHONPATH"]] if e.get("PYTHONPATH") else []))
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), path, str(L0), str(chunk), str(heads), str(kv_heads), str(hd)],
+                               env=e, cwd=os.path.dirname(os.path.abspath(__file__)), capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs[tag] = torch.from_numpy(np.load(path))
+    assert torch.equal(got, outs["shfl"]), float((got - outs["shfl"]).abs().max())
+    row = lambda a, b: float(((a - b).norm(dim=1) / b.norm(dim=1)).max())
+    assert row(got, outs["v2"]) <= 5e-3, row(got, outs["v2"])
+    ref = s.oracle_lm(kv_round_bf16=True).forward(x, s.oracle_lm(kv_round_bf16=True).new_cache())
+    assert row(got, ref) <= 8e-2, row(got, ref)
+    assert rel_err(got, ref) <= 4e-2, rel_err(got, ref)
+
+
+if __name__ == "__main__":                       # subprocess leg of test_prefill_attention_v3_rowwise
+    import sys
+    out_path, a = sys.argv[1], [int(v) for v in sys.argv[2:7]]
+    np.save(out_path, _prefill_probe(*a)[0].numpy())
