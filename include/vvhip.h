@@ -54,6 +54,10 @@ typedef struct vv_config {
 int vv_create(const vv_config* cfg, vv_ctx** out);
 void vv_destroy(vv_ctx* ctx);
 const char* vv_last_error(vv_ctx* ctx);
+/* "VVHIP_BUILD_ID=<sha256[:16] of the sources and flags the library was compiled from>": the Python loader refuses
+ * (or rebuilds) a binary whose id differs from the sources beside it.  New surface: the reference has no native
+ * code, hence no counterpart (its "is the install current" check is pip's, pyproject.toml:1-40). */
+const char* vv_build_id(void);
 
 /* ---- parameters.  Names are the reference state_dict keys with the prefixes
  * model.language_model.->"lm."  model.prediction_head.->"head."

@@ -53,7 +53,7 @@ class Schedule:
         timesteps = (
             np.linspace(0, last_timestep - 1, num_inference_steps + 1)
             .round()[::-1][:-1].copy().astype(np.int64))
-        sigmas = (((1 - ac) / ac) ** 0.5).numpy()
+        sigmas = (((1 - ac) / ac) ** 0.5).cpu().numpy()          # .cpu(): a no-op here; bench.py's eager-GPU leg runs under a cuda default device
         sigmas = np.interp(timesteps, np.arange(0, len(sigmas)), sigmas)
         sigmas = np.concatenate([sigmas, [0]]).astype(np.float32)
         self.timesteps = torch.from_numpy(timesteps)

@@ -25,6 +25,30 @@ def test_library_exports_every_declared_symbol():
     _lib.load()
 
 
+def test_binary_carries_the_hash_of_its_sources(tmp_path):
+    """libvvhip.so embeds sha256[:16] of the sources + flags it was compiled from (vv_build_id); build.stale() and the loader
+    compare it with the sources beside the binary -- content, not mtime -- so a stale in-tree .so is rebuilt or refused."""
+    import shutil
+    from vibevoice_amd import _lib, build
+    build.build()
+    sid = build.source_id()
+    assert build.binary_id() == sid and not build.stale()
+    assert _lib.load().vv_build_id() == b"VVHIP_BUILD_ID=" + sid.encode()
+    # an edited source changes the id: checked on a scratch copy of the tree (nothing is rebuilt here)
+    src = os.path.join(tmp_path, "csrc")
+    shutil.copytree(build.CSRC, src)
+    old_csrc, old_hdr = build.CSRC, build.HEADERS
+    try:
+        build.CSRC = src
+        build.HEADERS = [os.path.join(src, "vv_common.h"), old_hdr[1]]
+        assert build.source_id() == sid
+        with open(os.path.join(src, "misc.hip"), "a") as f:
+            f.write("\n// edited\n")
+        assert build.source_id() != sid and build.stale()
+    finally:
+        build.CSRC, build.HEADERS = old_csrc, old_hdr
+
+
 def test_engine_refuses_to_run_without_gpu():
     if torch.cuda.is_available():
         pytest.skip("GPU present")

@@ -61,6 +61,7 @@ _SIGS = {
     "vv_profile_end": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "vv_profile_replay": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "vv_stat": (C.c_int64, [_P, C.c_int]),
+    "vv_build_id": (C.c_char_p, []),
 }
 
 EXPORTS = tuple(_SIGS)
@@ -76,6 +77,15 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} is missing: the HIP engine has not been built "
             "(run `python -m vibevoice_amd.build`); there is no CPU/PyTorch fallback")
+    from . import build as _build
+    if _build.have_sources() and _build.binary_id(LIB_PATH) != _build.source_id():
+        # a binary from other sources must never run silently: rebuild where a compiler exists, refuse otherwise
+        try:
+            _build.build(force=True, verbose=False)
+        except Exception as ex:
+            raise RuntimeError(
+                f"{LIB_PATH} was built from different sources (binary id {_build.binary_id(LIB_PATH)}, sources "
+                f"{_build.source_id()}) and could not be rebuilt ({ex}); run `python -m vibevoice_amd.build`") from ex
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported

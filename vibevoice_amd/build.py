@@ -21,24 +21,61 @@ def _hipcc():
     raise RuntimeError("hipcc not found: libvvhip.so cannot be built")
 
 
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+         "-Wno-unused-value", "-Wno-unused-result", "-mllvm", "-amdgpu-kernarg-preload-count=16"]
+
+
+def _extra_flags():
+    return os.environ.get("VVHIP_CFLAGS", "").split()
+
+
+def source_id():
+    """sha256[:16] over the kernel sources, the headers and the compile flags: what the binary must have been built from."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in [os.path.join(CSRC, s) for s in SOURCES] + HEADERS:
+        h.update(os.path.basename(d).encode() + b"\0")
+        with open(d, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(FLAGS + _extra_flags()).encode())
+    return h.hexdigest()[:16]
+
+
+def binary_id(path=LIB):
+    """The id compiled into libvvhip.so (vv_build_id), read from the file without loading it; None if absent."""
+    try:
+        with open(path, "rb") as f:
+            blob = f.read()
+    except OSError:
+        return None
+    k = blob.find(b"VVHIP_BUILD_ID=")
+    if k < 0:
+        return None
+    return blob[k + 15:k + 31].decode("ascii", "replace")
+
+
+def have_sources():
+    return all(os.path.exists(d) for d in [os.path.join(CSRC, s) for s in SOURCES] + HEADERS)
+
+
 def stale():
+    """True when the in-tree binary is missing or was not compiled from the sources beside it (content hash, not mtime: a
+    checkout or a snapshot copy resets mtimes either way)."""
     if not os.path.exists(LIB):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
-    return any(os.path.getmtime(d) > t for d in deps)
+    return have_sources() and binary_id() != source_id()
 
 
 def build(force=False, verbose=True):
     if not force and not stale():
         return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-value", "-Wno-unused-result", "-mllvm", "-amdgpu-kernarg-preload-count=16"] + os.environ.get("VVHIP_CFLAGS", "").split() + \
-          [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
+    tmp = f"{LIB}.tmp{os.getpid()}"            # unique per process: concurrent ranks never share a half-written file
+    cmd = [_hipcc()] + FLAGS + _extra_flags() + [f'-DVV_BUILD_ID="{source_id()}"'] + \
+          [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
     if verbose:
         print("[vibevoice_amd] building libvvhip.so:", " ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
-    os.replace(LIB + ".tmp", LIB)
+    os.replace(tmp, LIB)
     return LIB
 
 

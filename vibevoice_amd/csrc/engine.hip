@@ -778,6 +778,13 @@ static int graphed(vv_ctx* ctx, const std::string& key, hipStream_t st, F&& body
 // ------------------------------------------------------------------ API
 extern "C" const char* vv_last_error(vv_ctx* ctx) { return ctx ? ctx->err : g_err; }
 
+// Content hash of the sources this library was compiled from (vibevoice_amd/build.py passes -DVV_BUILD_ID): the loader
+// compares it with the hash of the sources next to it, so a stale in-tree binary is rebuilt or refused instead of silently run.
+#ifndef VV_BUILD_ID
+#define VV_BUILD_ID "unknown"
+#endif
+extern "C" const char* vv_build_id() { return "VVHIP_BUILD_ID=" VV_BUILD_ID; }
+
 extern "C" int vv_create(const vv_config* cfg, vv_ctx** out) {
     vv_ctx* ctx = new vv_ctx();
     ctx->c = *cfg; ctx->err[0] = 0;
