@@ -710,8 +710,9 @@ __global__ __launch_bounds__(512) void vv_attn_prefill3_kernel(
     }
 
     // one stage = 64 positions (NB = 2 blocks) or, for the last stage of a ragged prefix, its first 32 (NB = 1); FAST: the
-    // whole stage lies below the causal diagonal of every query row of the workgroup
-    auto stage = [&](const unsigned char* cur, int p0, auto nb_c, auto fast_c) {
+    // whole stage lies below the causal diagonal of every query row of the workgroup.  st_next / nbuf: the stage whose LDS-DMA
+    // copies this wave issues during the stage (-1: none).
+    auto stage = [&](const unsigned char* cur, int p0, auto nb_c, auto fast_c, int st_next, unsigned char* nbuf) {
         constexpr int NB = decltype(nb_c)::value;
         constexpr bool FAST = decltype(fast_c)::value;
         // ---- S^T = K q^T: sc[rt][2 blk + half] = positions p0 + 32 blk + 16 half + 4 qg + r, query row = lane & 15 ----
@@ -720,20 +721,68 @@ __global__ __launch_bounds__(512) void vv_attn_prefill3_kernel(
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int i = 0; i < 2 * NB; ++i) sc[rt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (FAST) {
+            // every K fragment of the stage is requested from LDS FIRST, then the next stage's LDS-DMA copies are issued (their
+            // address arithmetic and issue slots run under the LDS latency instead of in front of it), then the 32 MFMAs
+            bf16x8 kf[NB][2 * KT];
 #pragma unroll
-        for (int blk = 0; blk < NB; ++blk) {
-            const unsigned char* kb_ = cur + blk * KF * 1024;
+            for (int blk = 0; blk < NB; ++blk)
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) {
-                const bf16x8 ka = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(kb_ + (kt * 64 + lane) * 16));
-                const bf16x8 kb = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(kb_ + ((KT + kt) * 64 + lane) * 16));
+                for (int f = 0; f < 2 * KT; ++f)
+                    kf[blk][f] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(cur + ((blk * KF + f) * 64 + lane) * 16));
+            if (st_next >= 0) issue(st_next, nbuf);
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) {
-                    sc[rt][2 * blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[rt][kt], sc[rt][2 * blk], 0, 0, 0);
-                    sc[rt][2 * blk + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb, qf[rt][kt], sc[rt][2 * blk + 1], 0, 0, 0);
+            for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        sc[rt][2 * blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[blk][kt], qf[rt][kt], sc[rt][2 * blk], 0, 0, 0);
+                        sc[rt][2 * blk + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[blk][KT + kt], qf[rt][kt], sc[rt][2 * blk + 1], 0, 0, 0);
+                    }
+        } else {
+            if (st_next >= 0) issue(st_next, nbuf);
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) {
+                const unsigned char* kb_ = cur + blk * KF * 1024;
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    // masked stages (the last one or two of a workgroup) carry the mask temporaries on top of everything else:
+                    // each k-step's K fragments are requested only after the previous step's MFMAs, or the kernel spills -- and a
+                    // scratch reload anywhere in the loop makes the compiler guard the mask-free body with s_waitcnt vmcnt(0),
+                    // i.e. with a wait for the NEXT stage's LDS-DMA copies (the waitcnt pass merges the pending-load state around
+                    // the back edge; with it 43 % of the wave cycles were parked, 33 % without)
+                    asm volatile("" ::: "memory");
+                    const bf16x8 ka = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(kb_ + (kt * 64 + lane) * 16));
+                    const bf16x8 kb = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(kb_ + ((KT + kt) * 64 + lane) * 16));
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        sc[rt][2 * blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[rt][kt], sc[rt][2 * blk], 0, 0, 0);
+                        sc[rt][2 * blk + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb, qf[rt][kt], sc[rt][2 * blk + 1], 0, 0, 0);
+                    }
                 }
             }
         }
+        // mask-free stages: the V fragments of the first half of the feature tiles are requested now and land under the softmax
+        // (register room: the K fragments are dead from here on), the second half between the two row tiles' updates
+        const unsigned char* vb_ = cur + 2 * KF * 1024;
+        constexpr int DH = DT / 2;
+        bf16x8 va[DH][NB], vbf[DH][NB];
+        auto load_va = [&]() {
+#pragma unroll
+            for (int dt = 0; dt < DH; ++dt)
+#pragma unroll
+                for (int blk = 0; blk < NB; ++blk)
+                    va[dt][blk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(vb_ + ((blk * DT + dt) * 64 + lane) * 16));
+        };
+        auto load_vb = [&]() {
+#pragma unroll
+            for (int dt = 0; dt < DH; ++dt)
+#pragma unroll
+                for (int blk = 0; blk < NB; ++blk)
+                    vbf[dt][blk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(vb_ + ((blk * DT + DH + dt) * 64 + lane) * 16));
+        };
+        if constexpr (FAST) { load_va(); __builtin_amdgcn_sched_barrier(0); }     // masked stages: plain loop below (registers)
         // ---- one online-softmax update per stage -> P as the B operands of P.V ----
         bf16x8 pb[RT][NB];
         float al[RT];
@@ -784,6 +833,7 @@ __global__ __launch_bounds__(512) void vv_attn_prefill3_kernel(
                 m[rt] = mn;                                            // dead: mn = m = -inf
             }
             al[rt] = alpha;
+            if constexpr (FAST) { if (rt == 0) { __builtin_amdgcn_sched_barrier(0); load_vb(); __builtin_amdgcn_sched_barrier(0); } }
         }
         // once the running maxima have settled (alpha == 1 in every lane of both row tiles) the accumulator rescale is skipped:
         // ONE wave-uniform branch per stage, then an unbroken run of MFMAs
@@ -794,18 +844,36 @@ __global__ __launch_bounds__(512) void vv_attn_prefill3_kernel(
                 for (int dt = 0; dt < DT; ++dt) o[rt][dt] *= al[rt];
         }
         // ---- O += P . V: NB k-steps per accumulator, every V fragment read from LDS once ----
-        const unsigned char* vb_ = cur + 2 * KF * 1024;
+        if constexpr (FAST) {
+            // every V fragment was requested during the softmax: no LDS round trip sits between two MFMAs (left alone, the
+            // scheduler requests each pair of fragments right in front of its MFMAs, on a single register pair)
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            bf16x8 vf[NB];
-#pragma unroll
-            for (int blk = 0; blk < NB; ++blk)
-                vf[blk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(vb_ + ((blk * DT + dt) * 64 + lane) * 16));
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
+            for (int dt = 0; dt < DH; ++dt)
 #pragma unroll
                 for (int blk = 0; blk < NB; ++blk)
-                    o[rt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[blk], pb[rt][blk], o[rt][dt], 0, 0, 0);
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+                        o[rt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[dt][blk], pb[rt][blk], o[rt][dt], 0, 0, 0);
+#pragma unroll
+            for (int dt = 0; dt < DH; ++dt)
+#pragma unroll
+                for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+                        o[rt][DH + dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vbf[dt][blk], pb[rt][blk], o[rt][DH + dt], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                bf16x8 vf[NB];
+#pragma unroll
+                for (int blk = 0; blk < NB; ++blk)
+                    vf[blk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(vb_ + ((blk * DT + dt) * 64 + lane) * 16));
+#pragma unroll
+                for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+                        o[rt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[blk], pb[rt][blk], o[rt][dt], 0, 0, 0);
+            }
         }
     };
     using c1 = std::integral_constant<int, 1>;
@@ -814,13 +882,14 @@ __global__ __launch_bounds__(512) void vv_attn_prefill3_kernel(
     for (int st = 0; st < n_stg; ++st) {
         unsigned char* cur = kv + (st & 1) * BUF;
         stage_sync();                             // stage st has landed (every wave drained its own copies first);
-                                                  // everyone has finished stage st-1, whose buffer is refilled now
-        if (st + 1 < n_stg) issue(st + 1, kv + ((st + 1) & 1) * BUF);
-        if (!act) continue;
+                                                  // everyone has finished stage st-1, whose buffer is refilled during this stage
+        const int st_next = (st + 1 < n_stg) ? st + 1 : -1;
+        unsigned char* nbuf = kv + ((st + 1) & 1) * BUF;
+        if (!act) { if (st_next >= 0) issue(st_next, nbuf); continue; }
         const int p0 = st * 64;
-        if (st < first_masked) stage(cur, p0, c2{}, std::true_type{});          // p0 + 63 < rw.pos + r0 <= every plim: 64 live positions
-        else if (p0 + 32 < pend) stage(cur, p0, c2{}, std::false_type{});
-        else stage(cur, p0, c1{}, std::false_type{});
+        if (st < first_masked) stage(cur, p0, c2{}, std::true_type{}, st_next, nbuf);   // p0 + 63 < rw.pos + r0 <= every plim: 64 live positions
+        else if (p0 + 32 < pend) stage(cur, p0, c2{}, std::false_type{}, st_next, nbuf);
+        else stage(cur, p0, c1{}, std::false_type{}, st_next, nbuf);
     }
     if (act) {
 #pragma unroll
