@@ -109,6 +109,15 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
+def _build_id():
+    """sha256[:16] of the kernel sources the loaded libvvhip.so was compiled from (vv_build_id)."""
+    try:
+        from vibevoice_amd import _lib
+        return _lib.load().vv_build_id().decode().split("=", 1)[1]
+    except Exception:
+        return None
+
+
 def respawn_ranks(args):
     """`python bench.py --gpus N` outside torchrun: start the N ranks (one process per GPU, RCCL rendezvous on 127.0.0.1)."""
     import socket
@@ -420,7 +429,7 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline):
                    "xsplit": args.xsplit, "hipgraph": not args.no_graph, "kv_len_timed": max(L0, kv_target) + W,
                    "parallelism": f"utterance-dp{world}"},
         "roofline": roof, "cpu_baseline": cpu, "gpu_eager_baseline": eager,
-        "extra": {"frames_timed": frames, "weights_load_s": round(load_s, 2),
+        "extra": {"frames_timed": frames, "weights_load_s": round(load_s, 2), "libvvhip_build_id": _build_id(),
                   "weights_broadcast": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in bc.items()},
                   "prefill_plus_first_frame_s": round(marks.get("prefill_done", t_gen0) - t_gen0, 4),
                   "prefill_phases": prefill_phases,
