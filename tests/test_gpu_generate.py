@@ -364,3 +364,70 @@ def test_graph_cache_is_bounded(monkeypatch):
         assert 0 < s.eng.stat(1) <= 4
     finally:
         s.eng.close()
+
+
+def test_sampling_path_at_vanishing_temperature_equals_greedy_batch2(sm):
+    """do_sample=True on the engine for a desynchronised batch of TWO: the sampling branch builds full-vocabulary rows from the
+    dense [n][n_valid] logits block (vibevoice_amd/modeling.py: the branch of ADVICE r1's row-stride finding that no GPU test
+    reached -- the reference draws on the device generator, so a seeded run cannot be compared with the CPU oracle).  At
+    temperature 1e-3 the categorical draw is the argmax (the tiny model's logit gaps are ~1e-1), so the sampled run must
+    reproduce the greedy run -- which test_generate_greedy_batch2_free_running holds to the oracle -- token by token and
+    sample by sample; a row reading another row's logits would not."""
+    from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference
+    o, h = run_both(sm, 2, None, with_speech=True, seed=61, max_new_tokens=10)
+    check(o, h)
+    ids, mask, sim, st, smk = make_inputs(sm, 2, True, 61)
+    g = synth.Gen(62)
+    pre = (g.normal((2,), 1.0, mat=False), g.normal((2, 3, 64), 1.0, mat=False))
+    bank = {}
+
+    def noise_fn(step, n2):
+        if (step, n2) not in bank:
+            bank[(step, n2)] = synth.Gen(61 * 1000 + step).normal((n2, 64), 1.0, mat=False)
+        return bank[(step, n2)]
+    cfgd = {"decoder_config": {"max_position_embeddings": sm.lmcfg.max_pos}, "diffusion_head_config": {"ddpm_num_inference_steps": 5},
+            "acoustic_tokenizer_config": {"fix_std": 0.5, "std_dist_type": "gaussian"}}
+    m = VibeVoiceForConditionalGenerationInference(cfgd, sm.eng, model_dtype=torch.float32)
+    m.set_speech_factors(sm.scaling, sm.bias)
+    m.set_ddpm_inference_steps(5)
+    tok = types.SimpleNamespace(speech_start_id=TOK.speech_start_id, speech_end_id=TOK.speech_end_id,
+                                speech_diffusion_id=TOK.speech_diffusion_id, eos_token_id=TOK.eos_token_id,
+                                bos_token_id=None, pad_token_id=TOK.pad_token_id)
+    torch.manual_seed(5)
+    out = m.generate(input_ids=ids, attention_mask=mask, speech_tensors=st, speech_masks=smk, speech_input_mask=sim, cfg_scale=1.3,
+                     tokenizer=tok, max_new_tokens=10, generation_config={"do_sample": True, "temperature": 1e-3},
+                     _noise_fn=noise_fn, _prefill_noise=pre, show_progress_bar=False)
+    greedy = h[0]
+    assert torch.equal(out.sequences.cpu(), greedy.sequences.cpu())
+    for a, b in zip(out.speech_outputs, greedy.speech_outputs):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.equal(a.cpu(), b.cpu())
+
+
+def test_abi_refuses_out_of_range_arguments(sm):
+    """The C ABI validates what would otherwise be an out-of-bounds device access and returns an error code + text
+    (vv_last_error) that the ctypes layer raises as EngineError: positions beyond max_ctx, cache ids beyond 2 * n_slots, more
+    rows than max_rows, a KV import past the end of the cache.  (The reference fails with PyTorch index errors at the
+    corresponding places; a native engine must not turn them into silent memory corruption.)"""
+    from vibevoice_amd.engine import EngineError
+    eng = sm.eng
+    H = sm.lmcfg.hidden
+    x = eng.new(4, H)
+    y = eng.new(4, H)
+    with pytest.raises(EngineError, match="exceeds max_ctx"):
+        eng.lm_forward([(0, eng.max_ctx)], x, y)
+    with pytest.raises(EngineError, match="cache id"):
+        eng.lm_forward([(2 * eng.cfg.n_slots, 0)], x, y)
+    with pytest.raises(EngineError, match="n_rows"):
+        big = eng.new(eng.cfg.max_rows + 1, H)
+        eng.lm_forward([(0, j) for j in range(eng.cfg.max_rows + 1)], big, big)
+    kvh, d = sm.lmcfg.kv_heads, sm.lmcfg.head_dim
+    k = torch.zeros(kvh, 8, d, device=eng.device)
+    with pytest.raises(EngineError, match="exceed max_ctx"):
+        eng.kv_import_at(0, 0, eng.max_ctx - 4, k, k)
+    eng.sync()
+    # the context is still usable after refused calls
+    eng.lm_forward([(0, 0)], x[:1], y[:1])
+    eng.sync()
+    assert torch.isfinite(y[:1]).all()
