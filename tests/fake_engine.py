@@ -272,3 +272,83 @@ class LoadableFakeEngine(FakeEngine):
     @om.setter
     def om(self, v):
         self._om = v
+
+
+class LoadableFakeStreamingEngine(FakeStreamingEngine):
+    """`Engine(ecfg, device)` stand-in for the streaming class's construction path (from_state_dict / from_pretrained /
+    WeightHandle): collects vv_upload()s under the engine's parameter names and builds the split oracle model from them
+    on first use (text LM = layers [0, n_lm) without final norm, TTS LM = the rest + `lm.norm`)."""
+
+    def __init__(self, ecfg, device=None):
+        self.ecfg = ecfg
+        self._w = {}
+        self._om = None
+        self._factors = (1.0, 0.0)
+        self._frozen = None
+        self.uploads = []
+        self.n_tts = ecfg.tts_layers
+        self.n_lm = ecfg.lm_layers - ecfg.tts_layers
+        self.device = torch.device("cpu")
+        self.stream = None
+        self.max_ctx = (ecfg.max_ctx + 127) // 128 * 128
+        self.cfg = types.SimpleNamespace(lm_hidden=ecfg.lm_hidden, latent_dim=ecfg.latent_dim, hop=ecfg.hop, sem_dim=0, n_slots=ecfg.n_slots,
+                                         max_rows=ecfg.max_rows, lm_layers=ecfg.lm_layers, tts_layers=ecfg.tts_layers)
+        self._caches = None
+        self.state = {}
+        self.n_steps = 5
+
+    def expected_weights(self):
+        return self._frozen if self._frozen is not None else LoadableFakeEngine._Any()
+
+    def missing_weights(self):
+        self._frozen = {k: int(v.numel()) for k, v in self._w.items()}
+        return []
+
+    def upload(self, name, t):
+        self._w[name] = t.detach().to(torch.float32).clone()
+        self.uploads.append(name)
+        self._om = None
+
+    def set_speech_factors(self, scaling, bias):
+        self._factors = (float(scaling), float(bias))
+        if self._om is not None:
+            self._om.scaling, self._om.bias = self._factors
+
+    @property
+    def om(self):
+        if self._om is None:
+            from oracle import generate_streaming as ogs
+            from oracle import lm as olm
+            c = self.ecfg
+            sub = lambda p: {k[len(p):]: v for k, v in self._w.items() if k.startswith(p)}
+            w = sub("lm.")
+            lm_w = {k: v for k, v in w.items() if k.startswith("embed") or any(k.startswith(f"layers.{i}.") for i in range(self.n_lm))}
+            tts_w = {"norm.weight": w["norm.weight"], "embed_tokens.weight": w["embed_tokens.weight"]}
+            for j in range(self.n_tts):
+                pre = f"layers.{self.n_lm + j}."
+                for k, v in w.items():
+                    if k.startswith(pre):
+                        tts_w[f"layers.{j}." + k[len(pre):]] = v
+            mk = lambda ww, L: olm.Qwen2Oracle(ww, L, c.lm_heads, c.lm_kv_heads, c.lm_head_dim, c.rope_theta, c.lm_eps, kv_round_bf16=False)
+            depths = list(c.enc_depths)
+            self._om = ogs.StreamingOracleModel(
+                lm=mk(lm_w, self.n_lm), tts_lm=mk(tts_w, self.n_tts), tts_types=self._w["tts_input_types.weight"], eos=sub("eos."),
+                head_w=sub("head."), head_layers=c.head_layers, ac_w={"decoder." + k: v for k, v in sub("dec.").items()},
+                ac_conn=sub("ac_conn."), ratios=list(c.ratios), dec_depths=list(reversed(depths)),
+                scaling=self._factors[0], bias=self._factors[1])
+        return self._om
+
+    @om.setter
+    def om(self, v):
+        self._om = v
+
+    @property
+    def caches(self):
+        if self._caches is None:
+            om = self.om
+            self._caches = {0: om.lm.new_cache(), 1: om.tts_lm.new_cache(), 2: om.tts_lm.new_cache()}
+        return self._caches
+
+    @caches.setter
+    def caches(self, v):
+        self._caches = v

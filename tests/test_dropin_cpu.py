@@ -351,3 +351,115 @@ def test_pcm16_reference_arithmetic():
         mine = data / peak if peak > 1.0 else data
         mine = np.trunc(mine * np.float32(32767.0)).astype(np.int16)
         assert np.array_equal(ref, mine)
+
+
+# ---------------------------------------------------------------- the streaming class (SURVEY 8b "Streaming variant")
+def tiny_streaming_checkpoint(tmp_path, eos_bias):
+    """The tiny split model of test_oracle_golden._oracle_streaming_small (same seeded weights) as a checkpoint directory
+    in the reference's layout: config.json (configuration_vibevoice_streaming.py: decoder_config + tts_backbone_num_hidden_layers)
+    and safetensors shards keyed like VibeVoiceStreamingForConditionalGenerationInference.state_dict()."""
+    from safetensors.torch import save_file
+    n_lm, n_tts = 1, 2
+    cfg = synth.LMCfg(hidden=128, layers=n_lm + n_tts, heads=2, kv_heads=1, inter=256, vocab=320)
+    H = cfg.hidden
+    w = synth.lm_weights(cfg)
+    hc = synth.HeadCfg(hidden=H, layers=2)
+    cc = synth.CodecCfg()
+    g = synth.Gen(900)
+    tts_types = g.normal((2, H), 0.5, mat=False)
+    eos = {"fc1.weight": g.linear(H, H), "fc1.bias": g.vec(H, 0.1), "fc2.weight": g.linear(1, H, 0.3), "fc2.bias": torch.full((1,), float(eos_bias))}
+    sd = {"model.language_model.embed_tokens.weight": w["embed_tokens.weight"], "model.tts_language_model.norm.weight": w["norm.weight"],
+          "model.tts_input_types.weight": tts_types, "model.speech_scaling_factor": torch.tensor(0.2), "model.speech_bias_factor": torch.tensor(-0.05)}
+    for k, v in w.items():
+        if k.startswith("layers."):
+            i = int(k.split(".")[1])
+            rest = k.split(".", 2)[2]
+            sd[(f"model.language_model.layers.{i}." if i < n_lm else f"model.tts_language_model.layers.{i - n_lm}.") + rest] = v
+    sd.update({"tts_eos_classifier." + k: v for k, v in eos.items()})
+    sd.update({"model.prediction_head." + k: v for k, v in synth.head_weights(hc).items()})
+    sd.update({"model.acoustic_tokenizer." + k: v for k, v in synth.decoder_weights(cc, 3).items()})
+    sd.update({"model.acoustic_connector." + k: v for k, v in synth.connector_weights(64, H, 4).items()})
+    config = tiny_reference_config()
+    config.pop("semantic_tokenizer_config")
+    config["tts_backbone_num_hidden_layers"] = n_tts
+    config["decoder_config"].update(hidden_size=H, intermediate_size=cfg.inter, num_attention_heads=cfg.heads, num_key_value_heads=cfg.kv_heads,
+                                    num_hidden_layers=cfg.layers, vocab_size=cfg.vocab, max_position_embeddings=512)
+    config["diffusion_head_config"]["hidden_size"] = H
+    d = tmp_path / "tiny-vibevoice-streaming"
+    d.mkdir()
+    (d / "config.json").write_text(json.dumps(config))
+    sd = {k: v.contiguous() for k, v in sd.items()}
+    keys = sorted(sd)
+    save_file({k: sd[k] for k in keys[::2]}, str(d / "model-00001-of-00002.safetensors"))
+    save_file({k: sd[k] for k in keys[1::2]}, str(d / "model-00002-of-00002.safetensors"))
+    return str(d)
+
+
+def test_reference_streaming_demo_call_sequence(monkeypatch, tmp_path, capsys):
+    """demo/streaming_inference_from_file.py:226-355 replayed line by line against the product's streaming class loaded from a
+    checkpoint directory (Engine replaced by the oracle-backed fake): from_pretrained(path, torch_dtype, device_map,
+    attn_implementation) -> eval() -> set_ddpm_inference_steps(num_steps=5) -> `hasattr(model.model, 'language_model')` +
+    the `_attn_implementation` read (:285-286) -> the voice preset as a dict of BaseModelOutputWithPast (:291), deep-copied
+    (:318) -> generate(**processor_inputs, max_new_tokens=None, cfg_scale, tokenizer, generation_config, verbose,
+    all_prefilled_outputs) -> the fields the demo reads (:325-341).  Preset, text and noise are the ones of the golden the
+    REFERENCE's streaming generate() recorded (streaming_eos.npz): same token count, waveform rel-L2 <= 1e-4."""
+    import copy
+    from transformers.modeling_outputs import BaseModelOutputWithPast
+    from vibevoice_amd import modeling_streaming
+    z = np.load(os.path.join(GOLD, "streaming_eos.npz"))
+    path = tiny_streaming_checkpoint(tmp_path, float(z["eos_bias"]))
+    draws = [torch.from_numpy(z[f"draw_{i}"]).reshape(2, 64) for i in range(int(z["n_draws"]))]
+
+    def branch(tag):
+        n = int(z[f"{tag}_layers"])
+        kv = [(torch.from_numpy(z[f"{tag}_k{li}"])[None], torch.from_numpy(z[f"{tag}_v{li}"])[None]) for li in range(n)]
+        hid = torch.zeros(1, kv[0][0].shape[2], 128)
+        hid[0, -1] = torch.from_numpy(z[f"{tag}_last"])
+        return BaseModelOutputWithPast(last_hidden_state=hid, past_key_values=kv)
+    all_prefilled_outputs = {"lm": branch("lm"), "tts_lm": branch("tts"), "neg_lm": None, "neg_tts_lm": branch("neg_tts")}
+    with fake_engine.cpu_cuda_shims(monkeypatch):
+        monkeypatch.setattr(modeling_streaming, "Engine", fake_engine.LoadableFakeStreamingEngine)
+        cls = modeling_streaming.VibeVoiceStreamingForConditionalGenerationInference
+        model = cls.from_pretrained(path, torch_dtype=torch.float32, device_map="cuda", attn_implementation="flash_attention_2")
+        model.eval()
+        model.set_ddpm_inference_steps(num_steps=5)
+        assert hasattr(model.model, "language_model")
+        print(f"Language model attention: {model.model.language_model.config._attn_implementation}")      # :285-286
+        assert "Language model attention: vvhip" in capsys.readouterr().out
+        assert model.requested_attn_implementation == "flash_attention_2"
+        # reference properties (modeling_vibevoice_streaming_inference.py:119-141) and the split decoder's two halves
+        assert model.prediction_head is model.model.prediction_head and model.acoustic_connector is model.model.acoustic_connector
+        assert model.acoustic_tokenizer is model.model.acoustic_tokenizer
+        assert model.model.language_model.config.num_hidden_layers == 1 and model.model.tts_language_model.config.num_hidden_layers == 2
+        assert abs(float(model.speech_scaling_factor) - 0.2) < 1e-7 and abs(float(model.model.speech_bias_factor) + 0.05) < 1e-7
+        assert next(model.parameters()).device == model.device and model.to("cuda") is model
+        assert model.config.tts_backbone_num_hidden_layers == 2 and list(model.noise_scheduler.timesteps[:2]) == [999, 799]
+        assert sorted(model.tts_eos_classifier.expected_keys()) == ["fc1.bias", "fc1.weight", "fc2.bias", "fc2.weight"]
+        assert "layers.1.mlp.up_proj.weight" in model.model.tts_language_model.expected_keys()
+        assert "layers.1.mlp.up_proj.weight" not in model.model.language_model.expected_keys()
+
+        prompt = torch.from_numpy(z["prompt"])[None]
+        text = torch.from_numpy(z["text"])[None]
+        lm_len = all_prefilled_outputs["lm"]["last_hidden_state"].size(1)
+        inputs = {"input_ids": torch.zeros(1, lm_len, dtype=torch.long), "attention_mask": torch.ones(1, lm_len, dtype=torch.long),
+                  "tts_lm_input_ids": prompt, "tts_lm_attention_mask": torch.ones_like(prompt), "tts_text_ids": text,
+                  "speech_input_mask": torch.zeros(1, prompt.shape[1], dtype=torch.bool), "speech_tensors": None, "speech_masks": None}
+        for k, v in inputs.items():
+            if torch.is_tensor(v):
+                inputs[k] = v.to("cpu")                                                   # the demo's .to(target_device)
+        outputs = model.generate(**inputs, max_new_tokens=None, cfg_scale=1.5, tokenizer=TOK, generation_config={"do_sample": False},
+                                 verbose=True, all_prefilled_outputs=copy.deepcopy(all_prefilled_outputs),
+                                 _noise_fn=lambda frame, n2: draws[frame])               # the recorded draws: the only test hook
+    assert outputs.speech_outputs and outputs.speech_outputs[0] is not None
+    audio_samples = outputs.speech_outputs[0].shape[-1]
+    assert audio_samples % 3200 == 0 and audio_samples > 0
+    input_tokens = inputs["tts_text_ids"].shape[1]
+    output_tokens = outputs.sequences.shape[1]
+    generated_tokens = output_tokens - input_tokens - all_prefilled_outputs["tts_lm"]["last_hidden_state"].size(1)     # :337-339
+    # (the demo's arithmetic; with an EOS inside the first speech window only 5 of the 12 text ids were consumed and the window's
+    # 6 speech tokens are all in `sequences` although one frame of audio was kept -- the reference's own bookkeeping, :646-700)
+    assert generated_tokens == int(z["n_tokens"]) - 12 - 23
+    assert output_tokens == int(z["n_tokens"]) and bool(outputs.reach_max_step_sample[0]) == bool(z["reach_max"][0])
+    ref = torch.from_numpy(z["audio"])
+    got = outputs.speech_outputs[0].reshape(-1)
+    assert got.shape == ref.shape and float((got - ref).norm() / ref.norm()) <= 1e-4

@@ -116,10 +116,13 @@ class WeightHandle:
     `load_state_dict(sd, strict=False)` (uploads -> the engine re-packs), `.to(device)`, `.eval()`, `.config`,
     `.device`, `parameters()` (one placeholder tensor, enough for `next(model.parameters()).device`)."""
 
-    def __init__(self, owner, ref_prefix: str, config: Optional[dict] = None):
+    def __init__(self, owner, ref_prefix: str, config: Optional[dict] = None, to_engine=None, to_reference=None):
         self._owner = owner
         self._ref_prefix = ref_prefix
         self.config = _Ns(config or {})
+        # reference state_dict key <-> engine parameter name (the streaming model splits its layers differently)
+        self._to_engine = to_engine or map_param_name
+        self._to_reference = to_reference or _engine_name_to_reference
 
     @property
     def device(self):
@@ -142,9 +145,9 @@ class WeightHandle:
         """state_dict keys (relative to this component) the engine holds"""
         out = []
         for name in self._owner.engine.expected_weights():
-            for a, b in _PREFIX_BACK:
-                if name.startswith(b) and a.startswith(self._ref_prefix):
-                    out.append((a + name[len(b):])[len(self._ref_prefix):])
+            key = self._to_reference(name)
+            if key is not None and key.startswith(self._ref_prefix):
+                out.append(key[len(self._ref_prefix):])
         return out
 
     def load_state_dict(self, state_dict, strict: bool = True):
@@ -153,7 +156,7 @@ class WeightHandle:
         exp = eng.expected_weights()
         seen, unexpected = set(), []
         for k, v in state_dict.items():
-            name = map_param_name(self._ref_prefix + k)
+            name = self._to_engine(self._ref_prefix + k)
             if name is None or name not in exp:
                 unexpected.append(k)
                 continue
@@ -171,6 +174,13 @@ _PREFIX_BACK = tuple((a, b) for a, b in (
     ("model.acoustic_tokenizer.decoder.", "dec."), ("model.acoustic_tokenizer.encoder.", "aenc."),
     ("model.semantic_tokenizer.encoder.", "senc."), ("model.acoustic_connector.", "ac_conn."),
     ("model.semantic_connector.", "sem_conn.")))
+
+
+def _engine_name_to_reference(name: str):
+    for a, b in _PREFIX_BACK:
+        if name.startswith(b):
+            return a + name[len(b):]
+    return None
 
 
 class _ModelNamespace:

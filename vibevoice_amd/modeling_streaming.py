@@ -11,8 +11,13 @@ from typing import Callable, Optional
 
 import torch
 
+import json
+import os
+
+import numpy as np
+
 from .engine import Engine, EngineConfig
-from .modeling import VibeVoiceGenerationOutput, engine_config_from_reference
+from .modeling import VibeVoiceGenerationOutput, WeightHandle, _Ns, engine_config_from_reference
 
 TTS_TEXT_WINDOW_SIZE = 5
 TTS_SPEECH_WINDOW_SIZE = 6
@@ -43,6 +48,59 @@ def map_streaming_param_name(key: str, n_lm: int):
     return None
 
 
+_STREAM_PREFIXES = (("tts_eos_classifier.", "eos."), ("model.prediction_head.", "head."),
+                    ("model.acoustic_tokenizer.decoder.", "dec."), ("model.acoustic_connector.", "ac_conn."))
+
+
+def unmap_streaming_param_name(name: str, n_lm: int):
+    """engine parameter name -> reference state_dict key (inverse of map_streaming_param_name)."""
+    import re
+    m = re.match(r"lm\.layers\.(\d+)\.(.*)", name)
+    if m:
+        i = int(m.group(1))
+        return (f"model.language_model.layers.{i}.{m.group(2)}" if i < n_lm
+                else f"model.tts_language_model.layers.{i - n_lm}.{m.group(2)}")
+    table = {"lm.embed_tokens.weight": "model.language_model.embed_tokens.weight",
+             "lm.norm.weight": "model.tts_language_model.norm.weight", "tts_input_types.weight": "model.tts_input_types.weight"}
+    if name in table:
+        return table[name]
+    for a, b in _STREAM_PREFIXES:
+        if name.startswith(b):
+            return a + name[len(b):]
+    return None
+
+
+class _StreamingModelNamespace:
+    """`model.model` (VibeVoiceStreamingModel, modeling_vibevoice_streaming.py:108-164) as far as callers read it:
+    the two halves of the split decoder, the diffusion head, the acoustic tokenizer / connector and the input-type embedding
+    as weight-snapshot handles, `language_model.config._attn_implementation` (demo/streaming_inference_from_file.py:285-286)."""
+
+    def __init__(self, owner, config: dict, attn_implementation: str):
+        d = dict(config.get("decoder_config", {}))
+        d["_attn_implementation"] = attn_implementation
+        n_lm = owner.n_lm
+        kw = dict(to_engine=lambda k: map_streaming_param_name(k, n_lm), to_reference=lambda n: unmap_streaming_param_name(n, n_lm))
+        self.language_model = WeightHandle(owner, "model.language_model.", dict(d, num_hidden_layers=n_lm), **kw)
+        self.tts_language_model = WeightHandle(owner, "model.tts_language_model.", dict(d, num_hidden_layers=owner.n_tts), **kw)
+        self.tts_input_types = WeightHandle(owner, "model.tts_input_types.", **kw)
+        self.prediction_head = WeightHandle(owner, "model.prediction_head.", config.get("diffusion_head_config"), **kw)
+        self.acoustic_tokenizer = WeightHandle(owner, "model.acoustic_tokenizer.", config.get("acoustic_tokenizer_config"), **kw)
+        self.acoustic_connector = WeightHandle(owner, "model.acoustic_connector.", **kw)
+        self._owner = owner
+
+    @property
+    def speech_scaling_factor(self):
+        return torch.tensor(self._owner.speech_scaling_factor)
+
+    @property
+    def speech_bias_factor(self):
+        return torch.tensor(self._owner.speech_bias_factor)
+
+    @property
+    def noise_scheduler(self):
+        return self._owner.noise_scheduler
+
+
 def _kv_layers(past):
     """[(k, v)] per layer from an HF DynamicCache (4.x `.key_cache`, 5.x `.layers`) or a plain list."""
     if hasattr(past, "key_cache"):
@@ -53,13 +111,25 @@ def _kv_layers(past):
 
 
 class VibeVoiceStreamingForConditionalGenerationInference:
-    def __init__(self, config: dict, engine: Engine, model_dtype=torch.bfloat16):
+    """Drop-in for the reference class on the streaming generate() path (demo/streaming_inference_from_file.py:226-355:
+    from_pretrained -> eval -> set_ddpm_inference_steps -> model.model.language_model.config._attn_implementation ->
+    generate(**processor_inputs, all_prefilled_outputs=preset, ...)), backed by libvvhip.so."""
+
+    def __init__(self, config: dict, engine: Engine, model_dtype=torch.bfloat16, attn_implementation: Optional[str] = None):
         self.config_dict = config
+        self.config = _Ns(config)
         self.engine = engine
         self.dtype = model_dtype
         self.device = engine.device
         self.n_tts = engine.cfg.tts_layers
         self.n_lm = engine.cfg.lm_layers - self.n_tts
+        # what the attention really is on this path; the value the caller asked for is kept beside it
+        self.requested_attn_implementation = attn_implementation
+        self._param_placeholder = torch.empty(0, dtype=model_dtype, device=self.device)
+        self.model = _StreamingModelNamespace(self, config, "vvhip_mfma_flash_decoding_gfx950")
+        self.tts_eos_classifier = WeightHandle(self, "tts_eos_classifier.",
+                                               to_engine=lambda k: map_streaming_param_name(k, self.n_lm),
+                                               to_reference=lambda n: unmap_streaming_param_name(n, self.n_lm))
         self.ddpm_inference_steps = config["diffusion_head_config"].get("ddpm_num_inference_steps", 20)
         self.max_position_embeddings = config["decoder_config"].get("max_position_embeddings", 8192)
         self.speech_scaling_factor = float("nan")
@@ -76,8 +146,49 @@ class VibeVoiceStreamingForConditionalGenerationInference:
         self._emb = e.new(1, H)
         self._eos = e.new(1)
 
+    # ---- reference properties (modeling_vibevoice_streaming_inference.py:119-141) ----
+    @property
+    def noise_scheduler(self):
+        from . import schedule as _schedule
+        tv, _ = _schedule.make_table(self.ddpm_inference_steps, False)
+        return _Ns(num_inference_steps=self.ddpm_inference_steps, timesteps=torch.from_numpy(np.asarray(tv)).long(),
+                   config=_Ns(self.config_dict["diffusion_head_config"]))
+
+    prediction_head = property(lambda self: self.model.prediction_head)
+    acoustic_tokenizer = property(lambda self: self.model.acoustic_tokenizer)
+    acoustic_connector = property(lambda self: self.model.acoustic_connector)
+
+    def parameters(self):
+        yield self._param_placeholder
+
+    def to(self, *a, **k):
+        return self
+
     @classmethod
-    def from_state_dict(cls, config: dict, state_dict, model_dtype=torch.bfloat16, device=None, **runtime):
+    def from_pretrained(cls, path, torch_dtype=torch.bfloat16, device_map=None, attn_implementation=None, **runtime):
+        """config.json + *.safetensors of a VibeVoice-Realtime / Streaming-0.5B checkpoint directory, with the reference's
+        keyword arguments (demo/streaming_inference_from_file.py:244-276)."""
+        from safetensors import safe_open
+        with open(os.path.join(path, "config.json")) as f:
+            config = json.load(f)
+        files = sorted(fn for fn in os.listdir(path) if fn.endswith(".safetensors"))
+        if not files:
+            raise FileNotFoundError(f"no .safetensors shards under {path}")
+
+        def it():
+            for fn in files:
+                with safe_open(os.path.join(path, fn), framework="pt", device="cpu") as sf:
+                    for k in sf.keys():
+                        yield k, sf.get_tensor(k)
+        device = None
+        if isinstance(device_map, (str, torch.device)) and str(device_map) not in ("auto", "cpu"):
+            device = torch.device(device_map)
+        m = cls.from_state_dict(config, it(), torch_dtype or torch.bfloat16, device, attn_implementation=attn_implementation, **runtime)
+        m.source_path = path
+        return m
+
+    @classmethod
+    def from_state_dict(cls, config: dict, state_dict, model_dtype=torch.bfloat16, device=None, attn_implementation=None, **runtime):
         n_tts = config["tts_backbone_num_hidden_layers"]
         runtime.setdefault("n_slots", 2)
         ecfg = engine_config_from_reference(dict(config, semantic_tokenizer_config=None), tts_layers=n_tts,
@@ -99,7 +210,7 @@ class VibeVoiceStreamingForConditionalGenerationInference:
         miss = eng.missing_weights()
         if miss:
             raise RuntimeError(f"checkpoint is missing {len(miss)} parameters, e.g. {miss[:4]}")
-        m = cls(config, eng, model_dtype)
+        m = cls(config, eng, model_dtype, attn_implementation=attn_implementation)
         if scaling is not None and bias is not None:
             m.set_speech_factors(scaling, bias)
         return m
@@ -128,6 +239,9 @@ class VibeVoiceStreamingForConditionalGenerationInference:
                  return_speech=True, cfg_scale=1.0, stop_check_fn: Optional[Callable[[], bool]] = None, **kwargs):
         e = self.engine
         all_pre = kwargs.pop("all_prefilled_outputs")
+        # the processor's prompt ids (vibevoice_streaming_processor.py:180-325): the preset's caches already hold them; the
+        # reference returns them in front of the generated ids (`sequences=tts_lm_input_ids`, :722)
+        prompt_ids = kwargs.pop("tts_lm_input_ids", None)
         noise_fn = kwargs.pop("_noise_fn", None)
         trace = kwargs.pop("_trace", None)
         marks = kwargs.pop("_marks", None)            # bench hook: first-audio timestamp
@@ -222,6 +336,9 @@ class VibeVoiceStreamingForConditionalGenerationInference:
                 audio_streamer.end()
             audio = torch.cat(chunks, dim=-1).to(self.dtype) if chunks else None
         e.sync()
-        return VibeVoiceGenerationOutput(sequences=torch.tensor([seq_tail], dtype=torch.long),
+        seq = torch.tensor([seq_tail], dtype=torch.long)
+        if prompt_ids is not None:
+            seq = torch.cat([prompt_ids.reshape(1, -1).to("cpu", torch.long), seq], dim=-1)
+        return VibeVoiceGenerationOutput(sequences=seq,
                                          speech_outputs=[audio] if return_speech else None,
                                          reach_max_step_sample=torch.tensor([reach_max]))
