@@ -70,14 +70,19 @@ def _alpha_sigma(sigma):
 class DPMState:
     """The mutable part of the scheduler (model_outputs history, counters)."""
 
-    def __init__(self, sched: Schedule):
+    def __init__(self, sched: Schedule, algorithm_type: str = "dpmsolver++"):
+        # "dpmsolver++" (the configuration the model classes build, modeling_vibevoice.py:138-142) or "sde-dpmsolver++" (what
+        # demo/gradio_demo.py:142-146 swaps in through noise_scheduler.from_config)
+        assert algorithm_type in ("dpmsolver++", "sde-dpmsolver++"), algorithm_type
         self.s = sched
+        self.sde = algorithm_type == "sde-dpmsolver++"
         self.step_index = 0
         self.lower_order_nums = 0
         self.model_outputs = [None, None]
 
-    def step(self, model_output, sample):
-        """One scheduler.step() (dpm_solver.py:935-1022) for solver_order=2."""
+    def step(self, model_output, sample, noise=None):
+        """One scheduler.step() (dpm_solver.py:935-1022) for solver_order=2.  `noise`: the fp32 variance noise of the stochastic
+        solver (drawn by the reference inside step(), :994-997, shape of model_output)."""
         s = self.s
         i = self.step_index
         lower_order_final = (i == s.n - 1)          # final_sigmas_type == "zero"
@@ -97,7 +102,11 @@ class DPMState:
             lambda_t = torch.log(alpha_t) - torch.log(sigma_t)
             lambda_s = torch.log(alpha_s) - torch.log(sigma_s)
             h = lambda_t - lambda_s
-            prev = (sigma_t / sigma_s) * sample - (alpha_t * (torch.exp(-h) - 1.0)) * x0
+            if self.sde:        # dpm_solver.py:680-686
+                prev = ((sigma_t / sigma_s * torch.exp(-h)) * sample + (alpha_t * (1 - torch.exp(-2.0 * h))) * x0
+                        + sigma_t * torch.sqrt(1.0 - torch.exp(-2 * h)) * noise.to(torch.float32))
+            else:
+                prev = (sigma_t / sigma_s) * sample - (alpha_t * (torch.exp(-h) - 1.0)) * x0
         else:
             sigma_t, sigma_s0, sigma_s1 = s.sigmas[i + 1], s.sigmas[i], s.sigmas[i - 1]
             alpha_t, sigma_t = _alpha_sigma(sigma_t)
@@ -110,9 +119,15 @@ class DPMState:
             h, h_0 = lambda_t - lambda_s0, lambda_s0 - lambda_s1
             r0 = h_0 / h
             D0, D1 = m0, (1.0 / r0) * (m0 - m1)
-            prev = ((sigma_t / sigma_s0) * sample
-                    - (alpha_t * (torch.exp(-h) - 1.0)) * D0
-                    - 0.5 * (alpha_t * (torch.exp(-h) - 1.0)) * D1)
+            if self.sde:        # dpm_solver.py:785-793 (midpoint)
+                prev = ((sigma_t / sigma_s0 * torch.exp(-h)) * sample
+                        + (alpha_t * (1 - torch.exp(-2.0 * h))) * D0
+                        + 0.5 * (alpha_t * (1 - torch.exp(-2.0 * h))) * D1
+                        + sigma_t * torch.sqrt(1.0 - torch.exp(-2 * h)) * noise.to(torch.float32))
+            else:
+                prev = ((sigma_t / sigma_s0) * sample
+                        - (alpha_t * (torch.exp(-h) - 1.0)) * D0
+                        - 0.5 * (alpha_t * (torch.exp(-h) - 1.0)) * D1)
         if self.lower_order_nums < 2:
             self.lower_order_nums += 1
         self.step_index += 1
@@ -120,7 +135,7 @@ class DPMState:
 
 
 def sample_speech_tokens(head_fn, condition, neg_condition, cfg_scale, num_steps,
-                         noise, t_cast_dtype=None):
+                         noise, t_cast_dtype=None, algorithm_type="dpmsolver++", step_noise=None):
     """modeling_vibevoice_inference.py:697-710.
 
     head_fn(noisy[2n,64], t[2n], cond[2n,H]) -> [2n,64]
@@ -130,12 +145,14 @@ def sample_speech_tokens(head_fn, condition, neg_condition, cfg_scale, num_steps
            (`t.repeat(..).to(combined)`, :705); pass torch.bfloat16 to
            reproduce the bf16 GPU path's 999->1000 rounding, None for fp32.
     """
+    # step_noise (stochastic solver only): [num_steps, 2n, 64] -- the draws scheduler.step() makes, one per solver step, with
+    # the shape of the model output (both CFG halves; only the first half survives the next step's `speech[:n]`)
     sched = Schedule(num_steps)
-    st = DPMState(sched)
+    st = DPMState(sched, algorithm_type)
     condition = torch.cat([condition, neg_condition], dim=0)
     speech = noise.to(condition)
     n2 = speech.shape[0]
-    for t in sched.timesteps:
+    for i, t in enumerate(sched.timesteps):
         half = speech[: n2 // 2]
         combined = torch.cat([half, half], dim=0)
         tt = t.repeat(n2).to(combined)
@@ -145,5 +162,5 @@ def sample_speech_tokens(head_fn, condition, neg_condition, cfg_scale, num_steps
         cond_eps, uncond_eps = torch.split(eps, n2 // 2, dim=0)
         half_eps = uncond_eps + cfg_scale * (cond_eps - uncond_eps)
         eps = torch.cat([half_eps, half_eps], dim=0)
-        speech = st.step(eps, speech)
+        speech = st.step(eps, speech, None if step_noise is None else step_noise[i])
     return speech[: n2 // 2]

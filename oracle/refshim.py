@@ -48,6 +48,15 @@ def install():
         def register_to_config(self, **kw):
             self.__dict__.setdefault("_internal_dict", _Cfg()).update(kw)
 
+        @classmethod
+        def from_config(cls, config, **kwargs):
+            # diffusers' ConfigMixin.from_config: the recorded __init__ arguments with the overrides applied
+            # (demo/gradio_demo.py:142-146 swaps the solver's algorithm_type this way).  Plumbing only.
+            names = set(inspect.signature(cls.__init__).parameters) - {"self"}
+            d = {k: v for k, v in dict(config).items() if k in names}
+            d.update({k: v for k, v in kwargs.items() if k in names})
+            return cls(**d)
+
     def register_to_config(init):
         @functools.wraps(init)
         def inner(self, *a, **kw):

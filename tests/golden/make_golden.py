@@ -102,6 +102,49 @@ def gen_dpm_and_head():
         save(f"sampler_{n_steps}.npz", pos=pos, neg=neg, noise=noise, cfg_scale=cfg_scale,
              latent=speech[:2], per_step=torch.stack(per_step), wsum=synth.checksum(w))
 
+    # the same loop with the scheduler demo/gradio_demo.py:142-146 installs (`noise_scheduler.from_config(config,
+    # algorithm_type='sde-dpmsolver++', beta_schedule='squaredcos_cap_v2')`): scheduler.step() draws its own variance noise
+    # (randn_tensor, dpm_solver.py:994-997) -- recorded here through the module's randn_tensor
+    import vibevoice.schedule.dpm_solver as ref_dpm
+    for n_steps in (5, 10):
+        base = DPMSolverMultistepScheduler(num_train_timesteps=1000, beta_schedule="cosine", prediction_type="v_prediction")
+        s = base.from_config(base.config, algorithm_type="sde-dpmsolver++", beta_schedule="squaredcos_cap_v2")
+        assert s.config.algorithm_type == "sde-dpmsolver++" and s.config.prediction_type == "v_prediction"
+        g = synth.Gen(300 + n_steps)
+        pos = g.normal((2, hc.hidden), 1.0, mat=False)
+        neg = g.normal((2, hc.hidden), 1.0, mat=False)
+        noise = g.normal((4, hc.latent), 1.0, mat=False)
+        cfg_scale = 1.3
+        s.set_timesteps(n_steps)
+        condition = torch.cat([pos, neg], dim=0)
+        speech = noise.clone()
+        per_step, draws = [], []
+        orig = ref_dpm.randn_tensor
+
+        def rec(shape, generator=None, device=None, dtype=None):
+            t = orig(shape, generator=generator, device=device, dtype=dtype)
+            draws.append(t.clone())
+            return t
+        ref_dpm.randn_tensor = rec
+        torch.manual_seed(4000 + n_steps)
+        try:
+            for t in s.timesteps:
+                half = speech[: len(speech) // 2]
+                combined = torch.cat([half, half], dim=0)
+                eps = head(combined, t.repeat(combined.shape[0]).to(combined), condition=condition)
+                cond_eps, uncond_eps = torch.split(eps, len(eps) // 2, dim=0)
+                half_eps = uncond_eps + cfg_scale * (cond_eps - uncond_eps)
+                eps = torch.cat([half_eps, half_eps], dim=0)
+                speech = s.step(eps, t, speech).prev_sample
+                per_step.append(speech[:2].clone())
+        finally:
+            ref_dpm.randn_tensor = orig
+        assert len(draws) == n_steps and tuple(draws[0].shape) == (4, hc.latent) and draws[0].dtype == torch.float32
+        torch.manual_seed(4000 + n_steps)            # the draws are plain torch.randn calls on the global generator
+        assert all(torch.equal(d, torch.randn(4, hc.latent)) for d in draws)
+        save(f"sampler_sde_{n_steps}.npz", pos=pos, neg=neg, noise=noise, cfg_scale=cfg_scale, seed=4000 + n_steps,
+             step_noise=torch.stack(draws), latent=speech[:2], per_step=torch.stack(per_step), wsum=synth.checksum(w))
+
 
 @torch.no_grad()
 def gen_codec():

@@ -58,6 +58,40 @@ def test_sampler(n):
     close(lat, g["latent"], 1e-4)
 
 
+@pytest.mark.parametrize("n", [5, 10])
+def test_sampler_sde(n):
+    """The stochastic solver demo/gradio_demo.py:142-146 installs (`noise_scheduler.from_config(..., algorithm_type=
+    'sde-dpmsolver++', beta_schedule='squaredcos_cap_v2')`): golden = the reference scheduler built exactly that way, its own
+    variance-noise draws recorded (they are plain torch.randn([2n, 64]) calls on the global generator, one per solver step)."""
+    g = load(f"sampler_sde_{n}.npz")
+    hc = synth.HeadCfg()
+    w = synth.head_weights(hc)
+    check_w(w, g)
+    lat = dpm.sample_speech_tokens(
+        lambda x, t, c: head.head_forward(w, x, t, c, hc.layers, hc.eps),
+        g["pos"], g["neg"], g["cfg_scale"], n, g["noise"], algorithm_type="sde-dpmsolver++", step_noise=g["step_noise"])
+    close(lat, g["latent"], 1e-4)
+    # the draws are the global generator's stream: seeded the same way, N x randn(2n, 64) reproduces them
+    torch.manual_seed(int(g["seed"]))
+    for i in range(n):
+        assert torch.equal(torch.randn(4, hc.latent), g["step_noise"][i])
+    # and the product's coefficient table (vibevoice_amd/schedule.py) restates the same update: x' = cs x + c0 x0 + c1 dx0 + cn eps
+    from vibevoice_amd import schedule
+    tv, coef = schedule.make_table(n, False, "sde-dpmsolver++")
+    assert coef.shape == (n, 6) and coef[-1, 5] == 0.0 and (coef[:-1, 5] > 0).all()
+    x = g["noise"][:2].clone().float()
+    x0p = torch.zeros_like(x)
+    cond = torch.cat([g["pos"], g["neg"]])
+    for i in range(n):
+        eps = head.head_forward(w, torch.cat([x, x]), torch.full((4,), float(tv[i])), cond, hc.layers, hc.eps)
+        v = eps[2:] + float(g["cfg_scale"]) * (eps[:2] - eps[2:])
+        a, s_, cs, c0, c1, cn = [float(c) for c in coef[i]]
+        x0 = a * x - s_ * v
+        x = cs * x + c0 * x0 + c1 * (x0 - x0p) + cn * g["step_noise"][i][:2]
+        x0p = x0
+        close(x, g["per_step"][i], 2e-4)
+
+
 def test_codec_decode_stream_and_reset():
     g = load("codec_decode.npz")
     cc = synth.CodecCfg()

@@ -41,18 +41,33 @@ def _as(sigma):
     return a, sigma * a
 
 
-def make_table(n_steps, t_cast_bf16=False):
-    """-> (t_values float32[n], coef float32[n,5])"""
+ALGORITHMS = ("dpmsolver++", "sde-dpmsolver++")
+
+
+def make_table(n_steps, t_cast_bf16=False, algorithm_type="dpmsolver++"):
+    """-> (t_values float32[n], coef float32[n,5]) for the deterministic solver the model classes build, or coef float32[n,6]
+    = {a, s, cs, c0, c1, cn} for "sde-dpmsolver++" (what demo/gradio_demo.py:142-146 swaps in):
+        x' = cs x + c0 x0 + c1 (x0 - x0_prev) + cn eps_i,  eps_i ~ N(0, 1) drawn once per solver step
+    with cs = (sigma_t / sigma_s) e^{-h}, c0 = alpha_t (1 - e^{-2h}), c1 = c0 / (2 r0), cn = sigma_t sqrt(1 - e^{-2h})
+    (dpm_solver.py:680-686, 785-793)."""
+    if algorithm_type not in ALGORITHMS:
+        raise NotImplementedError(f"noise scheduler algorithm_type={algorithm_type!r}: the HIP sampler implements {ALGORITHMS}")
+    sde = algorithm_type == "sde-dpmsolver++"
     ts, sig = timesteps_and_sigmas(n_steps)
-    coef = np.zeros((n_steps, 5), dtype=np.float32)
+    coef = np.zeros((n_steps, 6 if sde else 5), dtype=np.float32)
     for i in range(n_steps):
         a_i, s_i = _as(sig[i])
         a_t, s_t = _as(sig[i + 1])
         lam_t = torch.log(a_t) - torch.log(s_t)
         lam_s = torch.log(a_i) - torch.log(s_i)
         h = lam_t - lam_s
-        c0 = -(a_t * (torch.exp(-h) - 1.0))
-        cs = s_t / s_i
+        if sde:
+            c0 = a_t * (1 - torch.exp(-2.0 * h))
+            cs = s_t / s_i * torch.exp(-h)
+            cn = s_t * torch.sqrt(1.0 - torch.exp(-2 * h))
+        else:
+            c0 = -(a_t * (torch.exp(-h) - 1.0))
+            cs = s_t / s_i
         c1 = torch.zeros(())
         first_order = (i == 0) or (i == n_steps - 1)      # lower_order_nums<1 / final sigma == 0
         if not first_order:
@@ -60,7 +75,9 @@ def make_table(n_steps, t_cast_bf16=False):
             lam_p = torch.log(a_p) - torch.log(s_p)
             r0 = (lam_s - lam_p) / h
             c1 = 0.5 * c0 * (1.0 / r0)
-        coef[i] = [float(a_i), float(s_i), float(cs), float(c0), float(c1)]
+        coef[i, :5] = [float(a_i), float(s_i), float(cs), float(c0), float(c1)]
+        if sde:
+            coef[i, 5] = float(cn)
     tv = torch.from_numpy(ts).to(torch.float32)
     if t_cast_bf16:
         # the reference feeds `t.repeat(..).to(combined)` to the head
