@@ -78,6 +78,10 @@ int vv_set_valid_tokens(vv_ctx* ctx, const int* ids, int n);
  * {alpha_i, sigma_i, sigma_{i+1}/sigma_i, -alpha_{i+1}(e^{-h}-1), second-order term}
  * (dpm_solver.py:321-423,581-584,669-677,738-764) -- computed by vibevoice_amd/schedule.py */
 int vv_set_schedule(vv_ctx* ctx, int n_steps, const float* t, const float* coef, void* stream);
+/* The sde-dpmsolver++ table (noise_scheduler.from_config(..., algorithm_type='sde-dpmsolver++'), demo/gradio_demo.py:142-146):
+ * coef6[N][6] = {alpha_i, sigma_i, (sigma_{i+1}/sigma_i) e^{-h}, alpha_{i+1}(1 - e^{-2h}), second-order term,
+ * sigma_{i+1} sqrt(1 - e^{-2h})} (dpm_solver.py:680-686,785-793); sample with vv_diffusion_sample_sde */
+int vv_set_schedule_sde(vv_ctx* ctx, int n_steps, const float* t, const float* coef6, void* stream);
 
 /* ---- KV caches: cache id = 2*slot (+1 for the CFG-negative branch) */
 typedef struct vv_row { int cache; int pos; } vv_row;
@@ -120,6 +124,14 @@ int vv_lm_logits(vv_ctx* ctx, void* stream, int n, const float* hidden_dev, floa
  * conditions, noise_dev [n][latent], -> latent_out_dev [n][latent] */
 int vv_diffusion_sample(vv_ctx* ctx, void* stream, int n, const float* cond_dev, const float* noise_dev,
                         float cfg_scale, float* latent_out_dev);
+/* The same sampler under the stochastic solver the gradio demo installs (demo/gradio_demo.py:142-146:
+ * noise_scheduler.from_config(config, algorithm_type='sde-dpmsolver++', ...)): scheduler.step() adds
+ * sigma_t sqrt(1 - e^{-2h}) * eps_i with eps_i = randn(model_output.shape) drawn per solver step
+ * (vibevoice/schedule/dpm_solver.py:680-686, 785-793, 994-997).  step_noise_dev [n_steps][n][latent] fp32
+ * = those draws (first n rows of each: only they reach the next step, modeling_vibevoice_inference.py:703-704).
+ * Needs a table from vv_set_schedule_sde; vv_diffusion_sample refuses to run on a stochastic table. */
+int vv_diffusion_sample_sde(vv_ctx* ctx, void* stream, int n, const float* cond_dev, const float* noise_dev,
+                            const float* step_noise_dev, float cfg_scale, float* latent_out_dev);
 /* one prediction_head forward (modular_vibevoice_diffusion_head.py:254-280) for tests:
  * noisy [n][latent], t[n] (host), cond [n][H] -> out [n][latent].  Synchronous. */
 int vv_head_forward(vv_ctx* ctx, void* stream, int n, const float* noisy_dev, const float* t_host,

@@ -25,7 +25,7 @@ Negative (CFG) branch, compact form of :379-386, :549-565, :576-624:
 PARITY PINNED: the reference's own generate() runs in the build container under transformers 5.15 through the
 API shims of oracle/refshim.install_generate_shims(); tests/golden/make_golden.py::gen_generate recorded it on the
 tiny seeded model (generate_forced_b1 / _b2, generate_greedy_b1, generate_cap_b1, generate_ragged_voice_b1,
-generate_sampled_b1) and tests/test_oracle_golden.py holds this loop to those files (token sequences identical,
+generate_sampled_b1, generate_sde_b1 / _b2 under the gradio demo's stochastic scheduler) and tests/test_oracle_golden.py holds this loop to those files (token sequences identical,
 waveform rel-L2 <= 1e-4).  Caveat: the pinned dependency is transformers==4.51.3 (pyproject.toml:22), the recording
 ran on 5.15 with its 4.51.3 behaviours restored by the shims.
 """
@@ -100,8 +100,11 @@ def oracle_generate(m: OracleModel, tok: TokenIds, input_ids, attention_mask,
                     cfg_scale=1.3, num_steps=10, max_new_tokens=None, max_length_times=2,
                     noise_fn: Callable = None, prefill_noise=None,
                     forced_tokens: Optional[List[List[int]]] = None,
-                    do_sample=False, trace: Optional[Trace] = None):
-    """Returns (sequences [B, L0+steps], speech_outputs list, reach_max_step_sample)."""
+                    do_sample=False, trace: Optional[Trace] = None,
+                    algorithm_type="dpmsolver++", sde_noise_fn: Callable = None):
+    """Returns (sequences [B, L0+steps], speech_outputs list, reach_max_step_sample).
+    algorithm_type "sde-dpmsolver++": the scheduler demo/gradio_demo.py:142-146 installs; sde_noise_fn(step, N, 2n) ->
+    [N, 2n, 64], the variance noise scheduler.step() draws per solver step (dpm_solver.py:994-997)."""
     B, L0 = input_ids.shape
     if max_new_tokens is None:
         max_new_tokens = m.max_position_embeddings - L0
@@ -188,9 +191,11 @@ def oracle_generate(m: OracleModel, tok: TokenIds, input_ids, attention_mask,
             neg_hidden = torch.stack(neg_hidden)
             pos_cond = hidden[diff]
             noise = noise_fn(step, 2 * n)
+            sn = sde_noise_fn(step, num_steps, 2 * n) if algorithm_type == "sde-dpmsolver++" else None
             lat = dpm.sample_speech_tokens(
                 lambda x, t, c: head.head_forward(m.head_w, x, t, c, m.head_layers, m.head_eps),
-                pos_cond, neg_hidden, cfg_scale, num_steps, noise, m.t_cast_dtype)
+                pos_cond, neg_hidden, cfg_scale, num_steps, noise, m.t_cast_dtype,
+                algorithm_type=algorithm_type, step_noise=sn)
             scaled = lat / m.scaling - m.bias
             sem_list = []
             for j, b in enumerate(diff):

@@ -62,8 +62,9 @@ class FakeEngine:
     def set_valid_tokens(self, valid):
         self.valid = list(valid)
 
-    def set_num_steps(self, n, t_cast_bf16=False):
+    def set_num_steps(self, n, t_cast_bf16=False, algorithm_type="dpmsolver++"):
         self.n_steps = n
+        self.algorithm_type = algorithm_type
 
     def set_speech_factors(self, scaling, bias):
         pass
@@ -87,11 +88,15 @@ class FakeEngine:
         out.reshape(-1)[:n * nv].copy_(F.linear(hidden[:n], self.om.lm_head)[:, self.valid].reshape(-1))
 
     # ---- diffusion ----
-    def diffusion_sample(self, n, cond, noise, cfg_scale, latent_out):
+    def diffusion_sample(self, n, cond, noise, cfg_scale, latent_out, step_noise=None):
         om = self.om
         nz = torch.cat([noise[:n], noise[:n]])
+        algo = getattr(self, "algorithm_type", "dpmsolver++")
+        assert (step_noise is not None) == (algo == "sde-dpmsolver++")       # the C ABI refuses the mismatch too
+        sn = None if step_noise is None else torch.cat([step_noise[:, :n], step_noise[:, :n]], dim=1)    # [N, 2n, 64]
         lat = dpm.sample_speech_tokens(lambda x, t, c: head.head_forward(om.head_w, x, t, c, om.head_layers, om.head_eps),
-                                       cond[:n].clone(), cond[n:2 * n].clone(), cfg_scale, self.n_steps, nz, om.t_cast_dtype)
+                                       cond[:n].clone(), cond[n:2 * n].clone(), cfg_scale, self.n_steps, nz, om.t_cast_dtype,
+                                       algorithm_type=algo, step_noise=sn)
         latent_out[:n] = lat
         self.calls["samples"] += 1
 

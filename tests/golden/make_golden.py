@@ -330,7 +330,7 @@ def gen_generate():
             # NOTE: finished_flags deliberately left untouched -- the reference's own streamer sets them, which makes
             # generate() stop at the first finished sample (:443-447); here the whole batch is recorded.
 
-    def run(name, B, plans, seed, max_new_tokens=None, do_sample=False, wav_len=3 * 3200, streamer=False):
+    def run(name, B, plans, seed, max_new_tokens=None, do_sample=False, wav_len=3 * 3200, streamer=False, sde=False):
         g = synth.Gen(seed)
         lens = [21, 17][:B]
         L0 = max(lens)
@@ -374,6 +374,14 @@ def gen_generate():
             return t
         Ref._get_logits_processor = glp
         torch.randn, torch.randn_like = rec_randn, rec_like
+        base_sched = m.model.noise_scheduler
+        if sde:     # demo/gradio_demo.py:142-146, verbatim
+            m.model.noise_scheduler = m.model.noise_scheduler.from_config(
+                m.model.noise_scheduler.config,
+                algorithm_type='sde-dpmsolver++',
+                beta_schedule='squaredcos_cap_v2'
+            )
+            m.set_ddpm_inference_steps(num_steps=5)
         try:
             torch.manual_seed(seed)
             out = m.generate(input_ids=ids, attention_mask=mask, tokenizer=T(), cfg_scale=1.3, max_new_tokens=max_new_tokens,
@@ -385,6 +393,7 @@ def gen_generate():
         finally:
             torch.randn, torch.randn_like = o_randn, o_like
             Ref._get_logits_processor = orig_glp
+            m.model.noise_scheduler = base_sched
         arrs = dict(input_ids=ids, attention_mask=mask, speech_input_mask=sim, speech_tensors=speech, speech_masks=smask,
                     sequences=out.sequences, reach_max=out.reach_max_step_sample, n_draws=len(draws), seed=seed,
                     forced=np.array([p + [X] * (64 - len(p)) for p in plans]) if plans is not None else np.zeros((0,)),
@@ -408,6 +417,10 @@ def gen_generate():
     run("generate_ragged_voice_b1.npz", 1, [[D, D, X]], seed=53, wav_len=8000)
     # length cap: the forced plan would go on, max_new_tokens stops it (reach_max_step_sample bookkeeping, :523-539)
     run("generate_cap_b1.npz", 1, [[D] * 50], seed=41, max_new_tokens=6)
+    # the gradio demo's scheduler (stochastic sde-dpmsolver++): the solver's variance-noise draws join the recorded stream
+    # (per frame: the initial randn(2n, 64), then one randn(2n, 64) per solver step inside scheduler.step())
+    run("generate_sde_b1.npz", 1, [[D, D, D, E, S, D, D, X]], seed=67, sde=True)
+    run("generate_sde_b2.npz", 2, [[D, D, D, E, S, D, D, X], [D, D, E, S, D, X]], seed=71, sde=True)
 
 
 @torch.no_grad()

@@ -463,3 +463,68 @@ def test_reference_streaming_demo_call_sequence(monkeypatch, tmp_path, capsys):
     ref = torch.from_numpy(z["audio"])
     got = outputs.speech_outputs[0].reshape(-1)
     assert got.shape == ref.shape and float((got - ref).norm() / ref.norm()) <= 1e-4
+
+
+# ---------------------------------------------------------------- the gradio demo's scheduler swap (demo/gradio_demo.py:51-150,549-602)
+@pytest.mark.parametrize("name", ["generate_sde_b1", "generate_sde_b2"])
+def test_gradio_demo_scheduler_swap_and_generate(product, capsys, name):
+    """demo/gradio_demo.py:139-150 then :566-602 replayed against the product class: eval() ->
+    `model.model.noise_scheduler = model.model.noise_scheduler.from_config(config, algorithm_type='sde-dpmsolver++',
+    beta_schedule='squaredcos_cap_v2')` -> set_ddpm_inference_steps -> the attention print -> generate(**inputs,
+    max_new_tokens=None, cfg_scale, tokenizer, generation_config, generator=..., audio_streamer, stop_check_fn, verbose=False,
+    refresh_negative=True, is_prefill=...).  Nothing is injected but the forced token plan (random weights never emit
+    <speech_diffusion>): seeded like the run that recorded the golden with the REFERENCE's own generate() under the same
+    swap, the product's draws -- prefill, per-frame initial noise, one randn(2n, 64) per solver step for the stochastic
+    solver -- come off the global generator in the reference's order and the result lands on the golden."""
+    modeling, path = product
+    model = modeling.VibeVoiceForConditionalGenerationInference.from_pretrained(
+        path, torch_dtype=torch.float32, device_map="cuda", attn_implementation="flash_attention_2")
+    model.eval()
+    # Use SDE solver by default (:141-146)
+    model.model.noise_scheduler = model.model.noise_scheduler.from_config(
+        model.model.noise_scheduler.config,
+        algorithm_type='sde-dpmsolver++',
+        beta_schedule='squaredcos_cap_v2'
+    )
+    model.set_ddpm_inference_steps(num_steps=5)
+    if hasattr(model.model, 'language_model'):
+        print(f"Language model attention: {model.model.language_model.config._attn_implementation}")
+    assert "Language model attention: vvhip" in capsys.readouterr().out
+    sched = model.model.noise_scheduler
+    assert sched.config.algorithm_type == "sde-dpmsolver++" and sched.config.beta_schedule == "squaredcos_cap_v2"
+    assert sched.config.prediction_type == "v_prediction" and sched.config.solver_order == 2 and sched.num_inference_steps == 5
+    # configurations the HIP sampler does not implement are refused at the assignment, not run as something else
+    with pytest.raises(NotImplementedError):
+        model.model.noise_scheduler = sched.from_config(sched.config, algorithm_type="dpmsolver")
+    with pytest.raises(NotImplementedError):
+        model.model.noise_scheduler = sched.from_config(sched.config, use_karras_sigmas=True)
+    assert model.model.noise_scheduler.config.algorithm_type == "sde-dpmsolver++"      # a refused swap changes nothing
+
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    B = z["input_ids"].shape[0]
+    inputs = {"input_ids": torch.from_numpy(z["input_ids"]), "attention_mask": torch.from_numpy(z["attention_mask"]),
+              "speech_tensors": torch.from_numpy(z["speech_tensors"]), "speech_masks": torch.from_numpy(z["speech_masks"]),
+              "speech_input_mask": torch.from_numpy(z["speech_input_mask"])}
+    forced = [z["forced"][b][:int(z["forced_len"][b])].tolist() for b in range(B)]
+    stop_generation = False
+    generator = torch.Generator()                    # :579-586: created, seeded, passed -- and never consumed by generate()
+    generator.manual_seed(123)
+    model.set_ddpm_inference_steps(num_steps=int(5))                                     # :568
+    torch.manual_seed(int(z["seed"]))
+    outputs = model.generate(**inputs, max_new_tokens=None, cfg_scale=1.3, tokenizer=TOK, generation_config={'do_sample': False},
+                             generator=generator, audio_streamer=None, stop_check_fn=lambda: stop_generation, verbose=False,
+                             refresh_negative=True, is_prefill=True, _forced_tokens=forced)
+    assert torch.equal(outputs.sequences.cpu(), torch.from_numpy(z["sequences"]))
+    assert torch.equal(outputs.reach_max_step_sample.cpu(), torch.from_numpy(z["reach_max"]))
+    for b in range(B):
+        ref = torch.from_numpy(z[f"audio_{b}"])
+        got = outputs.speech_outputs[b].reshape(-1)
+        assert got.shape == ref.shape and float((got - ref).norm() / ref.norm()) <= 1e-4
+    # back to the deterministic solver: the same seeded call now reproduces the plain golden's behaviour class (no step draws)
+    model.model.noise_scheduler = sched.from_config(sched.config, algorithm_type="dpmsolver++")
+    assert model.model.noise_scheduler.config.algorithm_type == "dpmsolver++"
+    torch.manual_seed(int(z["seed"]))
+    out2 = model.generate(**inputs, max_new_tokens=None, cfg_scale=1.3, tokenizer=TOK, generation_config={'do_sample': False},
+                          verbose=False, is_prefill=True, _forced_tokens=forced)
+    assert torch.equal(out2.sequences.cpu(), outputs.sequences.cpu())
+    assert not torch.allclose(out2.speech_outputs[0].float(), outputs.speech_outputs[0].float())      # a different solver

@@ -431,3 +431,48 @@ def test_abi_refuses_out_of_range_arguments(sm):
     eng.lm_forward([(0, 0)], x[:1], y[:1])
     eng.sync()
     assert torch.isfinite(y[:1]).all()
+
+
+def test_generate_under_the_gradio_scheduler(sm):
+    """generate() on the engine after demo/gradio_demo.py:142-146's scheduler swap (sde-dpmsolver++): forced desynchronised
+    batch of 2 with a voice prompt against the oracle loop fed the same initial noise and the same per-step variance noise
+    (the oracle loop itself is pinned to the reference's generate() under that swap: tests/golden/generate_sde_b*.npz)."""
+    from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference
+    forced = [[D, D, D, E, S, D, D, X], [D, D, E, S, D, X]]
+    ids, mask, sim, st, smk = make_inputs(sm, 2, True, 83)
+    g = synth.Gen(84)
+    pre = (g.normal((2,), 1.0, mat=False), g.normal((2, 3, 64), 1.0, mat=False))
+    bank, sbank = {}, {}
+
+    def noise_fn(step, n2):
+        if (step, n2) not in bank:
+            bank[(step, n2)] = synth.Gen(83 * 1000 + step).normal((n2, 64), 1.0, mat=False)
+        return bank[(step, n2)]
+
+    def sde_fn(step, N, n2):
+        if (step, N, n2) not in sbank:
+            sbank[(step, N, n2)] = synth.Gen(83 * 2000 + step).normal((N, n2, 64), 1.0, mat=False)
+        return sbank[(step, N, n2)]
+    om = sm.oracle_model(kv_round_bf16=True)
+    otr = ogen.Trace()
+    oseq, oaud, omax = ogen.oracle_generate(om, TOK, ids, mask, st, smk, sim, cfg_scale=1.3, num_steps=5, noise_fn=noise_fn,
+                                            prefill_noise=pre, forced_tokens=forced, trace=otr,
+                                            algorithm_type="sde-dpmsolver++", sde_noise_fn=sde_fn)
+    cfgd = {"decoder_config": {"max_position_embeddings": sm.lmcfg.max_pos}, "diffusion_head_config": {"ddpm_num_inference_steps": 5},
+            "acoustic_tokenizer_config": {"fix_std": 0.5, "std_dist_type": "gaussian"}}
+    m = VibeVoiceForConditionalGenerationInference(cfgd, sm.eng, model_dtype=torch.float32)
+    m.set_speech_factors(sm.scaling, sm.bias)
+    m.model.noise_scheduler = m.model.noise_scheduler.from_config(m.model.noise_scheduler.config, algorithm_type="sde-dpmsolver++",
+                                                                  beta_schedule="squaredcos_cap_v2")
+    m.set_ddpm_inference_steps(num_steps=5)
+    tok = types.SimpleNamespace(speech_start_id=TOK.speech_start_id, speech_end_id=TOK.speech_end_id,
+                                speech_diffusion_id=TOK.speech_diffusion_id, eos_token_id=TOK.eos_token_id,
+                                bos_token_id=None, pad_token_id=TOK.pad_token_id)
+    htr = ogen.Trace()
+    try:
+        out = m.generate(input_ids=ids, attention_mask=mask, speech_tensors=st, speech_masks=smk, speech_input_mask=sim, cfg_scale=1.3,
+                         tokenizer=tok, generation_config={"do_sample": False}, _forced_tokens=forced, _noise_fn=noise_fn,
+                         _sde_noise_fn=sde_fn, _prefill_noise=pre, _trace=htr, show_progress_bar=False)
+    finally:
+        sm.eng.set_num_steps(5)                      # the module fixture goes back to the deterministic table
+    check((oseq, oaud, omax, otr), (out, htr))

@@ -310,6 +310,46 @@ def test_sampler(sm, n_steps, n):
     assert rel_err(out, ref) <= 5e-4, rel_err(out, ref)
 
 
+@pytest.mark.parametrize("n_steps", [5, 20])
+@pytest.mark.parametrize("n", [1, 2])
+def test_sampler_sde(sm, n_steps, n):
+    """vv_set_schedule_sde + vv_diffusion_sample_sde: the stochastic sde-dpmsolver++ update demo/gradio_demo.py:142-146 installs
+    (fused CFG + solver epilogue with the per-step variance-noise term) against the oracle sampler, which is pinned to the
+    reference scheduler built that way (tests/golden/sampler_sde_*.npz).  Then the ABI's guard rails: the deterministic entry
+    point refuses a stochastic table and vice versa, and switching back restores the deterministic result."""
+    from vibevoice_amd.engine import EngineError
+    eng = sm.eng
+    g = synth.Gen(700 + n_steps + n)
+    pos = g.normal((n, sm.hc.hidden), 1.0, mat=False)
+    neg = g.normal((n, sm.hc.hidden), 1.0, mat=False)
+    noise = g.normal((2 * n, 64), 1.0, mat=False)
+    step_noise = g.normal((n_steps, 2 * n, 64), 1.0, mat=False)
+    hf = lambda x, t, c: head.head_forward(sm.head_w, x, t, c, sm.hc.layers, sm.hc.eps)
+    ref = dpm.sample_speech_tokens(hf, pos, neg, 1.3, n_steps, noise, algorithm_type="sde-dpmsolver++", step_noise=step_noise)
+    ref_det = dpm.sample_speech_tokens(hf, pos, neg, 1.3, n_steps, noise)
+    assert rel_err(ref, ref_det) > 1e-2                                   # the noise term matters at this size
+    out = eng.new(n, 64)
+    cond, nz = dev(torch.cat([pos, neg]), eng), dev(noise[:n], eng)
+    sn = dev(step_noise[:, :n].contiguous(), eng)
+    try:
+        eng.set_num_steps(n_steps, algorithm_type="sde-dpmsolver++")
+        with torch.cuda.stream(eng.stream):
+            eng.diffusion_sample(n, cond, nz, 1.3, out, step_noise=sn)
+            eng.diffusion_sample(n, cond, nz, 1.3, out, step_noise=sn)     # second call: the captured graph replays
+        eng.sync()
+        assert rel_err(out, ref) <= 5e-4, rel_err(out, ref)
+        with pytest.raises(EngineError, match="stochastic"):
+            eng.diffusion_sample(n, cond, nz, 1.3, out)
+    finally:
+        eng.set_num_steps(n_steps)                                         # back to the model's own scheduler for the other tests
+    with pytest.raises(EngineError, match="deterministic"):
+        eng.diffusion_sample(n, cond, nz, 1.3, out, step_noise=sn)
+    with torch.cuda.stream(eng.stream):
+        eng.diffusion_sample(n, cond, nz, 1.3, out)
+    eng.sync()
+    assert rel_err(out, ref_det) <= 5e-4, rel_err(out, ref_det)
+
+
 def test_connectors(sm):
     eng = sm.eng
     g = synth.Gen(400)
@@ -504,6 +544,15 @@ def test_bf16_mode_batched_sampler_rows(n):
             eng.diffusion_sample(n, dev(torch.cat([pos, neg]), eng), dev(noise[:n], eng), 1.3, out)
         eng.sync()
         assert rel_err(out, ref) <= 5e-2, rel_err(out, ref)
+        # the stochastic solver through the 16-row forms (gradio scheduler, batched rows)
+        sn = g.normal((10, 2 * n, 64), 1.0, mat=False)
+        ref_s = dpm.sample_speech_tokens(lambda x, t, c: head.head_forward(s.head_w, x, t, c, s.hc.layers, s.hc.eps),
+                                         pos, neg, 1.3, 10, noise, algorithm_type="sde-dpmsolver++", step_noise=sn)
+        eng.set_num_steps(10, algorithm_type="sde-dpmsolver++")
+        with torch.cuda.stream(eng.stream):
+            eng.diffusion_sample(n, dev(torch.cat([pos, neg]), eng), dev(noise[:n], eng), 1.3, out, step_noise=dev(sn[:, :n].contiguous(), eng))
+        eng.sync()
+        assert rel_err(out, ref_s) <= 5e-2, rel_err(out, ref_s)
     finally:
         eng.close()
 

@@ -222,6 +222,38 @@ def test_generate_loop_matches_the_reference_generate(name):
         assert err <= 1e-4, err
 
 
+@pytest.mark.parametrize("name", ["generate_sde_b1", "generate_sde_b2"])
+def test_generate_loop_under_the_gradio_scheduler_matches_the_reference(name):
+    """Golden = the REFERENCE's own generate() after demo/gradio_demo.py:142-146's scheduler swap
+    (`model.model.noise_scheduler = noise_scheduler.from_config(config, algorithm_type='sde-dpmsolver++', ...)`): per frame the
+    recorded stream holds the initial randn(2n, 64) and then one randn(2n, 64) per solver step (scheduler.step()'s variance
+    noise).  The oracle loop, fed the same draws in the same order, reproduces sequences and waveforms."""
+    from oracle import generate as ogen
+    z = np.load(os.path.join(G, name + ".npz"))
+    tok = ogen.TokenIds(speech_start_id=301, speech_end_id=302, speech_diffusion_id=303, eos_token_id=304,
+                        bos_token_id=None, pad_token_id=305)
+    ids = torch.from_numpy(z["input_ids"])
+    B = ids.shape[0]
+    draws = [torch.from_numpy(z[f"draw_{i}"]) for i in range(int(z["n_draws"]))]
+    pre = (draws[0].reshape(B), draws[1].reshape(B, 3, 64))
+    it = iter(draws[2:])
+    forced = [z["forced"][b][:int(z["forced_len"][b])].tolist() for b in range(B)]
+    seq, audio, reach = ogen.oracle_generate(
+        _oracle_small(), tok, ids, torch.from_numpy(z["attention_mask"]), torch.from_numpy(z["speech_tensors"]),
+        torch.from_numpy(z["speech_masks"]), torch.from_numpy(z["speech_input_mask"]), cfg_scale=1.3, num_steps=5,
+        noise_fn=lambda step, n2: next(it).reshape(n2, 64), prefill_noise=pre, forced_tokens=forced,
+        algorithm_type="sde-dpmsolver++", sde_noise_fn=lambda step, N, n2: torch.stack([next(it).reshape(n2, 64) for _ in range(N)]))
+    assert torch.equal(seq, torch.from_numpy(z["sequences"]))
+    assert torch.equal(reach, torch.from_numpy(z["reach_max"]))
+    assert next(it, None) is None                      # every recorded draw was consumed, in order
+    for b in range(B):
+        ref = torch.from_numpy(z[f"audio_{b}"])
+        got = audio[b].reshape(-1)
+        assert got.shape == ref.shape
+        err = float((got - ref).norm() / ref.norm())
+        assert err <= 1e-4, err
+
+
 def _oracle_streaming_small(n_lm=1, n_tts=2, eos_bias=None):
     """The tiny split model of tests/test_gpu_streaming.py::build, oracle side only."""
     from oracle import generate_streaming as ogs

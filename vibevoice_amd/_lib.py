@@ -35,6 +35,7 @@ _SIGS = {
     "vv_set_speech_factors": (C.c_int, [_P, C.c_float, C.c_float]),
     "vv_set_valid_tokens": (C.c_int, [_P, C.POINTER(C.c_int), C.c_int]),
     "vv_set_schedule": (C.c_int, [_P, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), _P]),
+    "vv_set_schedule_sde": (C.c_int, [_P, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), _P]),
     "vv_lm_forward": (C.c_int, [_P, _P, C.c_int, C.POINTER(VVRow), _P, _P]),
     "vv_lm_forward_range": (C.c_int, [_P, _P, C.c_int, C.POINTER(VVRow), _P, _P, C.c_int, C.c_int, C.c_int]),
     "vv_kv_import": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int]),
@@ -44,6 +45,7 @@ _SIGS = {
     "vv_embed": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int), _P]),
     "vv_lm_logits": (C.c_int, [_P, _P, C.c_int, _P, _P]),
     "vv_diffusion_sample": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_float, _P]),
+    "vv_diffusion_sample_sde": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, C.c_float, _P]),
     "vv_head_forward": (C.c_int, [_P, _P, C.c_int, _P, C.POINTER(C.c_float), _P, _P]),
     "vv_codec_decode": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, C.c_int]),
     "vv_semantic_encode": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),

@@ -61,7 +61,7 @@ int vv_stem_conv_launch(const float* in, const void* wp, const float* bias, floa
 int vv_head_conv1_launch(const float* x, const void* wp, const float* bias, float* out, int T, int Cin, hipStream_t s);
 int vv_shift_rows_launch(const void* tab, int n_entries, int maxC, hipStream_t s);
 int vv_zero_hist_launch(const void* tab, int n_entries, hipStream_t s);
-int vv_cfg_dpm_launch(const float* eps, float* x, float* x0_prev, const float* coef, float cfg, int n, int L, hipStream_t s);
+int vv_cfg_dpm_launch(const float* eps, float* x, float* x0_prev, const float* coef, float cfg, int n, int L, const float* sde_noise, hipStream_t s);
 int vv_affine_launch(const float* x, float* y, float mul, float add, int n, hipStream_t s);
 int vv_add_launch(const float* a, const float* b, float* y, int n, hipStream_t s);
 int vv_tfreq_launch(const float* t, float* out, int n, hipStream_t s);
@@ -204,6 +204,7 @@ struct vv_ctx {
     void *h_in = nullptr, *h_cond = nullptr, *h_t0 = nullptr, *h_t2 = nullptr, *h_ada = nullptr, *h_out = nullptr;
     int n_steps = 0;
     float *temb = nullptr, *coef = nullptr, *tvals = nullptr;
+    bool sde_on = false;                   // the schedule table carries variance-noise scales (sde-dpmsolver++)
     float* mod_all = nullptr; size_t mod_all_bytes = 0;
     float* ada_in = nullptr;
     void* ada_p = nullptr;                 // the same rows as packed bf16 MFMA fragments (bf16 mode: one tile GEMM for all steps)
@@ -1042,17 +1043,34 @@ extern "C" int vv_set_valid_tokens(vv_ctx* ctx, const int* ids, int n) {
     return 0;
 }
 
+static int set_schedule(vv_ctx* ctx, int n_steps, const float* t, const float* coef, int width, void* stream);
+// coef: n_steps rows {a, s, cs, c0, c1} (the deterministic DPM-Solver++(2M) the model classes build)
 extern "C" int vv_set_schedule(vv_ctx* ctx, int n_steps, const float* t, const float* coef, void* stream) {
+    return set_schedule(ctx, n_steps, t, coef, 5, stream);
+}
+// coef: n_steps rows {a, s, cs, c0, c1, cn} -- sde-dpmsolver++ (demo/gradio_demo.py:142-146); sampling then needs the per-step
+// variance noise: vv_diffusion_sample_sde
+extern "C" int vv_set_schedule_sde(vv_ctx* ctx, int n_steps, const float* t, const float* coef6, void* stream) {
+    return set_schedule(ctx, n_steps, t, coef6, 6, stream);
+}
+static int set_schedule(vv_ctx* ctx, int n_steps, const float* t, const float* coef, int width, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (n_steps < 1 || n_steps > 64) return fail(ctx, "n_steps must be in [1,64]");
     const int H = ctx->H;
     if (!ctx->temb) {
         ctx->temb = (float*)dalloc(ctx, (size_t)64 * H * 4);
-        ctx->coef = (float*)dalloc(ctx, 64 * 5 * 4);
+        ctx->coef = (float*)dalloc(ctx, 64 * 6 * 4);
         ctx->tvals = (float*)dalloc(ctx, 64 * 4);
     }
+    float rows6[64 * 6];
+    bool sde = false;
+    for (int i = 0; i < n_steps; ++i) {
+        for (int j = 0; j < 6; ++j) rows6[i * 6 + j] = (j < width) ? coef[i * width + j] : 0.f;
+        if (rows6[i * 6 + 5] != 0.f) sde = true;
+    }
+    ctx->sde_on = sde;
     HIPCHK(ctx, hipStreamSynchronize(st));
-    HIPCHK(ctx, hipMemcpy(ctx->coef, coef, (size_t)n_steps * 5 * 4, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(ctx->coef, rows6, (size_t)n_steps * 6 * 4, hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(ctx->tvals, t, (size_t)n_steps * 4, hipMemcpyHostToDevice));
     // t_emb[i] = W2 . silu(W1 . sinusoid(t_i))   (TimestepEmbedder, modular_vibevoice_diffusion_head.py:66-93)
     VVCHK(vv_tfreq_launch(ctx->tvals, ctx->tmp2, n_steps, st));
@@ -1082,7 +1100,7 @@ extern "C" int vv_set_schedule(vv_ctx* ctx, int n_steps, const float* t, const f
         }
     }
     for (auto it = ctx->graphs.begin(); it != ctx->graphs.end();) {
-        if (it->first.rfind("samp", 0) == 0) { hipGraphExecDestroy(it->second.exec); it = ctx->graphs.erase(it); } else ++it;
+        if (it->first.rfind("samp", 0) == 0 || it->first.rfind("sde:", 0) == 0) { hipGraphExecDestroy(it->second.exec); it = ctx->graphs.erase(it); } else ++it;
     }
     return 0;
 }
@@ -1307,7 +1325,7 @@ extern "C" int vv_lm_logits(vv_ctx* ctx, void* stream, int n, const float* hidde
 
 // one head evaluation on 2n rows; mod/xh/hact/eps are ctx scratch. temb = t-embedding row for this step.
 static int head_eval(vv_ctx* ctx, hipStream_t st, int rows, const float* zrows, const float* temb_row, float* eps_out,
-                     const float* coef = nullptr, float cfg = 0.f, const float* mod_ready = nullptr) {
+                     const float* coef = nullptr, float cfg = 0.f, const float* mod_ready = nullptr, const float* sde_noise = nullptr) {
     const vv_config& c = ctx->c;
     const int H = ctx->H, L = c.latent_dim, HL = c.head_layers, HF = ctx->HF, MODW = ctx->MODW;
     const float* mod = mod_ready ? mod_ready : ctx->mod;
@@ -1349,12 +1367,14 @@ static int head_eval(vv_ctx* ctx, hipStream_t st, int rows, const float* zrows, 
     gf.xa = ctx->xh_parts + (size_t)(HL & 1) * 2 * xps; gf.n_xa = xp; gf.part_stride = xps;
     if (coef) {   // CFG + DPM-Solver++ update fused into the epilogue: the noisy latent is rewritten in place
         gf.epi = VV_EPI_CFG_DPM; gf.z = ctx->zz; gf.x0p = ctx->x0p; gf.coef = coef; gf.cfg = cfg; gf.n_cfg = rows / 2;
+        gf.sde_noise = sde_noise;
     }
     GEMM(gf);
     return 0;
 }
 
-static int sample_body(vv_ctx* ctx, hipStream_t st, int n, const float* cond, const float* noise, float cfg, float* latent_out) {
+static int sample_body(vv_ctx* ctx, hipStream_t st, int n, const float* cond, const float* noise, float cfg, float* latent_out,
+                       const float* step_noise = nullptr) {
     const vv_config& c = ctx->c;
     const int H = ctx->H, L = c.latent_dim;
     const int rows = 2 * n;
@@ -1393,7 +1413,8 @@ static int sample_body(vv_ctx* ctx, hipStream_t st, int n, const float* cond, co
     }
     for (int i = 0; i < ctx->n_steps; ++i) {
         const float* mod_i = batch_ada ? ctx->mod_all + (size_t)i * rows * MODW : nullptr;
-        if (head_eval(ctx, st, rows, ctx->zz, ctx->temb + (size_t)i * H, ctx->eps, ctx->coef + i * 5, cfg, mod_i)) return -1;
+        const float* sn = step_noise ? step_noise + (size_t)i * n * L : nullptr;
+        if (head_eval(ctx, st, rows, ctx->zz, ctx->temb + (size_t)i * H, ctx->eps, ctx->coef + i * 6, cfg, mod_i, sn)) return -1;
     }
     HIPCHK(ctx, hipMemcpyAsync(latent_out, ctx->zz, (size_t)n * L * 4, hipMemcpyDeviceToDevice, st));
     return 0;
@@ -1403,9 +1424,25 @@ extern "C" int vv_diffusion_sample(vv_ctx* ctx, void* stream, int n, const float
     hipStream_t st = (hipStream_t)stream;
     if (ctx->n_steps < 1) return fail(ctx, "vv_set_schedule has not been called");
     if (n < 1 || n > 8) return fail(ctx, "vv_diffusion_sample: n must be in [1,8]");
+    if (ctx->sde_on) return fail(ctx, "the schedule is stochastic (vv_set_schedule_sde): sample with vv_diffusion_sample_sde and its per-step noise");
     ctx->launches = 0;
     char key[128]; snprintf(key, 128, "samp:%d:%p:%p:%p:%a", n, (const void*)cond_dev, (const void*)noise_dev, (void*)latent_out_dev, cfg_scale);
     return graphed(ctx, key, st, [&]() { return sample_body(ctx, st, n, cond_dev, noise_dev, cfg_scale, latent_out_dev); });
+}
+
+// The stochastic solver: step_noise_dev = [n_steps][n][latent_dim] fp32, the variance noise scheduler.step() draws per solver step
+// (dpm_solver.py:994-997; the reference draws [2n][latent] and only the first n rows reach the next step, :703-704).
+extern "C" int vv_diffusion_sample_sde(vv_ctx* ctx, void* stream, int n, const float* cond_dev, const float* noise_dev,
+                                       const float* step_noise_dev, float cfg_scale, float* latent_out_dev) {
+    hipStream_t st = (hipStream_t)stream;
+    if (ctx->n_steps < 1) return fail(ctx, "vv_set_schedule_sde has not been called");
+    if (n < 1 || n > 8) return fail(ctx, "vv_diffusion_sample_sde: n must be in [1,8]");
+    if (!ctx->sde_on) return fail(ctx, "the schedule is deterministic (vv_set_schedule): sample with vv_diffusion_sample");
+    if (!step_noise_dev) return fail(ctx, "vv_diffusion_sample_sde: step_noise is null");
+    ctx->launches = 0;
+    char key[160]; snprintf(key, 160, "sde:%d:%p:%p:%p:%p:%a", n, (const void*)cond_dev, (const void*)noise_dev, (const void*)step_noise_dev,
+                            (void*)latent_out_dev, cfg_scale);
+    return graphed(ctx, key, st, [&]() { return sample_body(ctx, st, n, cond_dev, noise_dev, cfg_scale, latent_out_dev, step_noise_dev); });
 }
 
 extern "C" int vv_head_forward(vv_ctx* ctx, void* stream, int n, const float* noisy_dev, const float* t_host, const float* cond_dev, float* out_dev) {

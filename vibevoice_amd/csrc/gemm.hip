@@ -379,7 +379,8 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemm_kernel(const VVGemm a) {
                     const int64_t zi = (int64_t)frow * a.N + n;
                     const float zo = a.z[zi];
                     const float x0 = ca * zo - cs_ * v;
-                    const float zn = csx * zo + c0 * x0 + c1 * (x0 - a.x0p[zi]);
+                    float zn = csx * zo + c0 * x0 + c1 * (x0 - a.x0p[zi]);
+                    if (a.sde_noise) zn += a.coef[5] * a.sde_noise[zi];      // sde-dpmsolver++ variance noise
                     a.x0p[zi] = x0;
                     a.z[zi] = zn;
                     a.z[zi + (int64_t)nc * a.N] = zn;

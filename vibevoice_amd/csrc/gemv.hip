@@ -108,6 +108,7 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const u32x4* __restri
     asm volatile("" ::"s"(a.ld_mod), "s"(a.ld_gate), "s"(a.x_row_mod), "s"(a.add_rows_per_vec),
                  "s"(a.eps), "s"(a.z), "s"(a.x0p), "s"(a.coef), "s"(a.cfg), "s"(a.n_cfg));
     asm volatile("" ::"s"(a.yparts), "s"(a.xa), "s"(a.ya), "s"(a.n_xa), "s"(a.n_ya), "s"(a.part_stride));
+    if constexpr (EPI == VV_EPI_CFG_DPM) asm volatile("" ::"s"(a.sde_noise));
     VV_STAMP(0);
     VV_BSTAMP(0);
     const int lane = threadIdx.x & 63;
@@ -371,6 +372,7 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const u32x4* __restri
     if constexpr (EPI == VV_EPI_CFG_DPM) {
         const int nc = a.n_cfg;
         const float ca = a.coef[0], cs_ = a.coef[1], csx = a.coef[2], c0 = a.coef[3], c1 = a.coef[4];
+        const float cn = a.sde_noise ? a.coef[5] : 0.f;          // sde-dpmsolver++: + cn * eps_i (dpm_solver.py:680-686, 785-793)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float vu = __shfl(o[r], lane + nc);
@@ -380,7 +382,8 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const u32x4* __restri
                 const unsigned zi = (unsigned)(frow * pN + n);
                 const float zo = a.z[zi];
                 const float x0 = ca * zo - cs_ * v;
-                const float zn = csx * zo + c0 * x0 + c1 * (x0 - a.x0p[zi]);
+                float zn = csx * zo + c0 * x0 + c1 * (x0 - a.x0p[zi]);
+                if (a.sde_noise) zn += cn * a.sde_noise[zi];
                 a.x0p[zi] = x0;
                 a.z[zi] = zn;
                 a.z[zi + (unsigned)(nc * pN)] = zn;

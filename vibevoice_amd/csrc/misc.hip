@@ -349,7 +349,7 @@ __global__ void vv_zero_hist_kernel(const VVShift* __restrict__ tab) {
 //   x' = cs x + c0 x0 + c1 (x0 - x0_prev)       (c1 = 0 on first-order steps)
 // coef = {a, s, cs, c0, c1} for this step.
 __global__ void vv_cfg_dpm_kernel(const float* __restrict__ eps, float* __restrict__ x, float* __restrict__ x0_prev,
-                                  const float* __restrict__ coef, float cfg, int n, int L) {
+                                  const float* __restrict__ coef, float cfg, int n, int L, const float* __restrict__ sde_noise) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n * L) return;
     const float a = coef[0], s = coef[1], cs = coef[2], c0 = coef[3], c1 = coef[4];
@@ -357,7 +357,8 @@ __global__ void vv_cfg_dpm_kernel(const float* __restrict__ eps, float* __restri
     const float v = vu + cfg * (vc - vu);
     const float xi = x[i];
     const float x0 = a * xi - s * v;
-    const float xn = cs * xi + c0 * x0 + c1 * (x0 - x0_prev[i]);
+    float xn = cs * xi + c0 * x0 + c1 * (x0 - x0_prev[i]);
+    if (sde_noise) xn += coef[5] * sde_noise[i];               // sde-dpmsolver++: coef row = {a, s, cs, c0, c1, cn}
     x0_prev[i] = x0;
     x[i] = xn;
     x[i + n * L] = xn;        // both CFG halves see the same latent (modeling_vibevoice_inference.py:703-704)
@@ -593,8 +594,8 @@ int vv_zero_hist_launch(const void* tab, int n_entries, hipStream_t s) {
     hipLaunchKernelGGL(vv_zero_hist_kernel, dim3(n_entries, 8), dim3(256), 0, s, (const VVShift*)tab);
     return okk();
 }
-int vv_cfg_dpm_launch(const float* eps, float* x, float* x0_prev, const float* coef, float cfg, int n, int L, hipStream_t s) {
-    hipLaunchKernelGGL(vv_cfg_dpm_kernel, dim3((n * L + 255) / 256), dim3(256), 0, s, eps, x, x0_prev, coef, cfg, n, L);
+int vv_cfg_dpm_launch(const float* eps, float* x, float* x0_prev, const float* coef, float cfg, int n, int L, const float* sde_noise, hipStream_t s) {
+    hipLaunchKernelGGL(vv_cfg_dpm_kernel, dim3((n * L + 255) / 256), dim3(256), 0, s, eps, x, x0_prev, coef, cfg, n, L, sde_noise);
     return okk();
 }
 int vv_affine_launch(const float* x, float* y, float mul, float add, int n, hipStream_t s) {

@@ -54,9 +54,10 @@ struct VVGemm {
     // EPI_CFG_DPM (diffusion-head final layer): rows [0,n) cond, [n,2n) uncond -> CFG + DPM-Solver++ update in place
     float* z;              // [2n][N] noisy latent (both halves rewritten)
     float* x0p;            // [n][N] previous x0 prediction
-    const float* coef;     // {a, s, cs, c0, c1}
+    const float* coef;     // {a, s, cs, c0, c1, cn}: one 6-float row of the schedule table per solver step
     float cfg;
     int n_cfg;
+    const float* sde_noise; // stochastic solver (sde-dpmsolver++): this step's variance noise [n][N], added as cn * eps; null = off
     unsigned long long* dbg;   // optional phase timestamps (VV_GEMM_TIMING builds only)
     // row t reads activation row (t % x_row_mod) and, for PRO_ADD_SILU, the add-vector (t / add_rows_per_vec)
     // (0 = off).  Used to batch the diffusion head's adaLN GEMM over all solver steps of a frame.

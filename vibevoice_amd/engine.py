@@ -212,15 +212,20 @@ class Engine:
         self._chk(self.lib.vv_set_valid_tokens(self._ctx, arr, len(ids)), "vv_set_valid_tokens")
         self.n_valid = len(ids)
 
-    def set_num_steps(self, n_steps: int, t_cast_bf16: bool = False):
-        key = (int(n_steps), bool(t_cast_bf16))
+    def set_num_steps(self, n_steps: int, t_cast_bf16: bool = False, algorithm_type: str = "dpmsolver++"):
+        """Solver table for N steps.  algorithm_type: "dpmsolver++" (the model classes' scheduler) or "sde-dpmsolver++" (what
+        demo/gradio_demo.py:142-146 installs); the stochastic one is sampled with diffusion_sample(..., step_noise=...)."""
+        key = (int(n_steps), bool(t_cast_bf16), str(algorithm_type))
         if self._n_steps == key:
             return
-        tv, coef = _schedule.make_table(n_steps, t_cast_bf16)
-        self._chk(self.lib.vv_set_schedule(
-            self._ctx, n_steps, tv.ctypes.data_as(C.POINTER(C.c_float)),
-            np.ascontiguousarray(coef).ctypes.data_as(C.POINTER(C.c_float)), self._s), "vv_set_schedule")
+        tv, coef = _schedule.make_table(n_steps, t_cast_bf16, algorithm_type)
+        fn, name = ((self.lib.vv_set_schedule_sde, "vv_set_schedule_sde") if coef.shape[1] == 6
+                    else (self.lib.vv_set_schedule, "vv_set_schedule"))
+        self._chk(fn(self._ctx, n_steps, tv.ctypes.data_as(C.POINTER(C.c_float)),
+                     np.ascontiguousarray(coef).ctypes.data_as(C.POINTER(C.c_float)), self._s), name)
         self._n_steps = key
+        self.n_solver_steps = int(n_steps)
+        self.stochastic = coef.shape[1] == 6
 
     # ------------------------------------------------------------------ ops
     @staticmethod
@@ -292,9 +297,16 @@ class Engine:
     def lm_logits(self, n: int, hidden: torch.Tensor, logits_out: torch.Tensor):
         self._chk(self.lib.vv_lm_logits(self._ctx, self._s, n, self._p(hidden), self._p(logits_out)), "vv_lm_logits")
 
-    def diffusion_sample(self, n: int, cond: torch.Tensor, noise: torch.Tensor, cfg_scale: float, latent_out: torch.Tensor):
-        self._chk(self.lib.vv_diffusion_sample(self._ctx, self._s, n, self._p(cond), self._p(noise),
-                                               float(cfg_scale), self._p(latent_out)), "vv_diffusion_sample")
+    def diffusion_sample(self, n: int, cond: torch.Tensor, noise: torch.Tensor, cfg_scale: float, latent_out: torch.Tensor,
+                         step_noise: Optional[torch.Tensor] = None):
+        """step_noise [n_steps, n, latent] fp32 (contiguous, on the device): the per-step variance noise of the stochastic solver."""
+        if step_noise is None:
+            self._chk(self.lib.vv_diffusion_sample(self._ctx, self._s, n, self._p(cond), self._p(noise),
+                                                   float(cfg_scale), self._p(latent_out)), "vv_diffusion_sample")
+        else:
+            assert step_noise.dtype == torch.float32 and step_noise.is_contiguous() and step_noise.shape[1] == n
+            self._chk(self.lib.vv_diffusion_sample_sde(self._ctx, self._s, n, self._p(cond), self._p(noise), self._p(step_noise),
+                                                       float(cfg_scale), self._p(latent_out)), "vv_diffusion_sample_sde")
 
     def head_forward(self, noisy: torch.Tensor, t: float, cond: torch.Tensor, out: torch.Tensor):
         n = noisy.shape[0]

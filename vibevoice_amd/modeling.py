@@ -176,6 +176,50 @@ _PREFIX_BACK = tuple((a, b) for a, b in (
     ("model.semantic_connector.", "sem_conn.")))
 
 
+class _SchedulerView:
+    """`noise_scheduler` as callers use it (modeling_vibevoice_inference.py:91-93; demo/gradio_demo.py:142-146): `.config` (the
+    DPMSolverMultistepScheduler init arguments the model class passes, modeling_vibevoice.py:138-142, plus that class's
+    defaults), `.num_inference_steps`, `.timesteps`, and `.from_config(config, **overrides)` -> a new view, which the gradio
+    demo assigns back to `model.model.noise_scheduler` to switch the solver to 'sde-dpmsolver++'.  The arithmetic itself
+    lives in the engine's coefficient table (vibevoice_amd/schedule.py)."""
+
+    DEFAULTS = dict(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="cosine", trained_betas=None,
+                    solver_order=2, prediction_type="v_prediction", thresholding=False, dynamic_thresholding_ratio=0.995,
+                    sample_max_value=1.0, algorithm_type="dpmsolver++", solver_type="midpoint", lower_order_final=True,
+                    euler_at_final=False, use_karras_sigmas=False, use_lu_lambdas=False, final_sigmas_type="zero",
+                    lambda_min_clipped=-float("inf"), variance_type=None, timestep_spacing="linspace", steps_offset=0,
+                    rescale_betas_zero_snr=False)
+
+    def __init__(self, config: dict, num_inference_steps: Optional[int] = None):
+        self.config = _Ns(dict(self.DEFAULTS, **{k: v for k, v in dict(config).items() if k in self.DEFAULTS}))
+        self.num_inference_steps = num_inference_steps
+
+    def from_config(self, config, **kwargs):
+        return _SchedulerView(dict(dict(config), **kwargs), self.num_inference_steps)
+
+    @property
+    def timesteps(self):
+        from . import schedule as _schedule
+        tv, _ = _schedule.make_table(self.num_inference_steps or 20, False)
+        return torch.from_numpy(np.asarray(tv)).long()
+
+    def check_supported(self):
+        """the configurations the HIP sampler implements; anything else must fail loudly, not run a different solver"""
+        from . import schedule as _schedule
+        c = self.config
+        want = dict(num_train_timesteps=1000, trained_betas=None, solver_order=2, prediction_type="v_prediction", thresholding=False,
+                    solver_type="midpoint", lower_order_final=True, euler_at_final=False, use_karras_sigmas=False,
+                    use_lu_lambdas=False, final_sigmas_type="zero", timestep_spacing="linspace", steps_offset=0,
+                    rescale_betas_zero_snr=False)
+        bad = {k: c[k] for k, v in want.items() if c[k] != v}
+        if c["beta_schedule"] not in ("cosine", "squaredcos_cap_v2"):          # the same Glide cosine betas (dpm_solver.py:240-242)
+            bad["beta_schedule"] = c["beta_schedule"]
+        if c["algorithm_type"] not in _schedule.ALGORITHMS:
+            bad["algorithm_type"] = c["algorithm_type"]
+        if bad:
+            raise NotImplementedError(f"noise scheduler configuration not implemented by the HIP sampler: {bad}")
+
+
 def _engine_name_to_reference(name: str):
     for a, b in _PREFIX_BACK:
         if name.startswith(b):
@@ -209,6 +253,14 @@ class _ModelNamespace:
     @property
     def noise_scheduler(self):
         return self._owner.noise_scheduler
+
+    @noise_scheduler.setter
+    def noise_scheduler(self, view):
+        # demo/gradio_demo.py:142-146: model.model.noise_scheduler = model.model.noise_scheduler.from_config(config, algorithm_type=...)
+        if not isinstance(view, _SchedulerView):
+            raise TypeError("model.model.noise_scheduler takes the object noise_scheduler.from_config(...) returns")
+        view.check_supported()
+        self._owner._sched_cfg = dict(view.config)
 
 
 class _Utt:
@@ -254,6 +306,12 @@ class VibeVoiceForConditionalGenerationInference:
         # what the attention really is on this path; the value the caller asked for is kept beside it
         self.requested_attn_implementation = attn_implementation
         self._param_placeholder = torch.empty(0, dtype=model_dtype, device=self.device)
+        hcfg = config["diffusion_head_config"]
+        # the scheduler the model class builds (modeling_vibevoice.py:138-142)
+        self._sched_cfg = dict(_SchedulerView({"num_train_timesteps": hcfg.get("ddpm_num_steps", 1000),
+                                               "beta_schedule": hcfg.get("ddpm_beta_schedule", "cosine"),
+                                               "prediction_type": hcfg.get("prediction_type", "v_prediction")}).config)
+        self._sde_flat = None                    # per-step variance noise of the stochastic solver, [64 * MAX_BATCH * latent]
         self.model = _ModelNamespace(self, config, "vvhip_mfma_flash_decoding_gfx950")
         H = engine.cfg.lm_hidden
         e = engine
@@ -334,6 +392,9 @@ class VibeVoiceForConditionalGenerationInference:
         device = None
         if isinstance(device_map, (str, torch.device)) and str(device_map) not in ("auto", "cpu"):
             device = torch.device(device_map)
+        # the drop-in entry point: any batch generate() can take (MAX_BATCH utterances) works without an extra argument; the KV
+        # caches of 8 slots at the model's full context are 30 GB for the 7B model -- a tenth of the HBM
+        runtime.setdefault("n_slots", MAX_BATCH)
         m = cls.from_state_dict(config, it(), torch_dtype or torch.bfloat16, device, attn_implementation=attn_implementation, **runtime)
         m.source_path = path
 
@@ -353,6 +414,7 @@ class VibeVoiceForConditionalGenerationInference:
         cfg = live_model.config.to_dict() if hasattr(live_model.config, "to_dict") else dict(live_model.config)
         sd = live_model.state_dict()
         dt = next(iter(live_model.parameters())).dtype
+        runtime.setdefault("n_slots", MAX_BATCH)
         m = cls.from_state_dict(cfg, sd, dt, device, **runtime)
         m.base_tensor = lambda key: sd[key].detach().cpu()
         steps = getattr(live_model, "ddpm_inference_steps", None)
@@ -371,10 +433,7 @@ class VibeVoiceForConditionalGenerationInference:
 
     @property
     def noise_scheduler(self):
-        from . import schedule as _schedule
-        tv, _ = _schedule.make_table(self.ddpm_inference_steps, False)
-        return _Ns(num_inference_steps=self.ddpm_inference_steps, timesteps=torch.from_numpy(np.asarray(tv)).long(),
-                   config=_Ns(self.config_dict["diffusion_head_config"]))
+        return _SchedulerView(self._sched_cfg, self.ddpm_inference_steps)
 
     prediction_head = property(lambda self: self.model.prediction_head)
     acoustic_tokenizer = property(lambda self: self.model.acoustic_tokenizer)
@@ -574,7 +633,7 @@ class VibeVoiceForConditionalGenerationInference:
         # leaving the GPU idle; if the guess is wrong the latent is discarded and the RNG state restored.
         spec_sample, rng_state = False, None
         do_sample = S["do_sample"]
-        if (run and not fresh and self.speculate_sampling
+        if (run and not fresh and self.speculate_sampling and not S["sde"]      # a discarded guess would spend device-RNG draws
                 and not (do_sample and S["noise_fn"] is None and S["forced"] is None)   # keep the reference's RNG draw order
                 and all(u.last in (diff_id, start_id) for u in run)):
             nz = self._draw_noise(S, run)
@@ -680,7 +739,10 @@ class VibeVoiceForConditionalGenerationInference:
             if nz is None:
                 nz = torch.randn(2 * n, e.cfg.latent_dim)      # CPU global RNG, as the reference (:701)
             self._stage_noise(nz, n)
-            e.diffusion_sample(n, self._cond, self._noise, cfg_scale, self._latent)
+            if S["sde"]:
+                e.diffusion_sample(n, self._cond, self._noise, cfg_scale, self._latent, step_noise=self._sde_draws(S, n))
+            else:
+                e.diffusion_sample(n, self._cond, self._noise, cfg_scale, self._latent)
         if diff:
             # ---- codec decode, semantic encode, connectors (:636-672) ----
             if len(diff) > 1 and self.batched_codecs:
@@ -736,6 +798,23 @@ class VibeVoiceForConditionalGenerationInference:
             u.have_embeds = True
         return live
 
+    def _sde_draws(self, S, n):
+        """The variance noise of one frame's solver steps, [N, n, latent] fp32 on the device.  scheduler.step() draws
+        randn(model_output.shape = [2n, latent], device=model_output.device, float32) once per solver step on the device's
+        global generator (dpm_solver.py:994-997; generate() passes no generator); only the first n rows survive the next step's
+        `speech[:n]` (modeling_vibevoice_inference.py:703-704).  Same calls, same order -> same stream for a seeded run."""
+        e = self.engine
+        N, L = self.ddpm_inference_steps, e.cfg.latent_dim
+        if self._sde_flat is None:
+            self._sde_flat = e.new(64 * MAX_BATCH * L)
+        buf = self._sde_flat[:N * n * L].view(N, n, L)
+        if S["sde_noise_fn"] is not None:                     # test hook: the recorded draws, [N, 2n, latent]
+            buf.copy_(S["sde_noise_fn"](S["step"], N, 2 * n)[:, :n].to(buf.device, torch.float32))
+            return buf
+        for i in range(N):
+            buf[i].copy_(torch.randn(2 * n, L, device=self.device, dtype=torch.float32)[:n])
+        return buf
+
     @staticmethod
     def _draw_noise(S, utts):
         """explicit noise for `utts` (test / bench hooks), or None: draw torch.randn as the reference does"""
@@ -760,8 +839,10 @@ class VibeVoiceForConditionalGenerationInference:
         if self._valid_key != tuple(valid):
             e.set_valid_tokens(valid)
             self._valid_key = tuple(valid)
-        e.set_num_steps(self.ddpm_inference_steps, t_cast_bf16=(self.dtype == torch.bfloat16 and kwargs.get("_t_cast", True)))
-        return dict(nv=len(valid), valid_t=torch.tensor(valid, dtype=torch.long), start_id=start_id, end_id=end_id, diff_id=diff_id,
+        algo = self._sched_cfg["algorithm_type"]
+        e.set_num_steps(self.ddpm_inference_steps, t_cast_bf16=(self.dtype == torch.bfloat16 and kwargs.get("_t_cast", True)),
+                        **({} if algo == "dpmsolver++" else {"algorithm_type": algo}))
+        return dict(sde=(algo == "sde-dpmsolver++"), sde_noise_fn=kwargs.pop("_sde_noise_fn", None), nv=len(valid), valid_t=torch.tensor(valid, dtype=torch.long), start_id=start_id, end_id=end_id, diff_id=diff_id,
                     eos_id=eos_id, cfg_scale=cfg_scale, do_sample=do_sample, temperature=temperature,
                     trace=kwargs.pop("_trace", None), audio_streamer=audio_streamer, verbose=kwargs.get("verbose", False),
                     forced=kwargs.pop("_forced_tokens", None), noise_fn=kwargs.pop("_noise_fn", None), n_rows=n_rows,

@@ -17,7 +17,7 @@ import os
 import numpy as np
 
 from .engine import Engine, EngineConfig
-from .modeling import VibeVoiceGenerationOutput, WeightHandle, _Ns, engine_config_from_reference
+from .modeling import VibeVoiceGenerationOutput, WeightHandle, _Ns, _SchedulerView, engine_config_from_reference
 
 TTS_TEXT_WINDOW_SIZE = 5
 TTS_SPEECH_WINDOW_SIZE = 6
@@ -149,10 +149,9 @@ class VibeVoiceStreamingForConditionalGenerationInference:
     # ---- reference properties (modeling_vibevoice_streaming_inference.py:119-141) ----
     @property
     def noise_scheduler(self):
-        from . import schedule as _schedule
-        tv, _ = _schedule.make_table(self.ddpm_inference_steps, False)
-        return _Ns(num_inference_steps=self.ddpm_inference_steps, timesteps=torch.from_numpy(np.asarray(tv)).long(),
-                   config=_Ns(self.config_dict["diffusion_head_config"]))
+        hcfg = self.config_dict["diffusion_head_config"]
+        return _SchedulerView({"num_train_timesteps": hcfg.get("ddpm_num_steps", 1000), "beta_schedule": hcfg.get("ddpm_beta_schedule", "cosine"),
+                               "prediction_type": hcfg.get("prediction_type", "v_prediction")}, self.ddpm_inference_steps)
 
     prediction_head = property(lambda self: self.model.prediction_head)
     acoustic_tokenizer = property(lambda self: self.model.acoustic_tokenizer)
