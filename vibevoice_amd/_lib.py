@@ -82,6 +82,9 @@ def load():
     from . import build as _build
     if _build.have_sources() and _build.binary_id(LIB_PATH) != _build.source_id():
         # a binary from other sources must never run silently: rebuild where a compiler exists, refuse otherwise
+        import sys
+        print(f"[vibevoice_amd] {LIB_PATH} was built from other sources (binary id {_build.binary_id(LIB_PATH)}, sources "
+              f"{_build.source_id()}): rebuilding with hipcc (about two minutes)", file=sys.stderr, flush=True)
         try:
             _build.build(force=True, verbose=False)
         except Exception as ex:
