@@ -452,3 +452,33 @@ def test_host_generate_sampling_keeps_the_reference_rng_stream(monkeypatch):
     got = out.speech_outputs[0].reshape(-1)
     assert got.shape == ref.shape
     assert float((got - ref).norm() / ref.norm()) <= 1e-4
+
+
+def test_recorded_bench_line_keeps_the_driver_contract():
+    """profiles/r02_bench_default.json is the stdout of `python bench.py --steps 20 --warmup 5` on an MI355X: the one JSON line
+    the driver parses.  Its fields are the contract (metric / unit = BASELINE.json's, whole-job value, workload named in config,
+    `roofline` with algorithmic bytes over measured launch time against the 8 TB/s HBM peak, `cpu_baseline` on a bounded sample);
+    the numbers must be self-consistent."""
+    import json
+    with open(os.path.join(ROOT, "profiles", "r02_bench_default.json")) as f:
+        d = json.loads(f.read().strip().splitlines()[-1])
+    with open(os.path.join(ROOT, "BASELINE.json")) as f:
+        base = json.load(f)
+    assert d["metric"] in base["metric"] and d["unit"] == "audio-s/wall-s" and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "weak" and d["data"] == "synthetic"
+    assert d["vs_baseline"] is None and base["published"] == {}            # nothing published for this metric
+    assert d["dtype"] == "bf16" and "7B" in d["config"]["workload"].upper() and "model" in d["config"]
+    frames_per_s = d["value"] / (3200 / 24000)
+    assert abs(frames_per_s * d["ms_per_step"] / 1e3 - 1.0) < 0.03            # 19 of 20 timed steps are frames (one control token)... within 3 %
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] == "vv_gemv_kernel"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(r["achieved"] - r["bytes_per_launch"] / 1e9 / (r["avg_launch_us"] / 1e6)) / r["achieved"] < 0.01
+    assert 0.9 < r["traffic"] / r["bytes_per_launch"] < 1.1                  # PMC bytes ~ algorithmic bytes: no wasted re-reads
+    assert r["launches_per_step"] * r["avg_launch_us"] / 1e3 < d["ms_per_step"]      # the chain fits inside the step
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["unit"] == d["unit"] and c["value"] > 0 and "sample" in c
+    g = d["gpu_eager_baseline"]
+    assert g["value"] > c["value"] and abs(g["speedup_of_this_path"] - d["value"] / g["value"]) < 0.05
+    assert len(d["extra"]["libvvhip_build_id"]) == 16
+    assert set(d["extra"]["configs"]) == {"configs[1]", "configs[4]"}
