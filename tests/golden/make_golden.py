@@ -481,6 +481,18 @@ def gen_generate_streaming():
         def convert_tokens_to_ids(self, t):
             return 305
 
+    class RecStreamer:                      # what the streaming generate() tells an AudioStreamer, in order (flags left untouched)
+        def __init__(self):
+            self.finished_flags = [False]
+            self.log = []
+
+        def put(self, chunk, idx):
+            self.log.append([0, int(chunk.shape[0]), int(chunk.shape[-1])] + [int(i) for i in idx.tolist()])
+
+        def end(self, idx=None):
+            ids = [0] if idx is None else [int(i) for i in idx.tolist()]
+            self.log.append([1, len(ids), -1 if idx is None else 0] + ids)
+
     def run(name, n_text, max_new, seed, eos_bias=None):
         if eos_bias is not None:                       # make the binary EOS head fire (the seeded bias of -1.5 never does)
             m.tts_eos_classifier.fc2.bias.data.fill_(eos_bias)
@@ -507,6 +519,7 @@ def gen_generate_streaming():
             arrs[f"{tag}_layers"] = len(kc)
         draws = []
         o_randn = torch.randn
+        rec = RecStreamer()
 
         def rec_randn(*a, **k):
             t = o_randn(*a, **k)
@@ -517,9 +530,11 @@ def gen_generate_streaming():
             torch.manual_seed(seed)
             out = m.generate(input_ids=prompt, attention_mask=ones, tts_lm_input_ids=prompt.clone(), tts_lm_attention_mask=ones.clone(),
                              tts_text_ids=text, all_prefilled_outputs={"lm": lm_o, "tts_lm": tts_o, "neg_lm": nlm_o, "neg_tts_lm": ntts_o},
-                             tokenizer=Tok(), cfg_scale=1.5, max_new_tokens=max_new, show_progress_bar=False, return_speech=True)
+                             tokenizer=Tok(), cfg_scale=1.5, max_new_tokens=max_new, show_progress_bar=False, return_speech=True,
+                             audio_streamer=rec)
         finally:
             torch.randn = o_randn
+        arrs.update(sequences=out.sequences[0], streamer_log=np.array(rec.log))
         arrs.update(n_draws=len(draws), n_tokens=out.sequences.shape[1], reach_max=out.reach_max_step_sample,
                     audio=out.speech_outputs[0].reshape(-1) if out.speech_outputs[0] is not None else torch.zeros(0))
         for i, d in enumerate(draws):

@@ -401,6 +401,28 @@ def test_host_streaming_loop_matches_reference_goldens(monkeypatch, name):
         m.set_ddpm_inference_steps(5)
         out = m.generate(tts_text_ids=torch.from_numpy(z["text"])[None], all_prefilled_outputs=pre, cfg_scale=1.5,
                          max_new_tokens=int(z["max_new"]), _noise_fn=lambda frame, n2: draws[frame])
+        # the same call as the reference demo makes it: the processor's prompt ids go in, an AudioStreamer listens
+        log = []
+
+        class RecStreamer:
+            finished_flags = [False]
+
+            def put(self, chunk, idx):
+                log.append([0, int(chunk.shape[0]), int(chunk.shape[-1])] + [int(i) for i in idx.tolist()])
+
+            def end(self, idx=None):
+                ids = [0] if idx is None else [int(i) for i in idx.tolist()]
+                log.append([1, len(ids), -1 if idx is None else 0] + ids)
+        eng.caches = {0: eng.om.lm.new_cache(), 1: eng.om.tts_lm.new_cache(), 2: eng.om.tts_lm.new_cache()}
+        out2 = m.generate(tts_text_ids=torch.from_numpy(z["text"])[None], tts_lm_input_ids=torch.from_numpy(z["prompt"])[None],
+                          all_prefilled_outputs=pre, cfg_scale=1.5, max_new_tokens=int(z["max_new"]), audio_streamer=RecStreamer(),
+                          _noise_fn=lambda frame, n2: draws[frame])
+    # sequences = prompt + consumed text + one id per speech token, exactly the reference's tts_lm_input_ids (:722); the
+    # streamer sees the reference's put / end calls in the reference's order (a chunk per frame -- also after EOS inside a
+    # window -- end(idx) whenever the EOS head fires, a final end())
+    assert torch.equal(out2.sequences[0], torch.from_numpy(z["sequences"]))
+    assert log == z["streamer_log"].tolist(), (log, z["streamer_log"].tolist())
+    assert float((out2.speech_outputs[0] - out.speech_outputs[0]).norm() / out.speech_outputs[0].norm()) <= 1e-5
     assert int(z["prompt"].shape[0]) + out.sequences.shape[1] == int(z["n_tokens"])
     assert bool(out.reach_max_step_sample[0]) == bool(z["reach_max"][0])
     ref = torch.from_numpy(z["audio"])
