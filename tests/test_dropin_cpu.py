@@ -232,6 +232,45 @@ def test_continuous_admission_equals_one_by_one(monkeypatch):
     assert st["iterations"] < sum(own) and st["iterations"] >= max(own)
 
 
+def test_continuous_length_capped_utterance_leaves_the_others_intact(monkeypatch):
+    """an utterance retired by the LOOP-level conditions of generate() (range(max_steps) exhausted / max_length
+    reached -- not by EOS) while others stay in flight.  The survivors' next-step embeddings were packed in the old order; they must
+    follow the survivors.  3 requests on 2 slots, per-request max_new_tokens 3 / 8 / 6, forced plans that never reach EOS before
+    the cap: every request must still come out exactly as generate() produces it alone."""
+    from test_oracle_golden import _oracle_small
+    from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference
+    cfgd = {"decoder_config": {"max_position_embeddings": 4096}, "diffusion_head_config": {"ddpm_num_inference_steps": 5},
+            "acoustic_tokenizer_config": {"fix_std": 0.5, "std_dist_type": "gaussian"}}
+    D, E, S = TOK.speech_diffusion_id, TOK.speech_end_id, TOK.speech_start_id
+    reqs = _requests(3, 11)
+    caps = [3, 8, 6]
+    plans = [[D] * 12, [D, D, E, S] + [D] * 10, [D] * 12]
+    for r, c, p in zip(reqs, caps, plans):
+        r["max_new_tokens"] = c
+        r["_forced_tokens"] = p
+    with fake_engine.cpu_cuda_shims(monkeypatch):
+        solo = []
+        for r in reqs:
+            m1 = VibeVoiceForConditionalGenerationInference(cfgd, fake_engine.FakeEngine(_oracle_small(), n_slots=1), model_dtype=torch.float32)
+            m1.set_speech_factors(0.2, -0.05)
+            m1.set_ddpm_inference_steps(5)
+            solo.append(m1.generate(input_ids=r["input_ids"], attention_mask=r["attention_mask"], cfg_scale=1.3, tokenizer=TOK,
+                                    generation_config={"do_sample": False}, _forced_tokens=[r["_forced_tokens"]],
+                                    _noise_fn=r["_noise_fn"], max_new_tokens=r["max_new_tokens"], show_progress_bar=False))
+        m = VibeVoiceForConditionalGenerationInference(cfgd, fake_engine.FakeEngine(_oracle_small(), n_slots=2), model_dtype=torch.float32)
+        m.set_speech_factors(0.2, -0.05)
+        m.set_ddpm_inference_steps(5)
+        m.concurrent_codecs = False
+        outs = m.generate_continuous(reqs, tokenizer=TOK, generation_config={"do_sample": False}, cfg_scale=1.3)
+    assert m.last_stats["max_in_flight"] == 2
+    for a, b, c, r in zip(outs, solo, caps, reqs):
+        assert a.sequences.shape[1] - r["input_ids"].shape[1] == c          # really ended by the cap
+        assert torch.equal(a.sequences.cpu(), b.sequences.cpu()[:, :a.sequences.shape[1]])
+        assert a.speech_outputs[0].shape == b.speech_outputs[0].shape
+        d = (a.speech_outputs[0] - b.speech_outputs[0]).norm() / b.speech_outputs[0].norm()
+        assert float(d) <= 1e-5, float(d)
+
+
 def test_batch_limit_is_checked_at_entry(monkeypatch):
     from test_oracle_golden import _oracle_small
     from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference

@@ -86,7 +86,7 @@ def load():
         print(f"[vibevoice_amd] {LIB_PATH} was built from other sources (binary id {_build.binary_id(LIB_PATH)}, sources "
               f"{_build.source_id()}): rebuilding with hipcc (about two minutes)", file=sys.stderr, flush=True)
         try:
-            _build.build(force=True, verbose=False)
+            _build.build_locked()          # one process compiles; the other ranks of a torchrun job wait for its binary
         except Exception as ex:
             raise RuntimeError(
                 f"{LIB_PATH} was built from different sources (binary id {_build.binary_id(LIB_PATH)}, sources "

@@ -79,6 +79,20 @@ def build(force=False, verbose=True):
     return LIB
 
 
+def build_locked():
+    """Rebuild a stale binary under an exclusive file lock: under torchrun every rank finds the same stale .so at the same time;
+    the first one compiles (about two minutes), the others block on the lock and then find the binary current."""
+    import fcntl
+    with open(LIB + ".lock", "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            if stale():
+                build(force=True, verbose=False)
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
+    return LIB
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
     print(LIB)

@@ -1063,12 +1063,11 @@ static int set_schedule(vv_ctx* ctx, int n_steps, const float* t, const float* c
         ctx->tvals = (float*)dalloc(ctx, 64 * 4);
     }
     float rows6[64 * 6];
-    bool sde = false;
-    for (int i = 0; i < n_steps; ++i) {
+    for (int i = 0; i < n_steps; ++i)
         for (int j = 0; j < 6; ++j) rows6[i * 6 + j] = (j < width) ? coef[i * width + j] : 0.f;
-        if (rows6[i * 6 + 5] != 0.f) sde = true;
-    }
-    ctx->sde_on = sde;
+    // by the API used, not by the values: a one-step stochastic schedule has sigma_t = 0 on its only step (all noise scales
+    // zero) and must still be sampled through vv_diffusion_sample_sde, as the reference runs it (a noise-free first-order step)
+    ctx->sde_on = (width == 6);
     HIPCHK(ctx, hipStreamSynchronize(st));
     HIPCHK(ctx, hipMemcpy(ctx->coef, rows6, (size_t)n_steps * 6 * 4, hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(ctx->tvals, t, (size_t)n_steps * 4, hipMemcpyHostToDevice));

@@ -190,6 +190,12 @@ class Engine:
                                 1 if t.dtype == torch.bfloat16 else 0, t.numel())
         self._chk(rc, f"vv_upload({name})")
         self._loaded.add(name)
+        # state the engine DERIVES from parameters must follow them (load_state_dict on a live model, LoRA merges): the
+        # timestep-embedding table comes from head.t_embedder, the packed valid-token rows from lm_head / embed_tokens
+        if name.startswith("head."):
+            self._n_steps = None
+        if name in ("lm.embed_tokens.weight", "lm_head.weight") and getattr(self, "_valid_ids", None):
+            self.set_valid_tokens(self._valid_ids)
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor], mapped=False, strict=True):
         """sd keyed by reference names (model.language_model....) unless mapped=True."""
@@ -211,6 +217,7 @@ class Engine:
         arr = (C.c_int * len(ids))(*[int(i) for i in ids])
         self._chk(self.lib.vv_set_valid_tokens(self._ctx, arr, len(ids)), "vv_set_valid_tokens")
         self.n_valid = len(ids)
+        self._valid_ids = [int(i) for i in ids]
 
     def set_num_steps(self, n_steps: int, t_cast_bf16: bool = False, algorithm_type: str = "dpmsolver++"):
         """Solver table for N steps.  algorithm_type: "dpmsolver++" (the model classes' scheduler) or "sde-dpmsolver++" (what

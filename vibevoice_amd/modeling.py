@@ -593,9 +593,20 @@ class VibeVoiceForConditionalGenerationInference:
     def _block_rows(self, i: int):
         """row i of the frame store: [utterances in flight, hop] fp32, 64 rows per block"""
         b, r = divmod(i, 64)
+        w = getattr(self, "_frame_w", min(MAX_BATCH, max(1, self.engine.cfg.n_slots)))
+        if any(t is not None and t.shape[1] != w for t in self._audio_blocks):
+            self._audio_blocks = []
         while len(self._audio_blocks) <= b:
-            self._audio_blocks.append(self.engine.new(64, min(MAX_BATCH, max(1, self.engine.cfg.n_slots)), self.engine.cfg.hop))
+            self._audio_blocks.append(None)
+        if self._audio_blocks[b] is None:
+            self._audio_blocks[b] = self.engine.new(64, w, self.engine.cfg.hop)
         return self._audio_blocks[b][r]
+
+    def _release_frames(self):
+        """the frame store holds one row per diffusion iteration of the call that just ended; its outputs have been copied out
+        (torch.cat), so only the first block stays allocated for the next call"""
+        self._audio_blocks = [t for t in self._audio_blocks if t is not None][:1]
+        self._first_row = None
 
     # ------------------------------------------------------------------ one iteration of the hot loop over the active utterances
     def _iterate(self, S, act: List[_Utt]):
@@ -772,7 +783,10 @@ class VibeVoiceForConditionalGenerationInference:
             chunk = self._block_rows(S["frame_rows"])
             S["frame_rows"] += 1
             chunk[:n].copy_(self._audio[:n])
+            fr = getattr(self, "_first_row", None)
             for j, u in enumerate(diff):
+                if fr is not None and not u.chunks:
+                    fr[id(u)] = S["frame_rows"] - 1
                 u.chunks.append(chunk[j])
                 nxt_x[live.index(u)].copy_(self._emb_out[j])
             if audio_streamer is not None:
@@ -883,6 +897,7 @@ class VibeVoiceForConditionalGenerationInference:
             raise ValueError(f"batch {B} needs {2*B} LM rows > max_rows={e.cfg.max_rows}")
         S = self._session(tokenizer, generation_config, cfg_scale, kwargs, audio_streamer, B)
         S["sample_rows"] = lambda order: list(range(B))
+        self._frame_w = B                                 # frame-store rows are as wide as this call's batch
         if kwargs.get("max_new_tokens", None) is None:
             max_new_tokens = self.max_position_embeddings - L0
         else:
@@ -959,6 +974,7 @@ class VibeVoiceForConditionalGenerationInference:
                 if u.tokens:
                     seq[u.idx, L0:L0 + len(u.tokens)] = torch.tensor(u.tokens, dtype=torch.long)
         e.sync()
+        self._release_frames()
         self.last_stats = {"frames": S["n_frames"], "steps": n_steps}
         return VibeVoiceGenerationOutput(
             sequences=seq.to(self.device), speech_outputs=outs if return_speech else None,
@@ -986,6 +1002,8 @@ class VibeVoiceForConditionalGenerationInference:
         step_cb = kwargs.pop("_step_callback", None)
         S = self._session(tokenizer, generation_config, cfg_scale, kwargs, audio_streamer, n_req)
         S["sample_rows"] = lambda order: [u.idx for u in order]
+        self._frame_w = cap
+        self._first_row = {}
         queue = list(range(n_req))
         free = list(range(cap))
         done = [None] * n_req
@@ -1003,16 +1021,22 @@ class VibeVoiceForConditionalGenerationInference:
                         audio_streamer.end()
                     break
                 # ---- retire by the loop-level conditions of a batch-1 generate(): range(max_steps) exhausted / max_length ----
-                keep = []
-                for u in active:
+                keep, keep_rows = [], []
+                for i, u in enumerate(active):
                     if u.step >= u.max_steps:
                         u.finished = True
                     elif u.seq_len0 + u.step >= u.max_length:
                         u.finished = u.reach_max = True
                     if not u.finished:
                         keep.append(u)
+                        keep_rows.append(i)
                     elif audio_streamer is not None:
                         audio_streamer.end(torch.tensor([u.idx]))
+                if keep and len(keep) != len(active):
+                    # _iterate packed the next-step embeddings in the order of the utterances it returned (`active`) and reads
+                    # them back by position: the rows of the survivors move up to the survivors' new positions
+                    sel = torch.tensor(keep_rows, dtype=torch.long, device=self._x_in.device)
+                    self._x_in[:len(keep)] = self._x_in.index_select(0, sel)
                 active = keep
                 # ---- refill free slots ----
                 in_flight = {u.slot for u in active}
@@ -1051,8 +1075,22 @@ class VibeVoiceForConditionalGenerationInference:
                 if not active:
                     continue
                 stats["max_in_flight"] = max(stats["max_in_flight"], len(active))
+                before = active
                 active = self._iterate(S, active)
                 it += 1
+                # a finished utterance's frames leave the shared frame store at once (its own contiguous tensor); blocks no
+                # live utterance points into are dropped, so the store follows the audio IN FLIGHT, not the queue's total
+                ended = [u for u in before if u.finished]
+                for u in ended:
+                    if u.chunks:
+                        u.chunks = [torch.cat(u.chunks, dim=-1)]
+                if ended:
+                    rows0 = [self._first_row[id(u)] for u in active if id(u) in self._first_row]
+                    lo = min(rows0 + [S["frame_rows"]]) // 64
+                    for b in range(min(lo, len(self._audio_blocks))):
+                        self._audio_blocks[b] = None
+                    for u in ended:
+                        self._first_row.pop(id(u), None)
             if audio_streamer is not None:
                 audio_streamer.end()
             outs = []
@@ -1068,6 +1106,7 @@ class VibeVoiceForConditionalGenerationInference:
                 outs.append(VibeVoiceGenerationOutput(sequences=seq.to(self.device), speech_outputs=[audio] if return_speech else None,
                                                       reach_max_step_sample=torch.tensor([u.reach_max], device=self.device)))
         e.sync()
+        self._release_frames()
         stats["iterations"] = it
         self.last_stats = {"frames": S["n_frames"], "steps": it, **stats}
         return outs

@@ -93,6 +93,12 @@ class AudioStreamer:
         """Stop the drain thread and release the pinned ring (also happens by itself once every sample has ended)."""
         if not self._closed:
             self._closed = True
+            # a consumer blocked in get_stream() / __iter__ with timeout=None must wake up: every sample that has not ended
+            # gets its stop signal (ordered after its pending chunks) before the thread stops
+            for idx in range(self.batch_size):
+                if not self.finished_flags[idx]:
+                    self.finished_flags[idx] = True
+                    self._work.put(("end", idx, None, None, None))
             self._work.put((_CLOSE, None, None, None, None))
 
     def __del__(self):
