@@ -156,6 +156,11 @@ int vv_codec_chain_batch(vv_ctx* ctx, void* stream, int n, const int* slots, con
 /* acoustic_tokenizer.encode(wav).mean, non-streaming (:154; modular_vibevoice_tokenizer.py:1081-1085):
  * wav_dev [frames*hop] -> mean_out_dev [frames][latent] */
 int vv_acoustic_encode(vv_ctx* ctx, void* stream, int frames, const float* wav_dev, float* mean_out_dev);
+/* Frames the voice-prompt encoder takes per pass, 1..config.enc_frames (the buffers are sized for enc_frames; the default).
+ * The reference's non-streaming encode runs the whole prompt as one sequence (modular_vibevoice_tokenizer.py:384-418,
+ * 1081-1085); a pass of F frames is that computation on F frames with the causal history carried over, so the result does
+ * not depend on F -- tests/test_gpu_shipped.py holds every pass size to the oracle's one-sequence encode. */
+int vv_set_enc_pass_frames(vv_ctx* ctx, int frames_per_pass);
 /* 16-bit PCM of n chunks of `samples` fp32 samples each, on device, before the chunk leaves for the host: the arithmetic
  * of convert_to_16_bit_wav (demo/gradio_demo.py:1058-1073, applied per streamed chunk at :404-418): peak = max|x| of the
  * chunk; x /= peak when peak > 1; int16(trunc(x * 32767)).  audio_dev [n][samples] fp32 -> pcm_out_dev [n][samples] int16. */

@@ -41,6 +41,7 @@ class StreamingOracleModel:
     bias: float
     head_eps: float = 1e-5
     codec_eps: float = 1e-5
+    t_cast_dtype: Optional[torch.dtype] = None      # bf16 GPU path: the timestep is cast to the model dtype (999 -> 1000)
 
 
 @dataclass
@@ -96,7 +97,7 @@ def oracle_generate_streaming(m: StreamingOracleModel, preset: Preset, tts_text_
             noise = noise_fn(frame, 2)
             lat = dpm.sample_speech_tokens(
                 lambda x, t, c: head.head_forward(m.head_w, x, t, c, m.head_layers, m.head_eps),
-                tts_last[None], neg_last[None], cfg_scale, num_steps, noise)
+                tts_last[None], neg_last[None], cfg_scale, num_steps, noise, m.t_cast_dtype)
             scaled = lat / m.scaling - m.bias
             chunk = codec.decoder_forward(m.ac_w, scaled[0][None, :, None], m.ratios, m.dec_depths, state, m.codec_eps)
             if not finished:

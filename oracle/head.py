@@ -33,20 +33,31 @@ def timestep_embedding(t, dim=256, max_period=10000):
     return emb.to(t.dtype)
 
 
-def head_forward(w, noisy, timesteps, condition, n_layers, eps=1e-5):
-    x = F.linear(noisy, w["noisy_images_proj.weight"])
+def head_forward(w, noisy, timesteps, condition, n_layers, eps=1e-5, mfma_in_bf16=False):
+    """mfma_in_bf16: round every matrix-unit INPUT to bf16 (sums, norms and the residual stay fp32) -- the rounding points
+    of the HIP bf16 mode, see oracle/lm.py; the adaLN-modulated norm is fed as rs * W.(x*w*(1+scale)) + W.shift with the
+    two operands rounded separately, which is the same linear map."""
+    r = (lambda t: t.bfloat16().to(t.dtype)) if mfma_in_bf16 else (lambda t: t)
+    x = F.linear(r(noisy), w["noisy_images_proj.weight"])
     t_freq = timestep_embedding(timesteps)
-    t = F.linear(F.silu(F.linear(t_freq, w["t_embedder.mlp.0.weight"])),
+    t = F.linear(r(F.silu(F.linear(r(t_freq), w["t_embedder.mlp.0.weight"]))),
                  w["t_embedder.mlp.2.weight"])
-    c = F.linear(condition, w["cond_proj.weight"]) + t
+    c = F.linear(r(condition), w["cond_proj.weight"]) + t
+
+    def modulated(x, nw, scale, shift, W):
+        if not mfma_in_bf16:
+            return F.linear(rmsnorm(x, nw, eps) * (1 + scale) + shift, W)
+        xf = x.float()
+        rs = torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)
+        xm = xf * (1 + scale) if nw is None else xf * nw * (1 + scale)
+        return rs * F.linear(r(xm), W) + F.linear(r(shift), W)
     for i in range(n_layers):
         p = f"layers.{i}."
-        mod = F.linear(F.silu(c), w[p + "adaLN_modulation.1.weight"])
+        mod = F.linear(r(F.silu(c)), w[p + "adaLN_modulation.1.weight"])
         shift, scale, gate = mod.chunk(3, dim=-1)
-        m = rmsnorm(x, w[p + "norm.weight"], eps) * (1 + scale) + shift
-        u = F.silu(F.linear(m, w[p + "ffn.gate_proj.weight"])) * F.linear(m, w[p + "ffn.up_proj.weight"])
-        x = x + gate * F.linear(u, w[p + "ffn.down_proj.weight"])
-    mod = F.linear(F.silu(c), w["final_layer.adaLN_modulation.1.weight"])
+        nw = w[p + "norm.weight"]
+        u = F.silu(modulated(x, nw, scale, shift, w[p + "ffn.gate_proj.weight"])) * modulated(x, nw, scale, shift, w[p + "ffn.up_proj.weight"])
+        x = x + gate * F.linear(r(u), w[p + "ffn.down_proj.weight"])
+    mod = F.linear(r(F.silu(c)), w["final_layer.adaLN_modulation.1.weight"])
     shift, scale = mod.chunk(2, dim=-1)
-    x = rmsnorm(x, None, eps) * (1 + scale) + shift
-    return F.linear(x, w["final_layer.linear.weight"])
+    return modulated(x, None, scale, shift, w["final_layer.linear.weight"])

@@ -52,12 +52,19 @@ class KVCache:
 
 class Qwen2Oracle:
     def __init__(self, weights, n_layers, n_heads, n_kv_heads, head_dim,
-                 rope_theta=1e6, eps=1e-6, kv_round_bf16=False, rope_bf16=False):
+                 rope_theta=1e6, eps=1e-6, kv_round_bf16=False, rope_bf16=False, mfma_in_bf16=False, attn_rows=None):
         self.w = weights
         self.L, self.nh, self.nkv, self.d = n_layers, n_heads, n_kv_heads, head_dim
         self.theta, self.eps = rope_theta, eps
         self.kv_round_bf16 = kv_round_bf16   # emulate a bf16 KV cache (GPU bf16 path)
         self.rope_bf16 = rope_bf16           # emulate cos/sin cast to bf16 (HF casts to x.dtype)
+        # emulate the HIP bf16 mode's rounding points: every matrix-unit INPUT is rounded to bf16 (the normed rows fed to
+        # q/k/v and gate/up, the rotated query, the softmax weights, the attention output fed to o_proj, the SwiGLU product
+        # fed to down_proj) while sums, norms, softmax statistics and the residual stream stay fp32 -- the same algorithm, the
+        # roundings a bf16-activation GPU path (the reference on GPU rounds every op's output, :290-292 bf16 load) cannot
+        # avoid.  Against this form the HIP kernels are held to ~1e-3 instead of the ~3e-2 the fp32 form allows.
+        self.mfma_in_bf16 = mfma_in_bf16
+        self.attn_rows = attn_rows           # query rows per attention block (None: all at once); bounds the score matrix
         self.inv_freq = 1.0 / (rope_theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).float() / head_dim))
 
     def new_cache(self):
@@ -87,11 +94,12 @@ class Qwen2Oracle:
         h = embeds
         for i in range(self.L):
             p = f"layers.{i}."
-            n = rmsnorm(h, w[p + "input_layernorm.weight"], self.eps)
+            r16 = (lambda t: t.bfloat16().to(t.dtype)) if self.mfma_in_bf16 else (lambda t: t)
+            n = r16(rmsnorm(h, w[p + "input_layernorm.weight"], self.eps))
             q = F.linear(n, w[p + "self_attn.q_proj.weight"], w[p + "self_attn.q_proj.bias"]).view(T, self.nh, self.d)
             k = F.linear(n, w[p + "self_attn.k_proj.weight"], w[p + "self_attn.k_proj.bias"]).view(T, self.nkv, self.d)
             v = F.linear(n, w[p + "self_attn.v_proj.weight"], w[p + "self_attn.v_proj.bias"]).view(T, self.nkv, self.d)
-            q = self._rope(q, pos)
+            q = r16(self._rope(q, pos))
             k = self._rope(k, pos)
             if self.kv_round_bf16:
                 k, v = k.bfloat16().float(), v.bfloat16().float()
@@ -106,16 +114,29 @@ class Qwen2Oracle:
             g = self.nh // self.nkv
             Kr = K.repeat_interleave(g, dim=0)                # [nh, Ltot, d]
             Vr = V.repeat_interleave(g, dim=0)
-            sc = torch.einsum("thd,hld->htl", q, Kr) * (self.d ** -0.5)
             Ltot = p0 + T
-            mask = torch.arange(Ltot)[None, :] > pos[:, None]  # [T, Ltot]
-            sc = sc.masked_fill(mask[None], float("-inf"))
-            pr = torch.softmax(sc.float(), dim=-1).to(q.dtype)
-            a = torch.einsum("htl,hld->thd", pr, Vr).reshape(T, self.nh * self.d)
-            h = h + F.linear(a, w[p + "self_attn.o_proj.weight"])
-            n2 = rmsnorm(h, w[p + "post_attention_layernorm.weight"], self.eps)
-            mlp = F.linear(F.silu(F.linear(n2, w[p + "mlp.gate_proj.weight"])) *
-                           F.linear(n2, w[p + "mlp.up_proj.weight"]), w[p + "mlp.down_proj.weight"])
+            blk = self.attn_rows or T
+            a = torch.empty(T, self.nh * self.d, dtype=q.dtype, device=q.device)
+            for t0 in range(0, T, blk):                       # the same attention, `blk` query rows at a time
+                t1 = min(T, t0 + blk)
+                Lb = int(pos[t1 - 1]) + 1                     # causal: later positions carry zero weight for these rows
+                sc = torch.einsum("thd,hld->htl", q[t0:t1], Kr[:, :Lb]) * (self.d ** -0.5)
+                mask = torch.arange(Lb)[None, :] > pos[t0:t1, None]
+                sc = sc.masked_fill(mask[None], float("-inf"))
+                if self.mfma_in_bf16:
+                    # un-normalised weights exp(s - max) rounded to bf16, row sum kept in fp32 from the UNROUNDED weights,
+                    # normalisation after the product -- flash attention's arithmetic (the weights it multiplies are exp(s - m))
+                    ex = torch.exp(sc.float() - sc.float().amax(dim=-1, keepdim=True))
+                    den = ex.sum(dim=-1, keepdim=True)
+                    ab = torch.einsum("htl,hld->htd", r16(ex).to(q.dtype), Vr[:, :Lb]) / den.to(q.dtype)
+                    a[t0:t1] = ab.transpose(0, 1).reshape(t1 - t0, self.nh * self.d)
+                else:
+                    pr = torch.softmax(sc.float(), dim=-1).to(q.dtype)
+                    a[t0:t1] = torch.einsum("htl,hld->thd", pr, Vr[:, :Lb]).reshape(t1 - t0, self.nh * self.d)
+            h = h + F.linear(r16(a), w[p + "self_attn.o_proj.weight"])
+            n2 = r16(rmsnorm(h, w[p + "post_attention_layernorm.weight"], self.eps))
+            mlp = F.linear(r16(F.silu(F.linear(n2, w[p + "mlp.gate_proj.weight"])) *
+                               F.linear(n2, w[p + "mlp.up_proj.weight"])), w[p + "mlp.down_proj.weight"])
             h = h + mlp
         cache.length = p0 + T
         return rmsnorm(h, w["norm.weight"], self.eps) if final_norm else h

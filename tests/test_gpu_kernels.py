@@ -112,8 +112,10 @@ def test_prefill_gemm3(sm, epi, T, N, K):
     LDS-staged MFMA GEMM with the store / bias / residual / SwiGLU epilogues; ragged T (not a multiple of 128 / 16), N not a
     multiple of the 128-feature block, an odd number of 32-wide k-tiles (K = 416 -> 13), one-block problems.  The last two
     shapes fill the chip with 256 x 256 workgroups and therefore run the double-buffered kernel (vv_gemm4_kernel): ragged T
-    (4100 = 16 row blocks + 4 rows), 257 feature tiles, odd k-tile counts (13, 65), every epilogue.  Against fp32
-    torch on the same bf16-representable weights: bf16 activations inside the MFMA -> rel-L2 <= 2e-2."""
+    (4100 = 16 row blocks + 4 rows), 257 feature tiles, odd k-tile counts (13, 65), every epilogue.  The reference multiplies the
+    same bf16-ROUNDED activations (the packing kernel rounds once, after the norm) in fp32, so what is left is summation order:
+    rel-L2 <= 2e-4 for the fp32-out epilogues (a wrong k-tile in a hundred is ~1e-1), <= 3e-3 for SwiGLU, whose output is stored
+    as packed bf16 (one more rounding); the fp32-activation reference stays as the accuracy bound (<= 2e-2)."""
     eng = sm.eng
     g = synth.Gen(7000 + T + N + K + epi)
     w = g.normal((N, K), 1.0 / np.sqrt(K))
@@ -126,6 +128,10 @@ def test_prefill_gemm3(sm, epi, T, N, K):
     xin = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-5) * nw if norm else x
     acc = xin @ w.t()
     ref = {0: acc, 1: acc + bias, 4: y0 + acc, 3: torch.nn.functional.silu(acc) * (xin @ w2.t())}[epi]
+    x16 = synth.bf16_round(xin)
+    a16 = (x16.double() @ w.double().t()).float()
+    ref16 = {0: a16, 1: a16 + bias, 4: y0 + a16,
+             3: torch.nn.functional.silu(a16) * (x16.double() @ w2.double().t()).float()}[epi]
     y = dev(y0.clone(), eng)
     with torch.cuda.stream(eng.stream):
         eng.gemm3_raw(eng.pack_matrix(w), dev(x, eng), y, N, K, epi=epi, w2p=eng.pack_matrix(w2) if epi == 3 else None,
@@ -133,6 +139,9 @@ def test_prefill_gemm3(sm, epi, T, N, K):
     eng.sync()
     assert rel_err(y, ref) <= 2e-2, rel_err(y, ref)
     assert max_err(y, ref) <= 6e-2, max_err(y, ref)              # no tile is missing or misplaced
+    tight = 3e-3 if epi == 3 else 2e-4
+    assert rel_err(y, ref16) <= tight, (rel_err(y, ref16), tight)
+    assert max_err(y, ref16) <= 4 * tight, (max_err(y, ref16), tight)
 
 
 def test_lm_prefill_one_pass_and_ragged_chunks_match_the_oracle(sm):

@@ -13,13 +13,14 @@ from oracle import lm as olm
 pytestmark = pytest.mark.gpu
 
 
-def build(n_lm=1, n_tts=2, use_graph=False, xsplit=3):
+def build(n_lm=1, n_tts=2, use_graph=False, xsplit=3, lmcfg=None, head_layers=2, model_dtype=torch.float32):
     from vibevoice_amd.engine import Engine, EngineConfig
     from vibevoice_amd.modeling_streaming import VibeVoiceStreamingForConditionalGenerationInference
-    cfg = synth.LMCfg(hidden=128, layers=n_lm + n_tts, heads=2, kv_heads=1, inter=256, vocab=320)
+    cfg = lmcfg or synth.LMCfg(hidden=128, layers=n_lm + n_tts, heads=2, kv_heads=1, inter=256, vocab=320)
+    assert cfg.layers == n_lm + n_tts
     H = cfg.hidden
     w = synth.lm_weights(cfg)
-    hc = synth.HeadCfg(hidden=H, layers=2)
+    hc = synth.HeadCfg(hidden=H, layers=head_layers)
     cc = synth.CodecCfg()
     head_w = synth.head_weights(hc)
     ac_w = synth.decoder_weights(cc, 3)
@@ -51,7 +52,7 @@ def build(n_lm=1, n_tts=2, use_graph=False, xsplit=3):
     eng.load_state_dict(sd, mapped=True, strict=True)
     cfgd = {"decoder_config": {"max_position_embeddings": 512}, "diffusion_head_config": {"ddpm_num_inference_steps": 5},
             "tts_backbone_num_hidden_layers": n_tts}
-    model = VibeVoiceStreamingForConditionalGenerationInference(cfgd, eng, model_dtype=torch.float32)
+    model = VibeVoiceStreamingForConditionalGenerationInference(cfgd, eng, model_dtype=model_dtype)
     model.set_speech_factors(0.2, -0.05)
     model.set_ddpm_inference_steps(5)
     return om, model, cfg

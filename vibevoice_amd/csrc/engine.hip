@@ -215,6 +215,7 @@ struct vv_ctx {
     float *ct1 = nullptr;
     // codecs
     CodecNet dec, aenc, senc;
+    int enc_pass = 0;                      // frames per voice-prompt encoder pass (0: aenc.Fmax)
     // vv_codec_chain_batch: the per-utterance parts of a batch's tokenizer chains fork onto these streams (graph branches)
     hipStream_t side[8] = {}; hipEvent_t ev_fork = nullptr, ev_join[8] = {}; bool side_ready = false;
     float scaling = 1.f, bias = 0.f;
@@ -1585,11 +1586,19 @@ extern "C" int vv_acoustic_encode(vv_ctx* ctx, void* stream, int frames, const f
     CodecNet& net = ctx->aenc;
     if (zero_codec(ctx, net, 0, st)) return -1;
     const int L = ctx->c.latent_dim;
-    for (int f0 = 0; f0 < frames; f0 += net.Fmax) {
-        const int F = std::min(net.Fmax, frames - f0);
+    const int pass = ctx->enc_pass > 0 ? std::min(ctx->enc_pass, net.Fmax) : net.Fmax;
+    for (int f0 = 0; f0 < frames; f0 += pass) {
+        const int F = std::min(pass, frames - f0);
         HIPCHK(ctx, hipMemcpyAsync(net.in_buf[0] + 6, wav_dev + (size_t)f0 * ctx->hop, (size_t)F * ctx->hop * 4, hipMemcpyDeviceToDevice, st));
         if (run_codec(ctx, net, 0, F, mean_out_dev + (size_t)f0 * L, st)) return -1;
     }
+    return 0;
+}
+
+extern "C" int vv_set_enc_pass_frames(vv_ctx* ctx, int frames_per_pass) {
+    if (!ctx->c.has_acoustic_encoder) return fail(ctx, "no acoustic encoder configured");
+    if (frames_per_pass < 1 || frames_per_pass > ctx->aenc.Fmax) return fail(ctx, "frames_per_pass %d out of range [1,%d]", frames_per_pass, ctx->aenc.Fmax);
+    ctx->enc_pass = frames_per_pass;
     return 0;
 }
 

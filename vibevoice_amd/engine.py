@@ -349,6 +349,10 @@ class Engine:
         self._chk(self.lib.vv_acoustic_encode(self._ctx, self._s, frames, self._p(wav), self._p(mean_out)),
                   "vv_acoustic_encode")
 
+    def set_enc_pass_frames(self, frames_per_pass: int):
+        """frames per voice-prompt encoder pass, 1..cfg.enc_frames"""
+        self._chk(self.lib.vv_set_enc_pass_frames(self._ctx, int(frames_per_pass)), "vv_set_enc_pass_frames")
+
     def audio_to_pcm16(self, audio: torch.Tensor, pcm_out: torch.Tensor, stream=None):
         """audio [n, samples] fp32 (contiguous) -> pcm_out [n, samples] int16, per-chunk peak normalisation as the reference's
         convert_to_16_bit_wav (demo/gradio_demo.py:1058-1073)."""

@@ -243,6 +243,7 @@ class VibeVoiceStreamingForConditionalGenerationInference:
         prompt_ids = kwargs.pop("tts_lm_input_ids", None)
         noise_fn = kwargs.pop("_noise_fn", None)
         trace = kwargs.pop("_trace", None)
+        teacher = kwargs.pop("_teacher_latents", None)   # test hook (teacher-forced per step): frame -> latent [1, L]
         marks = kwargs.pop("_marks", None)            # bench hook: first-audio timestamp
         verbose = kwargs.get("verbose", False)
         tts_text_ids = tts_text_ids.reshape(-1).cpu()
@@ -295,6 +296,14 @@ class VibeVoiceStreamingForConditionalGenerationInference:
                     nz = noise_fn(frame, 2) if noise_fn is not None else torch.randn(2, e.cfg.latent_dim)
                     self._noise[0].copy_(nz[0].to(torch.float32))
                     e.diffusion_sample(1, self._cond, self._noise, cfg_scale, self._latent)
+                    own_latent = None
+                    if teacher is not None:
+                        # the frame's own latent is what gets compared; everything downstream of it (decoder, connector,
+                        # TTS-LM step) consumes the oracle's, so a bf16-mode run is held step by step without AR compounding
+                        own_latent = self._latent.cpu().clone()
+                        tl = teacher(frame)
+                        if tl is not None:
+                            self._latent.copy_(tl.to(self.device, torch.float32).reshape(self._latent.shape))
                     e.codec_decode(0, self._latent, self._audio[0])
                     chunk = self._audio.clone()
                     if marks is not None and "first_audio" not in marks:
@@ -322,7 +331,8 @@ class VibeVoiceStreamingForConditionalGenerationInference:
                     e.eos_logit(1, self._hid, self._eos)
                     logit = float(self._eos.cpu()[0])
                     if trace is not None:
-                        trace.append({"latent": self._latent.cpu().clone(), "tts_last": self._hid[0].cpu().clone(), "eos": logit})
+                        trace.append({"latent": own_latent if own_latent is not None else self._latent.cpu().clone(),
+                                      "tts_last": self._hid[0].cpu().clone(), "eos": logit})
                     if torch.sigmoid(torch.tensor(logit)).item() > 0.5:
                         finished = True
                         if audio_streamer is not None:
