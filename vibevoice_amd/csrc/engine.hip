@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <set>
 #include <string>
@@ -236,6 +237,10 @@ struct vv_ctx {
     std::vector<ProfRec> prof_rec;
     std::vector<VVGemm> prof_gemv;          // the decode-GEMV launches of the last profile window, in issue order (vv_profile_replay)
     double prof_gemv_bytes = 0.0;
+    // launches of the other timed kernel families recorded in the same window (vv_profile_replay_family): 1 = vv_gemv16p_kernel
+    // (batch decode projections), 2 = decode attention (vv_attn_fused_kernel + its vv_attn_merge2_kernel)
+    struct ProfLaunch { int family; double bytes; std::function<int(hipStream_t)> fn; };
+    std::vector<ProfLaunch> prof_other;
     int64_t prof_raw_ns = 0, prof_ev_over_ns = 0;
     hipStream_t prof_stream = nullptr;     // last vv_profile_end: uncalibrated GEMV total, one empty event pair
 #ifdef VV_GEMM_TIMING
@@ -1105,8 +1110,19 @@ static int set_schedule(vv_ctx* ctx, int n_steps, const float* t, const float* c
     return 0;
 }
 
+// batch-decode projection (gemv16p.hip); inside a profile window the launch is also recorded for the family replay
+static int p16_gemv(vv_ctx* ctx, hipStream_t st, const void* W, const void* W2, const void* Xp, float* Y, void* Yp, const float* bias,
+                    const float* gate, int T, int N, int K, int ldy, int ld_gate, int epi) {
+    if (ctx->prof_on) {
+        const double by = (double)vv_packed_elems(N, K) * 2.0 * (W2 ? 2.0 : 1.0) + (double)vv_packed_elems(16, K) * 2.0 +
+                          (Yp ? (double)T * N * 2.0 : (double)T * N * 4.0 * (epi == VV_EPI_RESID || epi == VV_EPI_GATED_RESID ? 2.0 : 1.0));
+        ctx->prof_other.push_back({1, by, [=](hipStream_t s) { return vv_gemv16p_launch(W, W2, Xp, Y, Yp, bias, gate, T, N, K, ldy, ld_gate, epi, s); }});
+    }
+    return vv_gemv16p_launch(W, W2, Xp, Y, Yp, bias, gate, T, N, K, ldy, ld_gate, epi, st);
+}
+
 static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float* hidden_out, int l0, int l1, int final_norm, bool fused_attn, bool contiguous,
-                   int attn_S, int attn_waves) {
+                   int attn_S, int attn_waves, int64_t kv_positions = 0) {
     const vv_config& c = ctx->c;
     const int H = ctx->H, D = ctx->D, Hq = ctx->Hq, Hkv = ctx->Hkv, I = ctx->I, QKV = ctx->QKV;
     HIPCHK(ctx, hipMemcpyAsync(ctx->h, x_in, (size_t)R * H * 4, hipMemcpyDeviceToDevice, st));
@@ -1141,7 +1157,7 @@ static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float*
         if (p16) {
             ctx->launches += 2;
             VVCHK(vv_pack16_launch(ctx->h, H, 1, L.ln1, c.lm_eps, nullptr, nullptr, 0, ctx->p16_x, R, H, st));
-            VVCHK(vv_gemv16p_launch(L.wqkv, nullptr, ctx->p16_x, ctx->qkv, nullptr, L.bqkv, nullptr, R, QKV, H, QKV, 0, VV_EPI_BIAS, st));
+            VVCHK(p16_gemv(ctx, st, L.wqkv, nullptr, ctx->p16_x, ctx->qkv, nullptr, L.bqkv, nullptr, R, QKV, H, QKV, 0, VV_EPI_BIAS));
         } else {
         VVGemm g = mk_gemm(L.wqkv, ctx->h, ctx->qkv, R, QKV, H, H, QKV);
         g.pro = VV_PRO_RMS; g.nw = L.ln1; g.eps = c.lm_eps; g.epi = VV_EPI_BIAS; g.bias = L.bqkv; g.nt = 1;
@@ -1153,6 +1169,14 @@ static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float*
         if (fused_attn) {
             // decode rows (one cache each): RoPE + KV append + split attention + last-arriver merge in ONE launch
             ctx->launches += 1;
+            if (ctx->prof_on) {
+                // algorithmic bytes: every cached position of every row once, K and V (bf16) + the row's q / new k, v / output
+                const double by = (double)kv_positions * Hkv * D * 2.0 * 2.0 + (double)R * (QKV + Hq * D) * 4.0;
+                const int xs = c.xsplit; vv_ctx* cx = ctx;
+                ctx->prof_other.push_back({2, by, [=](hipStream_t s) {
+                    return vv_attn_fused_launch(D, xs, cx->qkv, cx->rows_dev, cx->rope_tab, kl, vl, R, Hq, Hkv, cx->cache_stride,
+                                                cx->head_stride, attn_S, attn_waves, cx->pm, cx->pl, cx->po, cx->tickets, cx->attn, s); }});
+            }
             VVCHK(vv_attn_fused_launch(D, c.xsplit, ctx->qkv, ctx->rows_dev, ctx->rope_tab, kl, vl, R, Hq, Hkv, ctx->cache_stride,
                                        ctx->head_stride, attn_S, attn_waves, ctx->pm, ctx->pl, ctx->po, ctx->tickets, ctx->attn, st));
         } else {
@@ -1174,7 +1198,7 @@ static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float*
             if (o_packed) {
                 ctx->launches += 2;
                 VVCHK(vv_pack16_launch(ctx->attn, Hq * D, 0, nullptr, 0.f, nullptr, nullptr, 0, ctx->p16_x, R, Hq * D, st));
-                VVCHK(vv_gemv16p_launch(L.wo, nullptr, ctx->p16_x, ctx->h, nullptr, nullptr, nullptr, R, H, Hq * D, H, 0, VV_EPI_RESID, st));
+                VVCHK(p16_gemv(ctx, st, L.wo, nullptr, ctx->p16_x, ctx->h, nullptr, nullptr, nullptr, R, H, Hq * D, H, 0, VV_EPI_RESID));
             } else {
                 VVGemm go = mk_gemm(L.wo, ctx->attn, ctx->h, R, H, Hq * D, Hq * D, H);
                 go.epi = VV_EPI_RESID; go.nt = 1;
@@ -1182,8 +1206,8 @@ static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float*
             }
             ctx->launches += 3;
             VVCHK(vv_pack16_launch(ctx->h, H, 1, L.ln2, c.lm_eps, nullptr, nullptr, 0, ctx->p16_x, R, H, st));
-            VVCHK(vv_gemv16p_launch(L.wg, L.wu, ctx->p16_x, nullptr, ctx->p16_act, nullptr, nullptr, R, I, H, 0, 0, VV_EPI_SWIGLU, st));
-            VVCHK(vv_gemv16p_launch(L.wd, nullptr, ctx->p16_act, ctx->h, nullptr, nullptr, nullptr, R, H, I, H, 0, VV_EPI_RESID, st));
+            VVCHK(p16_gemv(ctx, st, L.wg, L.wu, ctx->p16_x, nullptr, ctx->p16_act, nullptr, nullptr, R, I, H, 0, 0, VV_EPI_SWIGLU));
+            VVCHK(p16_gemv(ctx, st, L.wd, nullptr, ctx->p16_act, ctx->h, nullptr, nullptr, nullptr, R, H, I, H, 0, VV_EPI_RESID));
             continue;
         }
         VVGemm go = mk_gemm(L.wo, ctx->attn, ctx->h, R, H, Hq * D, Hq * D, H);
@@ -1256,7 +1280,9 @@ extern "C" int vv_lm_forward_range(vv_ctx* ctx, void* stream, int n_rows, const 
     const int attn_waves = (max_len >= long_ctx) ? 8 : 4;
     char key[160]; snprintf(key, 160, "lm:%d:%p:%p:%d:%d:%d:%d:%d:%d", n_rows, (const void*)x_in_dev, (void*)hidden_out_dev, l0, l1, final_norm,
                             fused ? 1 : (contiguous ? 2 : 0), contiguous ? 0 : attn_S, fused ? attn_waves : 0);
-    return graphed(ctx, key, st, [&]() { return lm_body(ctx, st, n_rows, x_in_dev, hidden_out_dev, l0, l1, final_norm, fused, contiguous, attn_S, attn_waves); });
+    int64_t kv_positions = 0;
+    for (int i = 0; i < n_rows; ++i) kv_positions += rows[i].pos + 1;
+    return graphed(ctx, key, st, [&]() { return lm_body(ctx, st, n_rows, x_in_dev, hidden_out_dev, l0, l1, final_norm, fused, contiguous, attn_S, attn_waves, kv_positions); });
 }
 
 extern "C" int vv_kv_import_at(vv_ctx* ctx, void* stream, int cache, int layer, int pos0, int n_pos, const void* k_dev, const void* v_dev, int src_dtype) {
@@ -1344,8 +1370,8 @@ static int head_eval(vv_ctx* ctx, hipStream_t st, int rows, const float* zrows, 
             // batch rows: normalise + modulate + pack ONCE, then both projections stream weights against packed fragments
             ctx->launches += 3;
             VVCHK(vv_pack16_launch(ctx->xh, H, 2, ctx->hl[l].norm, c.head_eps, base + H, base, MODW, ctx->p16_x, rows, H, st));
-            VVCHK(vv_gemv16p_launch(ctx->hl[l].wg, ctx->hl[l].wu, ctx->p16_x, nullptr, ctx->p16_act, nullptr, nullptr, rows, HF, H, 0, 0, VV_EPI_SWIGLU, st));
-            VVCHK(vv_gemv16p_launch(ctx->hl[l].wd, nullptr, ctx->p16_act, ctx->xh, nullptr, nullptr, base + 2 * H, rows, H, HF, H, MODW, VV_EPI_GATED_RESID, st));
+            VVCHK(p16_gemv(ctx, st, ctx->hl[l].wg, ctx->hl[l].wu, ctx->p16_x, nullptr, ctx->p16_act, nullptr, nullptr, rows, HF, H, 0, 0, VV_EPI_SWIGLU));
+            VVCHK(p16_gemv(ctx, st, ctx->hl[l].wd, nullptr, ctx->p16_act, ctx->xh, nullptr, nullptr, base + 2 * H, rows, H, HF, H, MODW, VV_EPI_GATED_RESID));
             continue;
         }
         VVGemm g1 = mk_gemm(ctx->hl[l].wg, ctx->xh, ctx->hact, rows, HF, H, H, HF);
@@ -1661,7 +1687,7 @@ extern "C" int vv_gemm3_raw(void* stream, const void* w, const void* w2, const f
 extern "C" int vv_profile_begin(vv_ctx* ctx) {
     HIPCHK(ctx, hipDeviceSynchronize());
     ctx->prof_on = true; ctx->prof_n = 0; ctx->prof_bytes = 0.0; ctx->prof_rec.clear();
-    ctx->prof_gemv.clear(); ctx->prof_gemv_bytes = 0.0;
+    ctx->prof_gemv.clear(); ctx->prof_gemv_bytes = 0.0; ctx->prof_other.clear();
     return 0;
 }
 extern "C" int vv_profile_end(vv_ctx* ctx, int64_t* launches, double* total_ms, double* bytes) {
@@ -1713,16 +1739,23 @@ extern "C" int vv_profile_end(vv_ctx* ctx, int64_t* launches, double* total_ms, 
 // launch in a dependent chain = kernel time + the kernel boundary, which is what rocprofv3 --kernel-trace reports per kernel
 // under graph replay (profiles/): an upper bound on the kernel's own duration.  The replay re-runs residual epilogues on the
 // engine's scratch / codec state buffers: call it after the measurements that need those states.
-extern "C" int vv_profile_replay(vv_ctx* ctx, void* stream, int reps, int64_t* launches, double* total_ms, double* bytes) {
+extern "C" int vv_profile_replay_family(vv_ctx* ctx, void* stream, int family, int reps, int64_t* launches, double* total_ms, double* bytes) {
     hipStream_t st = (hipStream_t)stream;
     if (ctx->prof_on) return fail(ctx, "vv_profile_replay: call vv_profile_end first");
-    if (ctx->prof_gemv.empty()) return fail(ctx, "vv_profile_replay: the last profile window recorded no GEMV launches");
+    int64_t n = 0; double by = 0.0;
+    if (family == 0) { n = (int64_t)ctx->prof_gemv.size(); by = ctx->prof_gemv_bytes; }
+    else for (const auto& l : ctx->prof_other) if (l.family == family) { ++n; by += l.bytes; }
+    if (launches) *launches = 0;
+    if (total_ms) *total_ms = 0.0;
+    if (bytes) *bytes = 0.0;
+    if (n == 0) return family == 0 ? fail(ctx, "vv_profile_replay: the last profile window recorded no GEMV launches") : 0;
     if (reps < 1) reps = 1;
     HIPCHK(ctx, hipStreamSynchronize(st));
     hipGraph_t graph; hipGraphExec_t exec;
     HIPCHK(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
     int rr = 0;
-    for (const VVGemm& g : ctx->prof_gemv) { rr = vv_gemm_launch(g, ctx->c.xsplit, st); if (rr) break; }
+    if (family == 0) { for (const VVGemm& g : ctx->prof_gemv) { rr = vv_gemm_launch(g, ctx->c.xsplit, st); if (rr) break; } }
+    else for (const auto& l : ctx->prof_other) if (l.family == family) { rr = l.fn(st); if (rr) break; }
     hipError_t e = hipStreamEndCapture(st, &graph);
     if (rr) return fail(ctx, "vv_profile_replay: launch failed (%d)", rr);
     HIPCHK(ctx, e);
@@ -1739,10 +1772,13 @@ extern "C" int vv_profile_replay(vv_ctx* ctx, void* stream, int reps, int64_t* l
     HIPCHK(ctx, hipEventElapsedTime(&ms, e0, e1));
     hipEventDestroy(e0); hipEventDestroy(e1);
     hipGraphExecDestroy(exec);
-    if (launches) *launches = (int64_t)ctx->prof_gemv.size() * reps;
+    if (launches) *launches = n * reps;
     if (total_ms) *total_ms = ms;
-    if (bytes) *bytes = ctx->prof_gemv_bytes * reps;
+    if (bytes) *bytes = by * reps;
     return 0;
+}
+extern "C" int vv_profile_replay(vv_ctx* ctx, void* stream, int reps, int64_t* launches, double* total_ms, double* bytes) {
+    return vv_profile_replay_family(ctx, stream, 0, reps, launches, total_ms, bytes);
 }
 extern "C" int64_t vv_stat(vv_ctx* ctx, int what) {
     switch (what) {

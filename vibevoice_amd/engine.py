@@ -375,10 +375,12 @@ class Engine:
         self._chk(self.lib.vv_profile_end(self._ctx, n, ms, by), "vv_profile_end")
         return (n[0], ms[0], by[0]), (n[1], ms[1], by[1])
 
-    def profile_replay(self, reps=3):
-        """(launches, total_ms, bytes) of the recorded decode-GEMV launches replayed as one dependent hipGraph chain."""
+    def profile_replay(self, reps=3, family=0):
+        """(launches, total_ms, bytes) of the recorded launches of one kernel family replayed as one dependent hipGraph chain:
+        family 0 = vv_gemv_kernel, 1 = vv_gemv16p_kernel (batch decode), 2 = decode attention (fused kernel + merge)."""
         n, ms, by = C.c_int64(), C.c_double(), C.c_double()
-        self._chk(self.lib.vv_profile_replay(self._ctx, self._s, int(reps), C.byref(n), C.byref(ms), C.byref(by)), "vv_profile_replay")
+        self._chk(self.lib.vv_profile_replay_family(self._ctx, self._s, int(family), int(reps), C.byref(n), C.byref(ms), C.byref(by)),
+                  "vv_profile_replay_family")
         return n.value, ms.value, by.value
 
     def stat(self, what=0):
