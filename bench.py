@@ -105,8 +105,96 @@ def parse_args(argv=None):
     ap.add_argument("--continuous", type=int, default=0, help="queue this many utterances through generate_continuous() "
                     "(slots = --batch) instead of one synchronous batch")
     ap.add_argument("--max-ctx", type=int, default=0)
-    ap.add_argument("--enc-frames", type=int, default=5, help="voice-prompt frames per acoustic-encoder pass")
+    ap.add_argument("--enc-frames", type=int, default=75, help="voice-prompt frames per acoustic-encoder pass (the engine default)")
     return ap.parse_args(argv)
+
+
+CHECKPOINT_NAMES = {"1.5b": ("VibeVoice-1.5B", "vibevoice-1.5b", "1.5b"),
+                    "7b": ("VibeVoice-7B", "VibeVoice-Large", "vibevoice-7b", "7b"),
+                    "0.5b-streaming": ("VibeVoice-Realtime-0.5B", "VibeVoice-Streaming-0.5B", "vibevoice-streaming-0.5b", "0.5b-streaming")}
+
+
+def find_checkpoint(model_key, root=None):
+    """"if $VIBEVOICE_MODEL_DIR holds real checkpoints they are used instead" of the seeded synthetic weights.
+    A checkpoint is a directory with config.json + *.safetensors (what the reference's converter writes and from_pretrained
+    reads): $VIBEVOICE_MODEL_DIR/<name> for the names the released models go by, or $VIBEVOICE_MODEL_DIR itself when its
+    config.json has this model's decoder width and depth.  Returns the directory or None."""
+    from vibevoice_amd.configs import CONFIGS
+    root = root if root is not None else os.environ.get("VIBEVOICE_MODEL_DIR")
+    if not root or not os.path.isdir(root):
+        return None
+
+    def is_ckpt(d):
+        return os.path.isfile(os.path.join(d, "config.json")) and any(f.endswith(".safetensors") for f in os.listdir(d))
+    for name in CHECKPOINT_NAMES.get(model_key, ()):
+        d = os.path.join(root, name)
+        if os.path.isdir(d) and is_ckpt(d):
+            return d
+    if is_ckpt(root):
+        try:
+            with open(os.path.join(root, "config.json")) as f:
+                dc = json.load(f)["decoder_config"]
+            want = CONFIGS[model_key]["decoder_config"]
+            if all(dc.get(k) == want.get(k) for k in ("hidden_size", "num_hidden_layers", "num_attention_heads")):
+                return root
+        except Exception:
+            return None
+    return None
+
+
+def checkpoint_tensors(path):
+    """(key, tensor) over every *.safetensors shard of a checkpoint directory, one tensor in memory at a time"""
+    from safetensors import safe_open
+    for fn in sorted(f for f in os.listdir(path) if f.endswith(".safetensors")):
+        with safe_open(os.path.join(path, fn), framework="pt", device="cpu") as sf:
+            for k in sf.keys():
+                yield k, sf.get_tensor(k)
+
+
+def pmc_traffic(model_key, kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC pass (profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE in
+    its own run, x2 on gfx950 as /opt/skills/guides/MI355X_MICROARCH.md prescribes) -- only when that pass ran on the binary
+    that is loaded now (the file records the library's build id); otherwise null, with the reason."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            doc = json.load(f)
+        ent = doc.get(model_key, {})
+        fam = (ent.get("kernels") or {}).get(kernel)
+        if fam is None:
+            return None, f"profiles/pmc_traffic.json has no {kernel} entry for {model_key}"
+        if ent.get("libvvhip_build_id") != _build_id():
+            return None, (f"profiles/pmc_traffic.json was measured on build {ent.get('libvvhip_build_id')}, this run loads {_build_id()}: "
+                          "not carried over (re-run tools/pmc_refresh.sh)")
+        return fam["hbm_bytes_per_launch"], ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE (own pass, x2 gfx950 correction) on this "
+                                             f"build ({ent.get('libvvhip_build_id')}); algorithmic bytes of that pass {fam.get('algorithmic_bytes_per_launch')}")
+    except Exception as ex:
+        return None, f"profiles/pmc_traffic.json unreadable: {ex!r}"
+
+
+def first_audio_trials(fn, n_trials):
+    """first-audio latency = generate() entry -> the first chunk an AudioStreamer hands to a consumer on the host.
+    fn(streamer) runs one generate() with that streamer; a consumer thread blocks on sample 0's stream and stamps the arrival
+    of the first chunk.  Returns the latencies in ms."""
+    import threading
+    from vibevoice_amd.streamer import AudioStreamer
+    out = []
+    for _ in range(n_trials):
+        st = AudioStreamer(batch_size=1)
+        got = {}
+
+        def consume():
+            for _chunk in st.get_stream(0):
+                got.setdefault("t", time.perf_counter())
+        th = threading.Thread(target=consume, daemon=True)
+        th.start()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn(st)
+        th.join(timeout=30)
+        st.close()
+        if "t" in got:
+            out.append((got["t"] - t0) * 1e3)
+    return out
 
 
 def _build_id():
@@ -187,9 +275,9 @@ def main():
                     keep = {k: r[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup")}
                     keep["workload"] = r["config"]["workload"]
                     if r.get("roofline"):
-                        keep["roofline"] = {k: r["roofline"].get(k) for k in ("kernel", "achieved", "peak", "frac", "avg_launch_us",
-                                                                            "launches_per_step", "whole_step_frac")}
-                    for k in ("p50_first_audio_ms", "p90_first_audio_ms", "prefill_plus_first_frame_s"):
+                        keep["roofline"] = {k: r["roofline"].get(k) for k in ("kernel", "achieved", "peak", "frac", "avg_launch_us", "launches_per_step",
+                                                                            "bytes_per_launch", "whole_step_frac", "traffic", "attention")}
+                    for k in ("p50_first_audio_ms", "p90_first_audio_ms", "p50_first_chunk_on_device_ms", "prefill_plus_first_frame_s", "first_audio"):
                         if k in r.get("extra", {}):
                             keep[k] = r["extra"][k]
                     extra[sp["baseline_config"]] = keep
@@ -213,6 +301,10 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline):
     rank, world, device, use_dist = ctx["rank"], ctx["world"], ctx["device"], ctx["use_dist"]
     model_key = spec["model"]
     cfg = CONFIGS[model_key]
+    ckpt = find_checkpoint(model_key)
+    if ckpt:                                     # real weights ($VIBEVOICE_MODEL_DIR): the checkpoint's own config decides the shapes
+        with open(os.path.join(ckpt, "config.json")) as f:
+            cfg = json.load(f)
     K, W, NS = args.steps, max(1, args.warmup), spec["solver_steps"]
     B = max(1, min(8, args.batch))
     n_utt = max(B, args.continuous) if args.continuous else B
@@ -238,18 +330,29 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline):
     gen.manual_seed(0)
     make = lambda k, shape: synthetic.random_tensor(k, shape, gen, device, torch.bfloat16)
     bc = {}
-    for k, t in parallel.broadcast_packed(synthetic.param_shapes(cfg).items(), make, device, torch.bfloat16, stats=bc):
+    scaling, sbias = 0.2, -0.05
+    if ckpt:                                     # every rank reads the shards itself (page cache shared on one node): no collective
+        source = ((k, t) for k, t in checkpoint_tensors(ckpt))
+    else:
+        source = parallel.broadcast_packed(synthetic.param_shapes(cfg).items(), make, device, torch.bfloat16, stats=bc)
+    for k, t in source:
+        if k == "model.speech_scaling_factor":
+            scaling = float(t)
+            continue
+        if k == "model.speech_bias_factor":
+            sbias = float(t)
+            continue
         name = map_param_name(k)
         if name in exp:
             eng.upload(name, t)
         if keep_cpu:
-            cpu_sd[k] = t.to("cpu")
+            cpu_sd[k] = t.to("cpu", torch.bfloat16)
         del t
     miss = eng.missing_weights()
     if miss:
         raise SystemExit(f"engine parameters not provided: {miss[:5]}")
     model = VibeVoiceForConditionalGenerationInference(cfg, eng, model_dtype=torch.bfloat16)
-    model.set_speech_factors(0.2, -0.05)
+    model.set_speech_factors(scaling, sbias)
     model.set_ddpm_inference_steps(NS)
     load_s = time.time() - t_load0
 
@@ -285,17 +388,16 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline):
             marks["prefill_done"] = time.perf_counter()
 
     os.environ.setdefault("VVHIP_TIME_PREFILL", "1")        # sync + time the two prefill phases (outside the timed region)
-    if not args.continuous and not os.environ.get("VVHIP_COLD_PREFILL"):
-        # the reported prompt-prefill time is a warm engine's (a serving process): one throw-away pass of the same row count
-        # loads every prefill kernel's code object and pays the one-off launch-attribute calls; the real prefill overwrites the
-        # cache positions it touched
+    if not os.environ.get("VVHIP_COLD_PREFILL"):
+        # the reported times are a warm serving process's: model.warmup() (what from_pretrained runs) touches every kernel the
+        # request needs -- voice-prompt encoder, a prompt pass of the same row count, decode frames; the real prefill overwrites
+        # the cache positions it touched
         n_prompt = int(inputs["attention_mask"][0].sum())
-        wx = torch.zeros(min(n_prompt, eng.cfg.max_rows), d["hidden_size"], device=device)
-        wh = torch.empty_like(wx)
-        with torch.cuda.stream(eng.stream):
-            eng.lm_forward([(0, j) for j in range(wx.shape[0])], wx, wh)
-        eng.sync()
-        del wx, wh
+        t_w0 = time.perf_counter()
+        model.warmup(prompt_rows=[min(n_prompt, eng.cfg.max_rows)], voice_frames=spec["voice_frames"])
+        warm_s = time.perf_counter() - t_w0
+    else:
+        warm_s = 0.0
     t_gen0 = time.perf_counter()
     if args.continuous:
         reqs = []
@@ -329,6 +431,27 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline):
     audio_total = out.speech_outputs[0].shape[-1] / 24000.0
     prefill_phases = getattr(model, "last_prefill", None)
     cont_stats = dict(model.last_stats) if args.continuous else None
+    # every rank's own step time next to the max: an imbalance (a slow GPU, a straggling host loop) shows in the first SCALE run
+    per_rank_ms = [round(wall / K * 1e3, 4)]
+    if use_dist:
+        t_all = [torch.zeros(1, dtype=torch.float64, device=device) for _ in range(world)]
+        dist.all_gather(t_all, torch.tensor([wall / K * 1e3], dtype=torch.float64, device=device))
+        per_rank_ms = [round(float(t[0]), 4) for t in t_all]
+    # first-audio latency as SURVEY 8d defines it: generate() entry (voice-prompt encode + prompt prefill + first frame) -> the
+    # first chunk an AudioStreamer consumer receives on the host; 3 trials of the same request
+    first_audio = None
+    if rank == 0 and world == 1 and B == 1 and not args.continuous and not os.environ.get("VVHIP_NO_TTFA"):
+        try:
+            one_in = {k: v for k, v in inputs.items()}
+            lat = first_audio_trials(lambda st: model.generate(
+                tokenizer=synthetic.TOKENS, cfg_scale=args.cfg_scale, generation_config={"do_sample": False}, max_new_tokens=3,
+                show_progress_bar=False, _forced_tokens=forced, _noise_fn=lambda step, n2: noise_bank[step], audio_streamer=st, **one_in), 3)
+            if lat:
+                first_audio = {"p50_ms": round(sorted(lat)[len(lat) // 2], 2), "trials_ms": [round(x, 2) for x in lat],
+                               "definition": "generate() entry -> first chunk delivered to an AudioStreamer consumer thread on the host "
+                                             "(voice-prompt encode + prompt prefill + first frame + D2H + queue hand-off), warm process"}
+        except Exception as ex:
+            first_audio = {"error": repr(ex)[:200]}
 
     if os.environ.get("VVHIP_TIMELINE") and rank == 0:      # timing builds only: tools/step_timeline.py
         sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -357,9 +480,11 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline):
                 prof["res"] = eng.profile_end()
         inp2 = synthetic.synthetic_inputs(cfg, n_speakers=spec["speakers"], text_tokens=min(spec["text_tokens"], 220),
                                           voice_frames=spec["voice_frames"], seed=100, batch=B)
+        # the window is recorded at the timed KV length (the attention launches' bytes depend on it; the GEMV launches do not)
         model.generate(tokenizer=synthetic.TOKENS, cfg_scale=args.cfg_scale, generation_config={"do_sample": False},
                        max_new_tokens=kprof + 3, show_progress_bar=False, _forced_tokens=forced_p,
-                       _noise_fn=lambda step, n2: noise_bank[step], _step_callback=prof_cb, **inp2)
+                       _noise_fn=lambda step, n2: noise_bank[step], _step_callback=prof_cb,
+                       _kv_start=kv_target, _kv_fill_fn=kv_fill if kv_target else None, **inp2)
         (n_l, ms_cal, by), (n_o, ms_o, by_o) = prof["res"]       # [decode GEMV kernel], [other GEMM kernels]
         # (1) launch duration in the execution mode of the timed region: the recorded GEMV launches replayed as ONE dependent
         # hipGraph chain between two events (vv_profile_replay) = start-to-start period of a launch = what rocprofv3
@@ -369,16 +494,10 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline):
         ach = by_rep / 1e9 / (ms_rep / 1e3) if ms_rep > 0 else 0.0                      # GB/s
         # (2) secondary: hipEvent pair around each EAGER launch minus an in-stream empty pair (a lower bound on the duration)
         ach_pair = by / 1e9 / (ms_cal / 1e3) if ms_cal > 0 else 0.0
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                tj = json.load(f).get(model_key, {})
-                traffic = tj.get("hbm_bytes_per_launch")
-        except Exception:
-            pass
+        traffic, traffic_src = pmc_traffic(model_key, "vv_gemv_kernel")
         roof = {"bound": "hbm", "kernel": "vv_gemv_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                "traffic": traffic, "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2, committed; not re-measured in this run)",
+                "traffic": traffic, "traffic_source": traffic_src,
                 "method": "recorded vv_gemv_kernel launches of 6 live steps replayed as one dependent hipGraph chain, hipEvents around 3 replays "
                           "(vv_profile_replay): launch period = kernel + boundary, the quantity rocprofv3 --kernel-trace reports",
                 "launches_per_step": round(n_l / kprof, 1), "avg_launch_us": round(us_graph, 3),
@@ -392,12 +511,25 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline):
                 "formula_bytes_per_step": round(formula, 1), "formula_kv_bytes_per_utterance": round(kv_only, 1),
                 "whole_step_GBps": round(formula / 1e9 / (wall_max / K), 1),
                 "whole_step_frac": round(formula / 1e9 / (wall_max / K) / HBM_PEAK_GBS, 4)}
-        if B > 4 and args.xsplit == 1:
-            # batch decode: the LM / head projections run in vv_gemv16p_kernel (pre-packed activations), which this replay does
-            # not record -- the vv_gemv_kernel figure then covers the 16-row tokenizer / sampler launches only; the step-level
-            # fraction (all algorithmic bytes of the step over its wall time) is the number to read
-            roof["note"] = ("batch decode: projections run in vv_gemv16p_kernel (not in this replay); achieved / frac cover the remaining "
-                            "16-row vv_gemv_kernel launches only -- read whole_step_frac")
+        # the other timed kernel families of the same window, each replayed as its own dependent chain
+        def family(fid, name):
+            n_f, ms_f, by_f = eng.profile_replay(reps=3, family=fid)
+            if not n_f or ms_f <= 0:
+                return None
+            a_f = by_f / 1e9 / (ms_f / 1e3)
+            tr, tsrc = pmc_traffic(model_key, name.split(" ")[0])
+            return {"kernel": name, "achieved": round(a_f, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a_f / HBM_PEAK_GBS, 4),
+                    "launches_per_step": round(n_f / 3 / kprof, 1), "avg_launch_us": round(ms_f * 1e3 / n_f, 3),
+                    "bytes_per_launch": round(by_f / n_f, 1), "traffic": tr, "traffic_source": tsrc}
+        roof["attention"] = family(2, "vv_attn_fused_kernel (+ vv_attn_merge2_kernel): one unit per layer, KV bytes of every row")
+        p16 = family(1, "vv_gemv16p_kernel")
+        if p16 is not None:
+            # batch decode (5..16 rows): the LM / head projections run in vv_gemv16p_kernel (pre-packed activations) -- THAT is the
+            # dominant kernel of the step; the vv_gemv_kernel figures (the remaining 16-row tokenizer / sampler launches) move aside
+            roof["gemv_other"] = {k: roof[k] for k in ("kernel", "achieved", "frac", "launches_per_step", "avg_launch_us", "bytes_per_launch", "traffic")}
+            for k in ("kernel", "achieved", "frac", "launches_per_step", "avg_launch_us", "bytes_per_launch", "traffic", "traffic_source"):
+                roof[k] = p16[k]
+            roof["method"] = roof["method"].replace("vv_gemv_kernel", "vv_gemv16p_kernel")
 
     # ---- CPU baseline: the oracle loop on the host cores, bounded sample ----
     cpu = None
@@ -418,7 +550,7 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline):
     res = {
         "metric": "audio-sec/wall-sec", "value": round(value, 3), "unit": "audio-s/wall-s", "n_gpus": world,
         "steps": K, "warmup": W, "ms_per_step": round((marks[W + K] - marks[W]) / K * 1e3, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic" if not ckpt else "synthetic inputs, checkpoint weights",
         "config": {"workload": f"BASELINE {spec.get('baseline_config', '?')}: VibeVoice-{model_key.upper()} shapes, {spec['speakers']} speaker(s), "
                                f"{L0}-token prompt ({spec['text_tokens']} text + {spec['speakers']}x{spec['voice_frames']}-frame voice) prefilled through the engine, "
                                f"{NS} solver steps, cfg {args.cfg_scale}, decode timed at KV length {max(L0, kv_target) + W}..{max(L0, kv_target) + W + K}"
@@ -431,6 +563,9 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline):
         "roofline": roof, "cpu_baseline": cpu, "gpu_eager_baseline": eager,
         "extra": {"frames_timed": frames, "weights_load_s": round(load_s, 2), "libvvhip_build_id": _build_id(),
                   "weights_broadcast": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in bc.items()},
+                  "weights_source": (f"checkpoint {ckpt}" if ckpt else "synthetic (seeded N(0, 0.02^2) at the config's shapes)"),
+                  "per_rank_ms_per_step": per_rank_ms, "warmup_s": round(warm_s, 3), "first_audio": first_audio,
+                  "sharding": parallel.shard_report([L0] * (world * n_utt), [list(range(r * n_utt, (r + 1) * n_utt)) for r in range(world)]),
                   "prefill_plus_first_frame_s": round(marks.get("prefill_done", t_gen0) - t_gen0, 4),
                   "prefill_phases": prefill_phases,
                   "utterance_audio_s": round(audio_total, 2), "utterance_wall_s": round(t_gen1 - t_gen0, 3),
@@ -450,6 +585,26 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline):
     return res
 
 
+def streaming_bytes_per_frame(cfg, n_solver, kv_len):
+    """SURVEY 8(d), Streaming-0.5B: the TTS LM's layers once per frame (positive + negative rows share the pass), the head once per
+    solver step, the acoustic decoder, connector and EOS classifier once, one text window of the text LM + TTS LM per 6 frames, and
+    the TTS KV of both branches."""
+    from vibevoice_amd.synthetic import streaming_param_shapes
+    import math
+    sh = streaming_param_shapes(cfg)
+    cnt = lambda pre: sum(math.prod(v) for k, v in sh.items() if k.startswith(pre))
+    d = cfg["decoder_config"]
+    H = d["hidden_size"]
+    p_tts = cnt("model.tts_language_model.layers.") + H
+    p_lm = cnt("model.language_model.layers.")
+    p_head = cnt("model.prediction_head.")
+    p_dec = cnt("model.acoustic_tokenizer.decoder.")
+    p_small = cnt("model.acoustic_connector.") + cnt("tts_eos_classifier.")
+    n_tts = cfg["tts_backbone_num_hidden_layers"]
+    kv_tok = 2 * n_tts * d["num_key_value_heads"] * (H // d["num_attention_heads"]) * 2
+    return float(2 * p_tts + 2 * (p_head - H * H) * n_solver + 2 * H * H + 2 * p_dec + 2 * p_small + 2 * (p_lm + p_tts) / 6.0 + kv_tok * (kv_len + 1 + 6))
+
+
 def bench_streaming(args, spec, ctx):
     """BASELINE.json configs[4]: Streaming-0.5B, hipGraph-captured decode+diffusion step, p50 first-audio latency.
     Synthetic weights and an Emma-shaped synthetic preset (lm 74 / tts_lm 251 cached positions)."""
@@ -463,13 +618,20 @@ def bench_streaming(args, spec, ctx):
     NS = spec.get("solver_steps") or 5                                 # the streaming demo default is 5
     gen = torch.Generator(device=device)
     gen.manual_seed(0)
-    sd = ((k, synthetic.random_tensor(k, shp, gen, device, torch.bfloat16))
-          for k, shp in synthetic.streaming_param_shapes(cfg).items())
+    ckpt = find_checkpoint(spec["model"])
+    if ckpt:
+        with open(os.path.join(ckpt, "config.json")) as f:
+            cfg = json.load(f)
+        sd = checkpoint_tensors(ckpt)
+    else:
+        sd = ((k, synthetic.random_tensor(k, shp, gen, device, torch.bfloat16))
+              for k, shp in synthetic.streaming_param_shapes(cfg).items())
     model = VibeVoiceStreamingForConditionalGenerationInference.from_state_dict(
         cfg, sd, torch.bfloat16, device, xsplit=args.xsplit, use_graph=not args.no_graph, max_ctx=2048, n_slots=2)
-    model.set_speech_factors(0.2, -0.05)
+    if not ckpt:
+        model.set_speech_factors(0.2, -0.05)
     model.set_ddpm_inference_steps(NS)
-    model.engine.upload("eos.fc2.bias", torch.tensor([-30.0]))       # random weights: keep the EOS head from firing
+    model.engine.upload("eos.fc2.bias", torch.tensor([-30.0]))       # fixed-length runs: keep the EOS head from firing
     d = cfg["decoder_config"]
     H, kvh, hd = d["hidden_size"], d["num_key_value_heads"], d["hidden_size"] // d["num_attention_heads"]
     n_tts = cfg["tts_backbone_num_hidden_layers"]
@@ -504,16 +666,48 @@ def bench_streaming(args, spec, ctx):
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     audio_s = out.speech_outputs[0].shape[-1] / 24000.0
+    n_frames = audio_s / FRAME_SEC
+    # SURVEY 8d's first-audio latency: generate() entry -> first chunk handed to an AudioStreamer consumer on the host
+    text5 = torch.randint(0, 151000, (1, 5), generator=g)
+    lat_host = first_audio_trials(lambda st: model.generate(tts_text_ids=text5, all_prefilled_outputs=preset, cfg_scale=1.5, tokenizer=tok,
+                                                            max_new_tokens=5 + 6, audio_streamer=st), 30)
+    # roofline: the GEMV launches and the attention units of one text window + one speech window, replayed as dependent chains
+    roof = None
+    if not args.no_roofline:
+        eng = model.engine
+        eng.sync()
+        eng.profile_begin()
+        model.generate(tts_text_ids=text5, all_prefilled_outputs=preset, cfg_scale=1.5, tokenizer=tok, max_new_tokens=5 + 6)
+        (n_l, ms_cal, by), _ = eng.profile_end()
+        n_rep, ms_rep, by_rep = eng.profile_replay(reps=3)
+        ach = by_rep / 1e9 / (ms_rep / 1e3) if ms_rep > 0 else 0.0
+        formula = streaming_bytes_per_frame(cfg, NS, 251 + int(n_frames) // 2)
+        roof = {"bound": "hbm", "kernel": "vv_gemv_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(spec["model"], "vv_gemv_kernel")[0],
+                "traffic_source": pmc_traffic(spec["model"], "vv_gemv_kernel")[1],
+                "launches_per_step": round(n_l / 6.0, 1), "avg_launch_us": round(ms_rep * 1e3 / max(1, n_rep), 3),
+                "bytes_per_launch": round(by_rep / max(1, n_rep), 1),
+                "method": "vv_gemv_kernel launches of one generate() (text window of 5 + speech window of 6) replayed as one dependent hipGraph chain",
+                "formula_bytes_per_step": round(formula, 1), "whole_step_GBps": round(formula / 1e9 / (wall / n_frames), 1),
+                "whole_step_frac": round(formula / 1e9 / (wall / n_frames) / HBM_PEAK_GBS, 4)}
+        n_a, ms_a, by_a = eng.profile_replay(reps=3, family=2)
+        if n_a and ms_a > 0:
+            roof["attention"] = {"kernel": "vv_attn_fused_kernel", "achieved": round(by_a / 1e9 / (ms_a / 1e3), 1), "frac": round(by_a / 1e9 / (ms_a / 1e3) / HBM_PEAK_GBS, 4),
+                                 "avg_launch_us": round(ms_a * 1e3 / n_a, 3), "bytes_per_launch": round(by_a / n_a, 1)}
     res = {"metric": "audio-sec/wall-sec", "value": round(audio_s / wall, 3), "unit": "audio-s/wall-s", "n_gpus": 1,
            "steps": int(audio_s / FRAME_SEC + 0.5), "warmup": 33, "ms_per_step": round(wall / (audio_s / FRAME_SEC) * 1e3, 4),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
            "config": {"workload": f"BASELINE configs[4]: VibeVoice-Streaming-0.5B shapes, Emma-shaped synthetic preset (lm 74 / tts 251), {NS} solver steps, "
                                   "whole generate() incl. preset import, text windows of 5 / speech windows of 6",
                       "model": "VibeVoice-Streaming-0.5B", "solver_steps": NS, "hipgraph": not args.no_graph},
-           "roofline": None, "cpu_baseline": None,
-           "extra": {"p50_first_audio_ms": round(statistics.median(lat), 3), "p90_first_audio_ms": round(sorted(lat)[int(0.9 * len(lat))], 3),
-                     "trials": len(lat), "first_audio_definition": "generate() entry -> first 3200-sample chunk complete on the device "
-                     "(preset KV import + first text window + first frame)", "finished_by_eos_or_cap": True}}
+           "roofline": roof, "cpu_baseline": None,
+           "extra": {"p50_first_audio_ms": round(statistics.median(lat_host), 3) if lat_host else None,
+                     "p90_first_audio_ms": round(sorted(lat_host)[int(0.9 * len(lat_host))], 3) if lat_host else None,
+                     "trials": len(lat_host), "first_audio_definition": "generate() entry -> first 3200-sample chunk delivered to an AudioStreamer "
+                     "consumer thread on the host (preset KV import + first text window + first frame + D2H + queue hand-off); SURVEY 8d",
+                     "p50_first_chunk_on_device_ms": round(statistics.median(lat), 3),
+                     "weights_source": (f"checkpoint {ckpt}" if ckpt else "synthetic"), "libvvhip_build_id": _build_id(),
+                     "finished_by_eos_or_cap": True}}
     model.engine.close()
     del model
     torch.cuda.empty_cache()

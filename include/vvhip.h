@@ -197,10 +197,10 @@ int vv_profile_end(vv_ctx* ctx, int64_t* launches, double* total_ms, double* byt
  * the timed region, and what rocprofv3 --kernel-trace reports per kernel under graph replay.  Clobbers engine scratch and
  * streaming-codec state: call it last. */
 int vv_profile_replay(vv_ctx* ctx, void* stream, int reps, int64_t* launches, double* total_ms, double* bytes);
-/* The same replay for the other timed kernel families of the window: family 0 = vv_gemv_kernel (as above), 1 = vv_gemv16p_kernel
- * (the packed-activation projections of batch decode, 5..16 rows), 2 = decode attention (vv_attn_fused_kernel and, for contexts
+/* The same replay for the other timed kernel families of the window: family 0 = the GEMV kernel as above, 1 = vv_gemv16p_kernel,
+ * the packed-activation projections of batch decode with 5..16 rows, 2 = decode attention: vv_attn_fused_kernel and, for contexts
  * split over several workgroups, its vv_attn_merge2_kernel: one unit per layer; algorithmic bytes = every cached position's K and
- * V once).  launches = 0 when the window recorded none of that family.  bench.py's roofline for batch decode and for the
+ * V once.  launches = 0 when the window recorded none of that family.  bench.py's roofline for batch decode and for the
  * attention kernels. */
 int vv_profile_replay_family(vv_ctx* ctx, void* stream, int family, int reps, int64_t* launches, double* total_ms, double* bytes);
 /* number of kernel launches issued by the last engine call (graph nodes when replayed) */

@@ -378,3 +378,59 @@ def test_bf16_hip_against_bf16_pytorch_rocm_eager():
         assert wl <= 2e-2 and wh <= 2e-2 and wn <= 2e-2, (wl, wh, wn)
     finally:
         s.eng.close()
+
+
+# ---------------------------------------------------------------------------------------------- from_pretrained on the GPU engine
+def test_from_pretrained_checkpoint_directory_on_the_gpu_engine(tmp_path, monkeypatch):
+    """demo/inference_from_file.py:297-317 on the real engine: from_pretrained(<dir with config.json + safetensors shards>) --
+    including the warm-up it runs -- then generate() on the inputs, forced token plan and recorded noise draws of a golden the
+    REFERENCE's own generate() produced (tests/golden/generate_forced_b1.npz): sequences identical, waveform rel-L2 <= 1e-3
+    (xsplit = 3).  The same directory, placed under $VIBEVOICE_MODEL_DIR, is what bench.py's checkpoint hook picks up."""
+    import importlib.util
+    import json
+    import os
+    from safetensors.torch import save_file
+    from test_dropin_cpu import TOK, tiny_reference_config, tiny_reference_state_dict
+    from test_oracle_golden import G as GOLD
+    from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference
+    d = tmp_path / "VibeVoice-1.5B"
+    d.mkdir()
+    (d / "config.json").write_text(json.dumps(tiny_reference_config()))
+    sd = {k: v.contiguous() for k, v in tiny_reference_state_dict().items()}
+    keys = sorted(sd)
+    save_file({k: sd[k] for k in keys[::2]}, str(d / "model-00001-of-00002.safetensors"))
+    save_file({k: sd[k] for k in keys[1::2]}, str(d / "model-00002-of-00002.safetensors"))
+    model = VibeVoiceForConditionalGenerationInference.from_pretrained(str(d), torch_dtype=torch.float32, device_map="cuda",
+                                                                       xsplit=3, use_graph=True, max_ctx=512, n_slots=2, max_rows=16)
+    try:
+        model.eval()
+        model.set_ddpm_inference_steps(num_steps=5)
+        assert abs(float(model.speech_scaling_factor) - 0.2) < 1e-7
+        z = np.load(os.path.join(GOLD, "generate_forced_b1.npz"))
+        draws = [torch.from_numpy(z[f"draw_{i}"]) for i in range(int(z["n_draws"]))]
+        pre = (draws[0].reshape(1), draws[1].reshape(1, 3, 64))
+        it = iter(draws[2:])
+        forced = [z["forced"][0][:int(z["forced_len"][0])].tolist()]
+        out = model.generate(input_ids=torch.from_numpy(z["input_ids"]), attention_mask=torch.from_numpy(z["attention_mask"]),
+                             speech_tensors=torch.from_numpy(z["speech_tensors"]), speech_masks=torch.from_numpy(z["speech_masks"]),
+                             speech_input_mask=torch.from_numpy(z["speech_input_mask"]), cfg_scale=1.3, tokenizer=TOK,
+                             generation_config={"do_sample": False}, _forced_tokens=forced, _prefill_noise=pre,
+                             _noise_fn=lambda step, n2: next(it).reshape(n2, 64), show_progress_bar=False)
+        assert torch.equal(out.sequences.cpu(), torch.from_numpy(z["sequences"]))
+        ref = torch.from_numpy(z["audio_0"])
+        got = out.speech_outputs[0].reshape(-1).float().cpu()
+        assert got.shape == ref.shape
+        err = float((got - ref).norm() / ref.norm())
+        print(f"[from_pretrained on the GPU engine] waveform rel-L2 vs the reference's own generate() golden {err:.3e}")
+        assert err <= 1e-3, err
+    finally:
+        model.engine.close()
+    # bench.py's $VIBEVOICE_MODEL_DIR hook finds this directory by the released model's name; a directory without shards is not one
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_hook", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setenv("VIBEVOICE_MODEL_DIR", str(tmp_path))
+    assert bench.find_checkpoint("1.5b") == str(d)
+    assert bench.find_checkpoint("7b") is None
+    assert sorted(k for k, _ in bench.checkpoint_tensors(str(d))) == keys

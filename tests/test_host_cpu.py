@@ -504,3 +504,34 @@ def test_recorded_bench_line_keeps_the_driver_contract():
     assert g["value"] > c["value"] and abs(g["speedup_of_this_path"] - d["value"] / g["value"]) < 0.05
     assert len(d["extra"]["libvvhip_build_id"]) == 16
     assert set(d["extra"]["configs"]) == {"configs[1]", "configs[4]"}
+
+
+def test_bench_checkpoint_hook_resolves_model_directories(tmp_path, monkeypatch):
+    """"if $VIBEVOICE_MODEL_DIR holds real checkpoints they are used instead" -- bench.find_checkpoint() resolves the
+    released models' directory names (config.json + *.safetensors) or the root itself when its config has the model's decoder
+    geometry; anything else falls back to synthetic weights (None)."""
+    import importlib.util
+    import json
+    import os
+    from safetensors.torch import save_file
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_hook_cpu", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from vibevoice_amd.configs import CONFIGS
+    monkeypatch.delenv("VIBEVOICE_MODEL_DIR", raising=False)
+    assert bench.find_checkpoint("7b") is None
+    monkeypatch.setenv("VIBEVOICE_MODEL_DIR", str(tmp_path))
+    assert bench.find_checkpoint("7b") is None                              # empty root
+    d = tmp_path / "VibeVoice-Large"
+    d.mkdir()
+    (d / "config.json").write_text(json.dumps(CONFIGS["7b"]))
+    assert bench.find_checkpoint("7b") is None                              # no shards yet
+    save_file({"model.speech_scaling_factor": torch.tensor(0.19)}, str(d / "model-00001-of-00001.safetensors"))
+    assert bench.find_checkpoint("7b") == str(d) and bench.find_checkpoint("1.5b") is None
+    got = dict(bench.checkpoint_tensors(str(d)))
+    assert abs(float(got["model.speech_scaling_factor"]) - 0.19) < 1e-6
+    # the root itself is a checkpoint of the model whose geometry its config states
+    (tmp_path / "config.json").write_text(json.dumps(CONFIGS["1.5b"]))
+    save_file({"x": torch.zeros(1)}, str(tmp_path / "model.safetensors"))
+    assert bench.find_checkpoint("1.5b") == str(tmp_path) and bench.find_checkpoint("0.5b-streaming") is None

@@ -51,7 +51,9 @@ def _worker(rank, world, port, q):
         def setattr(self, obj, name, val):
             setattr(obj, name, val)
     with fake_engine.cpu_cuda_shims(MP()):
-        res = parallel.generate_sharded(_model(2), reqs, gather_to=0, tokenizer=TOK, generation_config={"do_sample": False}, cfg_scale=1.3)
+        shst = {}
+        res = parallel.generate_sharded(_model(2), reqs, gather_to=0, stats=shst, tokenizer=TOK, generation_config={"do_sample": False}, cfg_scale=1.3)
+    assert shst["utterances_per_rank"] == [3, 2] and sum(shst["load_per_rank"]) == sum(int(r["input_ids"].shape[-1]) for r in reqs)
     payload = None
     if res is not None:
         payload = [(r.sequences.tolist(), None if r.speech_outputs[0] is None else r.speech_outputs[0].double().sum().item(),
@@ -105,6 +107,26 @@ def test_two_rank_packed_broadcast_and_sharded_generation():
         assert (alen is None) == (a is None)
         if a is not None:
             assert alen == a.shape[-1] and abs(asum - a.double().sum().item()) <= 1e-3 * max(1.0, abs(asum))
+
+
+def test_sharding_cost_model_with_unequal_prompts():
+    """Longest-prompt-first over ranks (cost = prompt length, since max_steps = 2 x prompt length, modeling_vibevoice_inference.py:421):
+    every utterance exactly once, the most loaded rank within Graham's LPT bound (4/3 - 1/(3m)) of the best possible makespan,
+    and shard_report() states the loads / imbalance the job's scaling efficiency is bounded by."""
+    from vibevoice_amd.parallel import shard_report, shard_utterances
+    g = torch.Generator().manual_seed(8)
+    for world in (2, 4, 8):
+        for n in (world, 3 * world + 1, 40):
+            costs = torch.randint(200, 11000, (n,), generator=g).tolist()
+            shards = shard_utterances(costs, world)
+            assert sorted(i for sh in shards for i in sh) == list(range(n))
+            rep = shard_report(costs, shards)
+            assert rep["load_per_rank"] == [float(sum(costs[i] for i in sh)) for sh in shards]
+            lower = max(sum(costs) / world, max(costs))                  # no schedule ends before this
+            assert max(rep["load_per_rank"]) <= lower * (4.0 / 3.0 - 1.0 / (3.0 * world)) + 1e-9
+            assert abs(rep["imbalance_max_over_mean"] - max(rep["load_per_rank"]) / (sum(costs) / world)) < 1e-12
+    # equal prompts on every rank (bench.py --gpus N): perfectly balanced
+    assert shard_report([5000] * 8, shard_utterances([5000] * 8, 8))["imbalance_max_over_mean"] == 1.0
 
 
 def test_bench_gpus_flag_spawns_one_rank_per_gpu(monkeypatch):

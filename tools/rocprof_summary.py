@@ -42,24 +42,23 @@ def kernel_stats(db, out):
     return rows, tot
 
 
-CATS = [("gemv", r"vv_gemv_kernel"), ("attention", r"vv_attn_"), ("tokenizer blocks / convs", r"vv_block1d|vv_normdw|vv_stem_conv|vv_head_conv|vv_shift|vv_dwconv|vv_rmsnorm_rows|vv_gemm_tile|vv_affine"),
+CATS = [("gemv", r"vv_gemv_kernel"), ("gemv16p (batch decode)", r"vv_gemv16p_kernel|vv_pack16"), ("attention", r"vv_attn_"), ("tokenizer blocks / convs", r"vv_block1d|vv_normdw|vv_stem_conv|vv_head_conv|vv_shift|vv_dwconv|vv_rmsnorm_rows|vv_gemm_tile|vv_affine"),
         ("prefill gemm", r"vv_gemm3|vv_pack_rows|vv_rope_append"), ("torch / copies", r"at::|rocclr|Cijk|elementwise")]
 
 
 def timeline(db, out):
-    """Decode-phase occupancy of the GPU timeline.  Dispatches after the last prompt-prefill kernel (vv_attn_prefill2 /
-    vv_gemm4 / vv_rope_append) are grouped into bursts (a pause of more than 300 us between dispatches = the host is between
-    bench phases, not inside a step); inside the bursts: busy = union of the kernel intervals, gaps = the rest (kernel
-    boundaries, launch latency)."""
+    """Decode-phase occupancy of the GPU timeline.  Dispatches are grouped into bursts (a pause of more than 300 us between
+    dispatches = the host is between bench phases, not inside a step); a prompt-prefill kernel also ends a burst and is not counted;
+    inside the (decode) bursts: busy = union of the kernel intervals, gaps = the rest (kernel boundaries, launch
+    latency)."""
     cur = db.cursor()
     rows = cur.execute("select name, start, end from kernels order by start").fetchall()
     if not rows:
         return
-    t0 = rows[0][1]
-    for name, st, en in rows:
-        if "vv_attn_prefill2" in name or "vv_gemm4" in name or "vv_rope_append" in name:
-            t0 = max(t0, en)
-    win = [(n, s, e) for n, s, e in rows if s >= t0]
+    # every dispatch of the run is a candidate: a burst counts as decode when it holds no prompt-prefill kernel (the bench runs
+    # several generate() calls -- timed run, first-audio trials, roofline window -- each with its own prefill; cutting the
+    # trace at the LAST prefill kernel, as this function used to, dropped all but the last decode phase)
+    win = list(rows)
     if len(win) < 10:
         return
     span = busy = 0
@@ -67,6 +66,8 @@ def timeline(db, out):
     b_start = cur_s = cur_e = None
     kept = []
     burst = []
+
+    PREFILL = ("vv_gemm4", "vv_gemm3", "vv_attn_prefill", "vv_pack_rows", "vv_rope_append")
 
     def close(burst):
         nonlocal span, busy, n_bursts
@@ -85,6 +86,11 @@ def timeline(db, out):
         busy += ce - cs
     last_end = None
     for rec in win:
+        if any(p in rec[0] for p in PREFILL):            # a prompt-prefill kernel ends the decode burst before it and is not counted
+            close(burst)
+            burst = []
+            last_end = None
+            continue
         if last_end is not None and rec[1] - last_end > 300000:
             close(burst)
             burst = []

@@ -46,7 +46,8 @@ class EngineConfig:
     max_rows: int = 16
     xsplit: int = 2
     attn_splits: int = 128      # upper bound on flash-decoding splits; a launch uses one per 512 positions of its longest row
-    enc_frames: int = 4
+    enc_frames: int = 75         # voice-prompt frames per acoustic-encoder pass: one pass per 10-s speaker prompt (any pass size gives the
+                                 # same result, tests/test_gpu_shipped.py; 0.042 s at 5 frames per pass -> 0.027 s at 75 for two speakers)
     use_graph: bool = True
     tts_layers: int = 0          # Streaming-0.5B: the last tts_layers of lm_layers form the TTS LM
 

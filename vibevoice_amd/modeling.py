@@ -36,7 +36,7 @@ import json
 import os
 import time
 from dataclasses import dataclass
-from typing import Callable, List, Optional
+from typing import Callable, List, Optional, Sequence
 
 import numpy as np
 import torch
@@ -395,8 +395,11 @@ class VibeVoiceForConditionalGenerationInference:
         # the drop-in entry point: any batch generate() can take (MAX_BATCH utterances) works without an extra argument; the KV
         # caches of 8 slots at the model's full context are 30 GB for the 7B model -- a tenth of the HBM
         runtime.setdefault("n_slots", MAX_BATCH)
+        do_warm = runtime.pop("warmup", True)
         m = cls.from_state_dict(config, it(), torch_dtype or torch.bfloat16, device, attn_implementation=attn_implementation, **runtime)
         m.source_path = path
+        if do_warm and hasattr(m.engine, "acoustic_encode") and getattr(m.engine, "lib", None) is not None:
+            m.warmup()
 
         def base_tensor(key):          # lazy access to the checkpoint's own tensors (LoRA merge: vibevoice_amd/lora.py)
             for fn in files:
@@ -461,6 +464,49 @@ class VibeVoiceForConditionalGenerationInference:
 
     def set_ddpm_inference_steps(self, num_steps=None):
         self.ddpm_inference_steps = num_steps or self.config_dict["diffusion_head_config"].get("ddpm_num_inference_steps", 20)
+
+    def warmup(self, prompt_rows: Optional[Sequence[int]] = None, voice_frames: int = 75):
+        """Touch every kernel the first request needs, so that its time to first audio is a warm process's: the first launch
+        of a kernel pays for its code object and launch attributes (measured: voice-prompt encode 0.098 s cold, 0.042 s warm).
+        Runs the voice-prompt encoder + connector on silence, LM prompt passes of `prompt_rows` rows (default: one full
+        max_rows pass and a ragged remainder), and two decode frames (LM rows, restricted logits, sampler, both tokenizers,
+        connectors) on the model's own staging buffers, i.e. under the graph keys generate() will use.  Leaves no state
+        behind: caches are overwritten by the next prefill, the codec states are zeroed at the start of every generate()."""
+        e = self.engine
+        H, hop = e.cfg.lm_hidden, e.cfg.hop
+        R = e.cfg.max_rows
+        if prompt_rows is None:
+            prompt_rows = sorted({min(R, e.max_ctx - 8), max(1, min(R, e.max_ctx - 8) // 3 + 5)}, reverse=True)
+        with torch.cuda.stream(e.stream):
+            if getattr(e.cfg, "has_acoustic_encoder", False) and voice_frames > 0:
+                wav = e.new(voice_frames * hop)
+                mean = e.new(voice_frames, e.cfg.latent_dim)
+                e.acoustic_encode(voice_frames, wav, mean)
+                e.connect(voice_frames, mean, None, e.new(voice_frames, H))
+            for n in prompt_rows:
+                n = int(max(1, min(n, R, e.max_ctx - 8)))
+                x = torch.zeros(n, H, dtype=torch.float32, device=self.device)
+                hid = torch.empty_like(x)
+                if hasattr(e, "lm_forward_span"):
+                    e.lm_forward_span(0, 0, n, x, hid)
+                else:
+                    e.lm_forward([(0, j) for j in range(n)], x, hid)
+                del x, hid
+            e.set_valid_tokens([0, 1, 2, 3])
+            self._valid_key = None
+            e.set_num_steps(self.ddpm_inference_steps, t_cast_bf16=(self.dtype == torch.bfloat16))
+            e.codec_reset(0)
+            for step in range(3):                        # a graph key is captured on its second sight and replayed on the third
+                e.lm_forward([(0, step), (1, step)], self._x_in, self._hidden)
+                e.lm_logits(1, self._hidden, self._logits)
+                if not e.stochastic:
+                    e.diffusion_sample(1, self._hidden, self._noise, 1.3, self._latent)
+                e.codec_decode(0, self._latent[0:1], self._audio[0])
+                if e.cfg.sem_dim > 0:
+                    e.semantic_encode(0, self._audio[0], self._sem[0])
+                e.connect(1, self._latent, self._sem if e.cfg.sem_dim > 0 else None, self._emb_out)
+            e.codec_reset(0)
+        e.sync()
 
     # ------------------------------------------------------------------ helpers
     def _embed_ids(self, ids: List[int], out: torch.Tensor):

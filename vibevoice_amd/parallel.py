@@ -115,34 +115,94 @@ def broadcast_packed(shapes: Iterable[Tuple[str, tuple]], make: Callable[[str, t
                      GBps=(tot_bytes / 1e9 / tot_s) if tot_s > 0 else None)
 
 
-def generate_sharded(model, requests: Sequence[dict], gather_to: int = 0, **gen_kwargs):
+def shard_report(costs: Sequence[float], shards: Sequence[Sequence[int]]) -> dict:
+    """What the assignment costs: per-rank load under the cost model (prompt length), and the imbalance max / mean that bounds
+    the scaling efficiency of the whole job (every rank decodes at the same rate; the job ends with the most loaded rank)."""
+    load = [float(sum(costs[i] for i in sh)) for sh in shards]
+    mean = sum(load) / max(1, len(load))
+    return {"utterances_per_rank": [len(sh) for sh in shards], "load_per_rank": load,
+            "imbalance_max_over_mean": (max(load) / mean) if mean > 0 else 1.0}
+
+
+def _gather_rows(rows: List[torch.Tensor], dtype, device, gather_to):
+    """Variable-length 1-D tensors of every rank -> (on the receiving ranks) the list of every rank's rows, through ONE tensor
+    collective per call: lengths travel as a small int64 all_gather, payloads as one padded buffer per rank (dist.gather /
+    all_gather of tensors -- no pickling, no per-object CPU staging; on RCCL the buffers stay on the GPU)."""
+    rank, world = world_info()
+    n_max = torch.tensor([len(rows)], dtype=torch.int64, device=device)
+    dist.all_reduce(n_max, op=dist.ReduceOp.MAX)
+    lens = torch.zeros(int(n_max), dtype=torch.int64, device=device)
+    for j, r in enumerate(rows):
+        lens[j] = r.numel()
+    all_lens = [torch.zeros_like(lens) for _ in range(world)]
+    dist.all_gather(all_lens, lens)
+    width = max(1, max(int(l.sum()) for l in all_lens))
+    buf = torch.zeros(width, dtype=dtype, device=device)
+    o = 0
+    for r in rows:
+        buf[o:o + r.numel()] = r.reshape(-1).to(device=device, dtype=dtype)
+        o += r.numel()
+    if gather_to is None:
+        parts = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(parts, buf)
+    else:
+        parts = [torch.empty_like(buf) for _ in range(world)] if rank == gather_to else None
+        dist.gather(buf, parts, dst=gather_to)
+        if rank != gather_to:
+            return None
+    out = []
+    for p, l in zip(parts, all_lens):
+        o, rr = 0, []
+        for n in l.tolist():
+            rr.append(p[o:o + n])
+            o += n
+        out.append(rr)
+    return out
+
+
+def generate_sharded(model, requests: Sequence[dict], gather_to: int = 0, stats: dict = None, **gen_kwargs):
     """Utterance-parallel generation over the ranks of the current process group (BASELINE config 4): the
     requests (single-utterance processor outputs, as for model.generate_continuous) are assigned to ranks by
     longest-prompt-first (max_steps ~ prompt length, modeling_vibevoice_inference.py:421), every rank decodes its own shard
-    with continuous batching on ITS GPU -- no collective inside the step loop -- and the finished utterances
-    (sequences, audio, stop flag; CPU tensors) are gathered once at the end.  Returns, on rank `gather_to`
-    (every rank if gather_to is None), the list of VibeVoiceGenerationOutput in request order; None elsewhere."""
+    with continuous batching on ITS GPU -- no collective inside the step loop -- and the finished utterances come back ONCE at
+    the end as tensor collectives: one padded int64 buffer of token sequences and one padded buffer of waveforms per rank (a
+    45-minute utterance is 65 M samples: gathered as a tensor it never passes through pickle or a CPU staging copy; on RCCL it
+    goes GPU to GPU over xGMI).  Returns, on rank `gather_to` (every rank if gather_to is None), the list of
+    VibeVoiceGenerationOutput in request order; None elsewhere.  `stats` receives the sharding report (shard_report)."""
     from .modeling import VibeVoiceGenerationOutput
     rank, world = world_info()
     costs = [int(r["input_ids"].shape[-1]) for r in requests]
-    mine = shard_utterances(costs, world)[rank]
+    shards = shard_utterances(costs, world)
+    if stats is not None:
+        stats.update(shard_report(costs, shards))
+    mine = shards[rank]
     outs = model.generate_continuous([requests[i] for i in mine], **gen_kwargs) if mine else []
-    local = []
-    for i, o in zip(mine, outs):
-        audio = o.speech_outputs[0] if o.speech_outputs else None
-        local.append((i, o.sequences.cpu(), None if audio is None else audio.float().cpu(), o.reach_max_step_sample.cpu()))
     if not (dist.is_available() and dist.is_initialized()) or world == 1:
-        gathered = [local]
-    elif gather_to is None:
-        gathered = [None] * world
-        dist.all_gather_object(gathered, local)
-    else:
-        gathered = [None] * world if rank == gather_to else None
-        dist.gather_object(local, gathered, dst=gather_to)
-        if rank != gather_to:
-            return None
+        res = [None] * len(requests)
+        for i, o in zip(mine, outs):
+            audio = o.speech_outputs[0] if o.speech_outputs else None
+            res[i] = VibeVoiceGenerationOutput(sequences=o.sequences.cpu(), speech_outputs=[None if audio is None else audio.float().cpu()],
+                                               reach_max_step_sample=o.reach_max_step_sample.cpu())
+        return res
+    on_gpu = dist.get_backend() == "nccl"
+    device = model.device if on_gpu else torch.device("cpu")
+    seqs, auds, flags = [], [], []
+    for o in outs:
+        audio = o.speech_outputs[0] if o.speech_outputs else None
+        seqs.append(o.sequences.reshape(-1).to(torch.int64))
+        auds.append(torch.zeros(0) if audio is None else audio.reshape(-1))
+        flags.append(torch.tensor([int(bool(o.reach_max_step_sample.reshape(-1)[0])), 0 if audio is None else 1], dtype=torch.int64))
+    g_seq = _gather_rows(seqs, torch.int64, device, gather_to)
+    g_flag = _gather_rows(flags, torch.int64, device, gather_to)
+    g_aud = _gather_rows(auds, torch.float32 if not on_gpu else model.dtype, device, gather_to)
+    if g_seq is None:
+        return None
     res = [None] * len(requests)
-    for part in gathered:
-        for i, seq, audio, flag in part:
-            res[i] = VibeVoiceGenerationOutput(sequences=seq, speech_outputs=[audio], reach_max_step_sample=flag)
+    for r in range(world):
+        for j, i in enumerate(shards[r]):
+            has_audio = bool(g_flag[r][j][1])
+            res[i] = VibeVoiceGenerationOutput(
+                sequences=g_seq[r][j].reshape(1, -1).cpu(),
+                speech_outputs=[g_aud[r][j].reshape(1, -1).float().cpu() if has_audio else None],
+                reach_max_step_sample=torch.tensor([bool(g_flag[r][j][0])]))
     return res
