@@ -96,6 +96,8 @@ class Engine:
         self.lib = _lib.load()
         self.cfg = cfg
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if self.device.index is None:                 # device_map="cuda" (demo/inference_from_file.py:303): the current device
+            self.device = torch.device("cuda", torch.cuda.current_device())
         torch.cuda.set_device(self.device)
         c = _lib.VVConfig()
         for f in ("lm_hidden", "lm_layers", "lm_heads", "lm_kv_heads", "lm_head_dim", "lm_inter", "lm_vocab",

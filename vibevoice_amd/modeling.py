@@ -466,46 +466,63 @@ class VibeVoiceForConditionalGenerationInference:
         self.ddpm_inference_steps = num_steps or self.config_dict["diffusion_head_config"].get("ddpm_num_inference_steps", 20)
 
     def warmup(self, prompt_rows: Optional[Sequence[int]] = None, voice_frames: int = 75):
-        """Touch every kernel the first request needs, so that its time to first audio is a warm process's: the first launch
-        of a kernel pays for its code object and launch attributes (measured: voice-prompt encode 0.098 s cold, 0.042 s warm).
-        Runs the voice-prompt encoder + connector on silence, LM prompt passes of `prompt_rows` rows (default: one full
-        max_rows pass and a ragged remainder), and two decode frames (LM rows, restricted logits, sampler, both tokenizers,
-        connectors) on the model's own staging buffers, i.e. under the graph keys generate() will use.  Leaves no state
-        behind: caches are overwritten by the next prefill, the codec states are zeroed at the start of every generate()."""
+        """Touch everything the first request needs, so that its time to first audio is a warm process's: the first launch of
+        a kernel pays for its code object and launch attributes, and the first use of a torch op on the device (the Gaussian
+        draw of the voice-prompt latents, the masked scatter of the speech rows, ...) loads its module -- measured on the 7B
+        north-star request: voice-prompt encode 0.098 s cold against 0.03-0.04 s warm.  Runs (a) one LM prompt pass per entry
+        of `prompt_rows` (default: a full max_rows pass and a ragged remainder) and (b) a REAL generate() on a synthetic
+        one-speaker request (`voice_frames`-frame silent voice prompt, short prompt, three forced frames, explicit noise), i.e.
+        the request path itself: encoder, connectors, prompt scatter, decode steps under the graph keys generate() uses,
+        sampler, both tokenizers, streamer-free output assembly.  Draws nothing from any RNG (noise is passed in; the device
+        generator's state is saved and restored around it) and leaves no state behind: caches are overwritten by the next
+        prefill, codec states are zeroed at the start of every generate()."""
+        import types
         e = self.engine
-        H, hop = e.cfg.lm_hidden, e.cfg.hop
+        H, hop, L = e.cfg.lm_hidden, e.cfg.hop, e.cfg.latent_dim
         R = e.cfg.max_rows
+        cap = max(8, min(R, e.max_ctx - 16))
         if prompt_rows is None:
-            prompt_rows = sorted({min(R, e.max_ctx - 8), max(1, min(R, e.max_ctx - 8) // 3 + 5)}, reverse=True)
-        with torch.cuda.stream(e.stream):
-            if getattr(e.cfg, "has_acoustic_encoder", False) and voice_frames > 0:
-                wav = e.new(voice_frames * hop)
-                mean = e.new(voice_frames, e.cfg.latent_dim)
-                e.acoustic_encode(voice_frames, wav, mean)
-                e.connect(voice_frames, mean, None, e.new(voice_frames, H))
-            for n in prompt_rows:
-                n = int(max(1, min(n, R, e.max_ctx - 8)))
-                x = torch.zeros(n, H, dtype=torch.float32, device=self.device)
-                hid = torch.empty_like(x)
-                if hasattr(e, "lm_forward_span"):
-                    e.lm_forward_span(0, 0, n, x, hid)
-                else:
-                    e.lm_forward([(0, j) for j in range(n)], x, hid)
-                del x, hid
-            e.set_valid_tokens([0, 1, 2, 3])
+            prompt_rows = sorted({cap, max(8, cap // 3 + 5)}, reverse=True)
+        rng = torch.cuda.get_rng_state(self.device)
+        try:
+            with torch.cuda.stream(e.stream):
+                for n in prompt_rows:
+                    n = int(max(1, min(n, cap)))
+                    x = torch.zeros(n, H, dtype=torch.float32, device=self.device)
+                    hid = torch.empty_like(x)
+                    if hasattr(e, "lm_forward_span"):
+                        e.lm_forward_span(0, 0, n, x, hid)
+                    else:
+                        e.lm_forward([(0, j) for j in range(n)], x, hid)
+                    del x, hid
+            e.sync()
+            has_voice = bool(getattr(e.cfg, "has_acoustic_encoder", False)) and voice_frames > 0
+            vf = voice_frames if has_voice else 0
+            n_prompt = int(min(cap, e.max_ctx - 16, vf + 24))
+            vf = min(vf, n_prompt - 8)
+            tok = types.SimpleNamespace(speech_start_id=0, speech_end_id=1, speech_diffusion_id=2, eos_token_id=3, bos_token_id=None)
+            ids = torch.full((1, n_prompt), 4 % e.cfg.lm_vocab, dtype=torch.long)
+            sim = torch.zeros(1, n_prompt, dtype=torch.bool)
+            kw = {}
+            if vf > 0:
+                ids[0, 4:4 + vf] = tok.speech_diffusion_id
+                sim[0, 4:4 + vf] = True
+                kw = dict(speech_tensors=torch.zeros(1, vf * hop), speech_masks=torch.ones(1, vf, dtype=torch.bool), speech_input_mask=sim,
+                          _prefill_noise=(torch.zeros(1), torch.zeros(1, vf, L)))
+            ids[0, -1] = tok.speech_start_id
+            D = tok.speech_diffusion_id
+            scaled = not (self._scaling != self._scaling)              # speech factors may not be set yet (NaN): use neutral ones here
+            if not scaled:
+                self.engine.set_speech_factors(1.0, 0.0)
+                self._scaling, self._bias = 1.0, 0.0
+            self.generate(input_ids=ids, attention_mask=torch.ones_like(ids), tokenizer=tok, cfg_scale=1.3,
+                          generation_config={"do_sample": False}, max_new_tokens=4, show_progress_bar=False,
+                          _forced_tokens=[[D, D, D, tok.eos_token_id]], _noise_fn=lambda step, n2: torch.zeros(n2, L), **kw)
+            if not scaled:
+                self._scaling = self._bias = float("nan")
             self._valid_key = None
-            e.set_num_steps(self.ddpm_inference_steps, t_cast_bf16=(self.dtype == torch.bfloat16))
-            e.codec_reset(0)
-            for step in range(3):                        # a graph key is captured on its second sight and replayed on the third
-                e.lm_forward([(0, step), (1, step)], self._x_in, self._hidden)
-                e.lm_logits(1, self._hidden, self._logits)
-                if not e.stochastic:
-                    e.diffusion_sample(1, self._hidden, self._noise, 1.3, self._latent)
-                e.codec_decode(0, self._latent[0:1], self._audio[0])
-                if e.cfg.sem_dim > 0:
-                    e.semantic_encode(0, self._audio[0], self._sem[0])
-                e.connect(1, self._latent, self._sem if e.cfg.sem_dim > 0 else None, self._emb_out)
-            e.codec_reset(0)
+        finally:
+            torch.cuda.set_rng_state(rng, self.device)
         e.sync()
 
     # ------------------------------------------------------------------ helpers
