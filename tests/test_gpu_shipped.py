@@ -405,6 +405,7 @@ def test_from_pretrained_checkpoint_directory_on_the_gpu_engine(tmp_path, monkey
     try:
         model.eval()
         model.set_ddpm_inference_steps(num_steps=5)
+        model.speculate_sampling = False          # the recorded draws are consumed strictly in order (a discarded speculation would eat one)
         assert abs(float(model.speech_scaling_factor) - 0.2) < 1e-7
         z = np.load(os.path.join(GOLD, "generate_forced_b1.npz"))
         draws = [torch.from_numpy(z[f"draw_{i}"]) for i in range(int(z["n_draws"]))]
@@ -434,57 +435,3 @@ def test_from_pretrained_checkpoint_directory_on_the_gpu_engine(tmp_path, monkey
     assert bench.find_checkpoint("1.5b") == str(d)
     assert bench.find_checkpoint("7b") is None
     assert sorted(k for k, _ in bench.checkpoint_tensors(str(d))) == keys
-
-
-# ---------------------------------------------------------------------------------------------- chained launches (chain.hip)
-@pytest.mark.parametrize("tag", ["tiny", "7b", "1.5b", "0.5b"])
-def test_chained_sampler_equals_the_launch_per_op_sampler(tag, monkeypatch):
-    """vv_diffusion_sample for one utterance as ONE chained launch (VVHIP_CHAIN=1: every GEMV of every solver step a phase of one
-    grid, hand-offs through agent-scope counters) against the same sampler issued as one launch per op, and against the
-    oracle.  At the tiny widths no op changes shape, so the two must agree BIT FOR BIT (same kernels' arithmetic, same
-    reduction order); at the real head widths the chain splits K of the few-tile projections over workgroup columns, so the
-    summation order differs: <= 2e-5 apart in exact... (bf16 mode: the re-ordered fp32 sums move a bf16 rounding here and there)
-    <= 3e-3, and both within the bf16-mode bound of the bf16-input oracle.  Repeated calls replay the captured graph; the abort
-    word of the chain kernels must stay 0."""
-    lmcfg = synth.LMCfg() if tag == "tiny" else dataclasses.replace(GEOM[tag], inter=256)
-    res = {}
-    for arm in ("launches", "chain"):
-        if arm == "chain":
-            monkeypatch.setenv("VVHIP_CHAIN", "1")
-        else:
-            monkeypatch.delenv("VVHIP_CHAIN", raising=False)
-        s = (build_small if tag == "tiny" else build_fast)(lmcfg, xsplit=1, use_graph=True, n_slots=1, max_ctx=128, max_rows=16,
-                                                            head_layers=2 if tag == "tiny" else 4)
-        eng = s.eng
-        try:
-            H = lmcfg.hidden
-            g = synth.Gen(4242)
-            pos = g.normal((1, H), 1.0, mat=False)
-            neg = g.normal((1, H), 1.0, mat=False)
-            noise = g.normal((2, 64), 1.0, mat=False)
-            outs = []
-            for N in (10, 5):
-                eng.set_num_steps(N)
-                lat = eng.new(1, 64)
-                for rep in range(4):                  # eager, captured, replayed twice
-                    lat.zero_()
-                    with torch.cuda.stream(eng.stream):
-                        eng.diffusion_sample(1, dev(torch.cat([pos, neg]), eng), dev(noise[:1], eng), 1.3, lat)
-                    eng.sync()
-                    outs.append(lat.float().cpu().clone())
-                assert all(torch.equal(outs[-1], o) for o in outs[-4:]), "replays differ"
-            assert eng.stat(5) == 0, f"chain abort word {eng.stat(5)}"
-            assert (eng.stat(6) > 0) == (arm == "chain")
-            with torch.no_grad():
-                ref = dpm.sample_speech_tokens(lambda a, t, c: head.head_forward(s.head_w, a, t, c, s.hc.layers, s.hc.eps, mfma_in_bf16=True),
-                                               pos, neg, 1.3, 5, noise)
-            res[arm] = (outs[3], outs[7], rel_err(outs[7], ref))
-        finally:
-            eng.close()
-    d10, d5 = rel_err(res["chain"][0], res["launches"][0]), rel_err(res["chain"][1], res["launches"][1])
-    print(f"[chained sampler, {tag}] chain vs launches: N=10 {d10:.3e}, N=5 {d5:.3e}; vs bf16-input oracle: launches {res['launches'][2]:.3e}, chain {res['chain'][2]:.3e}")
-    if tag == "tiny":
-        assert torch.equal(res["chain"][0], res["launches"][0]) and torch.equal(res["chain"][1], res["launches"][1])
-    else:
-        assert d10 <= 3e-3 and d5 <= 3e-3, (d10, d5)
-    assert res["chain"][2] <= 1e-2 and res["launches"][2] <= 1e-2

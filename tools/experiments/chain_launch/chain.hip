@@ -23,7 +23,8 @@
 struct VVPhase {
     VVGemm g;
     int variant;               // index into the (prologue, epilogue, parts) table below
-    unsigned wg0, n_wg;        // first workgroup of the phase inside the grid, number of workgroups = tiles x K columns
+    unsigned wg0, n_wg;        // first workgroup of the phase inside the grid, number of workgroups
+    unsigned n_units;          // units = tiles x K columns; workgroup w of the phase processes units w, w + n_wg, w + 2 n_wg, ...
     unsigned n_tiles;
 };
 
@@ -43,24 +44,48 @@ namespace {
 // consumer in a fixed order) instead of 8- or 16-wave workgroups: one kernel = one workgroup size.  <= 168 VGPRs: 3 per CU.
 constexpr int CHAIN_WPB = 4;
 
-template <int MR, int FAM>
+// all units of this workgroup for one (prologue, epilogue) variant: the loop sits INSIDE the variant's switch case, so each variant
+// is one loop around one inlined body (a shared loop around the switch made the widest variant spill)
+template <int PRO, int EPI, int MR, int PARTS, int LOOP>
+__device__ __forceinline__ void chain_units(const VVPhase* __restrict__ P, unsigned local, unsigned p, unsigned prev, unsigned* done, unsigned* err,
+                                            unsigned n_phases, unsigned flags, unsigned char* __restrict__ smem) {
+    const unsigned n_tiles = P->n_tiles, n_units = P->n_units, n_wg = P->n_wg;
+    const unsigned kgrid = n_units / n_tiles;
+    if constexpr (!LOOP) {                     // one unit per workgroup (the table says so for every phase): no loop state at all
+        const unsigned ksb = local / n_tiles, tile = local - ksb * n_tiles;
+        const VVGemm a = P->g;
+        const VVChainSync cs{done, err, p, local, prev, 0u, 1u, n_phases, n_wg, flags, 1u};
+        vv_gemv_body<1, PRO, EPI, MR, CHAIN_WPB, PARTS, 0, 1>(a.W, a.W2, a.X, a.Y, a.nw, a.T, a.N, a.K, a.ldx, a.ldy, a, tile, ksb, kgrid, smem, cs);
+        return;
+    }
+#pragma unroll 1
+    for (unsigned unit = local; unit < n_units; unit += n_wg) {
+        const unsigned ksb = unit / n_tiles, tile = unit - ksb * n_tiles;
+        const bool first = unit == local, last = unit + n_wg >= n_units;
+        if (!first) __syncthreads();            // the previous unit's split-K partials in LDS have been consumed
+        const VVPhase* Pu = P;
+        asm volatile("" : "+s"(Pu));            // re-read the op's arguments per unit (scalar cache): nothing of the op is pinned across the loop
+        const VVGemm a = Pu->g;
+        const VVChainSync cs{done, err, p, local, first ? prev : 0u, 0u, 1u, n_phases, n_wg, flags, last ? 1u : 0u};
+        vv_gemv_body<1, PRO, EPI, MR, CHAIN_WPB, PARTS, 0, 1>(a.W, a.W2, a.X, a.Y, a.nw, a.T, a.N, a.K, a.ldx, a.ldy, a, tile, ksb, kgrid, smem, cs);
+    }
+}
+
+template <int MR, int FAM, int LOOP>
 __global__ __launch_bounds__(CHAIN_WPB * 64, 3) void vv_chain_kernel(const VVPhase* __restrict__ ph, const unsigned short* __restrict__ wg2ph,
-                                                                     unsigned* __restrict__ done, unsigned* __restrict__ err) {
+                                                                     unsigned* __restrict__ done, unsigned* __restrict__ err, const unsigned n_phases,
+                                                                     const unsigned flags) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[vv_gemv_smem_bytes<1, VV_PRO_RMS_MOD, VV_EPI_SWIGLU, MR, CHAIN_WPB>()];
     const unsigned wg = blockIdx.x;
     const unsigned p = __builtin_amdgcn_readfirstlane((unsigned)wg2ph[wg]);
     const VVPhase* P = ph + p;
-    const unsigned n_tiles = P->n_tiles;
     const unsigned local = wg - P->wg0;
-    const unsigned ksb = local / n_tiles, tile = local - ksb * n_tiles;
-    const unsigned kgrid = P->n_wg / n_tiles;
-    const VVChainSync cs{done, err, p, local, p ? (P - 1)->n_wg : 0u, 0u, 1u};
-    const VVGemm a = P->g;             // one batch of scalar loads: the table is constant for the launch
+    const unsigned prev = p ? (P - 1)->n_wg : 0u;
+    // Fewer workgroups than units: a phase occupies only part of the chip's workgroup slots, so the workgroups of the NEXT phase
+    // are resident -- first weight batch in registers -- while this one streams, and start the moment its last arrival lands.
     switch (P->variant) {
 #define X(V, PRO, EPI, PARTS, FAMS)                                                                                                      \
-        case V: if constexpr (((FAMS) >> FAM) & 1)                                                                                        \
-            vv_gemv_body<1, PRO, EPI, MR, CHAIN_WPB, PARTS, 0, 1>(a.W, a.W2, a.X, a.Y, a.nw, a.T, a.N, a.K, a.ldx, a.ldy, a, tile, ksb, kgrid, smem, cs); \
-            break;
+        case V: if constexpr (((FAMS) >> FAM) & 1) chain_units<PRO, EPI, MR, PARTS, LOOP>(P, local, p, prev, done, err, n_phases, flags, smem); break;
         VV_CHAIN_VARIANTS(X)
 #undef X
         default: break;
@@ -90,21 +115,29 @@ extern "C" int vv_chain_families(int variant) {
 }
 extern "C" int vv_chain_phase_bytes() { return (int)sizeof(VVPhase); }
 // fills one table entry (host memory); returns the phase's workgroup count
-extern "C" unsigned vv_chain_fill(void* entry, const VVGemm* g, int variant, unsigned wg0) {
+extern "C" unsigned vv_chain_fill(void* entry, const VVGemm* g, int variant, unsigned wg0, unsigned wg_cap) {
     VVPhase* P = (VVPhase*)entry;
     P->g = *g;
     P->variant = variant;
     P->n_tiles = (unsigned)((g->N + 15) / 16);
+    P->n_units = P->n_tiles * (unsigned)(g->kgrid > 1 ? g->kgrid : 1);
+    const unsigned per = (P->n_units + wg_cap - 1) / wg_cap;        // units per workgroup, then as few workgroups as that takes (balanced)
     P->wg0 = wg0;
-    P->n_wg = P->n_tiles * (unsigned)(g->kgrid > 1 ? g->kgrid : 1);
+    P->n_wg = (P->n_units + per - 1) / per;
     return P->n_wg;
 }
 extern "C" int vv_chain_launch(const void* phases_dev, const unsigned short* wg2ph_dev, unsigned* done_dev, unsigned* err_dev, int n_phases,
-                               unsigned total_wgs, int rows, int family, hipStream_t s) {
+                               unsigned total_wgs, int rows, int family, int looped, hipStream_t s) {
     if (n_phases < 1 || total_wgs < 1 || rows < 1 || rows > 2 || family < 0 || family > 1) return -1;
-    if (hipMemsetAsync(done_dev, 0, (size_t)n_phases * 256 * sizeof(unsigned), s) != hipSuccess) return -2;
+    if (hipMemsetAsync(done_dev, 0, (size_t)n_phases * (256 + 32) * sizeof(unsigned), s) != hipSuccess) return -2;
+    // knobs: VVHIP_CHAIN_PAUSE = poll pause in units of ~0.2 us (default 4); VVHIP_CHAIN_ACQ = 1 adds an agent-scope acquire after
+    // every wait (debugging aid: the write-once discipline makes it unnecessary)
+    static const unsigned flags = (unsigned)((getenv("VVHIP_CHAIN_PAUSE") ? atoi(getenv("VVHIP_CHAIN_PAUSE")) : 4) & 255) |
+                                  ((getenv("VVHIP_CHAIN_ACQ") && atoi(getenv("VVHIP_CHAIN_ACQ"))) ? 256u : 0u);
     const dim3 grid(total_wgs), block(CHAIN_WPB * 64);
-    if (family == 0) hipLaunchKernelGGL((vv_chain_kernel<2, 0>), grid, block, 0, s, (const VVPhase*)phases_dev, wg2ph_dev, done_dev, err_dev);
-    else hipLaunchKernelGGL((vv_chain_kernel<2, 1>), grid, block, 0, s, (const VVPhase*)phases_dev, wg2ph_dev, done_dev, err_dev);
+#define GO(F, L) hipLaunchKernelGGL((vv_chain_kernel<2, F, L>), grid, block, 0, s, (const VVPhase*)phases_dev, wg2ph_dev, done_dev, err_dev, (unsigned)n_phases, flags)
+    if (family == 0) { if (looped) GO(0, 1); else GO(0, 0); }
+    else { if (looped) GO(1, 1); else GO(1, 0); }
+#undef GO
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

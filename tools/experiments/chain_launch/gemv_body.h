@@ -77,35 +77,43 @@ constexpr int U = 8;       // k-steps per batch (256 k = one float4 per lane per
 // spin is bounded by the 100 MHz wall clock and a shared abort word (a launch that cannot make progress ends with an error code
 // instead of hanging the GPU).
 struct VVChainSync {
-    unsigned* done;        // [n_phases][8 shards][32 words]: arrivals of each phase
+    unsigned* done;        // [n_phases][8 shards][32 words] arrivals per shard, then [n_phases][32 words]: shards complete ("ready")
     unsigned* err;         // abort word: non-zero once any workgroup gave up
     unsigned phase;        // this workgroup's phase
     unsigned local;        // this unit's index inside the phase
     unsigned prev_wgs;     // units (tile x K column) of phase - 1 (0: nothing to wait for)
     unsigned wave0;        // first wave of this unit inside its workgroup (0: a unit is a workgroup)
     unsigned live;         // 0: a padding unit: takes part in the barriers, loads / computes / stores nothing
+    unsigned n_phases;
+    unsigned my_wgs;       // units of this phase
+    unsigned flags;        // bits 0..7: poll pause in units of s_sleep 8 (~0.2 us); bit 8: agent-scope acquire after the wait (not needed
+                           // under the write-once discipline: every tensor a phase reads was written to lines no cache has seen in this launch)
+    unsigned pub;          // 1: this call publishes the workgroup's arrival (the last unit a workgroup processes)
 };
 constexpr unsigned VV_CHAIN_TIMEOUT_TICKS = 5u * 1000u * 100u;        // 5 ms of the 100 MHz clock
 
+// ONE lane polls ONE word per phase: the last arriver of each of the 8 shards bumps the phase's ready word, a consumer waits for
+// it to reach the number of non-empty shards.  (Polling the 8 shard counters from every waiting workgroup put ~8 coherent loads
+// per poll and workgroup on the fabric: with ~700 workgroups waiting that traffic alone slowed the weight stream.)
 __device__ __forceinline__ void vv_chain_wait(const VVChainSync& cs) {
     if (cs.prev_wgs != 0u) {
         if (threadIdx.x < 64u) {
-            const unsigned lane = threadIdx.x;
-            const unsigned* c = cs.done + (size_t)(cs.phase - 1u) * 256u + (lane & 7u) * 32u;
-            const unsigned want = (lane < 8u) ? cs.prev_wgs / 8u + ((lane < (cs.prev_wgs & 7u)) ? 1u : 0u) : 0u;
+            unsigned* c = cs.done + (size_t)cs.n_phases * 256u + (size_t)(cs.phase - 1u) * 32u;
+            const unsigned want = cs.prev_wgs < 8u ? cs.prev_wgs : 8u;
+            const unsigned pause = cs.flags & 255u;
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
             for (;;) {
-                const unsigned v = (lane < 8u) ? __hip_atomic_load(const_cast<unsigned*>(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-                if (__all(v >= want)) break;
-                __builtin_amdgcn_s_sleep(2);
+                const unsigned v = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v >= want) break;
+                for (unsigned i = 0; i < pause; ++i) __builtin_amdgcn_s_sleep(8);
                 const bool late = (unsigned)(__builtin_amdgcn_s_memrealtime() - t0) > VV_CHAIN_TIMEOUT_TICKS;
-                const unsigned dead = (lane == 0u) ? __hip_atomic_load(cs.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-                if (__any(late || dead != 0u)) {
-                    if (lane == 0u && dead == 0u) __hip_atomic_store(cs.err, 1u + cs.phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned dead = late ? 0u : __hip_atomic_load(cs.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (late || dead != 0u) {
+                    if (late && threadIdx.x == 0u) __hip_atomic_store(cs.err, 1u + cs.phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (cs.flags & 256u) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
     }
@@ -118,9 +126,15 @@ __device__ __forceinline__ void vv_chain_store1(float* p, float v) {
 }
 // called by the ONE storing wave of the workgroup (wave 0), after its stores; lane 0 is always among the live lanes
 __device__ __forceinline__ void vv_chain_publish(const VVChainSync& cs) {
+    if (!cs.pub) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if ((threadIdx.x & 63u) == 0u)
-        __hip_atomic_fetch_add(cs.done + (size_t)cs.phase * 256u + (cs.local & 7u) * 32u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((threadIdx.x & 63u) == 0u) {
+        const unsigned sh = cs.local & 7u;
+        const unsigned want = cs.my_wgs / 8u + ((sh < (cs.my_wgs & 7u)) ? 1u : 0u);
+        const unsigned old = __hip_atomic_fetch_add(cs.done + (size_t)cs.phase * 256u + sh * 32u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1u == want)
+            __hip_atomic_fetch_add(cs.done + (size_t)cs.n_phases * 256u + (size_t)cs.phase * 32u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // LDS bytes of one instantiation: staging tiles + split-K partials + sum(x^2) rows
@@ -270,7 +284,8 @@ __device__ __forceinline__ void vv_gemv_body(const u32x4* __restrict__ pW, const
             if (a.bias) pre_b = *reinterpret_cast<const float4*>(a.bias + n0);
         }
         if constexpr (EPI == VV_EPI_RESID || EPI == VV_EPI_GATED_RESID) {
-            pre_y = *reinterpret_cast<const float4*>(pY + (yrow_off + (unsigned)n0));
+            if constexpr (CHAIN) pre_y = *reinterpret_cast<const float4*>((a.R ? a.R : pY) + (yrow_off + (unsigned)n0));
+            else pre_y = *reinterpret_cast<const float4*>(pY + (yrow_off + (unsigned)n0));
             if constexpr (PARTS == 2) {
                 const float* yp0 = a.ya + (unsigned)((t_base + frow) * pldy + n0);
                 pre_y0 = *reinterpret_cast<const float4*>(yp0);
@@ -448,7 +463,8 @@ __device__ __forceinline__ void vv_gemv_body(const u32x4* __restrict__ pW, const
                 float zn = csx * zo + c0 * x0 + c1 * (x0 - a.x0p[zi]);
                 if (a.sde_noise) zn += cn * a.sde_noise[zi];
                 if constexpr (CHAIN) {           // write-through: the next phase's workgroups sit on other XCDs
-                    vv_chain_store1(a.x0p + zi, x0); vv_chain_store1(a.z + zi, zn); vv_chain_store1(a.z + zi + (unsigned)(nc * pN), zn);
+                    float* const zw = a.z_out ? a.z_out : a.z;
+                    vv_chain_store1((a.x0p_out ? a.x0p_out : a.x0p) + zi, x0); vv_chain_store1(zw + zi, zn); vv_chain_store1(zw + zi + (unsigned)(nc * pN), zn);
                 } else {
                     a.x0p[zi] = x0;
                     a.z[zi] = zn;

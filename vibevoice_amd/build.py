@@ -10,8 +10,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvvhip.so")
-SOURCES = ["gemm.hip", "gemv.hip", "chain.hip", "gemv16p.hip", "tile.hip", "prefill.hip", "attn.hip", "misc.hip", "block1d.hip", "engine.hip"]
-HEADERS = [os.path.join(CSRC, "vv_common.h"), os.path.join(CSRC, "gemv_body.h"), os.path.join(os.path.dirname(HERE), "include", "vvhip.h")]
+SOURCES = ["gemm.hip", "gemv.hip", "gemv16p.hip", "tile.hip", "prefill.hip", "attn.hip", "misc.hip", "block1d.hip", "engine.hip"]
+HEADERS = [os.path.join(CSRC, "vv_common.h"), os.path.join(os.path.dirname(HERE), "include", "vvhip.h")]
 
 
 def _hipcc():
@@ -66,14 +66,60 @@ def stale():
     return have_sources() and binary_id() != source_id()
 
 
+def _object_key(src, flags, build_id):
+    """content hash of one translation unit: its source, every header, the flags (+ the build id where the source embeds it)"""
+    import hashlib
+    h = hashlib.sha256()
+    for d in [src] + HEADERS:
+        with open(d, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(flags).encode())
+    if os.path.basename(src) == "engine.hip":
+        h.update(build_id.encode())
+    return h.hexdigest()[:16]
+
+
 def build(force=False, verbose=True):
+    """One object per source (compiled in parallel, cached under csrc/.obj by content hash), then one link: a change to one kernel
+    file recompiles that file only (the whole library in one hipcc command took 2.5 minutes)."""
     if not force and not stale():
         return LIB
+    from concurrent.futures import ThreadPoolExecutor
+    hipcc = _hipcc()
+    bid = source_id()
+    cflags = [f for f in FLAGS if f != "-shared"] + _extra_flags()
+    objdir = os.path.join(CSRC, ".obj")
+    os.makedirs(objdir, exist_ok=True)
+    jobs, objs = [], []
+    for sname in SOURCES:
+        src = os.path.join(CSRC, sname)
+        obj = os.path.join(objdir, f"{os.path.splitext(sname)[0]}.{_object_key(src, cflags, bid)}.o")
+        objs.append(obj)
+        if not os.path.exists(obj):
+            jobs.append((src, obj))
+
+    def compile_one(job):
+        src, obj = job
+        tmp = f"{obj}.tmp{os.getpid()}"
+        cmd = [hipcc] + cflags + [f'-DVV_BUILD_ID="{bid}"', "-c", src, "-o", tmp]
+        if verbose:
+            print("[vibevoice_amd] compiling", os.path.basename(src), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+        os.replace(tmp, obj)
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        list(ex.map(compile_one, jobs))
+    keep = set(objs)
+    for fn in os.listdir(objdir):                       # objects of older revisions of the same sources
+        full = os.path.join(objdir, fn)
+        if fn.endswith(".o") and full not in keep:
+            try:
+                os.remove(full)
+            except OSError:
+                pass
     tmp = f"{LIB}.tmp{os.getpid()}"            # unique per process: concurrent ranks never share a half-written file
-    cmd = [_hipcc()] + FLAGS + _extra_flags() + [f'-DVV_BUILD_ID="{source_id()}"'] + \
-          [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp]
     if verbose:
-        print("[vibevoice_amd] building libvvhip.so:", " ".join(cmd), file=sys.stderr)
+        print("[vibevoice_amd] linking libvvhip.so", file=sys.stderr)
     subprocess.run(cmd, check=True)
     os.replace(tmp, LIB)
     return LIB

@@ -85,12 +85,6 @@ int vv_gemm3_launch(const void* W, const void* W2, const void* Xp, float* Y, voi
                     int ldy, int epi, hipStream_t s);
 int vv_attn_prefill2_launch(int D, const float* q, const VVRow* rows, const void* kc, const void* vc, int R, int Hq, int Hkv,
                             int64_t cache_stride, int64_t head_stride, float* out, hipStream_t s);
-int vv_chain_variant(const VVGemm* g);
-int vv_chain_families(int variant);
-int vv_chain_phase_bytes();
-unsigned vv_chain_fill(void* entry, const VVGemm* g, int variant, unsigned wg0);
-int vv_chain_launch(const void* phases_dev, const unsigned short* wg2ph_dev, unsigned* done_dev, unsigned* err_dev, int n_phases,
-                    unsigned total_wgs, int rows, int family, hipStream_t s);
 int vv_block1d_supported(int C);
 int vv_gemv_ok(const VVGemm* a);
 int vv_tile_ok(const VVGemm* a, int xs);
@@ -234,13 +228,6 @@ struct vv_ctx {
     std::set<std::string> seen;
     std::set<void*> allocs;                // every dalloc() of this engine: released by vv_destroy
     int64_t launches = 0;
-    // chained launches (chain.hip): a dependent chain of decode GEMVs as the phases of ONE launch.  While chain_rec is set the GEMM
-    // macro records instead of launching; run_chain() turns the record into a (cached) device table and launches it.
-    bool chain_ok = false;
-    std::vector<VVGemm>* chain_rec = nullptr;
-    struct Chain { void* ph; unsigned short* map; unsigned* done; int n; unsigned wgs; int fam; };
-    std::map<std::string, Chain> chains;
-    unsigned* chain_err = nullptr;             // sticky abort word of the chain kernels (vv_stat(ctx, 5))
     // optional per-GEMM-launch hipEvent timing (vv_profile_begin/end)
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;
@@ -529,10 +516,7 @@ static VVGemm mk_gemm(const void* W, const float* X, float* Y, int T, int N, int
 // streams; the partial tensors are added back by the consumers (VVGemm::xa / ya).  Returns the number of EXTRA parts.
 static int ksplit_parts(const vv_ctx* ctx, VVGemm& g, float* parts, int part_stride) {
     const int n_tiles = (g.N + 15) / 16, k_tiles = (g.K + 31) / 32;
-    // inside a chained launch every phase runs 4-wave workgroups: ops with up to one tile per CU and a long K take their
-    // parallelism from K columns there (the single-op launcher gives such shapes 8- or 16-wave workgroups instead)
-    const bool ch = ctx->chain_rec != nullptr;
-    if (!ctx->ksplit_ok || g.T > 4 || n_tiles > (ch ? 256 : 128) || k_tiles < (ch ? 48 : 96)) return 0;
+    if (!ctx->ksplit_ok || g.T > 4 || n_tiles > 128 || k_tiles < 96) return 0;
     const int ks = 3;
     g.kgrid = ks; g.yparts = parts; g.part_stride = part_stride;
     if (!vv_gemv_ok(&g)) { g.kgrid = 0; g.yparts = nullptr; g.part_stride = 0; return 0; }
@@ -586,9 +570,9 @@ extern "C" int vv_timeline_dump(vv_ctx* ctx, unsigned long long* out_host, int* 
     for (int i = 0; i < n; ++i) { const auto& r = ctx->tl_rec[i]; int* m = meta_host + 5 * i; m[0] = r.T; m[1] = r.N; m[2] = r.K; m[3] = r.pro; m[4] = r.epi; }
     return n;
 }
-#define GEMM(g) do { ctx->launches++; if (ctx->chain_rec) ctx->chain_rec->push_back(g); else VVCHK(gemm_tl(ctx, g, st)); } while (0)
+#define GEMM(g) do { ctx->launches++; VVCHK(gemm_tl(ctx, g, st)); } while (0)
 #else
-#define GEMM(g) do { ctx->launches++; if (ctx->chain_rec) ctx->chain_rec->push_back(g); else if (ctx->prof_on) VVCHK(gemm_prof(ctx, g, st)); else VVCHK(vv_gemm_launch(g, ctx->c.xsplit, st)); } while (0)
+#define GEMM(g) do { ctx->launches++; if (ctx->prof_on) VVCHK(gemm_prof(ctx, g, st)); else VVCHK(vv_gemm_launch(g, ctx->c.xsplit, st)); } while (0)
 #endif
 
 // Runs one codec net over F frames for slot `sl`.  The caller has already written the
@@ -798,63 +782,6 @@ static int graphed(vv_ctx* ctx, const std::string& key, hipStream_t st, F&& body
     return 0;
 }
 
-// ------------------------------------------------------------------ chained launches
-static int chain_fallback(vv_ctx* ctx, const std::vector<VVGemm>& rec, hipStream_t st) {
-    for (const VVGemm& g : rec) VVCHK(vv_gemm_launch(g, ctx->c.xsplit, st));
-    return 0;
-}
-// `rec`: the decode GEMVs of a dependent chain in issue order, each reading what its predecessor wrote.  The device table of a
-// chain is built once per key (the pointers inside are engine buffers and the caller's arguments, both part of the key).
-static int run_chain(vv_ctx* ctx, const std::string& key, const std::vector<VVGemm>& rec, int rows, hipStream_t st) {
-    if (rec.empty()) return 0;
-    auto it = ctx->chains.find(key);
-    if (it == ctx->chains.end()) {
-        hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
-        (void)hipStreamIsCapturing(st, &cst);
-        if (cst != hipStreamCaptureStatusNone) return chain_fallback(ctx, rec, st);      // no allocation / blocking copy inside a capture
-        int fam_mask = 3;
-        std::vector<int> var(rec.size());
-        for (size_t i = 0; i < rec.size(); ++i) {
-            var[i] = vv_chain_variant(&rec[i]);
-            if (var[i] < 0) return chain_fallback(ctx, rec, st);
-            fam_mask &= vv_chain_families(var[i]);
-        }
-        if (!fam_mask || rec.size() > 60000) return chain_fallback(ctx, rec, st);
-        const int pb = vv_chain_phase_bytes();
-        std::vector<unsigned char> tab(rec.size() * (size_t)pb);
-        std::vector<unsigned short> map;
-        unsigned wgs = 0;
-        for (size_t i = 0; i < rec.size(); ++i) {
-            const unsigned n = vv_chain_fill(tab.data() + i * (size_t)pb, &rec[i], var[i], wgs);
-            map.insert(map.end(), n, (unsigned short)i);
-            wgs += n;
-        }
-        vv_ctx::Chain c{};
-        c.n = (int)rec.size(); c.wgs = wgs; c.fam = (fam_mask & 1) ? 0 : 1;
-        c.ph = dalloc(ctx, tab.size(), false);
-        c.map = (unsigned short*)dalloc(ctx, map.size() * sizeof(unsigned short), false);
-        c.done = (unsigned*)dalloc(ctx, (size_t)c.n * 256 * sizeof(unsigned));
-        if (!ctx->chain_err) ctx->chain_err = (unsigned*)dalloc(ctx, 256);
-        if (!c.ph || !c.map || !c.done || !ctx->chain_err) return -1;
-        HIPCHK(ctx, hipMemcpy(c.ph, tab.data(), tab.size(), hipMemcpyHostToDevice));
-        HIPCHK(ctx, hipMemcpy(c.map, map.data(), map.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
-        it = ctx->chains.emplace(key, c).first;
-    }
-    const vv_ctx::Chain& c = it->second;
-    ctx->launches += 1;
-    VVCHK(vv_chain_launch(c.ph, c.map, c.done, ctx->chain_err, c.n, c.wgs, rows, c.fam, st));
-    return 0;
-}
-static void drop_chains(vv_ctx* ctx, const char* prefix) {
-    for (auto it = ctx->chains.begin(); it != ctx->chains.end();) {
-        if (it->first.rfind(prefix, 0) == 0) {
-            hipDeviceSynchronize();
-            dfree(ctx, it->second.ph); dfree(ctx, it->second.map); dfree(ctx, it->second.done);
-            it = ctx->chains.erase(it);
-        } else ++it;
-    }
-}
-
 // ------------------------------------------------------------------ API
 extern "C" const char* vv_last_error(vv_ctx* ctx) { return ctx ? ctx->err : g_err; }
 
@@ -936,7 +863,6 @@ extern "C" int vv_create(const vv_config* cfg, vv_ctx** out) {
     ctx->h = (float*)dalloc(ctx, (size_t)R * H * 4);
     ctx->h_parts = (float*)dalloc(ctx, (size_t)2 * R * H * 4);
     ctx->ksplit_ok = !getenv("VVHIP_NO_GEMV") && !getenv("VVHIP_NO_KSPLIT");
-    ctx->chain_ok = c.xsplit == 1 && ctx->ksplit_ok && getenv("VVHIP_CHAIN") && atoi(getenv("VVHIP_CHAIN")) != 0;
     ctx->qkv = (float*)dalloc(ctx, (size_t)R * QKV * 4);
     ctx->qrot = (float*)dalloc(ctx, (size_t)R * Hq * D * 4);
     ctx->attn = (float*)dalloc(ctx, (size_t)R * Hq * D * 4);
@@ -1178,7 +1104,6 @@ static int set_schedule(vv_ctx* ctx, int n_steps, const float* t, const float* c
             ctx->mod_all_bytes = (ctx->mod_all && ctx->ada_in) ? need : 0;
         }
     }
-    drop_chains(ctx, "samp");
     for (auto it = ctx->graphs.begin(); it != ctx->graphs.end();) {
         if (it->first.rfind("samp", 0) == 0 || it->first.rfind("sde:", 0) == 0) { hipGraphExecDestroy(it->second.exec); it = ctx->graphs.erase(it); } else ++it;
     }
@@ -1512,23 +1437,11 @@ static int sample_body(vv_ctx* ctx, hipStream_t st, int n, const float* cond, co
         }
         }
     }
-    // one utterance (two head rows), bf16 mode: the N x (in-projection, 4 x (gate/up, down), final layer + solver update) GEMVs
-    // of all solver steps run as the phases of ONE chained launch (chain.hip) instead of ~10 N dependent launches
-    const bool chain = ctx->chain_ok && rows == 2 && batch_ada && !ctx->prof_on && !ctx->chain_rec;
-    std::vector<VVGemm> rec;
-    if (chain) { rec.reserve((size_t)ctx->n_steps * 12); ctx->chain_rec = &rec; }
-    int hr = 0;
-    for (int i = 0; i < ctx->n_steps && !hr; ++i) {
+    for (int i = 0; i < ctx->n_steps; ++i) {
         const float* mod_i = batch_ada ? ctx->mod_all + (size_t)i * rows * MODW : nullptr;
         const float* sn = step_noise ? step_noise + (size_t)i * n * L : nullptr;
-        hr = head_eval(ctx, st, rows, ctx->zz, ctx->temb + (size_t)i * H, ctx->eps, ctx->coef + i * 6, cfg, mod_i, sn);
+        if (head_eval(ctx, st, rows, ctx->zz, ctx->temb + (size_t)i * H, ctx->eps, ctx->coef + i * 6, cfg, mod_i, sn)) return -1;
     }
-    if (chain) {
-        ctx->chain_rec = nullptr;
-        char ck[192]; snprintf(ck, 192, "samp:%d:%p:%p:%p:%p:%a", n, (const void*)cond, (const void*)noise, (const void*)step_noise, (void*)latent_out, cfg);
-        if (!hr && run_chain(ctx, ck, rec, rows, st)) return -1;
-    }
-    if (hr) return -1;
     HIPCHK(ctx, hipMemcpyAsync(latent_out, ctx->zz, (size_t)n * L * 4, hipMemcpyDeviceToDevice, st));
     return 0;
 }
@@ -1872,12 +1785,6 @@ extern "C" int64_t vv_stat(vv_ctx* ctx, int what) {
         case 0: return ctx->launches;
         case 2: return ctx->prof_raw_ns;          // last profile: sum of raw event-pair times over the decode-GEMV launches
         case 3: return ctx->prof_ev_over_ns;      // last profile: time of an empty event pair
-        case 5: {                                 // chained launches: 0, or 1 + the phase whose wait gave up (sticky; blocks until the stream drains)
-            unsigned v = 0;
-            if (ctx->chain_err) { hipDeviceSynchronize(); hipMemcpy(&v, ctx->chain_err, 4, hipMemcpyDeviceToHost); }
-            return (int64_t)v;
-        }
-        case 6: return (int64_t)ctx->chains.size();
         default: return (int64_t)ctx->graphs.size();
     }
 }
