@@ -7,7 +7,8 @@
   * decode attention over a LONG cache: 32,768 positions at the 7B geometry, 65,536 at the 1.5B geometry (12 / 2 x 128),
     8,192 at the 0.5B geometry -- random bf16 K/V placed with vv_kv_import(_at), every flash-decoding split and the
     last-arriver ticket merge of vv_attn_fused_kernel, against the oracle's eager attention (oracle/lm.py);
-  * prefill attention over >= 4K positions against the oracle (chunks of 512 rows through vv_attn_prefill_kernel).
+  * prefill attention over >= 4K positions against the oracle in 512-row chunks: vv_attn_prefill3_kernel in the bf16 mode; in the
+    exact modes the chunk's rows go through the split + merge attention pair, 64 rows per launch.
 
 One layer keeps the CPU oracle to seconds; every kernel runs at its real per-layer shape.  Weights are bf16-representable
 and the engine runs xsplit=3 unless stated, so bounds are fp32-class (bf16 KV cache mirrored by the oracle)."""
@@ -166,8 +167,9 @@ def test_decode_attention_over_the_full_context(tag, L, xs, tol):
 
 @pytest.mark.parametrize("xs,tol", [(3, 5e-4), (2, 1e-3), (1, 4e-2)])
 def test_prefill_attention_over_4k_positions(xs, tol):
-    """A 4,200-token prompt through one layer in 512-row chunks (MFMA tile GEMM where eligible + vv_attn_prefill_kernel:
-    16 query rows per workgroup walk the whole causal prefix) against the oracle's full causal attention."""
+    """A 4,200-token prompt through one layer in 512-row chunks against the oracle's full causal attention: xs = 1 runs the
+    packed-activation GEMMs + vv_attn_prefill3_kernel; xs = 2, 3 the tile / general GEMMs and, per chunk, eight 64-row launches of
+    the split + merge attention pair (every row attends its own causal prefix)."""
     c = synth.LMCfg(hidden=512, layers=1, heads=4, kv_heads=2, inter=512, vocab=64, max_pos=8192)
     s = build_fast(c, xsplit=xs, max_ctx=4352, max_rows=512, head_layers=1)
     eng = s.eng
@@ -209,46 +211,3 @@ def _prefill_probe(L0, chunk, heads, kv_heads, hd):
         return hid.float().cpu(), s, x
     finally:
         eng.close()
-
-
-PROBE_SHAPES = [(4180, 512, 4, 2, 128), (1000, 1024, 7, 1, 128), (1555, 1024, 14, 2, 64), (90, 128, 4, 2, 128)]
-
-
-@pytest.mark.parametrize("L0,chunk,heads,kv_heads,hd", PROBE_SHAPES)
-def test_prefill_attention_v3_rowwise(L0, chunk, heads, kv_heads, hd):
-    """vv_attn_prefill3_kernel (one softmax update per 64-position stage, v_permlane*_swap row exchange, mask-free path below
-    the diagonal) held ROW BY ROW to (a) the same kernel with the LDS-permute exchange (VVHIP_ATTN3_SHFL: must be bit-identical
-    -- pins the permlane16 / permlane32 swap semantics), (b) the v2 kernel (VVHIP_ATTN3=0; per-row rel-L2 <= 5e-3: only the
-    granularity of the running maximum, i.e. the bf16 rounding of P, differs) and (c) the oracle's causal attention (per-row
-    rel-L2 within the bf16-mode bound).  A masking or tail-stage slip shows up as an O(1) error in single rows, which a
-    whole-tensor norm hides.  Shapes: ragged tails with 1..32 and 33..64 live positions in the last stage, passes that start
-    at a non-zero position, GQA groups 2 / 7 (one idle wave pair), both head widths.  The other kernels' outputs come from
-    subprocesses because the engine reads its A/B switches once per process."""
-    import os
-    import subprocess
-    import sys
-    import tempfile
-    got, s, x = _prefill_probe(L0, chunk, heads, kv_heads, hd)
-    with tempfile.TemporaryDirectory() as td:
-        outs = {}
-        for tag, env in (("shfl", {"VVHIP_ATTN3_SHFL": "1"}), ("v2", {"VVHIP_ATTN3": "0"})):
-            path = os.path.join(td, tag + ".npy")
-            e = dict(os.environ, **env)
-            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-            e["PYTHONPATH"] = os.pathsep.join([root, os.path.join(root, "tests")] + ([e["PYTHONPATH"]] if e.get("PYTHONPATH") else []))
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), path, str(L0), str(chunk), str(heads), str(kv_heads), str(hd)],
-                               env=e, cwd=os.path.dirname(os.path.abspath(__file__)), capture_output=True, text=True, timeout=600)
-            assert r.returncode == 0, r.stderr[-2000:]
-            outs[tag] = torch.from_numpy(np.load(path))
-    assert torch.equal(got, outs["shfl"]), float((got - outs["shfl"]).abs().max())
-    row = lambda a, b: float(((a - b).norm(dim=1) / b.norm(dim=1)).max())
-    assert row(got, outs["v2"]) <= 5e-3, row(got, outs["v2"])
-    ref = s.oracle_lm(kv_round_bf16=True).forward(x, s.oracle_lm(kv_round_bf16=True).new_cache())
-    assert row(got, ref) <= 8e-2, row(got, ref)
-    assert rel_err(got, ref) <= 4e-2, rel_err(got, ref)
-
-
-if __name__ == "__main__":                       # subprocess leg of test_prefill_attention_v3_rowwise
-    import sys
-    out_path, a = sys.argv[1], [int(v) for v in sys.argv[2:7]]
-    np.save(out_path, _prefill_probe(*a)[0].numpy())

@@ -251,9 +251,14 @@ def test_one_pass_prefill_of_10922_rows_at_7b_widths():
 
 
 # ---------------------------------------------------------------------------------------------- (d) bf16-input references
-@pytest.mark.parametrize("L0,chunk,heads,kv_heads,hd", [(4180, 512, 4, 2, 128), (1000, 1024, 7, 1, 128), (1555, 1024, 14, 2, 64)])
+@pytest.mark.parametrize("L0,chunk,heads,kv_heads,hd", [(4180, 512, 4, 2, 128), (1000, 1024, 7, 1, 128), (1555, 1024, 14, 2, 64), (90, 128, 4, 2, 128)])
 def test_prefill_attention_v3_against_the_bf16_input_oracle(L0, chunk, heads, kv_heads, hd):
-    """vv_attn_prefill3 (+ the packed-activation GEMMs around it) row by row against the oracle with bf16 matrix-unit inputs"""
+    """vv_attn_prefill3 (+ the packed-activation GEMMs around it) ROW BY ROW against the oracle with bf16 matrix-unit inputs: one
+    softmax update per 64-position stage, v_permlane16/32_swap row exchange (a clang quirk reads the wrong element of the builtin's
+    result unless it goes through unsigned temporaries -- this test is what pins it), mask-free path below the diagonal.  A masking
+    or tail-stage slip is an O(1) error in single rows, which a whole-tensor norm hides.  Shapes: ragged tails with 1..32 and
+    33..64 live positions in the last stage, passes that start at a non-zero position, GQA groups 2 / 7 (one idle wave pair), both
+    head widths, a prompt shorter than one pass."""
     from test_gpu_geometry import _prefill_probe
     got, s, x = _prefill_probe(L0, chunk, heads, kv_heads, hd)
     c = s.lmcfg

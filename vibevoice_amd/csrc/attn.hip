@@ -234,21 +234,20 @@ __global__ void vv_rope_table_kernel(const float* __restrict__ inv_freq, float2*
 }
 
 // One launch per layer for decode steps (every row owns a different KV cache):
-//   RoPE(q) from the table, RoPE(k)/v of the new token appended to the cache by the workgroup whose chunk ends at
-//   `pos` (and patched into its own K/V fragments, so nothing waits on that store), split-KV attention as above,
-//   then -- if the sequence needed more than one chunk -- the LAST workgroup of a (row, kv head) to finish merges
-//   the partials: partial -> release fence -> ticket (device-scope atomic) -> acquire fence -> fixed-order merge.
-//   Replaces rope_append + split + merge (3 launches, 2 extra kernel boundaries per layer).
-// WAVES = waves per workgroup = 32-position blocks in flight per workgroup pass.  4 for short sequences (one workgroup, few
-// blocks); 8 for long ones: a wave keeps two K/V blocks (32 KiB) in flight, a CU streams at (bytes in flight) / (HBM
-// latency), so at 32K positions the 4-wave form ran at 1.7 TB/s -- twice the waves and twice the workgroups (see the
-// launcher: one split per 512 positions, up to attn_splits) put every CU on the KV stream.
+//   RoPE(q) from the table, RoPE(k)/v of the new token appended to the cache by the workgroup whose split holds `pos`
+//   (and patched into its own K/V fragments, so nothing waits on that store), split-KV attention as above.  A sequence that
+//   fits one split is finished here; otherwise each split writes its (m, l, o) partial and vv_attn_merge2_kernel -- a separate
+//   wide launch -- combines them in a fixed order (an in-kernel last-arriver merge paid a release fence + device-scope ticket
+//   per split and merged through a serial chain of L2 round trips: 25.9 us per layer at 32K positions against 15.5 + 4.9).
+//   Replaces rope_append + split + merge (3 launches) by 1 (short contexts) or 2.
+// WAVES = waves per workgroup = 32-position blocks in flight per workgroup pass (4: the 8-wave form measured no better at
+// 32K positions, twice -- a CU's streaming rate does not grow with its wave count -- and slower at short contexts).
 template <int D, int XS, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void vv_attn_fused_kernel(
     const float* __restrict__ qkv, const VVRow* __restrict__ rows, const float2* __restrict__ rope_tab,
     __bf16* __restrict__ kc, __bf16* __restrict__ vc, int Hq, int Hkv, int64_t cache_stride, int64_t head_stride,
     float q_scale, float* __restrict__ part_m, float* __restrict__ part_l, float* __restrict__ part_o,
-    unsigned* __restrict__ tickets, float* __restrict__ out, int cyclic, int defer_merge) {
+    float* __restrict__ out) {
     constexpr int KT = D / 32, DT = D / 16, HALF = D / 2;
     const int S = gridDim.x;
     const int split = blockIdx.x, kvh = blockIdx.y, r = blockIdx.z;
@@ -258,30 +257,16 @@ __global__ __launch_bounds__(WAVES * 64) void vv_attn_fused_kernel(
     const int pos = rw.pos, len = pos + 1;
     const int G = Hq / Hkv;
     const int g = lane & 15, qg = lane >> 4;
-    // Two ways to cut the sequence into `S` pieces.  contiguous: split s owns positions [s*chunk, (s+1)*chunk).  cyclic:
-    // split s owns the 32-position blocks b = s, s + S, s + 2S, ... -- at any moment the workgroups of a launch read one
-    // compact region of the cache, i.e. the concurrent requests spread over every HBM channel instead of marching through
-    // S far-apart regions in lockstep.  The online softmax does not care about the order.
-    int end, used, p_first, p_step;
-    bool owner;
-    if (cyclic) {
-        const int n_blocks = (len + 31) >> 5;
-        used = min(S, n_blocks);
-        if (split >= used) return;
-        owner = (split == ((pos >> 5) % S));             // the block holding the new token
-        end = len;
-        p_first = (split + S * wave) * 32;
-        p_step = S * WAVES * 32;
-    } else {
-        const int chunk = attn_chunk(len, S, WAVES * 32);
-        const int start = split * chunk;
-        end = min(len, start + chunk);
-        if (start >= len) return;
-        used = (len + chunk - 1) / chunk;
-        owner = (split == used - 1);                     // this chunk ends at the new token
-        p_first = start + wave * 32;
-        p_step = WAVES * 32;
-    }
+    // split s owns the 32-position blocks b = s, s + S, s + 2S, ...: at any moment the workgroups of a launch read one compact
+    // region of the cache, i.e. the concurrent requests spread over every HBM channel instead of marching through S far-apart
+    // regions in lockstep (the online softmax does not care about the order)
+    const int n_blocks = (len + 31) >> 5;
+    const int used = min(S, n_blocks);
+    if (split >= used) return;
+    const bool owner = (split == ((pos >> 5) % S));      // the block holding the new token
+    const int end = len;
+    const int p_first = (split + S * wave) * 32;
+    const int p_step = S * WAVES * 32;
     const int QW = (Hq + 2 * Hkv) * D;
     const float* qrow = qkv + (int64_t)r * QW;
     const float2* tp = rope_tab + (int64_t)pos * HALF;
@@ -453,7 +438,6 @@ __global__ __launch_bounds__(WAVES * 64) void vv_attn_fused_kernel(
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) so[wave][dt][lane] = o[dt];
     __syncthreads();
-    __shared__ int last_sh;
     const int64_t gidx = (int64_t)r * Hkv + kvh;
     float* orow = out + ((int64_t)r * Hq + kvh * G + g) * D + qg * 4;
     if (wave == 0) {
@@ -487,192 +471,8 @@ __global__ __launch_bounds__(WAVES * 64) void vv_attn_fused_kernel(
                 for (int dt = 0; dt < DT; ++dt)
                     *reinterpret_cast<float4*>(part_o + (pidx * 16 + g) * D + dt * 16 + qg * 4) = float4{O[dt][0], O[dt][1], O[dt][2], O[dt][3]};
             }
-            // deferred merge (long contexts): a separate, wide merge kernel follows in the stream -- no fence, no ticket
-            // publish, then take a ticket: the workgroup that draws the last one merges
-            if (!defer_merge) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            if (!defer_merge && lane == 0) {
-                const unsigned old = __hip_atomic_fetch_add(tickets + gidx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                last_sh = (old == (unsigned)(used - 1)) ? 1 : 0;
-                if (last_sh) tickets[gidx] = 0u;          // next launch starts from zero (kernel boundary orders it)
-            }
-        }
-    }
-    if (used == 1 || defer_merge) return;         // uniform over the workgroup
-    __syncthreads();
-    if (!last_sh) return;
-    // ---- merge of the `used` partials by ALL waves of the last arriver: wave w takes splits w, w + WAVES, ... (their loads
-    // overlap instead of forming one serial chain of L2 round trips), then the per-wave sums are added in wave order.  Which
-    // workgroup merges does not matter: the split -> wave assignment and both summation orders are fixed. ----
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    // Loads are issued in batches of MB independent requests (clamped addresses, masked use): a plain `for` over the splits
-    // compiles to one L2 round trip per split -- 8 .. 16 us of pure latency per layer at 32 .. 64 splits.
-    constexpr int MB = 4;
-    float mw_max = -INFINITY;
-    for (int base = wave; base < used; base += WAVES * 2 * MB) {
-        float mv[2 * MB];
-#pragma unroll
-        for (int u = 0; u < 2 * MB; ++u) {
-            const int s2 = base + u * WAVES;
-            mv[u] = part_m[(gidx * S + (s2 < used ? s2 : base)) * 16 + g];
-        }
-#pragma unroll
-        for (int u = 0; u < 2 * MB; ++u) mw_max = fmaxf(mw_max, mv[u]);           // a clamped duplicate does not change a max
-    }
-    if (lane < 16) sm[wave][lane] = mw_max;
-    __syncthreads();
-    float MM = -INFINITY;
-#pragma unroll
-    for (int w = 0; w < WAVES; ++w) MM = fmaxf(MM, sm[w][g]);
-    float LL = 0.f;
-    f32x4 OO[DT];
-#pragma unroll
-    for (int i = 0; i < DT; ++i) OO[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int gc = g < G ? g : 0;                 // columns >= G carry nothing: read column 0, never stored
-    for (int base = wave; base < used; base += WAVES * MB) {
-        float ms[MB], ls[MB];
-        float4 pv[MB][DT];
-#pragma unroll
-        for (int u = 0; u < MB; ++u) {
-            const int s2 = base + u * WAVES;
-            const int64_t pi = gidx * S + (s2 < used ? s2 : base);
-            ms[u] = part_m[pi * 16 + g];
-            ls[u] = part_l[pi * 16 + g];
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) pv[u][dt] = *reinterpret_cast<const float4*>(part_o + (pi * 16 + gc) * D + dt * 16 + qg * 4);
-        }
-#pragma unroll
-        for (int u = 0; u < MB; ++u) {            // fixed order inside a wave: u ascending = split ascending
-            const bool live = base + u * WAVES < used;
-            const float f = (!live || ms[u] == -INFINITY) ? 0.f : expf(ms[u] - MM);
-            LL += ls[u] * f;
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                OO[dt][0] += pv[u][dt].x * f; OO[dt][1] += pv[u][dt].y * f; OO[dt][2] += pv[u][dt].z * f; OO[dt][3] += pv[u][dt].w * f;
-            }
-        }
-    }
-    __syncthreads();                              // everyone has read sm[][] of the max pass
-    if (lane < 16) sl[wave][lane] = LL;
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) so[wave][dt][lane] = OO[dt];
-    __syncthreads();
-    if (wave != 0) return;
-    float Lt = 0.f;
-    f32x4 Ot[DT];
-#pragma unroll
-    for (int i = 0; i < DT; ++i) Ot[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int w = 0; w < WAVES; ++w) {
-        Lt += sl[w][g];
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) Ot[dt] += so[w][dt][lane];
-    }
-    if (g < G) {
-        const float inv = 1.0f / Lt;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-            *reinterpret_cast<float4*>(orow + dt * 16) = float4{Ot[dt][0] * inv, Ot[dt][1] * inv, Ot[dt][2] * inv, Ot[dt][3] * inv};
-    }
-}
-
-// Prompt prefill: the rows of the launch are consecutive positions of ONE cache (rows[0] = first).  A workgroup owns 16
-// consecutive query rows x one kv head; the 16 rows are the MFMA columns, so every K / V fragment is read once per 16
-// queries (the decode kernel above would read it once per query).  Wave w walks the whole causal prefix for query heads
-// w, w+4, ... of the group (online softmax, no cross-wave merge) and writes the normalised output rows directly.
-// Runs after vv_rope_append_kernel (q rotated + scaled in q_rot, the chunk's own K/V already in the cache).
-template <int D, int XS>
-__global__ __launch_bounds__(256) void vv_attn_prefill_kernel(
-    const float* __restrict__ q, const VVRow* __restrict__ rows, const __bf16* __restrict__ kc,
-    const __bf16* __restrict__ vc, int R, int Hq, int Hkv, int64_t cache_stride, int64_t head_stride,
-    float* __restrict__ out) {
-    constexpr int KT = D / 32, DT = D / 16;
-    const int r0 = blockIdx.x * 16, kvh = blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const VVRow rw = rows[0];
-    const int G = Hq / Hkv;
-    const int col = lane & 15, qg = lane >> 4;
-    const int row = r0 + col;                            // query row of this lane's column
-    const int plim = rw.pos + min(row, R - 1);           // last position that row may attend (causal)
-    const int pend = rw.pos + min(r0 + 15, R - 1) + 1;   // positions the tile walks
-    const u32x4* kt_base = reinterpret_cast<const u32x4*>(kc + (int64_t)rw.cache * cache_stride + (int64_t)kvh * head_stride);
-    const u32x4* vt_base = reinterpret_cast<const u32x4*>(vc + (int64_t)rw.cache * cache_stride + (int64_t)kvh * head_stride);
-    for (int g = wave; g < G; g += 4) {
-        const int h = kvh * G + g;
-        bf16x8 qf[KT][XS];
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-            float v[8];
-            const float* qp = q + ((int64_t)min(row, R - 1) * Hq + h) * D + kt * 32 + qg * 8;
-            const float4 a0 = *reinterpret_cast<const float4*>(qp), a1 = *reinterpret_cast<const float4*>(qp + 4);
-            v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
-            split8<XS>(v, qf[kt]);
-        }
-        float m = -INFINITY, lsum = 0.f;
-        f32x4 o[DT];
-#pragma unroll
-        for (int i = 0; i < DT; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int p0 = 0; p0 < pend; p0 += 32) {
-            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-            const int64_t t0 = (int64_t)(p0 >> 4) * KT;
-            u32x4 ka[KT], kb[KT], vt[DT];
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt) {
-                ka[kt] = kt_base[(t0 + kt) * 64 + lane];
-                kb[kt] = kt_base[(t0 + KT + kt) * 64 + lane];
-            }
-            const int64_t vt0 = (int64_t)(p0 >> 5) * DT;
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) vt[dt] = vt_base[(vt0 + dt) * 64 + lane];
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt) {
-#pragma unroll
-                for (int p = 0; p < XS; ++p) {
-                    s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ka[kt]), qf[kt][p], s0, 0, 0, 0);
-                    s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kb[kt]), qf[kt][p], s1, 0, 0, 0);
-                }
-            }
-            float sv[8];
-            float mx = -INFINITY;
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int pa = p0 + qg * 4 + rr;
-                sv[rr] = (pa <= plim) ? s0[rr] : -INFINITY;
-                sv[4 + rr] = (pa + 16 <= plim) ? s1[rr] : -INFINITY;
-                mx = fmaxf(mx, fmaxf(sv[rr], sv[4 + rr]));
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float mn = fmaxf(m, mx);
-            // a column whose whole block is masked (query earlier than this block) keeps its state untouched
-            const float alpha = (m == -INFINITY) ? 0.f : expf(m - mn);
-            float pv[8];
-            float ps = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                pv[j] = (sv[j] == -INFINITY) ? 0.f : expf(sv[j] - mn);
-                ps += pv[j];
-            }
-            if (mn != -INFINITY) { lsum = lsum * alpha + ps; m = mn; }
-            bf16x8 pb[XS];
-            split8<XS>(pv, pb);
-            const float al = (mn == -INFINITY) ? 1.f : alpha;
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                o[dt] *= al;
-#pragma unroll
-                for (int p = 0; p < XS; ++p)
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vt[dt]), pb[p], o[dt], 0, 0, 0);
-            }
-        }
-        lsum += __shfl_xor(lsum, 16);
-        lsum += __shfl_xor(lsum, 32);
-        if (row < R) {
-            const float inv = 1.0f / lsum;
-            float* orow = out + ((int64_t)row * Hq + h) * D + qg * 4;
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-                *reinterpret_cast<float4*>(orow + dt * 16) = float4{o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv};
+            // several splits: the partials are merged by vv_attn_merge2_kernel, a separate wide launch that follows in the
+            // stream -- no fence, no ticket, no serial chain of L2 round trips inside the last workgroup to arrive
         }
     }
 }
@@ -703,7 +503,7 @@ __global__ void vv_attn_merge_kernel(const float* __restrict__ part_m, const flo
     out[((int64_t)r * Hq + h) * D + d] = acc / L;
 }
 
-// Merge of the split partials written by vv_attn_fused_kernel in deferred mode: grid (R, Hq), 512 threads = D output
+// Merge of the split partials written by vv_attn_fused_kernel: grid (R, Hq), 512 threads = D output
 // dimensions x 512/D split groups.  Group j takes splits j, j + NG, ...: eight (m, l, o) triples are requested at once, so a
 // 32-way merge is ONE round trip per thread instead of a chain of them inside the last attention workgroup (which also paid a
 // release fence + device-scope ticket per split: 0.33 us per split at 32K positions).  Rows that needed one split were
@@ -711,7 +511,7 @@ __global__ void vv_attn_merge_kernel(const float* __restrict__ part_m, const flo
 template <int D>
 __global__ __launch_bounds__(512) void vv_attn_merge2_kernel(const float* __restrict__ part_m, const float* __restrict__ part_l,
                                                              const float* __restrict__ part_o, const VVRow* __restrict__ rows,
-                                                             float* __restrict__ out, int Hq, int Hkv, int S, int cyclic, int gran) {
+                                                             float* __restrict__ out, int Hq, int Hkv, int S) {
     constexpr int NG = 512 / D, MB = 8;
     __shared__ float sm[NG][D], sl[NG][D], sa[NG][D];
     const int r = blockIdx.x, h = blockIdx.y;
@@ -719,9 +519,7 @@ __global__ __launch_bounds__(512) void vv_attn_merge2_kernel(const float* __rest
     const int G = Hq / Hkv;
     const int kvh = h / G, g = h - kvh * G;
     const int len = rows[r].pos + 1;
-    int used;
-    if (cyclic) used = min(S, (len + 31) >> 5);
-    else { const int chunk = attn_chunk(len, S, gran); used = (len + chunk - 1) / chunk; }
+    const int used = min(S, (len + 31) >> 5);
     if (used <= 1) return;
     const int64_t base = ((int64_t)r * Hkv + kvh) * S;
     float mrun = -INFINITY, lrun = 0.f, arun = 0.f;
@@ -792,20 +590,6 @@ static void attn_go(const float* q, const VVRow* rows, const void* kc, const voi
     hipLaunchKernelGGL((vv_attn_merge_kernel<D>), dim3(R, Hq), dim3(D), 0, s, pm, pl, po, rows, out, Hq, Hkv, S);
 }
 
-// rows = consecutive positions of one cache (rows[0] first); q_rot / cache already written by vv_rope_append_launch
-extern "C" int vv_attn_prefill_launch(int D, int xs, const float* q, const VVRow* rows, const void* kc, const void* vc, int R,
-                                      int Hq, int Hkv, int64_t cache_stride, int64_t head_stride, float* out, hipStream_t s) {
-    if (Hq % Hkv != 0) return -1;
-#define VV_P(D_, XS_)                                                                                              \
-    hipLaunchKernelGGL((vv_attn_prefill_kernel<D_, XS_>), dim3((R + 15) / 16, Hkv), dim3(256), 0, s, q, rows,      \
-                       (const __bf16*)kc, (const __bf16*)vc, R, Hq, Hkv, cache_stride, head_stride, out)
-    if (D == 128) { if (xs == 1) VV_P(128, 1); else if (xs == 2) VV_P(128, 2); else VV_P(128, 3); }
-    else if (D == 64) { if (xs == 1) VV_P(64, 1); else if (xs == 2) VV_P(64, 2); else VV_P(64, 3); }
-    else return -1;
-#undef VV_P
-    return hipGetLastError() == hipSuccess ? 0 : -2;
-}
-
 extern "C" int vv_rope_table_launch(const float* inv_freq, void* tab, int n_pos, int half, hipStream_t s) {
     const int64_t n = (int64_t)n_pos * half;
     hipLaunchKernelGGL(vv_rope_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, inv_freq, (float2*)tab, n_pos, half);
@@ -815,27 +599,21 @@ extern "C" int vv_rope_table_launch(const float* inv_freq, void* tab, int n_pos,
 // Decode-step attention in one launch; requires every row to own a different cache (the new token of row r must not
 // be visible to -- or needed by -- another row of the same launch).
 extern "C" int vv_attn_fused_launch(int D, int xs, const float* qkv, const VVRow* rows, const void* rope_tab, void* kc, void* vc,
-                                    int R, int Hq, int Hkv, int64_t cache_stride, int64_t head_stride, int S, int waves,
-                                    float* pm, float* pl, float* po, unsigned* tickets, float* out, hipStream_t s) {
-    if (Hq % Hkv != 0 || Hq / Hkv > 16 || (waves != 4 && waves != 8)) return -1;
+                                    int R, int Hq, int Hkv, int64_t cache_stride, int64_t head_stride, int S,
+                                    float* pm, float* pl, float* po, float* out, hipStream_t s) {
+    if (Hq % Hkv != 0 || Hq / Hkv > 16) return -1;
     const float scale = 1.0f / sqrtf((float)D);
-    static const int cyclic = getenv("VVHIP_ATTN_CONTIGUOUS") ? 0 : 1;
-    // several splits: the partials are merged by a separate wide kernel (no per-split fence / ticket inside the attention kernel)
-    static const int defer_ok = getenv("VVHIP_ATTN_TICKET_MERGE") ? 0 : 1;
-    const int defer = (S > 1 && defer_ok) ? 1 : 0;
-#define VV_F(D_, XS_, W_)                                                                                     \
-    hipLaunchKernelGGL((vv_attn_fused_kernel<D_, XS_, W_>), dim3(S, Hkv, R), dim3(W_ * 64), 0, s, qkv, rows,  \
+#define VV_F(D_, XS_)                                                                                         \
+    hipLaunchKernelGGL((vv_attn_fused_kernel<D_, XS_, 4>), dim3(S, Hkv, R), dim3(256), 0, s, qkv, rows,       \
                        (const float2*)rope_tab, (__bf16*)kc, (__bf16*)vc, Hq, Hkv, cache_stride, head_stride, scale, \
-                       pm, pl, po, tickets, out, cyclic, defer)
-#define VV_FW(D_, XS_) do { if (waves == 8) VV_F(D_, XS_, 8); else VV_F(D_, XS_, 4); } while (0)
-    if (D == 128) { if (xs == 1) VV_FW(128, 1); else if (xs == 2) VV_FW(128, 2); else VV_FW(128, 3); }
-    else if (D == 64) { if (xs == 1) VV_FW(64, 1); else if (xs == 2) VV_FW(64, 2); else VV_FW(64, 3); }
+                       pm, pl, po, out)
+    if (D == 128) { if (xs == 1) VV_F(128, 1); else if (xs == 2) VV_F(128, 2); else VV_F(128, 3); }
+    else if (D == 64) { if (xs == 1) VV_F(64, 1); else if (xs == 2) VV_F(64, 2); else VV_F(64, 3); }
     else return -1;
-#undef VV_FW
 #undef VV_F
-    if (defer) {
-        if (D == 128) hipLaunchKernelGGL((vv_attn_merge2_kernel<128>), dim3(R, Hq), dim3(512), 0, s, pm, pl, po, rows, out, Hq, Hkv, S, cyclic, waves * 32);
-        else hipLaunchKernelGGL((vv_attn_merge2_kernel<64>), dim3(R, Hq), dim3(512), 0, s, pm, pl, po, rows, out, Hq, Hkv, S, cyclic, waves * 32);
+    if (S > 1) {      // rows that needed one split were finished by the attention kernel; the merge kernel skips them
+        if (D == 128) hipLaunchKernelGGL((vv_attn_merge2_kernel<128>), dim3(R, Hq), dim3(512), 0, s, pm, pl, po, rows, out, Hq, Hkv, S);
+        else hipLaunchKernelGGL((vv_attn_merge2_kernel<64>), dim3(R, Hq), dim3(512), 0, s, pm, pl, po, rows, out, Hq, Hkv, S);
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

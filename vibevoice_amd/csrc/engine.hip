@@ -22,12 +22,10 @@ int vv_pack_launch(const void* src, int src_is_bf16, void* dst, int N, int K, in
                    int stride, hipStream_t s);
 int vv_rope_append_launch(int D, const float* qkv, const VVRow* rows, const float* inv_freq, float* q_out, void* kc,
                           void* vc, int R, int Hq, int Hkv, int64_t cache_stride, int64_t head_stride, hipStream_t s);
-int vv_attn_prefill_launch(int D, int xs, const float* q, const VVRow* rows, const void* kc, const void* vc, int R,
-                           int Hq, int Hkv, int64_t cache_stride, int64_t head_stride, float* out, hipStream_t s);
 int vv_rope_table_launch(const float* inv_freq, void* tab, int n_pos, int half, hipStream_t s);
 int vv_attn_fused_launch(int D, int xs, const float* qkv, const VVRow* rows, const void* rope_tab, void* kc, void* vc,
-                         int R, int Hq, int Hkv, int64_t cache_stride, int64_t head_stride, int S, int waves,
-                         float* pm, float* pl, float* po, unsigned* tickets, float* out, hipStream_t s);
+                         int R, int Hq, int Hkv, int64_t cache_stride, int64_t head_stride, int S,
+                         float* pm, float* pl, float* po, float* out, hipStream_t s);
 int vv_attn_launch(int D, int xs, const float* q, const VVRow* rows, const void* kc, const void* vc, int R, int Hq,
                    int Hkv, int64_t cache_stride, int64_t head_stride, int S, float* pm, float* pl, float* po,
                    float* out, hipStream_t s);
@@ -83,7 +81,7 @@ int vv_gemv16p_launch(const void* W, const void* W2, const void* Xp, float* Y, v
 int vv_ada_pack_launch(const float* cproj, const float* temb, void* xp, int rows, int n_steps, int H, hipStream_t s);
 int vv_gemm3_launch(const void* W, const void* W2, const void* Xp, float* Y, void* Yp, const float* bias, int T, int N, int K,
                     int ldy, int epi, hipStream_t s);
-int vv_attn_prefill2_launch(int D, const float* q, const VVRow* rows, const void* kc, const void* vc, int R, int Hq, int Hkv,
+int vv_attn_prefill3_launch(int D, const float* q, const VVRow* rows, const void* kc, const void* vc, int R, int Hq, int Hkv,
                             int64_t cache_stride, int64_t head_stride, float* out, hipStream_t s);
 int vv_block1d_supported(int C);
 int vv_gemv_ok(const VVGemm* a);
@@ -176,7 +174,7 @@ struct vv_ctx {
     std::vector<Layer> layers;
     float *lm_norm = nullptr, *inv_freq = nullptr;
     int ws_rows = 0;
-    void* rope_tab = nullptr; bool rope_ready = false; unsigned* tickets = nullptr; bool fused_attn_ok = true;
+    void* rope_tab = nullptr; bool rope_ready = false;
     float *tts_types = nullptr, *eos_b1 = nullptr, *eos_b2 = nullptr; void *eos_w1 = nullptr, *eos_w2 = nullptr;
     void *embed = nullptr, *lm_head = nullptr;
     bool lm_head_loaded = false;
@@ -196,7 +194,6 @@ struct vv_ctx {
     bool tile3_ok = false, attn2_ok = false;
     // batch decode (5..16 rows, bf16 mode): activations packed once per op into one 16-row fragment tile (gemv16p.hip)
     void *p16_x = nullptr, *p16_act = nullptr; bool p16_ok = false;
-    bool ksplit_ok = true;
     float *pm = nullptr, *pl = nullptr, *po = nullptr;
     // head
     int HF = 0, MODW = 0;
@@ -408,11 +405,10 @@ static int build_codec(vv_ctx* ctx, CodecNet& net, const std::string& pfx, bool 
     }
     for (int i = 0; i < ns; ++i) {
         const int hist = (i == ns - 1) ? 6 : (decoder ? 1 : ratios[i]);
-        const bool fused = vv_block1d_supported(C[i]) && Tpf[i] >= 8 && !sw[i].blocks.empty() && !getenv("VVHIP_NO_FUSED_BLOCK");
+        const bool fused = vv_block1d_supported(C[i]) && Tpf[i] >= 8 && !sw[i].blocks.empty();
         // unfused stages ping-pong between xs and xs2 when a one-launch norm + depthwise-conv kernel exists for them:
         // channel-sliced (T <= 8, C = 1024 / 2048) or row-tiled (middle stages, any T)
-        const bool pp = !fused && !sw[i].blocks.empty() && !getenv("VVHIP_NO_SLICED_NORMDW") &&
-                        (vv_normdw_sliced_ok(Tpf[i], C[i]) || (vv_normdw_rows_ok(Tpf[i], C[i]) && !getenv("VVHIP_NO_ROWS_NORMDW")));
+        const bool pp = !fused && !sw[i].blocks.empty() && (vv_normdw_sliced_ok(Tpf[i], C[i]) || vv_normdw_rows_ok(Tpf[i], C[i]));
         const int64_t xstride = (int64_t)pad64((size_t)(hist + (size_t)Tpf[i] * Fmax) * C[i]);
         float* xs_all = (float*)dalloc(ctx, (size_t)n_slots * xstride * 4);
         float* xs2_all = (fused || pp) ? (float*)dalloc(ctx, (size_t)n_slots * xstride * 4) : nullptr;
@@ -451,7 +447,7 @@ static int build_codec(vv_ctx* ctx, CodecNet& net, const std::string& pfx, bool 
         auto ok = [&](int i) {
             const Stage& s = net.st[0][i];
             if (off || s.blocks.empty() || (s.C & 31)) return false;
-            const bool stem = (i == 0 && s.in.K == 7 && s.in.ldx == 1 && !getenv("VVHIP_NO_CONV_KERNELS"));
+            const bool stem = (i == 0 && s.in.K == 7 && s.in.ldx == 1);
             if (!stem && !gemm_ok(s.in, i == 0 ? net.in_stride : net.st[0][i - 1].sl_stride, s.sl_stride)) return false;
             if (s.pp && vv_normdw_sliced_ok(s.Tpf, s.C)) return true;
             if (heavy_only) return false;
@@ -461,7 +457,7 @@ static int build_codec(vv_ctx* ctx, CodecNet& net, const std::string& pfx, bool 
         if (decoder) { while (net.kd < ns && ok(net.kd)) net.kd++; }
         else { while (net.ke > 0 && ok(net.ke - 1)) net.ke--; }
         const ConvG& h = net.head;
-        const bool conv1 = h.N == 1 && h.K == 7 * h.ldx && (h.ldx & 3) == 0 && h.ldx <= 1024 && !getenv("VVHIP_NO_CONV_KERNELS");
+        const bool conv1 = h.N == 1 && h.K == 7 * h.ldx && (h.ldx & 3) == 0 && h.ldx <= 1024;
         net.head_batch = !off && !heavy_only && (conv1 || gemm_ok(h, net.st[0][ns - 1].sl_stride, 0));
         if (!decoder && net.ke < ns && !(conv1 || gemm_ok(h, net.st[0][ns - 1].sl_stride, 0))) net.ke = ns;   // encoder tail needs its head batched
     }
@@ -516,7 +512,7 @@ static VVGemm mk_gemm(const void* W, const float* X, float* Y, int T, int N, int
 // streams; the partial tensors are added back by the consumers (VVGemm::xa / ya).  Returns the number of EXTRA parts.
 static int ksplit_parts(const vv_ctx* ctx, VVGemm& g, float* parts, int part_stride) {
     const int n_tiles = (g.N + 15) / 16, k_tiles = (g.K + 31) / 32;
-    if (!ctx->ksplit_ok || g.T > 4 || n_tiles > 128 || k_tiles < 96) return 0;
+    if (g.T > 4 || n_tiles > 128 || k_tiles < 96) return 0;
     const int ks = 3;
     g.kgrid = ks; g.yparts = parts; g.part_stride = part_stride;
     if (!vv_gemv_ok(&g)) { g.kgrid = 0; g.yparts = nullptr; g.part_stride = 0; return 0; }
@@ -594,7 +590,7 @@ static int run_codec(vv_ctx* ctx, CodecNet& net, int sl, int F, float* out, hipS
             const ConvG& cg = s.in;
             const float* X = (i == 0) ? net.in_buf[sl] : stages[i - 1].xfinal;
             const int Trows = cg.rows_per_frame * F;
-            if (i == 0 && cg.K == 7 && cg.ldx == 1 && !getenv("VVHIP_NO_CONV_KERNELS")) {
+            if (i == 0 && cg.K == 7 && cg.ldx == 1) {
                 ctx->launches++;                 // encoder stem: mono input, k = 7 (not an MFMA shape)
                 VVCHK(vv_stem_conv_launch(X, cg.w, cg.bias, x, Trows, cg.N, st));
             } else {
@@ -644,7 +640,7 @@ static int run_codec(vv_ctx* ctx, CodecNet& net, int sl, int F, float* out, hipS
     if (head) {   // head conv
         const ConvG& cg = net.head;
         Stage& s = stages[ns - 1];
-        if (cg.N == 1 && cg.K == 7 * cg.ldx && (cg.ldx & 3) == 0 && cg.ldx <= 1024 && !getenv("VVHIP_NO_CONV_KERNELS")) {
+        if (cg.N == 1 && cg.K == 7 * cg.ldx && (cg.ldx & 3) == 0 && cg.ldx <= 1024) {
             ctx->launches++;                     // decoder head: k = 7 conv to one channel
             VVCHK(vv_head_conv1_launch(s.xfinal, cg.w, cg.bias, out, cg.rows_per_frame * F, cg.ldx, st));
         } else {
@@ -681,7 +677,7 @@ static int run_codec_batch(vv_ctx* ctx, CodecNet& net, const int* ids, int n, in
             const ConvG& cg = s.in;
             const float* X = (i == 0) ? net.in_buf[0] : st0[i - 1].xfinal;
             const int64_t sx = (i == 0) ? net.in_stride : st0[i - 1].sl_stride;
-            if (i == 0 && cg.K == 7 && cg.ldx == 1 && !getenv("VVHIP_NO_CONV_KERNELS")) {
+            if (i == 0 && cg.K == 7 && cg.ldx == 1) {
                 ctx->launches++;
                 VVCHK(vv_stem_conv_slots_launch(X, cg.w, cg.bias, x, cg.rows_per_frame, cg.N, ids, n, sx, s.sl_stride, st));
             } else {
@@ -721,7 +717,7 @@ static int run_codec_batch(vv_ctx* ctx, CodecNet& net, const int* ids, int n, in
     if (head) {
         const ConvG& cg = net.head;
         Stage& s = st0[ns - 1];
-        if (cg.N == 1 && cg.K == 7 * cg.ldx && (cg.ldx & 3) == 0 && cg.ldx <= 1024 && !getenv("VVHIP_NO_CONV_KERNELS")) {
+        if (cg.N == 1 && cg.K == 7 * cg.ldx && (cg.ldx & 3) == 0 && cg.ldx <= 1024) {
             ctx->launches++;                     // decoder head: k = 7 conv to one channel; dense [n][rows] output
             VVCHK(vv_head_conv1_slots_launch(s.xfinal, cg.w, cg.bias, out, cg.rows_per_frame, cg.ldx, ids, n, s.sl_stride, cg.rows_per_frame, st));
         } else {
@@ -862,7 +858,6 @@ extern "C" int vv_create(const vv_config* cfg, vv_ctx** out) {
     hipHostMalloc((void**)&ctx->ids_pin, sizeof(int) * (size_t)ctx->ids_cap * vv_ctx::RING);
     ctx->h = (float*)dalloc(ctx, (size_t)R * H * 4);
     ctx->h_parts = (float*)dalloc(ctx, (size_t)2 * R * H * 4);
-    ctx->ksplit_ok = !getenv("VVHIP_NO_GEMV") && !getenv("VVHIP_NO_KSPLIT");
     ctx->qkv = (float*)dalloc(ctx, (size_t)R * QKV * 4);
     ctx->qrot = (float*)dalloc(ctx, (size_t)R * Hq * D * 4);
     ctx->attn = (float*)dalloc(ctx, (size_t)R * Hq * D * 4);
@@ -871,18 +866,16 @@ extern "C" int vv_create(const vv_config* cfg, vv_ctx** out) {
         // prompt prefill in bf16-activation mode: LDS-staged 128 x 128 MFMA GEMM over packed activations (prefill.hip)
         ctx->xp = dalloc(ctx, (size_t)vv_packed_elems(R, std::max(H, Hq * D)) * 2);
         ctx->actp = dalloc(ctx, (size_t)vv_packed_elems(R, I) * 2);
-        ctx->tile3_ok = c.xsplit == 1 && !getenv("VVHIP_NO_TILE3");
+        ctx->tile3_ok = c.xsplit == 1;
     }
-    ctx->attn2_ok = c.xsplit == 1 && !getenv("VVHIP_NO_ATTN2");
-    if (c.xsplit == 1 && R > 4 && (H % 32) == 0 && ((Hq * D) % 32) == 0 && (I % 32) == 0 && !getenv("VVHIP_NO_P16")) {
+    ctx->attn2_ok = c.xsplit == 1;
+    if (c.xsplit == 1 && R > 4 && (H % 32) == 0 && ((Hq * D) % 32) == 0 && (I % 32) == 0) {
         const int kx = std::max(H, Hq * D), ka = std::max(I, c.head_ffn);
         ctx->p16_x = dalloc(ctx, (size_t)vv_packed_elems(16, kx) * 2);
         ctx->p16_act = dalloc(ctx, (size_t)vv_packed_elems(16, ka + 32) * 2);
         ctx->p16_ok = ctx->p16_x && ctx->p16_act;
     }
     ctx->rope_tab = dalloc(ctx, (size_t)c.max_ctx * (D / 2) * 8, false);
-    ctx->tickets = (unsigned*)dalloc(ctx, (size_t)R * Hkv * 4);
-    ctx->fused_attn_ok = !getenv("VVHIP_NO_FUSED_ATTN");
     // split-attention partials exist for decode rows and short ragged launches only (prompt chunks use the prefill kernel)
     ctx->ws_rows = std::min(R, 64);
     const size_t np = (size_t)ctx->ws_rows * Hkv * c.attn_splits * 16;
@@ -1122,7 +1115,7 @@ static int p16_gemv(vv_ctx* ctx, hipStream_t st, const void* W, const void* W2, 
 }
 
 static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float* hidden_out, int l0, int l1, int final_norm, bool fused_attn, bool contiguous,
-                   int attn_S, int attn_waves, int64_t kv_positions = 0) {
+                   int attn_S, int64_t kv_positions = 0) {
     const vv_config& c = ctx->c;
     const int H = ctx->H, D = ctx->D, Hq = ctx->Hq, Hkv = ctx->Hkv, I = ctx->I, QKV = ctx->QKV;
     HIPCHK(ctx, hipMemcpyAsync(ctx->h, x_in, (size_t)R * H * 4, hipMemcpyDeviceToDevice, st));
@@ -1139,7 +1132,7 @@ static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float*
             VVCHK(vv_gemm3_launch(L.wqkv, nullptr, ctx->xp, ctx->qkv, nullptr, L.bqkv, R, QKV, H, QKV, VV_EPI_BIAS, st));
             VVCHK(vv_rope_append_launch(D, ctx->qkv, ctx->rows_dev, ctx->inv_freq, ctx->qrot, kl, vl,
                                         R, Hq, Hkv, ctx->cache_stride, ctx->head_stride, st));
-            VVCHK(vv_attn_prefill2_launch(D, ctx->qrot, ctx->rows_dev, kl, vl, R, Hq, Hkv, ctx->cache_stride, ctx->head_stride, ctx->attn, st));
+            VVCHK(vv_attn_prefill3_launch(D, ctx->qrot, ctx->rows_dev, kl, vl, R, Hq, Hkv, ctx->cache_stride, ctx->head_stride, ctx->attn, st));
             VVCHK(vv_pack_rows_launch(ctx->attn, Hq * D, nullptr, 0.f, ctx->xp, R, Hq * D, st));
             VVCHK(vv_gemm3_launch(L.wo, nullptr, ctx->xp, ctx->h, nullptr, nullptr, R, H, Hq * D, H, VV_EPI_RESID, st));
             VVCHK(vv_pack_rows_launch(ctx->h, H, L.ln2, c.lm_eps, ctx->xp, R, H, st));
@@ -1175,35 +1168,32 @@ static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float*
                 const int xs = c.xsplit; vv_ctx* cx = ctx;
                 ctx->prof_other.push_back({2, by, [=](hipStream_t s) {
                     return vv_attn_fused_launch(D, xs, cx->qkv, cx->rows_dev, cx->rope_tab, kl, vl, R, Hq, Hkv, cx->cache_stride,
-                                                cx->head_stride, attn_S, attn_waves, cx->pm, cx->pl, cx->po, cx->tickets, cx->attn, s); }});
+                                                cx->head_stride, attn_S, cx->pm, cx->pl, cx->po, cx->attn, s); }});
             }
             VVCHK(vv_attn_fused_launch(D, c.xsplit, ctx->qkv, ctx->rows_dev, ctx->rope_tab, kl, vl, R, Hq, Hkv, ctx->cache_stride,
-                                       ctx->head_stride, attn_S, attn_waves, ctx->pm, ctx->pl, ctx->po, ctx->tickets, ctx->attn, st));
+                                       ctx->head_stride, attn_S, ctx->pm, ctx->pl, ctx->po, ctx->attn, st));
         } else {
             // rows of one launch share caches (prefill chunks): every append must land before any row attends
             ctx->launches += 3;
             VVCHK(vv_rope_append_launch(D, ctx->qkv, ctx->rows_dev, ctx->inv_freq, ctx->qrot, kl, vl,
                                         R, Hq, Hkv, ctx->cache_stride, ctx->head_stride, st));
             if (contiguous && ctx->attn2_ok)      // prompt chunk, bf16 mode: 64 query rows x all heads of the group share every K/V block
-                VVCHK(vv_attn_prefill2_launch(D, ctx->qrot, ctx->rows_dev, kl, vl, R, Hq, Hkv, ctx->cache_stride, ctx->head_stride, ctx->attn, st));
-            else if (contiguous)      // prompt chunk: 16 query rows share every K/V fragment
-                VVCHK(vv_attn_prefill_launch(D, c.xsplit, ctx->qrot, ctx->rows_dev, kl, vl, R, Hq, Hkv, ctx->cache_stride,
-                                             ctx->head_stride, ctx->attn, st));
-            else
-                VVCHK(vv_attn_launch(D, c.xsplit, ctx->qrot, ctx->rows_dev, kl, vl, R, Hq, Hkv, ctx->cache_stride,
-                                     ctx->head_stride, attn_S, ctx->pm, ctx->pl, ctx->po, ctx->attn, st));
+                VVCHK(vv_attn_prefill3_launch(D, ctx->qrot, ctx->rows_dev, kl, vl, R, Hq, Hkv, ctx->cache_stride, ctx->head_stride, ctx->attn, st));
+            else {
+                // ragged row sets (the streaming model's text windows) and the prompt chunks of the exact modes (xsplit 2, 3): the
+                // split + merge pair, at most ws_rows rows per launch (its partial buffers); every row attends its own causal prefix
+                for (int g0 = 0; g0 < R; g0 += ctx->ws_rows) {
+                    const int ng = std::min(ctx->ws_rows, R - g0);
+                    if (g0) ctx->launches += 2;
+                    VVCHK(vv_attn_launch(D, c.xsplit, ctx->qrot + (size_t)g0 * Hq * D, ctx->rows_dev + g0, kl, vl, ng, Hq, Hkv, ctx->cache_stride,
+                                         ctx->head_stride, attn_S, ctx->pm, ctx->pl, ctx->po, ctx->attn + (size_t)g0 * Hq * D, st));
+                }
+            }
         }
         if (p16) {
-            static const bool o_packed = !getenv("VVHIP_P16_NO_OPROJ");
-            if (o_packed) {
-                ctx->launches += 2;
-                VVCHK(vv_pack16_launch(ctx->attn, Hq * D, 0, nullptr, 0.f, nullptr, nullptr, 0, ctx->p16_x, R, Hq * D, st));
-                VVCHK(p16_gemv(ctx, st, L.wo, nullptr, ctx->p16_x, ctx->h, nullptr, nullptr, nullptr, R, H, Hq * D, H, 0, VV_EPI_RESID));
-            } else {
-                VVGemm go = mk_gemm(L.wo, ctx->attn, ctx->h, R, H, Hq * D, Hq * D, H);
-                go.epi = VV_EPI_RESID; go.nt = 1;
-                GEMM(go);
-            }
+            ctx->launches += 2;
+            VVCHK(vv_pack16_launch(ctx->attn, Hq * D, 0, nullptr, 0.f, nullptr, nullptr, 0, ctx->p16_x, R, Hq * D, st));
+            VVCHK(p16_gemv(ctx, st, L.wo, nullptr, ctx->p16_x, ctx->h, nullptr, nullptr, nullptr, R, H, Hq * D, H, 0, VV_EPI_RESID));
             ctx->launches += 3;
             VVCHK(vv_pack16_launch(ctx->h, H, 1, L.ln2, c.lm_eps, nullptr, nullptr, 0, ctx->p16_x, R, H, st));
             VVCHK(p16_gemv(ctx, st, L.wg, L.wu, ctx->p16_x, nullptr, ctx->p16_act, nullptr, nullptr, R, I, H, 0, 0, VV_EPI_SWIGLU));
@@ -1249,14 +1239,14 @@ extern "C" int vv_lm_forward_range(vv_ctx* ctx, void* stream, int n_rows, const 
     HIPCHK(ctx, hipMemcpyAsync(ctx->rows_dev, pin, sizeof(VVRow) * n_rows, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipEventRecord(ctx->ring_ev[slot], st));
     ctx->launches = 0;
-    bool fused = ctx->fused_attn_ok;
+    bool fused = true;
     for (int i = 0; i < n_rows && fused; ++i)
         for (int j = 0; j < i; ++j) if (rows[i].cache == rows[j].cache) { fused = false; break; }
     if (fused && !ctx->rope_ready) {          // (cos, sin) table of every position, once the inv_freq parameter is in place
         VVCHK(vv_rope_table_launch(ctx->inv_freq, ctx->rope_tab, ctx->c.max_ctx, ctx->D / 2, st));
         ctx->rope_ready = true;
     }
-    bool contiguous = !fused && n_rows >= 8 && !getenv("VVHIP_NO_PREFILL_ATTN");      // one cache, consecutive positions
+    bool contiguous = !fused && n_rows >= 8;      // one cache, consecutive positions
     for (int i = 1; i < n_rows && contiguous; ++i)
         if (rows[i].cache != rows[0].cache || rows[i].pos != rows[0].pos + i) contiguous = false;
     if (!contiguous && n_rows > ctx->ws_rows)
@@ -1266,23 +1256,19 @@ extern "C" int vv_lm_forward_range(vv_ctx* ctx, void* stream, int n_rows, const 
     // growing context re-captures the step graph every 512 positions.
     int max_len = 1;
     for (int i = 0; i < n_rows; ++i) max_len = std::max(max_len, rows[i].pos + 1);
-    // 8-wave workgroups measured no better than 4-wave ones at 32K positions (the per-CU streaming rate does not grow with the
-    // wave count); the form stays reachable for experiments
-    static const int long_ctx = getenv("VVHIP_ATTN_LONG") ? atoi(getenv("VVHIP_ATTN_LONG")) : (1 << 30);
-    static const int split_pos = getenv("VVHIP_ATTN_SPLIT_POS") ? std::max(256, atoi(getenv("VVHIP_ATTN_SPLIT_POS"))) : 1024;
     // ... and no more splits than it takes to put ~256 workgroups on the chip: with eight 32K-context utterances in flight the
-    // rows themselves are the parallelism (8 splits of 4096 positions: 122 us per layer against 162 us with 32 splits)
-    static const int target_wgs = getenv("VVHIP_ATTN_TARGET_WGS") ? std::max(1, atoi(getenv("VVHIP_ATTN_TARGET_WGS"))) : 256;
+    // rows themselves are the parallelism (8 splits of 4096 positions: 122 us per layer against 162 us with 32 splits).
+    // Measured and left alone: 512 / 256 positions per split (no gain once the merge is its own launch), 8-wave workgroups.
+    constexpr int split_pos = 1024, target_wgs = 256;
     int n_long = 0;
     for (int i = 0; i < n_rows; ++i) if (rows[i].pos + 1 > split_pos) ++n_long;
     const int by_wgs = std::max(1, (target_wgs + std::max(1, n_long) * ctx->Hkv - 1) / (std::max(1, n_long) * ctx->Hkv));
     const int attn_S = std::min(std::min(ctx->c.attn_splits, by_wgs), std::max(1, (max_len + split_pos - 1) / split_pos));
-    const int attn_waves = (max_len >= long_ctx) ? 8 : 4;
-    char key[160]; snprintf(key, 160, "lm:%d:%p:%p:%d:%d:%d:%d:%d:%d", n_rows, (const void*)x_in_dev, (void*)hidden_out_dev, l0, l1, final_norm,
-                            fused ? 1 : (contiguous ? 2 : 0), contiguous ? 0 : attn_S, fused ? attn_waves : 0);
+    char key[160]; snprintf(key, 160, "lm:%d:%p:%p:%d:%d:%d:%d:%d", n_rows, (const void*)x_in_dev, (void*)hidden_out_dev, l0, l1, final_norm,
+                            fused ? 1 : (contiguous ? 2 : 0), (contiguous && ctx->attn2_ok) ? 0 : attn_S);
     int64_t kv_positions = 0;
     for (int i = 0; i < n_rows; ++i) kv_positions += rows[i].pos + 1;
-    return graphed(ctx, key, st, [&]() { return lm_body(ctx, st, n_rows, x_in_dev, hidden_out_dev, l0, l1, final_norm, fused, contiguous, attn_S, attn_waves, kv_positions); });
+    return graphed(ctx, key, st, [&]() { return lm_body(ctx, st, n_rows, x_in_dev, hidden_out_dev, l0, l1, final_norm, fused, contiguous, attn_S, kv_positions); });
 }
 
 extern "C" int vv_kv_import_at(vv_ctx* ctx, void* stream, int cache, int layer, int pos0, int n_pos, const void* k_dev, const void* v_dev, int src_dtype) {
@@ -1415,15 +1401,14 @@ static int sample_body(vv_ctx* ctx, hipStream_t st, int n, const float* cond, co
     // up front, <=16 rows per GEMM, so the (3*layers+2)*H x H modulation matrix is streamed ceil(2nN/16) times per
     // frame instead of N times (the reference recomputes it inside every head call)
     const int MODW = ctx->MODW;
-    const bool batch_ada = ctx->mod_all_bytes != 0 && !getenv("VVHIP_NO_ADA_BATCH");
+    const bool batch_ada = ctx->mod_all_bytes != 0;
     if (batch_ada) {
         // SiLU(cond + t) for all (step, row) pairs in one small launch: the GEMM workgroups (one per 16 output features,
         // > 1000 of them) then stage plain rows instead of each re-evaluating 16 x H SiLUs
         const int total = rows * ctx->n_steps;
         // bf16 mode, three or more 16-row passes: ONE MFMA tile GEMM over all (step, row) pairs instead -- the modulation
         // matrix (360 MB for the 7B head) is streamed once, not once per 16 rows (8 utterances x 20 steps: 20 passes)
-        static const bool ada_tile = !getenv("VVHIP_NO_ADA_GEMM3");
-        if (ada_tile && ctx->ada_p && total > 32 && (MODW & 3) == 0) {
+        if (ctx->ada_p && total > 32 && (MODW & 3) == 0) {
             ctx->launches += 2;
             VVCHK(vv_ada_pack_launch(ctx->cproj, ctx->temb, ctx->ada_p, rows, ctx->n_steps, H, st));
             VVCHK(vv_gemm3_launch(ctx->h_ada, nullptr, ctx->ada_p, ctx->mod_all, nullptr, nullptr, total, MODW, H, MODW, VV_EPI_STORE, st));

@@ -484,18 +484,16 @@ extern "C" int vv_gemv_launch(VVGemm a, int xs, hipStream_t s);
 extern "C" int vv_tile_ok(const VVGemm* a, int xs);
 extern "C" int vv_tile_launch(VVGemm a, int xs, hipStream_t s);
 extern "C" int vv_gemm_launch(VVGemm a, int xs, hipStream_t s) {
-    static const bool no_gemv = getenv("VVHIP_NO_GEMV") != nullptr;
-    static const bool no_tile = getenv("VVHIP_NO_TILE") != nullptr;
     if (a.sl_n > 0) {                  // slot-batched rows exist only in the 16-row GEMV form
         if (xs > 2 || !vv_gemv_ok(&a)) return -4;
         const int r = vv_gemv_launch(a, xs, s);
         return r == -3 ? -4 : r;
     }
-    if (!no_gemv && !no_tile && vv_tile_ok(&a, xs)) {      // tall activations: MFMA tile GEMM (tile.hip)
+    if (vv_tile_ok(&a, xs)) {      // tall activations: MFMA tile GEMM (tile.hip)
         const int r = vv_tile_launch(a, xs, s);
         if (r != -3) return r;
     }
-    if (!no_gemv && a.ksplit <= 0 && vv_gemv_ok(&a) && (a.T <= 4 || xs <= 2)) {
+    if (a.ksplit <= 0 && vv_gemv_ok(&a) && (a.T <= 4 || xs <= 2)) {
         const int r = vv_gemv_launch(a, xs, s);
         if (r != -3) return r;                 // -3: no instantiation for this (pair, rows, split mode): general kernel
     }

@@ -493,7 +493,7 @@ extern "C" int vv_gemv_launch(VVGemm a, int xs, hipStream_t s) {
     if (a.T > 4 || a.sl_n > 0) {
         if (xs > 2) return -3;       // 16-row staging tiles of the exact mode exceed the LDS: general kernel
         grid.y = (a.T + 15) / 16;
-        static const int wide4_wgs = getenv("VVHIP_WIDE4_WGS") ? atoi(getenv("VVHIP_WIDE4_WGS")) : 128;
+        constexpr int wide4_wgs = 128;
         // The 16-row tiles are used by the codec (T = 5..16 rows): above ~half a workgroup per CU the 4-wave form
         // (2x the resident workgroups per CU) wins; measured 3.117 -> 3.053 ms/frame on the 1.5B config for
         // thresholds 64..128 vs 512 (DESIGN.md section 8 lists the sweep).
@@ -541,14 +541,12 @@ extern "C" int vv_gemv_launch(VVGemm a, int xs, hipStream_t s) {
 #undef VV_GOP
         return -3;
     }
-    static const bool wpb8_only = getenv("VVHIP_GEMV_WPB8") != nullptr;      // A/B switch
     if (a.kgrid > 1) grid.y = a.kgrid;
-    if (xs == 1 && !wpb8_only && a.kgrid <= 1) {
+    if (xs == 1 && a.kgrid <= 1) {
         if (n_tiles > 256) {
             // one utterance = two rows (cond + uncond): the 2-row form halves the activation registers and the staging tile, so
             // one more workgroup fits per SIMD (RMS_MOD + SwiGLU: 160 -> <= 128 VGPRs) and a 672-tile launch is resident at once
-            static const bool no_mr2 = getenv("VVHIP_NO_MR2") != nullptr;
-            if (a.T <= 2 && !no_mr2) {
+            if (a.T <= 2) {
 #define X(P, E) if (a.pro == P && a.epi == E) VV_GO(1, P, E, 2, 4);
                 VV_GEMV_W4(X)
 #undef X

@@ -227,7 +227,7 @@ int vv_gemv16p_launch(const void* W, const void* W2, const void* Xp, float* Y, v
     a.T = T; a.N = N; a.K = K; a.ldy = ldy; a.ld_gate = ld_gate;
     const int n_tiles = (N + 15) / 16;
     // waves per workgroup as in vv_gemv_launch: 4 once there are more tiles than CUs (every workgroup resident at once), else 8
-    static const int wide_tiles = getenv("VVHIP_P16_WIDE") ? atoi(getenv("VVHIP_P16_WIDE")) : 256;
+    constexpr int wide_tiles = 256;
     const bool w4 = n_tiles > wide_tiles;
 #define VV_P(E_) do { if (w4) hipLaunchKernelGGL((vv_gemv16p_kernel<E_, 4>), dim3(n_tiles), dim3(256), 0, s, a); \
                       else hipLaunchKernelGGL((vv_gemv16p_kernel<E_, 8>), dim3(n_tiles), dim3(512), 0, s, a); } while (0)

@@ -14,11 +14,11 @@
 //                           conflicts on the ds_read_b128 that follow); epilogues bias / residual / SwiGLU, the SwiGLU one
 //                           writing its result as packed bf16 fragments for the down projection.  Workgroup ids are mapped
 //                           so that one XCD (own L2) owns a contiguous range of feature blocks.
-//   vv_attn_prefill2_kernel causal attention for a chunk of consecutive positions: a workgroup owns 64 query rows x 4 query
+//   vv_attn_prefill3_kernel causal attention for a chunk of consecutive positions: a workgroup owns 64 query rows x 4 query
 //                           heads of one kv head, streams the causal prefix ONCE, 64 positions per stage, through a
-//                           double-buffered LDS stage (global_load_lds); each wave runs the online softmax of one query
-//                           head over 4 row tiles (K / V fragments read from LDS once per block, reused for the 4 tiles):
-//                           16 x fewer K/V reads per query row than vv_attn_prefill_kernel.
+//                           double-buffered LDS stage (global_load_lds); 8 waves = 4 query heads x 2 row halves, one
+//                           online-softmax update per stage (K / V fragments read from LDS once per block, reused for the
+//                           row tiles): 16 x fewer K/V reads per query row than a 16-row-per-workgroup kernel.
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -441,180 +441,12 @@ __global__ __launch_bounds__(512, 1) void vv_gemm4_kernel(const VVGemm3 a) {
 }
 
 // ------------------------------------------------------------------------------------------------ prefill attention
-// rows = consecutive positions of ONE cache (rows[0] first); q_rot (rotated, scaled by 1/sqrt(D)) and the chunk's own K/V
-// are already in place (vv_rope_append_kernel).  grid (ceil(R / 64), Hkv, ceil(G / 4)), 256 threads: a workgroup owns 64
-// query rows x 4 query heads of one kv head (one head per wave).  KV-cache layout: attn.hip header.
-template <int D, int RT>
-__global__ __launch_bounds__(64 * 4 * (4 / RT)) void vv_attn_prefill2_kernel(
-    const float* __restrict__ q, const VVRow* __restrict__ rows, const __bf16* __restrict__ kc,
-    const __bf16* __restrict__ vc, int R, int Hq, int Hkv, int64_t cache_stride, int64_t head_stride,
-    float* __restrict__ out) {
-    constexpr int KT = D / 32, DT = D / 16;
-    constexpr int KF = 2 * KT;                       // K fragments of a 32-position block (2 position tiles x KT)
-    constexpr int SF = 2 * (KF + DT);                // fragments of one 64-position stage: K of 2 blocks, then V of 2 blocks
-    constexpr int BUF = SF * 1024;
-    extern __shared__ __attribute__((aligned(16))) unsigned char kv[];          // 2 stages
-    // RT = row tiles (16 query rows each) per wave.  RT = 4: 4 waves, one per SIMD, 389 registers -- softmax VALU work and
-    // MFMAs of a wave cannot overlap.  RT = 2: 8 waves (4 heads x 2 row halves), two per SIMD at <= 256 registers: one wave's
-    // exp / max / convert work runs under the other's MFMAs, at the price of every K/V fragment being read from LDS twice.
-    constexpr int NW = 4 * (4 / RT);
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // longest workgroups first: the last query tile walks the whole prefix
-    const int qt = (int)gridDim.x - 1 - (int)blockIdx.x;
-    const int r0 = qt * 64, kvh = blockIdx.y;
-    const int rw0 = r0 + (wave >> 2) * (RT * 16);    // first query row of this wave
-    const VVRow rw = rows[0];
-    const int G = Hq / Hkv;
-    const int g = (int)blockIdx.z * 4 + (wave & 3);  // this wave's query head inside the group
-    const bool act = g < G;
-    const int h = kvh * G + (act ? g : 0);
-    const int col = lane & 15, qg = lane >> 4;
-    const int pend = rw.pos + min(r0 + 63, R - 1) + 1;              // positions this tile walks: [0, pend)
-    const int n_stg = (pend + 63) >> 6;
-    const int first_masked = (rw.pos + r0) >> 5;                      // blocks below this one are visible to every query row
-    const u32x4* kt_base = reinterpret_cast<const u32x4*>(kc + (int64_t)rw.cache * cache_stride + (int64_t)kvh * head_stride);
-    const u32x4* vt_base = reinterpret_cast<const u32x4*>(vc + (int64_t)rw.cache * cache_stride + (int64_t)kvh * head_stride);
-    constexpr float LOG2E = 1.4426950408889634f;
-
-    // stage s = blocks 2s, 2s+1: K tiles (2s)*KF .. +2KF and V tiles (2s)*DT .. +2DT are both contiguous; wave w copies every 4th
-    auto issue = [&](int st, unsigned char* buf) {
-        const u32x4* ks = kt_base + (int64_t)st * 2 * KF * 64 + lane;
-        const u32x4* vs = vt_base + (int64_t)st * 2 * DT * 64 + lane;
-#pragma unroll
-        for (int f = 0; f < SF; ++f) {
-            if ((f % NW) == wave) {                                   // uniform per wave
-                if (f < 2 * KF) glds16(ks + f * 64, buf + f * 1024);
-                else glds16(vs + (f - 2 * KF) * 64, buf + f * 1024);
-            }
-        }
-    };
-    issue(0, kv);
-
-    // ---- q fragments of the 4 row tiles, in the log2 domain (scores * log2 e: p = exp2(s - m)) ----
-    bf16x8 qf[RT][KT];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        const int row = min(rw0 + rt * 16 + col, R - 1);
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-            const float* qp = q + ((int64_t)row * Hq + h) * D + kt * 32 + qg * 8;
-            const float4 a0 = *reinterpret_cast<const float4*>(qp), a1 = *reinterpret_cast<const float4*>(qp + 4);
-            const float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-#pragma unroll
-            for (int j = 0; j < 8; ++j) qf[rt][kt][j] = (__bf16)(v[j] * LOG2E);
-        }
-    }
-    float m[RT], lsum[RT];
-    f32x4 o[RT][DT];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        m[rt] = -INFINITY; lsum[rt] = 0.f;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) o[rt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll 1
-    for (int st = 0; st < n_stg; ++st) {
-        unsigned char* cur = kv + (st & 1) * BUF;
-        stage_sync();                             // stage st has landed (every wave drained its own copies first);
-                                                  // everyone has finished stage st-1, whose buffer is refilled now
-        if (st + 1 < n_stg) issue(st + 1, kv + ((st + 1) & 1) * BUF);
-        if (!act) continue;
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            const int b = st * 2 + sub;
-            const int p0 = b * 32;
-            if (p0 >= pend) break;                // uniform
-            const bool masked = b >= first_masked;
-            const unsigned char* kb_ = cur + sub * KF * 1024;
-            const unsigned char* vb_ = cur + (2 * KF + sub * DT) * 1024;
-            // ---- S^T = K q^T for the 4 row tiles: every K fragment is read from LDS once ----
-            f32x4 s0[RT], s1[RT];
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) { s0[rt] = f32x4{0.f, 0.f, 0.f, 0.f}; s1[rt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt) {
-                const bf16x8 ka = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(kb_ + (kt * 64 + lane) * 16));
-                const bf16x8 kb = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(kb_ + ((KT + kt) * 64 + lane) * 16));
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) {
-                    s0[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[rt][kt], s0[rt], 0, 0, 0);
-                    s1[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb, qf[rt][kt], s1[rt], 0, 0, 0);
-                }
-            }
-            // ---- online softmax per row tile -> P as the B operand of P.V ----
-            bf16x8 pb[RT];
-            float al[RT];
-            bool resc[RT];                        // wave-uniform: some column of this row tile moved its running max
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                float sv[8];
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) { sv[rr] = s0[rt][rr]; sv[4 + rr] = s1[rt][rr]; }
-                if (masked) {
-                    const int plim = rw.pos + min(rw0 + rt * 16 + col, R - 1);    // last position this column's query may attend
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) {
-                        const int pa = p0 + qg * 4 + rr;
-                        if (pa > plim) sv[rr] = -INFINITY;
-                        if (pa + 16 > plim) sv[4 + rr] = -INFINITY;
-                    }
-                }
-                float mx = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
-                mx = fmaxf(mx, __shfl_xor(mx, 16));
-                mx = fmaxf(mx, __shfl_xor(mx, 32));
-                const float mn = fmaxf(m[rt], mx);
-                // a column whose whole block is masked (query earlier than this block) keeps its state untouched
-                const bool dead = (mn == -INFINITY);
-                const float alpha = (m[rt] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m[rt] - mn);
-                float ps = 0.f;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float p = (sv[j] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(sv[j] - mn);
-                    ps += p;
-                    pb[rt][j] = (__bf16)p;
-                }
-                if (!dead) { lsum[rt] = lsum[rt] * alpha + ps; m[rt] = mn; }
-                al[rt] = dead ? 1.f : alpha;
-                // once the running maxima have settled (alpha == 1 in every lane) the 32 accumulator multiplies are skipped
-                resc[rt] = __builtin_amdgcn_ballot_w64(al[rt] != 1.0f) != 0;
-            }
-            // ---- O += P . V: every V fragment is read from LDS once ----
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                const bf16x8 vt = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(vb_ + (dt * 64 + lane) * 16));
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) {
-                    if (resc[rt]) o[rt][dt] *= al[rt];
-                    o[rt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, pb[rt], o[rt][dt], 0, 0, 0);
-                }
-            }
-        }
-    }
-    if (act) {
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            float l = lsum[rt];
-            l += __shfl_xor(l, 16);
-            l += __shfl_xor(l, 32);
-            const int row = rw0 + rt * 16 + col;
-            if (row < R) {
-                const float inv = 1.0f / l;
-                float* orow = out + ((int64_t)row * Hq + h) * D + qg * 4;
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
-                    *reinterpret_cast<float4*>(orow + dt * 16) =
-                        float4{o[rt][dt][0] * inv, o[rt][dt][1] * inv, o[rt][dt][2] * inv, o[rt][dt][3] * inv};
-            }
-        }
-    }
-}
-
-
-// ------------------------------------------------------------------------------------------------ prefill attention, v3
-// Same data path as vv_attn_prefill2_kernel<D, 2> (8 waves = 4 query heads x 2 row halves, 64 positions per LDS stage), with
-// the softmax restructured after the rocprof / PMC pass on the 7B prompt (MFMA busy 18 %: per 32 positions a wave issued 32
-// MFMAs and ~200 VALU / LDS-permute instructions in one dependent chain):
+// rows = consecutive positions of ONE cache (rows[0] first); q = the rotated queries (vv_rope_append_kernel), fp32 [R][Hq][D]; the
+// softmax scale is applied here.
+// 8 waves = 4 query heads x 2 row halves, 64 positions per LDS stage.  The softmax is organised around what the rocprof / PMC
+// passes on the 7B prompt showed (the first form of this kernel -- one update per 32-position block, LDS-permute exchanges,
+// masks everywhere -- ran the MFMA pipe 18 % busy: per 32 positions a wave issued 32 MFMAs and ~200 VALU / LDS-permute
+// instructions in one dependent chain):
 //   * ONE online-softmax update per 64-position stage instead of one per 32-position block: the row maximum, the running
 //     rescale factor, the exchange across the 4 lane rows and the rescale vote are paid once per 16 scores per lane, and the
 //     32 S^T MFMAs (then the 32 P.V MFMAs) of a stage issue back to back, so the partner wave on the SIMD has a full
@@ -623,13 +455,10 @@ __global__ __launch_bounds__(64 * 4 * (4 / RT)) void vv_attn_prefill2_kernel(
 //     ds_bpermute round trips through the LDS pipe, which the K / V fragment reads already keep busy;
 //   * stages wholly below the causal diagonal (all but the last one or two of a workgroup) take a path with no -inf
 //     compares / selects: every score is finite there, exp2(-inf - m) of the very first stage is the hardware's 0.
-template <bool PL>
 __device__ __forceinline__ float a3_xrow_max(float v) {
-    // max over the 4 lanes that share (lane & 15): rows of 16 lanes exchanged pairwise, then the two halves of the wave
-    if constexpr (!PL) {                 // A/B form (VVHIP_ATTN3_SHFL): the LDS-permute exchange of the v2 kernel
-        v = fmaxf(v, __shfl_xor(v, 16));
-        return fmaxf(v, __shfl_xor(v, 32));
-    }
+    // max over the 4 lanes that share (lane & 15): rows of 16 lanes exchanged pairwise, then the two halves of the wave.
+    // NB: going through `unsigned` temporaries is deliberate -- bit-casting element 1 of the builtin's result directly reads
+    // element 0 (clang); the per-row parity tests (tests/test_gpu_shipped.py, test_gpu_geometry.py) pin the exchange.
     unsigned x = __float_as_uint(v);
     auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
     unsigned r0 = r[0], r1 = r[1];
@@ -640,7 +469,7 @@ __device__ __forceinline__ float a3_xrow_max(float v) {
     return fmaxf(__uint_as_float(t0), __uint_as_float(t1));
 }
 
-template <int D, bool PL>
+template <int D>
 __global__ __launch_bounds__(512) void vv_attn_prefill3_kernel(
     const float* __restrict__ q, const VVRow* __restrict__ rows, const __bf16* __restrict__ kc,
     const __bf16* __restrict__ vc, int R, int Hq, int Hkv, int64_t cache_stride, int64_t head_stride,
@@ -800,7 +629,7 @@ __global__ __launch_bounds__(512) void vv_attn_prefill3_kernel(
             for (int i = 0; i < 2 * NB; ++i)
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) mx = fmaxf(mx, sc[rt][i][rr]);
-            mx = a3_xrow_max<PL>(mx);
+            mx = a3_xrow_max(mx);
             const float mn = fmaxf(m[rt], mx);
             float alpha, ps = 0.f;
             if constexpr (FAST) {
@@ -941,13 +770,11 @@ int vv_gemm3_launch(const void* W, const void* W2, const void* Xp, float* Y, voi
     a.W = (const u32x4*)W; a.W2 = (const u32x4*)W2; a.Xp = (const u32x4*)Xp; a.Y = Y; a.Yp = (u32x4*)Yp; a.bias = bias;
     a.T = T; a.N = N; a.K = K; a.ldy = ldy;
     const int n_tiles = (N + 15) / 16;
-    // long prompts: the 256 x 256 double-buffered kernel whenever its grid fills the chip at least once (VVHIP_GEMM4=0 off,
-    // =all regardless of the grid); smaller problems keep the 128-feature kernel, whose tiles quantise better.  Measured per
-    // launch at T = 10,922 (7B layer): gate/up 3188 -> 2460 us, down 1751 -> 1460, o 432 -> 343, qkv 518 -> 416.
-    static const char* g4 = getenv("VVHIP_GEMM4");
-    const bool g4_all = g4 && !strcmp(g4, "all"), g4_off = g4 && !strcmp(g4, "0");
+    // long prompts: the 256 x 256 double-buffered kernel whenever its grid fills the chip at least once; smaller problems keep
+    // the 128-feature kernel, whose tiles quantise better.  Measured per launch at T = 10,922 (7B layer): gate/up 3188 -> 2460 us,
+    // down 1751 -> 1460, o 432 -> 343, qkv 518 -> 416.
     const int64_t wgs4 = (int64_t)((n_tiles + ((epi == VV_EPI_SWIGLU) ? 8 : 16) - 1) / ((epi == VV_EPI_SWIGLU) ? 8 : 16)) * ((T + 255) / 256);
-    if (!g4_off && (g4_all || wgs4 >= 256) &&
+    if (wgs4 >= 256 &&
         (epi == VV_EPI_SWIGLU || epi == VV_EPI_RESID || epi == VV_EPI_BIAS || epi == VV_EPI_STORE)) {
         const int ft4 = (epi == VV_EPI_SWIGLU) ? 8 : 16;
         a.n_blocks = (n_tiles + ft4 - 1) / ft4;
@@ -971,8 +798,7 @@ int vv_gemm3_launch(const void* W, const void* W2, const void* Xp, float* Y, voi
     const int ft = (epi == VV_EPI_SWIGLU) ? 4 : 8;
     a.n_blocks = (n_tiles + ft - 1) / ft;
     // 256-row workgroups once the problem is tall enough to fill the chip with them
-    static const int tr_env = getenv("VVHIP_GEMM3_TR") ? atoi(getenv("VVHIP_GEMM3_TR")) : 0;
-    const int tr = tr_env == 4 || tr_env == 8 ? tr_env : ((int64_t)a.n_blocks * ((T + 255) / 256) >= 768 ? 8 : 4);
+    const int tr = (int64_t)a.n_blocks * ((T + 255) / 256) >= 768 ? 8 : 4;
     a.t_blocks = (T + 32 * tr - 1) / (32 * tr);
     const dim3 grid((unsigned)(a.n_blocks * a.t_blocks));
 #define VV_G3(E_) do { if (tr == 8) hipLaunchKernelGGL((vv_gemm3_kernel<E_, 8>), grid, dim3(256), 0, s, a); \
@@ -993,42 +819,21 @@ int vv_gemm3_launch(const void* W, const void* W2, const void* Xp, float* Y, voi
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-int vv_attn_prefill2_launch(int D, const float* q, const VVRow* rows, const void* kc, const void* vc, int R, int Hq, int Hkv,
+// causal prefill attention of R consecutive rows of one cache (64 query rows x the GQA group of one kv head per workgroup)
+int vv_attn_prefill3_launch(int D, const float* q, const VVRow* rows, const void* kc, const void* vc, int R, int Hq, int Hkv,
                             int64_t cache_stride, int64_t head_stride, float* out, hipStream_t s) {
-    if (Hq % Hkv != 0) return -1;
+    if (Hq % Hkv != 0 || (D != 128 && D != 64)) return -1;
     const int G = Hq / Hkv;
     const dim3 grid((R + 63) / 64, Hkv, (G + 3) / 4);
-    static const bool rt4 = getenv("VVHIP_ATTN2_RT4") != nullptr;          // A/B: 4 waves x 4 row tiles (one wave per SIMD)
-    static const bool v3 = !rt4 && !(getenv("VVHIP_ATTN3") && atoi(getenv("VVHIP_ATTN3")) == 0);   // VVHIP_ATTN3=0: the v2 kernel
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_attn_prefill3_kernel<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_attn_prefill3_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_attn_prefill3_kernel<128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_attn_prefill3_kernel<64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_attn_prefill2_kernel<128, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_attn_prefill2_kernel<64, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_attn_prefill2_kernel<128, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_attn_prefill2_kernel<64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_attn_prefill3_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_attn_prefill3_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-#define VV_A2(D_, RT_, SM_)                                                                                         \
-    hipLaunchKernelGGL((vv_attn_prefill2_kernel<D_, RT_>), grid, dim3(64 * 4 * (4 / RT_)), SM_, s, q, rows, (const __bf16*)kc, \
-                       (const __bf16*)vc, R, Hq, Hkv, cache_stride, head_stride, out)
-    if (v3 && (D == 128 || D == 64)) {
-        static const bool shfl = getenv("VVHIP_ATTN3_SHFL") != nullptr;     // A/B: ds_bpermute row exchange instead of v_permlane*_swap
-        const int sm = 2 * 2 * (2 * (D / 32) + D / 16) * 1024;
-#define VV_A3(D_, PL_) hipLaunchKernelGGL((vv_attn_prefill3_kernel<D_, PL_>), grid, dim3(512), sm, s, q, rows, (const __bf16*)kc, \
-                                          (const __bf16*)vc, R, Hq, Hkv, cache_stride, head_stride, out)
-        if (D == 128) { if (shfl) VV_A3(128, false); else VV_A3(128, true); }
-        else { if (shfl) VV_A3(64, false); else VV_A3(64, true); }
-#undef VV_A3
-        return hipGetLastError() == hipSuccess ? 0 : -2;
-    }
-    if (D == 128) { if (rt4) VV_A2(128, 4, 2 * 2 * (2 * 4 + 8) * 1024); else VV_A2(128, 2, 2 * 2 * (2 * 4 + 8) * 1024); }
-    else if (D == 64) { if (rt4) VV_A2(64, 4, 2 * 2 * (2 * 2 + 4) * 1024); else VV_A2(64, 2, 2 * 2 * (2 * 2 + 4) * 1024); }
-    else return -1;
-#undef VV_A2
+    const int sm = 2 * 2 * (2 * (D / 32) + D / 16) * 1024;
+    if (D == 128) hipLaunchKernelGGL((vv_attn_prefill3_kernel<128>), grid, dim3(512), sm, s, q, rows, (const __bf16*)kc, (const __bf16*)vc, R, Hq, Hkv, cache_stride, head_stride, out);
+    else hipLaunchKernelGGL((vv_attn_prefill3_kernel<64>), grid, dim3(512), sm, s, q, rows, (const __bf16*)kc, (const __bf16*)vc, R, Hq, Hkv, cache_stride, head_stride, out);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

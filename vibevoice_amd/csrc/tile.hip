@@ -233,7 +233,7 @@ extern "C" int vv_tile_ok(const VVGemm* a, int xs) {
     {   // enough workgroups to occupy the chip; smaller problems (tokenizer stages at decode) stay on the row-tiled GEMV
         const int per_wg = 4 * (a->epi == VV_EPI_SWIGLU ? 1 : 2);
         const int64_t wgs = (int64_t)(((a->N + 15) / 16 + per_wg - 1) / per_wg) * ((a->T + BM - 1) / BM);
-        static const int min_wgs = getenv("VVHIP_TILE_MIN_WGS") ? atoi(getenv("VVHIP_TILE_MIN_WGS")) : 48;
+        constexpr int min_wgs = 48;
         if (wgs < min_wgs) return 0;
     }
     if ((a->K & 3) || (a->ldx & 3) || (a->N & 3) || (a->ldy & 3)) return 0;

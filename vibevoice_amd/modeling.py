@@ -339,10 +339,11 @@ class VibeVoiceForConditionalGenerationInference:
         self._join_ev = torch.cuda.Event()
         self._side_streams = [torch.cuda.Stream(device=self.device) for _ in range(min(NB, engine.cfg.n_slots))] if engine.cfg.n_slots > 1 else []
         self._audio_blocks = []                                       # output frames, 64 steps per block (no per-step allocation)
-        self.concurrent_codecs = os.environ.get("VVHIP_SERIAL_CODECS") is None
-        # several utterances' tokenizer chains of a step as ONE engine call (vv_codec_chain_batch); off: one chain per utterance
-        self.batched_codecs = os.environ.get("VVHIP_NO_BATCH_CHAIN") is None and hasattr(engine, "codec_chain_batch")
-        self.speculate_sampling = os.environ.get("VVHIP_NO_SPEC") is None
+        # plain attributes (tests flip them): per-utterance tokenizer chains on forked streams; several utterances' chains of a step
+        # as ONE engine call (vv_codec_chain_batch); the sampler enqueued speculatively behind the LM pass
+        self.concurrent_codecs = True
+        self.batched_codecs = hasattr(engine, "codec_chain_batch")
+        self.speculate_sampling = True
         self.last_stats = {}
 
     # ------------------------------------------------------------------ construction
