@@ -31,6 +31,7 @@ class AudioStreamer:
         self._pcm_engine = pcm16                  # vibevoice_amd.Engine (or None: chunks keep the producer's dtype)
         self._ring = [None] * ring_slots          # pinned host buffers, allocated on first use (shape of the first chunk)
         self._pcm_dev = [None] * ring_slots       # device int16 staging per ring slot (pcm16 mode)
+        self._copy_stream = None                  # D2H copies run here (created on the first device chunk)
         self._free = Queue()
         for i in range(ring_slots):
             self._free.put(i)
@@ -74,9 +75,21 @@ class AudioStreamer:
         if buf is None or buf.shape[1:] != need[1:] or buf.shape[0] < need[0] or buf.dtype != src.dtype:
             buf = torch.empty((max(need[0], self.batch_size),) + tuple(need[1:]), dtype=src.dtype).pin_memory()
             self._ring[slot] = buf
-        buf[:need[0]].copy_(src, non_blocking=True)
+        # The D2H copy runs on the streamer's OWN stream, ordered behind the producer by an event: the drain thread then waits on an
+        # event of a stream that never enters hipGraph capture.  (Waiting on an event of the producing stream raced with the
+        # engine's stream captures -- hipEventSynchronize refuses an event whose stream is capturing, hipErrorCapturedEvent --
+        # whenever a new graph key was captured while a chunk was still in flight.)
+        prod = torch.cuda.current_stream(audio_chunks.device)
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=audio_chunks.device)
+        ready = torch.cuda.Event()
+        ready.record(prod)
+        self._copy_stream.wait_event(ready)
+        with torch.cuda.stream(self._copy_stream):
+            buf[:need[0]].copy_(src, non_blocking=True)
+        src.record_stream(self._copy_stream)
         ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(audio_chunks.device))
+        ev.record(self._copy_stream)
         self._work.put(("slot", live, slot, ev, need[0]))
 
     def end(self, sample_indices=None):
