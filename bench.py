@@ -151,7 +151,7 @@ def checkpoint_tensors(path):
                 yield k, sf.get_tensor(k)
 
 
-def pmc_traffic(model_key, kernel):
+def pmc_traffic(model_key, kernel, bytes_per_launch=None):
     """HBM bytes per launch of `kernel` from the committed PMC pass (profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE in
     its own run, x2 on gfx950 as /opt/skills/guides/MI355X_MICROARCH.md prescribes) -- only when that pass ran on the binary
     that is loaded now (the file records the library's build id); otherwise null, with the reason."""
@@ -165,6 +165,10 @@ def pmc_traffic(model_key, kernel):
         if ent.get("libvvhip_build_id") != _build_id():
             return None, (f"profiles/pmc_traffic.json was measured on build {ent.get('libvvhip_build_id')}, this run loads {_build_id()}: "
                           "not carried over (re-run tools/pmc_refresh.sh)")
+        alg = fam.get("algorithmic_bytes_per_launch")
+        if bytes_per_launch and alg and abs(bytes_per_launch - alg) > 0.05 * alg:
+            return None, (f"profiles/pmc_traffic.json holds a pass of another launch geometry for {kernel} ({alg:.0f} algorithmic bytes per launch "
+                          f"there, {bytes_per_launch:.0f} here): not comparable")
         return fam["hbm_bytes_per_launch"], ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE (own pass, x2 gfx950 correction) on this "
                                              f"build ({ent.get('libvvhip_build_id')}); algorithmic bytes of that pass {fam.get('algorithmic_bytes_per_launch')}")
     except Exception as ex:
@@ -506,7 +510,7 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline):
         ach = by_rep / 1e9 / (ms_rep / 1e3) if ms_rep > 0 else 0.0                      # GB/s
         # (2) secondary: hipEvent pair around each EAGER launch minus an in-stream empty pair (a lower bound on the duration)
         ach_pair = by / 1e9 / (ms_cal / 1e3) if ms_cal > 0 else 0.0
-        traffic, traffic_src = pmc_traffic(model_key, "vv_gemv_kernel")
+        traffic, traffic_src = pmc_traffic(model_key, "vv_gemv_kernel", by_rep / max(1, n_rep))
         roof = {"bound": "hbm", "kernel": "vv_gemv_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "traffic_source": traffic_src,
@@ -529,7 +533,7 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline):
             if not n_f or ms_f <= 0:
                 return None
             a_f = by_f / 1e9 / (ms_f / 1e3)
-            tr, tsrc = pmc_traffic(model_key, name.split(" ")[0])
+            tr, tsrc = pmc_traffic(model_key, name.split(" ")[0], by_f / n_f)
             return {"kernel": name, "achieved": round(a_f, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a_f / HBM_PEAK_GBS, 4),
                     "launches_per_step": round(n_f / 3 / kprof, 1), "avg_launch_us": round(ms_f * 1e3 / n_f, 3),
                     "bytes_per_launch": round(by_f / n_f, 1), "traffic": tr, "traffic_source": tsrc}
@@ -695,8 +699,8 @@ def bench_streaming(args, spec, ctx):
         ach = by_rep / 1e9 / (ms_rep / 1e3) if ms_rep > 0 else 0.0
         formula = streaming_bytes_per_frame(cfg, NS, 251 + int(n_frames) // 2)
         roof = {"bound": "hbm", "kernel": "vv_gemv_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(spec["model"], "vv_gemv_kernel")[0],
-                "traffic_source": pmc_traffic(spec["model"], "vv_gemv_kernel")[1],
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(spec["model"], "vv_gemv_kernel", by_rep / max(1, n_rep))[0],
+                "traffic_source": pmc_traffic(spec["model"], "vv_gemv_kernel", by_rep / max(1, n_rep))[1],
                 "launches_per_step": round(n_l / 6.0, 1), "avg_launch_us": round(ms_rep * 1e3 / max(1, n_rep), 3),
                 "bytes_per_launch": round(by_rep / max(1, n_rep), 1),
                 "method": "vv_gemv_kernel launches of one generate() (text window of 5 + speech window of 6) replayed as one dependent hipGraph chain",

@@ -67,7 +67,10 @@ def timeline(db, out):
     kept = []
     burst = []
 
-    PREFILL = ("vv_gemm4", "vv_gemm3", "vv_attn_prefill", "vv_pack_rows", "vv_rope_append")
+    # kernels that only run outside the step loop: prompt prefill, weight upload / re-packing, the bench's KV fill (torch.randn +
+    # vv_kv_import).  Each ends the burst before it and is not counted.
+    PREFILL = ("vv_gemm4", "vv_gemm3", "vv_attn_prefill", "vv_pack_rows", "vv_rope_append", "vv_pack_kernel", "vv_kv_import",
+               "distribution_elementwise", "vv_cvt_kernel")
 
     def close(burst):
         nonlocal span, busy, n_bursts
