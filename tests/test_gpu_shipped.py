@@ -440,3 +440,46 @@ def test_from_pretrained_checkpoint_directory_on_the_gpu_engine(tmp_path, monkey
     assert bench.find_checkpoint("1.5b") == str(d)
     assert bench.find_checkpoint("7b") is None
     assert sorted(k for k, _ in bench.checkpoint_tensors(str(d))) == keys
+
+
+# ---------------------------------------------------------------------------------------------- utterance sharding over RCCL
+def test_generate_sharded_over_an_rccl_process_group():
+    """parallel.generate_sharded on the real engine with torch.distributed's "nccl" backend (= RCCL; a one-rank group is what a
+    1-GPU box offers): the finished utterances travel as padded device tensors through dist.gather -- token sequences as int64,
+    waveforms in the model dtype -- and come back in request order, identical to generate_continuous() on the same queue.  The
+    2-rank behaviour of the same code (unequal shards, both ranks contributing) is covered on CPU with gloo
+    (tests/test_parallel_cpu.py)."""
+    import socket
+    import torch.distributed as dist
+    from test_gpu_generate import _mk_requests, D, E, S, X
+    from vibevoice_amd import parallel
+    from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference
+    sm = build_small(synth.LMCfg(), xsplit=3, n_slots=2, max_ctx=512, use_graph=True)
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=sm.eng.device)
+    try:
+        reqs = _mk_requests(sm, 4, 13)
+        cfgd = {"decoder_config": {"max_position_embeddings": sm.lmcfg.max_pos}, "diffusion_head_config": {"ddpm_num_inference_steps": 5},
+                "acoustic_tokenizer_config": {"fix_std": 0.5, "std_dist_type": "gaussian"}}
+        m = VibeVoiceForConditionalGenerationInference(cfgd, sm.eng, model_dtype=torch.bfloat16)
+        m.set_speech_factors(sm.scaling, sm.bias)
+        m.set_ddpm_inference_steps(5)
+        tok = types.SimpleNamespace(speech_start_id=S, speech_end_id=E, speech_diffusion_id=D, eos_token_id=X, bos_token_id=None, pad_token_id=305)
+        kw = dict(tokenizer=tok, generation_config={"do_sample": False}, cfg_scale=1.3)
+        solo = m.generate_continuous(reqs, **kw)
+        st = {}
+        got = parallel.generate_sharded(m, reqs, gather_to=0, stats=st, **kw)
+        assert st["utterances_per_rank"] == [4] and st["imbalance_max_over_mean"] == 1.0
+        assert len(got) == 4
+        for a, b in zip(got, solo):
+            assert torch.equal(a.sequences.cpu(), b.sequences.cpu())
+            assert bool(a.reach_max_step_sample[0]) == bool(b.reach_max_step_sample[0])
+            assert a.speech_outputs[0].shape == b.speech_outputs[0].shape
+            assert torch.equal(a.speech_outputs[0].float().cpu(), b.speech_outputs[0].float().cpu())     # bf16 waveforms travel unchanged
+        every = parallel.generate_sharded(m, reqs, gather_to=None, **kw)                                      # the all_gather form
+        assert all(torch.equal(a.sequences, b.sequences) for a, b in zip(every, got))
+    finally:
+        dist.destroy_process_group()
+        sm.eng.close()
