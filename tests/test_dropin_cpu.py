@@ -232,6 +232,45 @@ def test_continuous_admission_equals_one_by_one(monkeypatch):
     assert st["iterations"] < sum(own) and st["iterations"] >= max(own)
 
 
+def test_continuous_frame_store_follows_the_audio_in_flight(monkeypatch):
+    """the frame store used to grow by one row per diffusion iteration of the whole queue and was never released.
+    Now a finished utterance's frames leave it at once and blocks no live utterance points into are dropped.  With 4-row blocks the
+    dropping happens several times inside this 6-utterance queue: every result must stay identical to generate() alone, the store
+    must end with at most one block, and it must never hold more than the blocks the two utterances in flight span."""
+    from test_oracle_golden import _oracle_small
+    from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference
+    cfgd = {"decoder_config": {"max_position_embeddings": 4096}, "diffusion_head_config": {"ddpm_num_inference_steps": 5},
+            "acoustic_tokenizer_config": {"fix_std": 0.5, "std_dist_type": "gaussian"}}
+    reqs = _requests(6, 5)
+    with fake_engine.cpu_cuda_shims(monkeypatch):
+        solo = []
+        for r in reqs:
+            m1 = VibeVoiceForConditionalGenerationInference(cfgd, fake_engine.FakeEngine(_oracle_small(), n_slots=1), model_dtype=torch.float32)
+            m1.set_speech_factors(0.2, -0.05)
+            m1.set_ddpm_inference_steps(5)
+            solo.append(m1.generate(input_ids=r["input_ids"], attention_mask=r["attention_mask"], cfg_scale=1.3, tokenizer=TOK,
+                                    generation_config={"do_sample": False}, _forced_tokens=[r["_forced_tokens"]],
+                                    _noise_fn=r["_noise_fn"], show_progress_bar=False))
+            assert len(m1._audio_blocks) <= 1
+        m = VibeVoiceForConditionalGenerationInference(cfgd, fake_engine.FakeEngine(_oracle_small(), n_slots=2), model_dtype=torch.float32)
+        m.set_speech_factors(0.2, -0.05)
+        m.set_ddpm_inference_steps(5)
+        m.concurrent_codecs = False
+        m.frame_block = 4
+        peak = []
+        outs = m.generate_continuous(reqs, tokenizer=TOK, generation_config={"do_sample": False}, cfg_scale=1.3,
+                                     _step_callback=lambda it: peak.append(sum(b is not None for b in m._audio_blocks)))
+    frames_total = sum(o.speech_outputs[0].shape[-1] // 3200 for o in outs if o.speech_outputs[0] is not None)
+    assert frames_total > 4 * 4                                    # the queue spans several blocks ...
+    assert max(peak) <= 3, peak                                    # ... but the store never holds more than the live span
+    assert len(m._audio_blocks) <= 1
+    for a, b in zip(outs, solo):
+        assert torch.equal(a.sequences.cpu(), b.sequences.cpu())
+        if b.speech_outputs[0] is not None:
+            d = (a.speech_outputs[0] - b.speech_outputs[0]).norm() / b.speech_outputs[0].norm()
+            assert float(d) <= 1e-5, float(d)
+
+
 def test_continuous_length_capped_utterance_leaves_the_others_intact(monkeypatch):
     """an utterance retired by the LOOP-level conditions of generate() (range(max_steps) exhausted / max_length
     reached -- not by EOS) while others stay in flight.  The survivors' next-step embeddings were packed in the old order; they must

@@ -338,7 +338,8 @@ class VibeVoiceForConditionalGenerationInference:
         self._fork_ev = torch.cuda.Event()
         self._join_ev = torch.cuda.Event()
         self._side_streams = [torch.cuda.Stream(device=self.device) for _ in range(min(NB, engine.cfg.n_slots))] if engine.cfg.n_slots > 1 else []
-        self._audio_blocks = []                                       # output frames, 64 steps per block (no per-step allocation)
+        self._audio_blocks = []                                       # output frames, FRAME_BLOCK steps per block (no per-step allocation)
+        self.frame_block = 64
         # plain attributes (tests flip them): per-utterance tokenizer chains on forked streams; several utterances' chains of a step
         # as ONE engine call (vv_codec_chain_batch); the sampler enqueued speculatively behind the LM pass
         self.concurrent_codecs = True
@@ -655,15 +656,15 @@ class VibeVoiceForConditionalGenerationInference:
             u.pos_len = kv_start
 
     def _block_rows(self, i: int):
-        """row i of the frame store: [utterances in flight, hop] fp32, 64 rows per block"""
-        b, r = divmod(i, 64)
+        """row i of the frame store: [utterances in flight, hop] fp32, frame_block rows per block"""
+        b, r = divmod(i, self.frame_block)
         w = getattr(self, "_frame_w", min(MAX_BATCH, max(1, self.engine.cfg.n_slots)))
         if any(t is not None and t.shape[1] != w for t in self._audio_blocks):
             self._audio_blocks = []
         while len(self._audio_blocks) <= b:
             self._audio_blocks.append(None)
         if self._audio_blocks[b] is None:
-            self._audio_blocks[b] = self.engine.new(64, w, self.engine.cfg.hop)
+            self._audio_blocks[b] = self.engine.new(self.frame_block, w, self.engine.cfg.hop)
         return self._audio_blocks[b][r]
 
     def _release_frames(self):
@@ -1150,7 +1151,7 @@ class VibeVoiceForConditionalGenerationInference:
                         u.chunks = [torch.cat(u.chunks, dim=-1)]
                 if ended:
                     rows0 = [self._first_row[id(u)] for u in active if id(u) in self._first_row]
-                    lo = min(rows0 + [S["frame_rows"]]) // 64
+                    lo = min(rows0 + [S["frame_rows"]]) // self.frame_block
                     for b in range(min(lo, len(self._audio_blocks))):
                         self._audio_blocks[b] = None
                     for u in ended:
