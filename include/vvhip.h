@@ -182,8 +182,10 @@ int vv_gemm_raw(void* stream, const void* w_packed_dev, const void* w2_packed_de
                 int xsplit, int ksplit, int nontemporal);
 /* The prompt-prefill GEMM (bf16-activation mode): x_dev fp32 [T][K] is packed (RMS-normalised when nw_dev != NULL) into
  * xp_scratch (vv_packed_bytes(T, K)); epi 0/1/4 (store / bias / residual) -> fp32 y_dev [T][N]; epi 3 (SwiGLU: w = gate,
- * w2 = up) -> packed bf16 in yp_scratch (vv_packed_bytes(T, N), zero-initialised), unpacked into y_dev.  K % 8 == 0, N % 4 == 0. */
-int vv_gemm3_raw(void* stream, const void* w_packed_dev, const void* w2_packed_dev, const float* x_dev, int T, int N, int K,
+ * w2 = up) -> packed bf16 in yp_scratch (vv_packed_bytes(T, N), zero-initialised), unpacked into y_dev.  K % 8 == 0, N % 4 == 0.
+ * ctx lends its K-split workspace (the partial last round of the 256 x 256 kernel is split along K, as in the prompt prefill);
+ * ctx == NULL: every tile is computed whole. */
+int vv_gemm3_raw(vv_ctx* ctx, void* stream, const void* w_packed_dev, const void* w2_packed_dev, const float* x_dev, int T, int N, int K,
                  int epi, const float* nw_dev, float eps, const float* bias_dev, float* y_dev, void* xp_scratch, void* yp_scratch);
 /* hipEvent timing of every GEMM launch issued between begin and end (graphs are bypassed meanwhile):
  * number of launches, summed kernel time, summed algorithmic bytes (packed weights once + activations

@@ -250,6 +250,52 @@ def test_one_pass_prefill_of_10922_rows_at_7b_widths():
         eng.close()
 
 
+# ---------------------------------------------------------------------------------------------- (c2) the GEMM's K-split partial round
+@pytest.mark.parametrize("epi", [0, 1, 4, 3])
+@pytest.mark.parametrize("T,N,K", [(4100, 4112, 2080), (4352, 4096, 2048), (1100, 8200, 1024)])
+def test_prefill_gemm4_k_split_round(epi, T, N, K):
+    """vv_gemm4_kernel with the tiles past its last whole round of 256 workgroups split along K (prefill.hip): the contributors'
+    partial accumulators travel through the workspace (write-through + arrival word), the last part adds them in part order
+    and runs the epilogue.  Shapes: 289 tiles with ragged T / N and an odd k-tile count (XCD 0 has one more remainder tile than the
+    others: the early-exit path), 272 tiles (2 remainder tiles per XCD, split 4), 5 x 65 (SwiGLU: 5 x 129) tiles.  Against the
+    bf16-rounded-activation reference at the bounds of test_prefill_gemm3, against the unsplit kernel (summation order only),
+    and launched twice (the arrival words are reset by the consumer)."""
+    s = build_fast(GEOM["0.5b"], xsplit=1, max_ctx=128, max_rows=1024, head_layers=1)
+    eng = s.eng
+    try:
+        g = _FastGen(7700 + T + N + K + epi)
+        w = g.normal((N, K), 1.0 / np.sqrt(K))
+        w2 = g.normal((N, K), 1.0 / np.sqrt(K))
+        x = g.normal((T, K), 1.0, mat=False)
+        nw = g.vec(K, 0.1, 1.0)
+        bias = g.vec(N, 0.3)
+        y0 = g.normal((T, N), 1.0, mat=False)
+        norm = epi == 1
+        xin = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-5) * nw if norm else x
+        x16 = synth.bf16_round(xin)
+        mm = lambda a, b: (a.to(eng.device, torch.float64) @ b.to(eng.device, torch.float64).t()).float().cpu()   # reference only
+        a16 = mm(x16, w)
+        ref16 = {0: a16, 1: a16 + bias, 4: y0 + a16, 3: torch.nn.functional.silu(a16) * (mm(x16, w2) if epi == 3 else 0.0)}[epi]
+        wp, w2p = eng.pack_matrix(w), (eng.pack_matrix(w2) if epi == 3 else None)
+        xd = dev(x, eng)
+        outs = []
+        for ksplit in (True, True, False):
+            y = dev(y0.clone(), eng)
+            with torch.cuda.stream(eng.stream):
+                eng.gemm3_raw(wp, xd, y, N, K, epi=epi, w2p=w2p, nw=dev(nw, eng) if norm else None, eps=1e-5,
+                              bias=dev(bias, eng) if epi == 1 else None, ksplit=ksplit)
+            eng.sync()
+            outs.append(y.float().cpu())
+        tight = 3e-3 if epi == 3 else 2e-4
+        for y in outs:
+            assert rel_err(y, ref16) <= tight, (rel_err(y, ref16), tight)
+            assert float((y - ref16).abs().max()) <= 4 * tight * float(ref16.abs().max()), float((y - ref16).abs().max())
+        assert torch.equal(outs[0], outs[1])                                   # deterministic: fixed part order
+        assert rel_err(outs[0], outs[2]) <= (3e-3 if epi == 3 else 2e-6), rel_err(outs[0], outs[2])
+    finally:
+        eng.close()
+
+
 # ---------------------------------------------------------------------------------------------- (d) bf16-input references
 @pytest.mark.parametrize("L0,chunk,heads,kv_heads,hd", [(4180, 512, 4, 2, 128), (1000, 1024, 7, 1, 128), (1555, 1024, 14, 2, 64), (90, 128, 4, 2, 128)])
 def test_prefill_attention_v3_against_the_bf16_input_oracle(L0, chunk, heads, kv_heads, hd):

@@ -59,7 +59,7 @@ _SIGS = {
     "vv_pack_matrix": (C.c_int, [_P, _P, _P, C.c_int, C.c_int]),
     "vv_gemm_raw": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                               _P, C.c_float, _P, _P, C.c_int, C.c_int, C.c_int]),
-    "vv_gemm3_raw": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_float, _P, _P, _P, _P]),
+    "vv_gemm3_raw": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_float, _P, _P, _P, _P]),
     "vv_profile_begin": (C.c_int, [_P]),
     "vv_profile_end": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "vv_profile_replay": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

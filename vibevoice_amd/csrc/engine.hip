@@ -80,7 +80,7 @@ int vv_gemv16p_launch(const void* W, const void* W2, const void* Xp, float* Y, v
                       int T, int N, int K, int ldy, int ld_gate, int epi, hipStream_t s);
 int vv_ada_pack_launch(const float* cproj, const float* temb, void* xp, int rows, int n_steps, int H, hipStream_t s);
 int vv_gemm3_launch(const void* W, const void* W2, const void* Xp, float* Y, void* Yp, const float* bias, int T, int N, int K,
-                    int ldy, int epi, hipStream_t s);
+                    int ldy, int epi, const VVGemmWs* ws, hipStream_t s);
 int vv_attn_prefill3_launch(int D, const float* q, const VVRow* rows, const void* kc, const void* vc, int R, int Hq, int Hkv,
                             int64_t cache_stride, int64_t head_stride, float* out, hipStream_t s);
 int vv_block1d_supported(int C);
@@ -192,6 +192,7 @@ struct vv_ctx {
     float *h_parts = nullptr, *xh_parts = nullptr;     // K-split partial tensors of the residual streams (2 x [rows][H] each)
     void *xp = nullptr, *actp = nullptr;               // prefill (prefill.hip): activations as packed bf16 MFMA fragments
     bool tile3_ok = false, attn2_ok = false;
+    VVGemmWs gws = {nullptr, nullptr, nullptr};         // K-split workspace of the long-prompt GEMM (null: never split)
     // batch decode (5..16 rows, bf16 mode): activations packed once per op into one 16-row fragment tile (gemv16p.hip)
     void *p16_x = nullptr, *p16_act = nullptr; bool p16_ok = false;
     float *pm = nullptr, *pl = nullptr, *po = nullptr;
@@ -867,6 +868,12 @@ extern "C" int vv_create(const vv_config* cfg, vv_ctx** out) {
         ctx->xp = dalloc(ctx, (size_t)vv_packed_elems(R, std::max(H, Hq * D)) * 2);
         ctx->actp = dalloc(ctx, (size_t)vv_packed_elems(R, I) * 2);
         ctx->tile3_ok = c.xsplit == 1;
+        if (ctx->tile3_ok && R >= 1024) {              // prompts long enough for the 256 x 256 GEMM: its partial round is split along K
+            ctx->gws.partials = (float*)dalloc(ctx, (size_t)256 * 32 * 512 * 16, false);
+            ctx->gws.flags = (unsigned*)dalloc(ctx, 256 * sizeof(unsigned));
+            if (hipHostMalloc((void**)&ctx->gws.err, sizeof(unsigned), hipHostMallocMapped) == hipSuccess && ctx->gws.err) *ctx->gws.err = 0u;
+            else ctx->gws.err = nullptr;
+        }
     }
     ctx->attn2_ok = c.xsplit == 1;
     if (c.xsplit == 1 && R > 4 && (H % 32) == 0 && ((Hq * D) % 32) == 0 && (I % 32) == 0) {
@@ -943,6 +950,7 @@ extern "C" void vv_destroy(vv_ctx* ctx) {
     ctx->allocs.clear();
     if (ctx->stage) hipFree(ctx->stage);
     hipHostFree(ctx->rows_pin); hipHostFree(ctx->ids_pin);
+    if (ctx->gws.err) hipHostFree(ctx->gws.err);
     for (int i = 0; i < vv_ctx::RING; ++i) if (ctx->ring_ev[i]) hipEventDestroy(ctx->ring_ev[i]);
     delete ctx;
 }
@@ -1129,15 +1137,15 @@ static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float*
             char* vl = (char*)ctx->vc + (size_t)l * ctx->layer_stride * 2;
             ctx->launches += 9;
             VVCHK(vv_pack_rows_launch(ctx->h, H, L.ln1, c.lm_eps, ctx->xp, R, H, st));
-            VVCHK(vv_gemm3_launch(L.wqkv, nullptr, ctx->xp, ctx->qkv, nullptr, L.bqkv, R, QKV, H, QKV, VV_EPI_BIAS, st));
+            VVCHK(vv_gemm3_launch(L.wqkv, nullptr, ctx->xp, ctx->qkv, nullptr, L.bqkv, R, QKV, H, QKV, VV_EPI_BIAS, &ctx->gws, st));
             VVCHK(vv_rope_append_launch(D, ctx->qkv, ctx->rows_dev, ctx->inv_freq, ctx->qrot, kl, vl,
                                         R, Hq, Hkv, ctx->cache_stride, ctx->head_stride, st));
             VVCHK(vv_attn_prefill3_launch(D, ctx->qrot, ctx->rows_dev, kl, vl, R, Hq, Hkv, ctx->cache_stride, ctx->head_stride, ctx->attn, st));
             VVCHK(vv_pack_rows_launch(ctx->attn, Hq * D, nullptr, 0.f, ctx->xp, R, Hq * D, st));
-            VVCHK(vv_gemm3_launch(L.wo, nullptr, ctx->xp, ctx->h, nullptr, nullptr, R, H, Hq * D, H, VV_EPI_RESID, st));
+            VVCHK(vv_gemm3_launch(L.wo, nullptr, ctx->xp, ctx->h, nullptr, nullptr, R, H, Hq * D, H, VV_EPI_RESID, &ctx->gws, st));
             VVCHK(vv_pack_rows_launch(ctx->h, H, L.ln2, c.lm_eps, ctx->xp, R, H, st));
-            VVCHK(vv_gemm3_launch(L.wg, L.wu, ctx->xp, nullptr, ctx->actp, nullptr, R, I, H, 0, VV_EPI_SWIGLU, st));
-            VVCHK(vv_gemm3_launch(L.wd, nullptr, ctx->actp, ctx->h, nullptr, nullptr, R, H, I, H, VV_EPI_RESID, st));
+            VVCHK(vv_gemm3_launch(L.wg, L.wu, ctx->xp, nullptr, ctx->actp, nullptr, R, I, H, 0, VV_EPI_SWIGLU, &ctx->gws, st));
+            VVCHK(vv_gemm3_launch(L.wd, nullptr, ctx->actp, ctx->h, nullptr, nullptr, R, H, I, H, VV_EPI_RESID, &ctx->gws, st));
         }
         ctx->launches++;
         if (final_norm) VVCHK(vv_rmsnorm_rows_launch(ctx->h, H, hidden_out, H, ctx->lm_norm, R, H, c.lm_eps, st));
@@ -1229,6 +1237,7 @@ extern "C" int vv_lm_forward_range(vv_ctx* ctx, void* stream, int n_rows, const 
     hipStream_t st = (hipStream_t)stream;
     if (l0 < 0 || l1 > ctx->c.lm_layers || l0 >= l1) return fail(ctx, "layer range [%d,%d) invalid", l0, l1);
     if (n_rows < 1 || n_rows > ctx->c.max_rows) return fail(ctx, "n_rows %d out of range [1,%d]", n_rows, ctx->c.max_rows);
+    if (ctx->gws.err && *ctx->gws.err) return fail(ctx, "prefill GEMM: a K-split hand-off timed out earlier (device state is suspect)");
     for (int i = 0; i < n_rows; ++i) {
         if (rows[i].cache < 0 || rows[i].cache >= 2 * ctx->c.n_slots) return fail(ctx, "row %d: cache id %d out of range", i, rows[i].cache);
         if (rows[i].pos < 0 || rows[i].pos >= ctx->c.max_ctx) return fail(ctx, "row %d: position %d exceeds max_ctx %d", i, rows[i].pos, ctx->c.max_ctx);
@@ -1411,7 +1420,7 @@ static int sample_body(vv_ctx* ctx, hipStream_t st, int n, const float* cond, co
         if (ctx->ada_p && total > 32 && (MODW & 3) == 0) {
             ctx->launches += 2;
             VVCHK(vv_ada_pack_launch(ctx->cproj, ctx->temb, ctx->ada_p, rows, ctx->n_steps, H, st));
-            VVCHK(vv_gemm3_launch(ctx->h_ada, nullptr, ctx->ada_p, ctx->mod_all, nullptr, nullptr, total, MODW, H, MODW, VV_EPI_STORE, st));
+            VVCHK(vv_gemm3_launch(ctx->h_ada, nullptr, ctx->ada_p, ctx->mod_all, nullptr, nullptr, total, MODW, H, MODW, VV_EPI_STORE, nullptr, st));
         } else {
         VVCHK(vv_ada_in_launch(ctx->cproj, ctx->temb, ctx->ada_in, rows, ctx->n_steps, H, st));
         ctx->launches++;
@@ -1659,12 +1668,13 @@ extern "C" int vv_gemm_raw(void* stream, const void* w, const void* w2, const fl
 }
 // tests: Y = f(X) . W^T through the prefill GEMM (prefill.hip): X fp32 [T][K] is packed (optionally RMS-normalised) into xp_scratch,
 // epi STORE/BIAS/RESID write fp32 Y [T][N]; epi SWIGLU (W = gate, W2 = up) writes packed bf16 into yp_scratch, unpacked to Y.
-extern "C" int vv_gemm3_raw(void* stream, const void* w, const void* w2, const float* x_dev, int T, int N, int K, int epi,
+extern "C" int vv_gemm3_raw(vv_ctx* ctx, void* stream, const void* w, const void* w2, const float* x_dev, int T, int N, int K, int epi,
                             const float* nw_dev, float eps, const float* bias_dev, float* y_dev, void* xp_scratch, void* yp_scratch) {
     hipStream_t st = (hipStream_t)stream;
+    if (ctx && ctx->gws.err && *ctx->gws.err) return fail(ctx, "prefill GEMM: a K-split hand-off timed out earlier (device state is suspect)");
     int r = vv_pack_rows_launch(x_dev, K, nw_dev, eps, xp_scratch, T, K, st);
     if (r) return r;
-    r = vv_gemm3_launch(w, w2, xp_scratch, y_dev, yp_scratch, bias_dev, T, N, K, N, epi, st);
+    r = vv_gemm3_launch(w, w2, xp_scratch, y_dev, yp_scratch, bias_dev, T, N, K, N, epi, ctx ? &ctx->gws : nullptr, st);
     if (r) return r;
     if (epi == VV_EPI_SWIGLU) r = vv_unpack_rows_launch(yp_scratch, y_dev, T, N, st);
     return r;

@@ -144,6 +144,13 @@ struct VVGemm3 {
     const float* bias;     // [N] or null
     int T, N, K, ldy;
     int n_blocks, t_blocks;
+    // vv_gemm4 only: the tiles past the last whole round of 256 workgroups are split along K (see the kernel)
+    int sfw;               // feature blocks per strip of the workgroup -> tile order (L2 blocking)
+    int full_idx;          // per XCD: tiles [0, full_idx) of its range are computed whole
+    int split;             // k-parts of every remaining tile (1: no split)
+    float* ws;             // partial accumulators: [256 slots][32 accumulators][512 threads] f32x4
+    unsigned* flags;       // [256] arrival words, zero between launches
+    unsigned* err;         // host-visible word: set when a wait timed out
 };
 
 __device__ __forceinline__ float g3_silu(float u) { return u / (1.0f + __expf(-u)); }
@@ -292,101 +299,107 @@ __global__ __launch_bounds__(256, TR == 8 ? 2 : 4) void vv_gemm3_kernel(const VV
     }
 }
 
-// ------------------------------------------------------------------------------------------------ GEMM, 256 x 256 tile
-// The long-prompt form of vv_gemm3_kernel.  What bounds the 128-feature kernel above is not LDS bandwidth or the MFMA pipe but
-// the ~1.3 us a stage's LDS-DMA copies take to land: it waits for every stage in full and hides the wait only behind the other
-// one or three workgroups of its CU (MfmaUtil 45 % on gate/up).  Here a workgroup owns 256 features x 256 rows (8 waves as
-// 2 x 4, 128 x 64 each: 32 accumulators), a K step of 64 is a 64 KiB stage and carries 2048 MFMA cycles per SIMD -- more than
-// the copy latency -- and there are two stage buffers: stage s+1 is in flight while stage s is multiplied.  One barrier per
-// stage; every DMA has been waited for when the barrier is reached, so the plain __syncthreads() stays a bare s_barrier.
-// SwiGLU: the 256 weight rows are 128 gate + 128 up features, the workgroup emits 128 output features.
+// workgroup -> (feature block, row block) of the 256 x 256 kernels, XCD-major (see vv_gemm3_kernel), plus the K-split of the
+// partial last round: part < 0: a whole tile; else this workgroup's k-part of a split tile, slot0 = the tile's first partial slot.
+// Returns false for the padding workgroups of XCDs whose range is one tile shorter (split region only).
+__device__ __forceinline__ bool g4_map(const VVGemm3& a, int& nb, int& tb, int& part, int& slot0) {
+    const int split = a.split;
+    part = 0; slot0 = 0;
+    const int total = a.n_blocks * a.t_blocks;
+    const int bid = blockIdx.x;
+    const int q = total >> 3, r = total & 7;
+    int xcd, idx;
+    if (split <= 1 || bid < 8 * a.full_idx) {
+        xcd = bid & 7; idx = bid >> 3;
+        part = -1;
+    } else {
+        // the last, partial round: `split` consecutive workgroups of an XCD share one tile, each takes 1/split of K; the
+        // LAST of them (highest id: dispatched after the others, so what it waits for is already running) adds the others'
+        // partial accumulators in part order and runs the epilogue
+        const int b2 = bid - 8 * a.full_idx;
+        xcd = b2 & 7;
+        const int j = b2 >> 3, tr = j / split;
+        part = j - tr * split;
+        idx = a.full_idx + tr;
+        slot0 = xcd * 32 + tr * (split - 1);
+    }
+    if (idx >= q + (xcd < r ? 1 : 0)) return false;
+    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    // lin -> tile in STRIP order: strips of `sfw` feature blocks, inside a strip row block by row block.  The ~32 workgroups an
+    // XCD runs at any time are consecutive lin = sfw feature blocks x 32 / sfw row blocks: per K stage its L2 fetches sfw weight
+    // slabs + 32 / sfw activation slabs instead of 1 + 32 (feature-major order: every workgroup's activation rows came over
+    // the fabric -- 12.0 GB of L2 misses per 7B gate/up GEMM at T = 10,922, 4.8 TB/s: the kernel was fabric-bound).
+    const int sfw = a.sfw;
+    const int strip = sfw * a.t_blocks;
+    int sf = lin / strip;
+    const int n_sf = (a.n_blocks + sfw - 1) / sfw;
+    if (sf > n_sf - 1) sf = n_sf - 1;
+    const int wdt = (sf == n_sf - 1) ? a.n_blocks - sf * sfw : sfw;      // the last strip may be narrower
+    const int rem = lin - sf * strip;
+    tb = rem / wdt;
+    nb = sf * sfw + (rem - tb * wdt);
+    return true;
+}
+
+// what follows the K loop of a 256 x 256 workgroup (8 waves as 2 x 4: features wf * 128.., rows wr * 64..): the hand-over of a
+// split tile's partial accumulators, then the epilogue.  Lane holds D[n = tile*16 + fq*4 + r][t = ttile*16 + frow].
 template <int EPI>
-__global__ __launch_bounds__(512, 1) void vv_gemm4_kernel(const VVGemm3 a) {
+__device__ __forceinline__ void g4_finish(const VVGemm3& a, f32x4 (&acc)[8][4], int part, int slot0, int ft0, int tt0, int wf, int wr) {
     constexpr bool DUAL = (EPI == VV_EPI_SWIGLU);
-    constexpr int FT = DUAL ? 8 : 16;              // feature tiles (per matrix) per workgroup
-    constexpr int STAGE = 64 * 1024;               // 32 A fragments then 32 B fragments: [frag][64 lanes][16 B]
-    extern __shared__ __attribute__((aligned(16))) unsigned char ring[];      // 2 stages
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 15, fq = lane >> 4;
-    const int KT = (a.K + 31) >> 5;
     const int n_tiles = (a.N + 15) >> 4, t_tiles = (a.T + 15) >> 4;
-    int nb, tb;
-    {   // XCD-major order over (feature block, row block): see vv_gemm3_kernel
-        const int total = a.n_blocks * a.t_blocks;
-        const int bid = blockIdx.x;
-        const int xcd = bid & 7, idx = bid >> 3;
-        const int q = total >> 3, r = total & 7;
-        const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        nb = lin / a.t_blocks;
-        tb = lin - nb * a.t_blocks;
-    }
-    const int ft0 = nb * FT, tt0 = tb * 16;
-    const int wf = wave & 1, wr = wave >> 1;       // features wf * 128 .. (DUAL: gate/up slots of half wf), rows wr * 64 ..
-    // loader: wave w copies fragments 8w .. 8w+7 of the 64.  f < 32: A slot f >> 1, k-tile f & 1; else B row tile (f - 32) >> 1
-    const u32x4* src[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int f = wave * 8 + i;
-        if (f < 32) {
-            const int slot = f >> 1;
-            const u32x4* base = (DUAL && slot >= 8) ? a.W2 : a.W;
-            int ft = ft0 + (DUAL ? (slot & 7) : slot);
-            if (ft > n_tiles - 1) ft = n_tiles - 1;
-            src[i] = base + (int64_t)ft * KT * 64 + lane;
-        } else {
-            int tt = tt0 + ((f - 32) >> 1);
-            if (tt > t_tiles - 1) tt = t_tiles - 1;
-            src[i] = a.Xp + (int64_t)tt * KT * 64 + lane;
-        }
-    }
-    auto issue = [&](int s, int b) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int f = wave * 8 + i;
-            int kt = s * 2 + (f & 1);
-            if (kt > KT - 1) kt = KT - 1;                              // odd K tail: re-reads the last k-tile, MFMA skipped
-            glds16(src[i] + (int64_t)kt * 64, ring + b * STAGE + f * 1024);
-        }
-    };
-    f32x4 acc[8][4];                               // [feature tile of this wave][row tile of this wave]
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int n_steps = (KT + 1) >> 1;
-    issue(0, 0);
-#pragma unroll 1
-    for (int s = 0; s < n_steps; ++s) {
-        stage_sync();                                                 // stage s has landed for every wave; stage s-1 is read out
-        if (s + 1 < n_steps) issue(s + 1, (s + 1) & 1);
-        const unsigned char* st = ring + (s & 1) * STAGE;
-        // both k-tiles' fragments are requested before the first MFMA (two register sets): the second tile's LDS reads run under
-        // the first tile's 32 MFMAs instead of one read -> wait -> 4 MFMAs chains on a single fragment register
-        bf16x8 af[2][8], bfr[2][4];
-        const bool two = s * 2 + 1 < KT;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            if (kk == 1 && !two) break;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int slot = DUAL ? ((i < 4) ? (wf * 4 + i) : (8 + wf * 4 + (i - 4))) : (wf * 8 + i);
-                af[kk][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(st + ((slot * 2 + kk) * 64 + lane) * 16));
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                bfr[kk][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(st + ((32 + (wr * 4 + j) * 2 + kk) * 64 + lane) * 16));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            if (kk == 1 && !two) break;
+    const int split = a.split;
+    if (part >= 0) {
+        // ---- split tile: hand the partial accumulators over (cdna_hip_programming.md, Guideline 16: write-through payload,
+        // drained by every wave, one agent-scope arrival word per contributor; the consumer polls relaxed, acquires once) ----
+        constexpr size_t SLOT = (size_t)32 * 512 * 4;                 // floats per partial slot
+        const unsigned voff = (unsigned)tid * 16u;                      // byte offset of this thread inside one accumulator plane
+        if (part < split - 1) {
+            const char* sbase = reinterpret_cast<const char*>(a.ws + (size_t)(slot0 + part) * SLOT);      // wave-uniform
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][i], bfr[kk][j], acc[i][j], 0, 0, 0);
+                    asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(voff), "v"(acc[i][j]), "s"(sbase + (size_t)(i * 4 + j) * 8192) : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                __hip_atomic_store(a.flags + slot0 + part, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
         }
+        if (tid < 64) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            for (int p = 0; p < split - 1; ++p) {
+                for (;;) {
+                    if (__hip_atomic_load(a.flags + slot0 + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                    __builtin_amdgcn_s_sleep(16);
+                    if ((unsigned long long)(__builtin_amdgcn_s_memrealtime() - t0) > 20000000ull) {      // 200 ms of the 100 MHz clock
+                        if (tid == 0) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int p = 0; p < split - 1; ++p) {
+            const char* sbase = reinterpret_cast<const char*>(a.ws + (size_t)(slot0 + p) * SLOT);        // wave-uniform
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                f32x4 v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(v[j]) : "v"(voff), "s"(sbase + (size_t)(i * 4 + j) * 8192) : "memory");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] += v[j];
+            }
+        }
+        if (tid < split - 1) __hip_atomic_store(a.flags + slot0 + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     }
     // ---- epilogue: lane holds D[n = tile*16 + fq*4 + r][t = ttile*16 + frow] ----
     if constexpr (DUAL) {
@@ -438,6 +451,154 @@ __global__ __launch_bounds__(512, 1) void vv_gemm4_kernel(const VVGemm3 a) {
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------ GEMM, 256 x 256 tile
+// The long-prompt form of vv_gemm3_kernel: a workgroup owns 256 features x 256 rows (8 waves as 2 x 4, 128 x 64 each: 32
+// accumulators; SwiGLU: 128 gate + 128 up features -> 128 output features), K in 32-wide stages through a 4-slot ring of
+// 32 KiB (16 A + 16 B fragments per slot, LDS-DMA).  The workgroup's two halves (waves 0-3 / 4-7: one wave of each per SIMD)
+// run in ANTI-PHASE (MI355X_MICROARCH.md, "Two waves per SIMD"): while one half issues the 32 MFMAs of a stage from fragment
+// registers, the other reads ITS fragments of the stage it computes next and issues its share of the DMA four stages ahead;
+// one barrier per phase, two phases per stage:
+//   phase 2q    half 0: MFMAs of stage q                      half 1: read fragments(q), DMA pieces of stage q-1+4
+//   phase 2q+1  half 0: read fragments(q+1), DMA(q+4)         half 1: MFMAs of stage q
+//   landing  at the end of every even phase each wave waits until at most 2 of its 4-piece stages are in flight (vmcnt),
+//            i.e. stage q+1 has landed; the barrier then makes that true for all waves' pieces.
+//   reuse    the slot of stage q is last read in phase 2q (half 1) and refilled in phase 2q+1 (half 0) / 2q+2 (half 1).
+// DMA past the k range re-reads the last k-tile (keeps the vmcnt bookkeeping uniform; nobody reads those slots).
+// Round 2's form of this kernel (one 64-wide stage per barrier, two 64 KiB buffers, all 8 waves issuing DMA -> fragment reads
+// -> MFMAs in step) left the matrix pipe idle while both waves of a SIMD loaded; this schedule, bit-identical results, is
+// 7-17 % faster per launch at T = 10,922 (tools/experiments/gemm_pingpong, profiles/r03_gemm_pingpong_ab*.json).  The same
+// A/B measured three more schedules (fragment reads / DMA interleaved into the MFMA stream with one barrier per stage;
+// register-staged fills instead of LDS-DMA) within a few % of each other and slower: under these GEMMs the package sits at
+// its 1.4 kW limit with the shader clock at ~1.9 GHz (rocm-smi while the kernel loops), so what pays is activity removed per
+// flop (the strip order of g4_map: 12 -> 4.4 GB of L2 misses per gate/up launch), not a denser issue pattern.
+// a bare s_barrier that nothing is scheduled across (the phases ARE the schedule: MFMAs must stay between their two barriers)
+__device__ __forceinline__ void pp_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+// explicit waits as the builtin (the compiler's own counter bookkeeping sees them; an asm wait is invisible to it and it then
+// guards the first use of already-waited-for fragments with a full lgkmcnt(0)).  gfx9 encoding: vmcnt [3:0] + [15:14],
+// expcnt [6:4], lgkmcnt [11:8]; a field of all ones = no wait on that counter.
+template <int N> __device__ __forceinline__ void pp_vmcnt() {
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void pp_lgkm0() {
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    asm volatile("" ::: "memory");
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void vv_gemm4_kernel(const VVGemm3 a) {
+    constexpr int NSLOT = 4;
+    constexpr bool DUAL = (EPI == VV_EPI_SWIGLU);
+    constexpr int FT = DUAL ? 8 : 16;
+    constexpr int SLOT = 32 * 1024;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ring[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int KT = (a.K + 31) >> 5;
+    const int n_tiles = (a.N + 15) >> 4, t_tiles = (a.T + 15) >> 4;
+    int nb, tb, part, slot0;
+    if (!g4_map(a, nb, tb, part, slot0)) return;
+    const int split = a.split;
+    const int ft0 = nb * FT, tt0 = tb * 16;
+    const int wf = wave & 1, wr = wave >> 1;
+    const int half = wave >> 2;
+    // k range, in the 64-wide steps vv_gemm4 splits by (both kernels cut a split tile at the same k)
+    const int n_steps = (KT + 1) >> 1;
+    const int s0 = part < 0 ? 0 : (int)((int64_t)part * n_steps / split);
+    const int s1 = part < 0 ? n_steps : (int)((int64_t)(part + 1) * n_steps / split);
+    const int kt0 = s0 * 2, kt1 = (s1 * 2 < KT) ? s1 * 2 : KT;
+    const int n = kt1 - kt0;                       // stages (k-tiles) of this workgroup
+    // loader: wave w copies pieces 4w .. 4w+3 of a stage's 32.  f < 16: A slot f (DUAL: 0-7 gate, 8-15 up); else B row tile f - 16
+    const u32x4* src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = wave * 4 + i;
+        if (f < 16) {
+            const u32x4* base = (DUAL && f >= 8) ? a.W2 : a.W;
+            int ft = ft0 + (DUAL ? (f & 7) : f);
+            if (ft > n_tiles - 1) ft = n_tiles - 1;
+            src[i] = base + ((int64_t)ft * KT + kt0) * 64 + lane;
+        } else {
+            int tt = tt0 + (f - 16);
+            if (tt > t_tiles - 1) tt = t_tiles - 1;
+            src[i] = a.Xp + ((int64_t)tt * KT + kt0) * 64 + lane;
+        }
+    }
+    auto issue = [&](int g, int slot) {            // stage g (k-tile kt0 + g, clamped) into ring slot `slot`
+        const int gg = g < n - 1 ? g : n - 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(src[i] + (int64_t)gg * 64, ring + slot * SLOT + (wave * 4 + i) * 1024);
+    };
+    bf16x8 af[8], bfr[4];
+    auto read = [&](int slot) {
+        const unsigned char* st = ring + slot * SLOT;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int sl = DUAL ? ((i < 4) ? (wf * 4 + i) : (8 + wf * 4 + (i - 4))) : (wf * 8 + i);
+            af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(st + (sl * 64 + lane) * 16));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(st + ((16 + wr * 4 + j) * 64 + lane) * 16));
+    };
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto compute = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    };
+#pragma unroll
+    for (int g = 0; g < NSLOT; ++g) issue(g, g);
+    pp_vmcnt<(NSLOT - 1) * 4>();
+    pp_barrier();                                                     // stage 0 has landed
+    // two straight-line loops (same barrier count): a branch on the half around the MFMAs inside ONE loop makes the 128
+    // accumulator registers phi values and the allocator spills them
+    if (half == 0) {
+        read(0);
+        pp_lgkm0();
+        int sq = 0;                                                   // ring slot of stage q
+#pragma unroll 1
+        for (int q = 0; q < n; ++q) {
+            const int sq1 = (sq + 1 == NSLOT) ? 0 : sq + 1;
+            compute();                                                // phase 2q
+            pp_vmcnt<(NSLOT - 2) * 4>();
+            pp_barrier();
+            if (q + 1 < n) read(sq1);                                 // phase 2q + 1
+            issue(q + NSLOT, sq);
+            pp_lgkm0();
+            pp_barrier();
+            sq = sq1;
+        }
+    } else {
+        int sq = 0;
+#pragma unroll 1
+        for (int q = 0; q < n; ++q) {
+            const int sq1 = (sq + 1 == NSLOT) ? 0 : sq + 1;
+            const int sqm = (sq == 0) ? NSLOT - 1 : sq - 1;           // slot of stage q - 1, refilled with stage q - 1 + NSLOT
+            read(sq);                                                 // phase 2q
+            if (q >= 1) issue(q - 1 + NSLOT, sqm);
+            pp_lgkm0();
+            pp_vmcnt<(NSLOT - 2) * 4>();
+            pp_barrier();
+            compute();                                                // phase 2q + 1
+            pp_barrier();
+            sq = sq1;
+        }
+    }
+    pp_vmcnt<0>();                                                    // no DMA may land in an LDS allocation that has been released
+    g4_finish<EPI>(a, acc, part, slot0, ft0, tt0, wf, wr);
 }
 
 // ------------------------------------------------------------------------------------------------ prefill attention
@@ -764,15 +925,17 @@ int vv_ada_pack_launch(const float* cproj, const float* temb, void* xp, int rows
 }
 
 int vv_gemm3_launch(const void* W, const void* W2, const void* Xp, float* Y, void* Yp, const float* bias, int T, int N, int K,
-                    int ldy, int epi, hipStream_t s) {
+                    int ldy, int epi, const VVGemmWs* ws, hipStream_t s) {
     if (T < 1 || N < 1 || K < 32 || (N & 3)) return -1;
     VVGemm3 a;
     a.W = (const u32x4*)W; a.W2 = (const u32x4*)W2; a.Xp = (const u32x4*)Xp; a.Y = Y; a.Yp = (u32x4*)Yp; a.bias = bias;
     a.T = T; a.N = N; a.K = K; a.ldy = ldy;
+    a.full_idx = 0; a.split = 1; a.ws = nullptr; a.flags = nullptr; a.err = nullptr; a.sfw = 4;
     const int n_tiles = (N + 15) / 16;
-    // long prompts: the 256 x 256 double-buffered kernel whenever its grid fills the chip at least once; smaller problems keep
-    // the 128-feature kernel, whose tiles quantise better.  Measured per launch at T = 10,922 (7B layer): gate/up 3188 -> 2460 us,
-    // down 1751 -> 1460, o 432 -> 343, qkv 518 -> 416.
+    // long prompts: the 256 x 256 kernel whenever its grid fills the chip at least once; smaller problems keep the 128-feature
+    // kernel, whose tiles quantise better.  Per launch at T = 10,922 (7B layer), 128-feature kernel -> round-2 256 x 256 ->
+    // round-3 schedule + strip order + K-split: gate/up 3188 -> 2650 -> 2350 us, down 1751 -> 1470 -> 1390, qkv 518 -> 404 -> 315,
+    // o 432 -> 340 -> 271.
     const int64_t wgs4 = (int64_t)((n_tiles + ((epi == VV_EPI_SWIGLU) ? 8 : 16) - 1) / ((epi == VV_EPI_SWIGLU) ? 8 : 16)) * ((T + 255) / 256);
     if (wgs4 >= 256 &&
         (epi == VV_EPI_SWIGLU || epi == VV_EPI_RESID || epi == VV_EPI_BIAS || epi == VV_EPI_STORE)) {
@@ -781,7 +944,29 @@ int vv_gemm3_launch(const void* W, const void* W2, const void* Xp, float* Y, voi
         a.t_blocks = (T + 255) / 256;
         if (epi == VV_EPI_SWIGLU && (!W2 || !Yp)) return -1;
         if (epi != VV_EPI_SWIGLU && (!Y || (ldy & 3))) return -1;
-        const dim3 grid4((unsigned)(a.n_blocks * a.t_blocks));
+        // One workgroup per CU (128 KiB of LDS): the grid runs in rounds of 256 and the tiles past the last whole round (T =
+        // 10,922 at 7B widths: 602 tiles for down / o = 2.35 rounds, 774 for QKV = 3.02) cost most of a round however few they
+        // are.  Each XCD's share of that remainder (<= 32 tiles) is split along K by the largest factor that still fits one
+        // round (g4_map / g4_finish).  Measured (tools/experiments/gemm_pingpong): it pays when the remainder is a handful of
+        // tiles (QKV: split 7, -6 %) or the parts stay long (down: K = 18,944 halved, -3.5 %); halving K = 3584 tiles does not
+        // (o: +6 %; gate/up: neutral) -- a partial round is not a lost round on this chip: the package is at its power limit
+        // under these kernels and the clock rises when fewer CUs compute -- so those launches stay whole.
+        unsigned n_wgs = (unsigned)(a.n_blocks * a.t_blocks);
+        if (ws && ws->partials && ws->flags && ws->err) {
+            const int total = a.n_blocks * a.t_blocks, q = total >> 3, r = total & 7;
+            const int full_idx = (total / 256) * 32;
+            const int max_rem = q + (r ? 1 : 0) - full_idx;           // 0..32 tiles per XCD in the partial round
+            const int n_steps = ((K + 31) / 32 + 1) / 2;
+            int split = max_rem > 0 ? 32 / max_rem : 1;
+            if (split > 8) split = 8;
+            if (split > n_steps / 8) split = n_steps / 8;             // a part keeps >= 8 of the 64-wide steps
+            if (split == 2 && n_steps < 256) split = 1;               // halves of a short K: see above
+            if (split > 1) {
+                a.full_idx = full_idx; a.split = split; a.ws = ws->partials; a.flags = ws->flags; a.err = ws->err;
+                n_wgs = (unsigned)(8 * full_idx + 8 * max_rem * split);
+            }
+        }
+        const dim3 grid4(n_wgs);
         static bool attr4 = false;
         if (!attr4) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_gemm4_kernel<VV_EPI_SWIGLU>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -789,7 +974,7 @@ int vv_gemm3_launch(const void* W, const void* W2, const void* Xp, float* Y, voi
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_gemm4_kernel<VV_EPI_BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr4 = true;
         }
-        const size_t smem4 = 2 * 64 * 1024;
+        const size_t smem4 = 4 * 32 * 1024;
         if (epi == VV_EPI_SWIGLU) hipLaunchKernelGGL((vv_gemm4_kernel<VV_EPI_SWIGLU>), grid4, dim3(512), smem4, s, a);
         else if (epi == VV_EPI_RESID) hipLaunchKernelGGL((vv_gemm4_kernel<VV_EPI_RESID>), grid4, dim3(512), smem4, s, a);
         else hipLaunchKernelGGL((vv_gemm4_kernel<VV_EPI_BIAS>), grid4, dim3(512), smem4, s, a);

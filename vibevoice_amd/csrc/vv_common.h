@@ -27,6 +27,13 @@ struct VVRow {
     int pos;     // position of this token == cache length before the append
 };
 
+// ---- workspace of the prefill GEMM's K-split partial round (prefill.hip: vv_gemm4_kernel) ----
+struct VVGemmWs {
+    float* partials;     // 256 slots x 256 KiB (a workgroup's 32 accumulators x 512 threads x f32x4)
+    unsigned* flags;     // 256 arrival words, zero whenever no launch is in flight
+    unsigned* err;       // host-mapped word, set by a wait that timed out
+};
+
 // ---- generic skinny GEMM -----------------------------------------------------
 // Y[t][n] (op)= sum_k f(X[t][k]) * W[n][k]
 enum { VV_PRO_NONE = 0, VV_PRO_RMS = 1, VV_PRO_RMS_MOD = 2, VV_PRO_ADD_SILU = 3 };

@@ -401,13 +401,13 @@ class Engine:
         self.sync()
         return out
 
-    def gemm3_raw(self, wp, x, y, N, K, epi=0, w2p=None, nw=None, eps=1e-6, bias=None):
-        """the prefill GEMM (prefill.hip) on fp32 rows x [T, K] -> y [T, N]"""
+    def gemm3_raw(self, wp, x, y, N, K, epi=0, w2p=None, nw=None, eps=1e-6, bias=None, ksplit=True):
+        """the prefill GEMM (prefill.hip) on fp32 rows x [T, K] -> y [T, N]; ksplit=False computes every tile whole"""
         T = x.shape[0]
         xp = torch.zeros(int(self.lib.vv_packed_bytes(T, K)), dtype=torch.uint8, device=self.device)
         yp = torch.zeros(int(self.lib.vv_packed_bytes(T, N)), dtype=torch.uint8, device=self.device)
         torch.cuda.synchronize(self.device)
-        rc = self.lib.vv_gemm3_raw(self._s, self._p(wp), self._p(w2p), self._p(x), T, N, K, epi, self._p(nw), float(eps),
+        rc = self.lib.vv_gemm3_raw(self._ctx if ksplit else None, self._s, self._p(wp), self._p(w2p), self._p(x), T, N, K, epi, self._p(nw), float(eps),
                                    self._p(bias), self._p(y), self._p(xp), self._p(yp))
         if rc != 0:
             raise EngineError(f"vv_gemm3_raw failed ({rc})")
