@@ -81,7 +81,7 @@ int vv_gemv16p_launch(const void* W, const void* W2, const void* Xp, float* Y, v
 int vv_ada_pack_launch(const float* cproj, const float* temb, void* xp, int rows, int n_steps, int H, hipStream_t s);
 int vv_gemm3_launch(const void* W, const void* W2, const void* Xp, float* Y, void* Yp, const float* bias, int T, int N, int K,
                     int ldy, int epi, const VVGemmWs* ws, hipStream_t s);
-int vv_attn_prefill3_launch(int D, const float* q, const VVRow* rows, const void* kc, const void* vc, int R, int Hq, int Hkv,
+int vv_attn_prefill4_launch(int D, const float* q, const VVRow* rows, const void* kc, const void* vc, int R, int Hq, int Hkv,
                             int64_t cache_stride, int64_t head_stride, float* out, hipStream_t s);
 int vv_block1d_supported(int C);
 int vv_gemv_ok(const VVGemm* a);
@@ -1140,7 +1140,7 @@ static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float*
             VVCHK(vv_gemm3_launch(L.wqkv, nullptr, ctx->xp, ctx->qkv, nullptr, L.bqkv, R, QKV, H, QKV, VV_EPI_BIAS, &ctx->gws, st));
             VVCHK(vv_rope_append_launch(D, ctx->qkv, ctx->rows_dev, ctx->inv_freq, ctx->qrot, kl, vl,
                                         R, Hq, Hkv, ctx->cache_stride, ctx->head_stride, st));
-            VVCHK(vv_attn_prefill3_launch(D, ctx->qrot, ctx->rows_dev, kl, vl, R, Hq, Hkv, ctx->cache_stride, ctx->head_stride, ctx->attn, st));
+            VVCHK(vv_attn_prefill4_launch(D, ctx->qrot, ctx->rows_dev, kl, vl, R, Hq, Hkv, ctx->cache_stride, ctx->head_stride, ctx->attn, st));
             VVCHK(vv_pack_rows_launch(ctx->attn, Hq * D, nullptr, 0.f, ctx->xp, R, Hq * D, st));
             VVCHK(vv_gemm3_launch(L.wo, nullptr, ctx->xp, ctx->h, nullptr, nullptr, R, H, Hq * D, H, VV_EPI_RESID, &ctx->gws, st));
             VVCHK(vv_pack_rows_launch(ctx->h, H, L.ln2, c.lm_eps, ctx->xp, R, H, st));
@@ -1186,7 +1186,7 @@ static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float*
             VVCHK(vv_rope_append_launch(D, ctx->qkv, ctx->rows_dev, ctx->inv_freq, ctx->qrot, kl, vl,
                                         R, Hq, Hkv, ctx->cache_stride, ctx->head_stride, st));
             if (contiguous && ctx->attn2_ok)      // prompt chunk, bf16 mode: 64 query rows x all heads of the group share every K/V block
-                VVCHK(vv_attn_prefill3_launch(D, ctx->qrot, ctx->rows_dev, kl, vl, R, Hq, Hkv, ctx->cache_stride, ctx->head_stride, ctx->attn, st));
+                VVCHK(vv_attn_prefill4_launch(D, ctx->qrot, ctx->rows_dev, kl, vl, R, Hq, Hkv, ctx->cache_stride, ctx->head_stride, ctx->attn, st));
             else {
                 // ragged row sets (the streaming model's text windows) and the prompt chunks of the exact modes (xsplit 2, 3): the
                 // split + merge pair, at most ws_rows rows per launch (its partial buffers); every row attends its own causal prefix

@@ -602,20 +602,6 @@ __global__ __launch_bounds__(512, 1) void vv_gemm4_kernel(const VVGemm3 a) {
 }
 
 // ------------------------------------------------------------------------------------------------ prefill attention
-// rows = consecutive positions of ONE cache (rows[0] first); q = the rotated queries (vv_rope_append_kernel), fp32 [R][Hq][D]; the
-// softmax scale is applied here.
-// 8 waves = 4 query heads x 2 row halves, 64 positions per LDS stage.  The softmax is organised around what the rocprof / PMC
-// passes on the 7B prompt showed (the first form of this kernel -- one update per 32-position block, LDS-permute exchanges,
-// masks everywhere -- ran the MFMA pipe 18 % busy: per 32 positions a wave issued 32 MFMAs and ~200 VALU / LDS-permute
-// instructions in one dependent chain):
-//   * ONE online-softmax update per 64-position stage instead of one per 32-position block: the row maximum, the running
-//     rescale factor, the exchange across the 4 lane rows and the rescale vote are paid once per 16 scores per lane, and the
-//     32 S^T MFMAs (then the 32 P.V MFMAs) of a stage issue back to back, so the partner wave on the SIMD has a full
-//     softmax's worth of matrix work to hide under;
-//   * the cross-row maximum by v_permlane16_swap / v_permlane32_swap (gfx950 VALU lane exchanges) instead of two
-//     ds_bpermute round trips through the LDS pipe, which the K / V fragment reads already keep busy;
-//   * stages wholly below the causal diagonal (all but the last one or two of a workgroup) take a path with no -inf
-//     compares / selects: every score is finite there, exp2(-inf - m) of the very first stage is the hardware's 0.
 __device__ __forceinline__ float a3_xrow_max(float v) {
     // max over the 4 lanes that share (lane & 15): rows of 16 lanes exchanged pairwise, then the two halves of the wave.
     // NB: going through `unsigned` temporaries is deliberate -- bit-casting element 1 of the builtin's result directly reads
@@ -630,8 +616,36 @@ __device__ __forceinline__ float a3_xrow_max(float v) {
     return fmaxf(__uint_as_float(t0), __uint_as_float(t1));
 }
 
+// rows = consecutive positions of ONE cache (rows[0] first); q = the rotated queries (vv_rope_append_kernel), fp32 [R][Hq][D]; the
+// softmax scale is applied here.  A workgroup = 64 query rows x 4 query heads of one kv head, 8 waves = head x row half (two
+// 16-row tiles per wave), the causal prefix streamed ONCE, 64 positions per stage through a 4-slot LDS ring (LDS-DMA).
+// Round 2's form of this kernel (all waves in step: S^T MFMAs -> softmax -> P.V MFMAs between two barriers per stage) ran the
+// matrix pipe 31-33 % busy: both waves of a SIMD contended for it, then both for the VALU.  Here the two waves of a SIMD (w and
+// w + 4: one head's two row halves) alternate a MATRIX segment with a VALU segment, one barrier per phase (the schedule of
+// vv_gemm4_kernel; MI355X_MICROARCH.md, "Two waves per SIMD"):
+//   per wave and stage s:   V(s) = softmax of S(s) -> P(s)            M(s) = O += P(s).V(s), then S(s+1) = K(s+1) q^T
+//   phase 2s    half 0: V(s), DMA pieces of stage s+2        half 1: M(s-1)
+//   phase 2s+1  half 0: M(s)                                half 1: V(s), DMA pieces of stage s+3
+//   ring     4 slots of one stage (K fragments, then V fragments); stage s is live from S(s) of half 0 (phase 2s-1) to the V(s)
+//            fragment reads of half 1 (phase 2s+1); at the end of every even phase each wave waits until at most ONE of its
+//            stages is in flight (vmcnt), which is "stage s+1 has landed" for both halves.
+//   traffic  V(s) fragments are requested at the head of the VALU segment (they land under the softmax), each K(s+1) fragment
+//            between the P.V MFMAs, into the registers of the V fragment just multiplied: no MFMA run starts with an LDS trip.
+// and the softmax is cut to what the phase stamps showed it must be (the VALU segment was the longer one: ~1750 of a 4700-tick
+// stage, tools/experiments/attn_pingpong):
+//   * the S^T accumulators START at -m (m = the query row's reference exponent, in the MFMA's C operand), so the scores arrive
+//     as S - m and are exponentiated as they are: no subtraction per score;
+//   * LAZY rescaling: m is the row maximum of stage 0 and is raised only when a later stage exceeds it by more than 2^8 (a
+//     wave-uniform vote per stage).  P is formed relative to m -- exp2(S - m) <= 256 cannot overflow, and O / l does not depend
+//     on m -- so the common stage has no running-maximum update and no rescale of O at all;
+//   * the row sums l = sum P go through the matrix pipe (4 MFMAs per stage against an all-ones A operand) instead of 32 VALU
+//     adds per lane and a final cross-lane reduction.
+// Copies past the last stage re-read it (uniform vmcnt bookkeeping); the ragged last stage is walked whole and masked.
+// 7B prompt of 10,922 rows: 1205 -> 1035 us per layer (0.71 -> 0.83 PFLOP/s); what is left per stage: the matrix segment's own
+// MFMAs (1088 cycles) + ~25 cycles of issue per LDS fragment read + two barriers, and whichever wave loses the SIMD's
+// arbitration runs ~25 % longer (s_setprio only moves that to the other half).
 template <int D>
-__global__ __launch_bounds__(512) void vv_attn_prefill3_kernel(
+__global__ __launch_bounds__(512) void vv_attn_prefill4_kernel(
     const float* __restrict__ q, const VVRow* __restrict__ rows, const __bf16* __restrict__ kc,
     const __bf16* __restrict__ vc, int R, int Hq, int Hkv, int64_t cache_stride, int64_t head_stride,
     float* __restrict__ out) {
@@ -640,14 +654,17 @@ __global__ __launch_bounds__(512) void vv_attn_prefill3_kernel(
     constexpr int KF = 2 * KT;                       // K fragments of a 32-position block (2 position tiles x KT)
     constexpr int SF = 2 * (KF + DT);                // fragments of one 64-position stage: K of 2 blocks, then V of 2 blocks
     constexpr int BUF = SF * 1024;
-    constexpr int NW = 8;
+    constexpr int NW = 8, NS = 4;
+    constexpr int PW = SF / NW;                      // copies per wave and stage
     static_assert((2 * KF) % NW == 0 && (2 * DT) % NW == 0, "every wave copies the same number of K and of V fragments");
-    extern __shared__ __attribute__((aligned(16))) unsigned char kv[];          // 2 stages
+    static_assert(KF == DT, "K and V fragments of a block share one register set");
+    extern __shared__ __attribute__((aligned(16))) unsigned char kv[];          // NS stages
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int half = wave >> 2;
     const int qt = (int)gridDim.x - 1 - (int)blockIdx.x;                        // longest workgroups first
     const int r0 = qt * 64, kvh = blockIdx.y;
-    const int rw0 = r0 + (wave >> 2) * (RT * 16);    // first query row of this wave
+    const int rw0 = r0 + half * (RT * 16);           // first query row of this wave
     const VVRow rw = rows[0];
     const int G = Hq / Hkv;
     const int g = (int)blockIdx.z * 4 + (wave & 3);  // this wave's query head inside the group
@@ -655,25 +672,27 @@ __global__ __launch_bounds__(512) void vv_attn_prefill3_kernel(
     const int h = kvh * G + (act ? g : 0);
     const int col = lane & 15, qg = lane >> 4;
     const int pend = rw.pos + min(r0 + 63, R - 1) + 1;              // positions this tile walks: [0, pend)
-    const int n_stg = (pend + 63) >> 6;
+    const int n = (pend + 63) >> 6;                                   // stages
     const int first_masked = (rw.pos + r0) >> 6;                      // stages below this one are visible to every query row
     const u32x4* kt_base = reinterpret_cast<const u32x4*>(kc + (int64_t)rw.cache * cache_stride + (int64_t)kvh * head_stride);
     const u32x4* vt_base = reinterpret_cast<const u32x4*>(vc + (int64_t)rw.cache * cache_stride + (int64_t)kvh * head_stride);
     constexpr float LOG2E = 1.4426950408889634f;
 
-    // stage copy: wave w moves K fragments w, w + 8, .. and V fragments w, w + 8, .. of the stage (no per-fragment branches)
     const u32x4* ksrc = kt_base + wave * 64 + lane;
     const u32x4* vsrc = vt_base + wave * 64 + lane;
-    auto issue = [&](int st, unsigned char* buf) {
-        const u32x4* ks = ksrc + (int64_t)st * (2 * KF * 64);
-        const u32x4* vs = vsrc + (int64_t)st * (2 * DT * 64);
-        unsigned char* kd = buf + wave * 1024;
+    auto issue = [&](int st) {                       // stage st (clamped) into slot st & 3: wave w moves K / V fragments w, w + 8, ..
+        const int sc_ = st < n - 1 ? st : n - 1;
+        const u32x4* ks = ksrc + (int64_t)sc_ * (2 * KF * 64);
+        const u32x4* vs = vsrc + (int64_t)sc_ * (2 * DT * 64);
+        unsigned char* kd = kv + (st & (NS - 1)) * BUF + wave * 1024;
 #pragma unroll
         for (int i = 0; i < (2 * KF) / NW; ++i) glds16(ks + i * (NW * 64), kd + i * (NW * 1024));
 #pragma unroll
         for (int i = 0; i < (2 * DT) / NW; ++i) glds16(vs + i * (NW * 64), kd + (2 * KF + i * NW) * 1024);
     };
-    issue(0, kv);
+    issue(0);
+    issue(1);
+    if (half == 1) issue(2);
 
     bf16x8 qf[RT][KT];
     int plim[RT];                                    // last position this lane's query row (column of S^T) may attend
@@ -690,206 +709,162 @@ __global__ __launch_bounds__(512) void vv_attn_prefill3_kernel(
             for (int j = 0; j < 8; ++j) qf[rt][kt][j] = (__bf16)(v[j] * LOG2E);
         }
     }
-    float m[RT], lsum[RT];
-    f32x4 o[RT][DT];
+    f32x4 o[RT][DT], sc[RT][4];
+    f32x4 ol[RT];                                    // row sums (every lane: its query row's)
+    float negm[RT];                                  // -m (m = the row's reference exponent, log2 domain): the S^T accumulators' start value
+    bf16x8 pb[RT][2];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-        m[rt] = -INFINITY; lsum[rt] = 0.f;
+        ol[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        negm[rt] = 0.f;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) o[rt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-
-    // one stage = 64 positions (NB = 2 blocks) or, for the last stage of a ragged prefix, its first 32 (NB = 1); FAST: the
-    // whole stage lies below the causal diagonal of every query row of the workgroup.  st_next / nbuf: the stage whose LDS-DMA
-    // copies this wave issues during the stage (-1: none).
-    auto stage = [&](const unsigned char* cur, int p0, auto nb_c, auto fast_c, int st_next, unsigned char* nbuf) {
-        constexpr int NB = decltype(nb_c)::value;
-        constexpr bool FAST = decltype(fast_c)::value;
-        // ---- S^T = K q^T: sc[rt][2 blk + half] = positions p0 + 32 blk + 16 half + 4 qg + r, query row = lane & 15 ----
-        f32x4 sc[RT][2 * NB];
+    bf16x8 fr[2][DT];                                // ONE set of fragment registers: V(s), then K(s+1)
+    auto load_k1 = [&](int s, int blk, int f) {
+        const unsigned char* cur = kv + (s & (NS - 1)) * BUF;
+        fr[blk][f] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(cur + ((blk * KF + f) * 64 + lane) * 16));
+    };
+    auto load_v = [&](int s) {
+        const unsigned char* vb_ = kv + (s & (NS - 1)) * BUF + 2 * KF * 1024;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                fr[blk][dt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(vb_ + ((blk * DT + dt) * 64 + lane) * 16));
+    };
+    // ---- S^T - m = K q^T - m (K fragments in fr): sc[rt][2 blk + hf] = positions 64 s + 32 blk + 16 hf + 4 qg + r, query row = lane & 15 ----
+    auto qk_mfma = [&]() {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int i = 0; i < 2 * NB; ++i) sc[rt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (FAST) {
-            // every K fragment of the stage is requested from LDS FIRST, then the next stage's LDS-DMA copies are issued (their
-            // address arithmetic and issue slots run under the LDS latency instead of in front of it), then the 32 MFMAs
-            bf16x8 kf[NB][2 * KT];
+            for (int i = 0; i < 4; ++i) sc[rt][i] = f32x4{negm[rt], negm[rt], negm[rt], negm[rt]};
 #pragma unroll
-            for (int blk = 0; blk < NB; ++blk)
+        for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-                for (int f = 0; f < 2 * KT; ++f)
-                    kf[blk][f] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(cur + ((blk * KF + f) * 64 + lane) * 16));
-            if (st_next >= 0) issue(st_next, nbuf);
+            for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-            for (int blk = 0; blk < NB; ++blk)
-#pragma unroll
-                for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) {
-                        sc[rt][2 * blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[blk][kt], qf[rt][kt], sc[rt][2 * blk], 0, 0, 0);
-                        sc[rt][2 * blk + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[blk][KT + kt], qf[rt][kt], sc[rt][2 * blk + 1], 0, 0, 0);
-                    }
-        } else {
-            if (st_next >= 0) issue(st_next, nbuf);
-#pragma unroll
-            for (int blk = 0; blk < NB; ++blk) {
-                const unsigned char* kb_ = cur + blk * KF * 1024;
-#pragma unroll
-                for (int kt = 0; kt < KT; ++kt) {
-                    // masked stages (the last one or two of a workgroup) carry the mask temporaries on top of everything else:
-                    // each k-step's K fragments are requested only after the previous step's MFMAs, or the kernel spills -- and a
-                    // scratch reload anywhere in the loop makes the compiler guard the mask-free body with s_waitcnt vmcnt(0),
-                    // i.e. with a wait for the NEXT stage's LDS-DMA copies (the waitcnt pass merges the pending-load state around
-                    // the back edge; with it 43 % of the wave cycles were parked, 33 % without)
-                    asm volatile("" ::: "memory");
-                    const bf16x8 ka = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(kb_ + (kt * 64 + lane) * 16));
-                    const bf16x8 kb = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(kb_ + ((KT + kt) * 64 + lane) * 16));
-#pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) {
-                        sc[rt][2 * blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[rt][kt], sc[rt][2 * blk], 0, 0, 0);
-                        sc[rt][2 * blk + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb, qf[rt][kt], sc[rt][2 * blk + 1], 0, 0, 0);
-                    }
+                for (int rt = 0; rt < RT; ++rt) {
+                    sc[rt][2 * blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[blk][kt], qf[rt][kt], sc[rt][2 * blk], 0, 0, 0);
+                    sc[rt][2 * blk + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[blk][KT + kt], qf[rt][kt], sc[rt][2 * blk + 1], 0, 0, 0);
                 }
+    };
+    // the matrix segment: O += P . V of the stage whose V fragments are in fr, each V fragment's registers refilled with a K
+    // fragment of stage sk right after its two MFMAs, l += sum P (all-ones A operand), then S^T of stage sk
+    auto matrix = [&](bool do_pv, int sk) {
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                if (do_pv) {
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+                        o[rt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[blk][dt], pb[rt][blk], o[rt][dt], 0, 0, 0);
+                }
+                if (sk >= 0) load_k1(sk, blk, dt);
             }
+        if (do_pv) {
+            u32x4 one4 = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};      // eight bf16 1.0; rebuilt per stage: registers
+            asm volatile("" : "+v"(one4));                                        // are scarcer here than 4 v_mov
+            const bf16x8 ones = __builtin_bit_cast(bf16x8, one4);
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) ol[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb[rt][blk], ol[rt], 0, 0, 0);
         }
-        // mask-free stages: the V fragments of the first half of the feature tiles are requested now and land under the softmax
-        // (register room: the K fragments are dead from here on), the second half between the two row tiles' updates
-        const unsigned char* vb_ = cur + 2 * KF * 1024;
-        constexpr int DH = DT / 2;
-        bf16x8 va[DH][NB], vbf[DH][NB];
-        auto load_va = [&]() {
-#pragma unroll
-            for (int dt = 0; dt < DH; ++dt)
-#pragma unroll
-                for (int blk = 0; blk < NB; ++blk)
-                    va[dt][blk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(vb_ + ((blk * DT + dt) * 64 + lane) * 16));
-        };
-        auto load_vb = [&]() {
-#pragma unroll
-            for (int dt = 0; dt < DH; ++dt)
-#pragma unroll
-                for (int blk = 0; blk < NB; ++blk)
-                    vbf[dt][blk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(vb_ + ((blk * DT + DH + dt) * 64 + lane) * 16));
-        };
-        if constexpr (FAST) { load_va(); __builtin_amdgcn_sched_barrier(0); }     // masked stages: plain loop below (registers)
-        // ---- one online-softmax update per stage -> P as the B operands of P.V ----
-        bf16x8 pb[RT][NB];
-        float al[RT];
+        if (sk >= 0) qk_mfma();
+    };
+    // ---- the softmax step of stage s: sc (= S - m) -> pb; on the rare re-base also m, O, l ----
+    auto softmax = [&](int s) {
+        const int p0 = s * 64;
+        const bool fast = s < first_masked;          // the whole stage lies below the causal diagonal of every query row
+        float mx[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-            if constexpr (!FAST) {
+            if (!fast) {
 #pragma unroll
-                for (int i = 0; i < 2 * NB; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr)
                         if (p0 + i * 16 + qg * 4 + rr > plim[rt]) sc[rt][i][rr] = -INFINITY;
             }
-            float mx = sc[rt][0][0];
+            float v = sc[rt][0][0];
 #pragma unroll
-            for (int i = 0; i < 2 * NB; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) mx = fmaxf(mx, sc[rt][i][rr]);
-            mx = a3_xrow_max(mx);
-            const float mn = fmaxf(m[rt], mx);
-            float alpha, ps = 0.f;
-            if constexpr (FAST) {
-                // every score is finite; on the very first stage m = -inf and exp2(-inf) is the hardware's 0
-                alpha = __builtin_amdgcn_exp2f(m[rt] - mn);
-#pragma unroll
-                for (int i = 0; i < 2 * NB; ++i)
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) {
-                        const float p = __builtin_amdgcn_exp2f(sc[rt][i][rr] - mn);
-                        ps += p;
-                        pb[rt][i >> 1][(i & 1) * 4 + rr] = (__bf16)p;
-                    }
-                lsum[rt] = lsum[rt] * alpha + ps;
-                m[rt] = mn;
-            } else {
-                // a column whose whole stage is masked (query row earlier than this stage) keeps its state untouched
-                const bool dead = (mn == -INFINITY);
-                const float msafe = dead ? 0.f : mn;                   // -inf - 0 = -inf -> p = 0, never -inf - -inf
-                alpha = dead ? 1.f : __builtin_amdgcn_exp2f(m[rt] - mn);     // m = -inf, mn finite: 0
-#pragma unroll
-                for (int i = 0; i < 2 * NB; ++i)
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) {
-                        const float p = __builtin_amdgcn_exp2f(sc[rt][i][rr] - msafe);
-                        ps += p;
-                        pb[rt][i >> 1][(i & 1) * 4 + rr] = (__bf16)p;
-                    }
-                lsum[rt] = lsum[rt] * alpha + ps;                      // dead: alpha = 1, ps = 0
-                m[rt] = mn;                                            // dead: mn = m = -inf
-            }
-            al[rt] = alpha;
-            if constexpr (FAST) { if (rt == 0) { __builtin_amdgcn_sched_barrier(0); load_vb(); __builtin_amdgcn_sched_barrier(0); } }
+                for (int rr = 0; rr < 4; ++rr) v = fmaxf(v, sc[rt][i][rr]);
+            mx[rt] = a3_xrow_max(v);
         }
-        // once the running maxima have settled (alpha == 1 in every lane of both row tiles) the accumulator rescale is skipped:
-        // ONE wave-uniform branch per stage, then an unbroken run of MFMAs
-        if (__builtin_amdgcn_ballot_w64(al[0] != 1.0f || al[1] != 1.0f) != 0) {
+        const bool rebase = (s == 0) || __builtin_amdgcn_ballot_w64(mx[0] > 8.0f || mx[1] > 8.0f) != 0;   // wave-uniform
+        if (!rebase) {
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt) o[rt][dt] *= al[rt];
-        }
-        // ---- O += P . V: NB k-steps per accumulator, every V fragment read from LDS once ----
-        if constexpr (FAST) {
-            // every V fragment was requested during the softmax: no LDS round trip sits between two MFMAs (left alone, the
-            // scheduler requests each pair of fragments right in front of its MFMAs, on a single register pair)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int dt = 0; dt < DH; ++dt)
-#pragma unroll
-                for (int blk = 0; blk < NB; ++blk)
-#pragma unroll
-                    for (int rt = 0; rt < RT; ++rt)
-                        o[rt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[dt][blk], pb[rt][blk], o[rt][dt], 0, 0, 0);
-#pragma unroll
-            for (int dt = 0; dt < DH; ++dt)
-#pragma unroll
-                for (int blk = 0; blk < NB; ++blk)
-#pragma unroll
-                    for (int rt = 0; rt < RT; ++rt)
-                        o[rt][DH + dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vbf[dt][blk], pb[rt][blk], o[rt][DH + dt], 0, 0, 0);
+                    for (int rr = 0; rr < 4; ++rr)
+                        pb[rt][i >> 1][(i & 1) * 4 + rr] = (__bf16)__builtin_amdgcn_exp2f(sc[rt][i][rr]);
         } else {
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                bf16x8 vf[NB];
+            for (int rt = 0; rt < RT; ++rt) {
+                // stage 0: the reference becomes the stage maximum (finite: position 0 is visible to every row); later: rows
+                // above the threshold move up to their stage maximum, the others (and rows whose stage is all masked) stay
+                const float dl = (s == 0) ? mx[rt] : (mx[rt] > 8.0f ? mx[rt] : 0.f);
+                const float alpha = __builtin_amdgcn_exp2f(-dl);
 #pragma unroll
-                for (int blk = 0; blk < NB; ++blk)
-                    vf[blk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(vb_ + ((blk * DT + dt) * 64 + lane) * 16));
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int blk = 0; blk < NB; ++blk)
+                    for (int rr = 0; rr < 4; ++rr)
+                        pb[rt][i >> 1][(i & 1) * 4 + rr] = (__bf16)__builtin_amdgcn_exp2f(sc[rt][i][rr] - dl);
 #pragma unroll
-                    for (int rt = 0; rt < RT; ++rt)
-                        o[rt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[blk], pb[rt][blk], o[rt][dt], 0, 0, 0);
+                for (int dt = 0; dt < DT; ++dt) o[rt][dt] *= alpha;
+                ol[rt] *= alpha;
+                negm[rt] -= dl;
             }
         }
     };
-    using c1 = std::integral_constant<int, 1>;
-    using c2 = std::integral_constant<int, 2>;
+    // two straight-line loops with the same barrier count (a branch on the half inside one loop makes the accumulators phi values)
+    if (half == 0) {
+        pp_vmcnt<PW>();                                               // stages 0, 1 in flight: stage 0 has landed
+        pp_barrier();
+        if (act) matrix(false, 0);                                    // phase -1: S(0)
+        pp_lgkm0();
+        pp_barrier();
 #pragma unroll 1
-    for (int st = 0; st < n_stg; ++st) {
-        unsigned char* cur = kv + (st & 1) * BUF;
-        stage_sync();                             // stage st has landed (every wave drained its own copies first);
-                                                  // everyone has finished stage st-1, whose buffer is refilled during this stage
-        const int st_next = (st + 1 < n_stg) ? st + 1 : -1;
-        unsigned char* nbuf = kv + ((st + 1) & 1) * BUF;
-        if (!act) { if (st_next >= 0) issue(st_next, nbuf); continue; }
-        const int p0 = st * 64;
-        if (st < first_masked) stage(cur, p0, c2{}, std::true_type{}, st_next, nbuf);   // p0 + 63 < rw.pos + r0 <= every plim: 64 live positions
-        else if (p0 + 32 < pend) stage(cur, p0, c2{}, std::false_type{}, st_next, nbuf);
-        else stage(cur, p0, c1{}, std::false_type{}, st_next, nbuf);
+        for (int s = 0; s < n; ++s) {
+            if (act) { load_v(s); softmax(s); }                       // phase 2s
+            issue(s + 2);
+            pp_lgkm0();
+            pp_vmcnt<PW>();
+            pp_barrier();
+            if (act) matrix(true, s + 1 < n ? s + 1 : -1);            // phase 2s + 1: O += P(s).V(s), S(s+1)
+            pp_lgkm0();
+            pp_barrier();
+        }
+    } else {
+        pp_vmcnt<2 * PW>();                                           // stages 0, 1, 2 in flight
+        pp_barrier();
+        pp_barrier();                                                 // phase -1: nothing to do yet
+#pragma unroll 1
+        for (int s = 0; s < n; ++s) {
+            if (act) matrix(s >= 1, s);                               // phase 2s: O += P(s-1).V(s-1), S(s)
+            pp_lgkm0();
+            pp_vmcnt<PW>();
+            pp_barrier();
+            if (act) { load_v(s); softmax(s); }                       // phase 2s + 1
+            issue(s + 3);
+            pp_lgkm0();
+            pp_barrier();
+        }
+        if (act) matrix(true, -1);                                    // phase 2n: V(n-1) is in registers
     }
+    pp_vmcnt<0>();                                                    // no copy may land in an LDS allocation that has been released
     if (act) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-            float l = lsum[rt];
-            l += __shfl_xor(l, 16);
-            l += __shfl_xor(l, 32);
             const int row = rw0 + rt * 16 + col;
             if (row < R) {
-                const float inv = 1.0f / l;
+                const float inv = 1.0f / ol[rt][0];
                 float* orow = out + ((int64_t)row * Hq + h) * D + qg * 4;
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt)
@@ -1005,20 +980,20 @@ int vv_gemm3_launch(const void* W, const void* W2, const void* Xp, float* Y, voi
 }
 
 // causal prefill attention of R consecutive rows of one cache (64 query rows x the GQA group of one kv head per workgroup)
-int vv_attn_prefill3_launch(int D, const float* q, const VVRow* rows, const void* kc, const void* vc, int R, int Hq, int Hkv,
+int vv_attn_prefill4_launch(int D, const float* q, const VVRow* rows, const void* kc, const void* vc, int R, int Hq, int Hkv,
                             int64_t cache_stride, int64_t head_stride, float* out, hipStream_t s) {
     if (Hq % Hkv != 0 || (D != 128 && D != 64)) return -1;
     const int G = Hq / Hkv;
     const dim3 grid((R + 63) / 64, Hkv, (G + 3) / 4);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_attn_prefill3_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_attn_prefill3_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_attn_prefill4_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_attn_prefill4_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    const int sm = 2 * 2 * (2 * (D / 32) + D / 16) * 1024;
-    if (D == 128) hipLaunchKernelGGL((vv_attn_prefill3_kernel<128>), grid, dim3(512), sm, s, q, rows, (const __bf16*)kc, (const __bf16*)vc, R, Hq, Hkv, cache_stride, head_stride, out);
-    else hipLaunchKernelGGL((vv_attn_prefill3_kernel<64>), grid, dim3(512), sm, s, q, rows, (const __bf16*)kc, (const __bf16*)vc, R, Hq, Hkv, cache_stride, head_stride, out);
+    const int sm = 4 * 2 * (2 * (D / 32) + D / 16) * 1024;          // 4 stages of K + V fragments
+    if (D == 128) hipLaunchKernelGGL((vv_attn_prefill4_kernel<128>), grid, dim3(512), sm, s, q, rows, (const __bf16*)kc, (const __bf16*)vc, R, Hq, Hkv, cache_stride, head_stride, out);
+    else hipLaunchKernelGGL((vv_attn_prefill4_kernel<64>), grid, dim3(512), sm, s, q, rows, (const __bf16*)kc, (const __bf16*)vc, R, Hq, Hkv, cache_stride, head_stride, out);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
