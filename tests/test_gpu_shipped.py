@@ -250,6 +250,53 @@ def test_one_pass_prefill_of_10922_rows_at_7b_widths():
         eng.close()
 
 
+def test_two_pass_prefill_with_the_fused_qkv_epilogue_at_a_position_offset():
+    """Two consecutive 3,700-row passes of one 7B-width layer (vv_gemm4 shapes: QKV = 18 x 15 tiles -> bias + RoPE + KV append run
+    in the GEMM's epilogue; the attention writes the o-projection's packed operand): the second pass starts at position 3,700, so the
+    epilogue's rotation angles and cache addresses and the attention's causal prefix all depend on rows[0].pos.  Row by row against
+    the oracle's single 7,400-row forward, then a decode step on top of the cache both passes wrote."""
+    L1 = 3700
+    c = GEOM["7b"]
+    s = build_fast(c, xsplit=1, max_ctx=2 * L1 + 128, max_rows=L1, head_layers=1)
+    eng = s.eng
+    try:
+        H = c.hidden
+        g = _FastGen(3700)
+        x = g.normal((2 * L1 + 1, H), 1.0, mat=False)
+        xd = dev(x, eng)
+        xin, hid, out1 = eng.new(L1, H), eng.new(L1, H), eng.new(1, H)
+        with torch.cuda.stream(eng.stream):
+            # the same buffers for both passes: the second one REPLAYS the first one's captured graph, only the row table differs
+            xin.copy_(xd[:L1])
+            eng.lm_forward_span(0, 0, L1, xin, hid)
+            hid_a = hid.clone()
+            xin.copy_(xd[L1:2 * L1])
+            eng.lm_forward_span(0, L1, L1, xin, hid)
+            hid_b = hid.clone()
+            eng.lm_forward([(0, 2 * L1)], xd[2 * L1:], out1)
+        eng.sync()
+        got = torch.cat([hid_a.float().cpu(), hid_b.float().cpu()])
+        got1 = out1.float().cpu()
+        from oracle import lm as olm
+        m16 = olm.Qwen2Oracle(s.lm_w, c.layers, c.heads, c.kv_heads, c.head_dim, c.theta, c.eps, kv_round_bf16=True, attn_rows=512,
+                              mfma_in_bf16=True)
+        with _Threads():
+            with torch.no_grad():
+                c16 = m16.new_cache()
+                ref = m16.forward(x[:2 * L1], c16)
+                ref1 = m16.forward(x[2 * L1:], c16)
+        e_a, e_b = rel_err(got[:L1], ref[:L1]), rel_err(got[L1:], ref[L1:])
+        r_a, r_b = row_err(got[:L1], ref[:L1]), row_err(got[L1:], ref[L1:])
+        d1 = rel_err(got1, ref1)
+        print(f"[two-pass prefill, fused QKV epilogue] pass 1: rel-L2 {e_a:.3e}, worst row {r_a:.3e}; pass 2 (pos 3700..): {e_b:.3e}, "
+              f"worst row {r_b:.3e}; decode step: {d1:.3e}")
+        assert e_a <= 3e-3 and r_a <= 6e-3, (e_a, r_a)
+        assert e_b <= 3e-3 and r_b <= 6e-3, (e_b, r_b)
+        assert d1 <= 6e-3, d1
+    finally:
+        eng.close()
+
+
 # ---------------------------------------------------------------------------------------------- (c2) the GEMM's K-split partial round
 @pytest.mark.parametrize("epi", [0, 1, 4, 3])
 @pytest.mark.parametrize("T,N,K", [(4100, 4112, 2080), (4352, 4096, 2048), (1100, 8200, 1024)])

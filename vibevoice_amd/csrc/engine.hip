@@ -81,8 +81,11 @@ int vv_gemv16p_launch(const void* W, const void* W2, const void* Xp, float* Y, v
 int vv_ada_pack_launch(const float* cproj, const float* temb, void* xp, int rows, int n_steps, int H, hipStream_t s);
 int vv_gemm3_launch(const void* W, const void* W2, const void* Xp, float* Y, void* Yp, const float* bias, int T, int N, int K,
                     int ldy, int epi, const VVGemmWs* ws, hipStream_t s);
+int vv_gemm_qkv_rope_launch(const void* W, const void* Xp, const float* bias, int T, int K, int D, int Hq, int Hkv, const VVRow* rows_dev,
+                            const void* rope_tab, float* q_out, void* kc, void* vc, int64_t cache_stride, int64_t head_stride,
+                            const VVGemmWs* ws, hipStream_t s);
 int vv_attn_prefill4_launch(int D, const float* q, const VVRow* rows, const void* kc, const void* vc, int R, int Hq, int Hkv,
-                            int64_t cache_stride, int64_t head_stride, float* out, hipStream_t s);
+                            int64_t cache_stride, int64_t head_stride, float* out, void* out_packed, hipStream_t s);
 int vv_block1d_supported(int C);
 int vv_gemv_ok(const VVGemm* a);
 int vv_tile_ok(const VVGemm* a, int xs);
@@ -1137,11 +1140,20 @@ static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float*
             char* vl = (char*)ctx->vc + (size_t)l * ctx->layer_stride * 2;
             ctx->launches += 9;
             VVCHK(vv_pack_rows_launch(ctx->h, H, L.ln1, c.lm_eps, ctx->xp, R, H, st));
-            VVCHK(vv_gemm3_launch(L.wqkv, nullptr, ctx->xp, ctx->qkv, nullptr, L.bqkv, R, QKV, H, QKV, VV_EPI_BIAS, &ctx->gws, st));
-            VVCHK(vv_rope_append_launch(D, ctx->qkv, ctx->rows_dev, ctx->inv_freq, ctx->qrot, kl, vl,
-                                        R, Hq, Hkv, ctx->cache_stride, ctx->head_stride, st));
-            VVCHK(vv_attn_prefill4_launch(D, ctx->qrot, ctx->rows_dev, kl, vl, R, Hq, Hkv, ctx->cache_stride, ctx->head_stride, ctx->attn, st));
-            VVCHK(vv_pack_rows_launch(ctx->attn, Hq * D, nullptr, 0.f, ctx->xp, R, Hq * D, st));
+            // long prompts at head_dim 128: bias + RoPE + cache append in the QKV GEMM's epilogue; otherwise GEMM, then vv_rope_append
+            const int fq = vv_gemm_qkv_rope_launch(L.wqkv, ctx->xp, L.bqkv, R, H, D, Hq, Hkv, ctx->rows_dev, ctx->rope_tab, ctx->qrot, kl, vl,
+                                                   ctx->cache_stride, ctx->head_stride, &ctx->gws, st);
+            if (fq < 0) return fail(ctx, "vv_gemm_qkv_rope_launch failed (%d)", fq);
+            if (fq == 0) {
+                VVCHK(vv_gemm3_launch(L.wqkv, nullptr, ctx->xp, ctx->qkv, nullptr, L.bqkv, R, QKV, H, QKV, VV_EPI_BIAS, &ctx->gws, st));
+                VVCHK(vv_rope_append_launch(D, ctx->qkv, ctx->rows_dev, ctx->inv_freq, ctx->qrot, kl, vl,
+                                            R, Hq, Hkv, ctx->cache_stride, ctx->head_stride, st));
+            }
+            // the attention writes the o-projection's packed operand itself (K = Hq * D: whole 32-wide k-tiles)
+            const bool apk = ((Hq * D) & 31) == 0;
+            VVCHK(vv_attn_prefill4_launch(D, ctx->qrot, ctx->rows_dev, kl, vl, R, Hq, Hkv, ctx->cache_stride, ctx->head_stride, ctx->attn,
+                                          apk ? ctx->xp : nullptr, st));
+            if (!apk) VVCHK(vv_pack_rows_launch(ctx->attn, Hq * D, nullptr, 0.f, ctx->xp, R, Hq * D, st));
             VVCHK(vv_gemm3_launch(L.wo, nullptr, ctx->xp, ctx->h, nullptr, nullptr, R, H, Hq * D, H, VV_EPI_RESID, &ctx->gws, st));
             VVCHK(vv_pack_rows_launch(ctx->h, H, L.ln2, c.lm_eps, ctx->xp, R, H, st));
             VVCHK(vv_gemm3_launch(L.wg, L.wu, ctx->xp, nullptr, ctx->actp, nullptr, R, I, H, 0, VV_EPI_SWIGLU, &ctx->gws, st));
@@ -1186,7 +1198,7 @@ static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float*
             VVCHK(vv_rope_append_launch(D, ctx->qkv, ctx->rows_dev, ctx->inv_freq, ctx->qrot, kl, vl,
                                         R, Hq, Hkv, ctx->cache_stride, ctx->head_stride, st));
             if (contiguous && ctx->attn2_ok)      // prompt chunk, bf16 mode: 64 query rows x all heads of the group share every K/V block
-                VVCHK(vv_attn_prefill4_launch(D, ctx->qrot, ctx->rows_dev, kl, vl, R, Hq, Hkv, ctx->cache_stride, ctx->head_stride, ctx->attn, st));
+                VVCHK(vv_attn_prefill4_launch(D, ctx->qrot, ctx->rows_dev, kl, vl, R, Hq, Hkv, ctx->cache_stride, ctx->head_stride, ctx->attn, nullptr, st));
             else {
                 // ragged row sets (the streaming model's text windows) and the prompt chunks of the exact modes (xsplit 2, 3): the
                 // split + merge pair, at most ws_rows rows per launch (its partial buffers); every row attends its own causal prefix
@@ -1251,7 +1263,7 @@ extern "C" int vv_lm_forward_range(vv_ctx* ctx, void* stream, int n_rows, const 
     bool fused = true;
     for (int i = 0; i < n_rows && fused; ++i)
         for (int j = 0; j < i; ++j) if (rows[i].cache == rows[j].cache) { fused = false; break; }
-    if (fused && !ctx->rope_ready) {          // (cos, sin) table of every position, once the inv_freq parameter is in place
+    if (!ctx->rope_ready) {                   // (cos, sin) table of every position, once the inv_freq parameter is in place
         VVCHK(vv_rope_table_launch(ctx->inv_freq, ctx->rope_tab, ctx->c.max_ctx, ctx->D / 2, st));
         ctx->rope_ready = true;
     }

@@ -151,6 +151,14 @@ struct VVGemm3 {
     float* ws;             // partial accumulators: [256 slots][32 accumulators][512 threads] f32x4
     unsigned* flags;       // [256] arrival words, zero between launches
     unsigned* err;         // host-visible word: set when a wait timed out
+    // VV_EPI_QKV_ROPE (vv_gemm4 only, head_dim 128): N = (Hq + 2 Hkv) * 128 features = [q heads | k heads | v heads]
+    const VVRow* rows;     // rows[0] = (cache, first position); row t is position rows[0].pos + t of that cache
+    const float2* rope_tab;    // (cos, sin)[pos][64]
+    float* q_out;          // fp32 [T][Hq][128]: rotated, scaled queries
+    __bf16* kc; __bf16* vc;    // this layer's K / V caches (tile layouts of attn.hip)
+    int64_t cache_stride, head_stride;
+    int Hq, Hkv;
+    float q_scale;
 };
 
 __device__ __forceinline__ float g3_silu(float u) { return u / (1.0f + __expf(-u)); }
@@ -402,6 +410,78 @@ __device__ __forceinline__ void g4_finish(const VVGemm3& a, f32x4 (&acc)[8][4], 
         if (tid < split - 1) __hip_atomic_store(a.flags + slot0 + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     }
     // ---- epilogue: lane holds D[n = tile*16 + fq*4 + r][t = ttile*16 + frow] ----
+    if constexpr (EPI == VV_EPI_QKV_ROPE) {
+        // this wave's 128 features are ONE head: bias, rotate-half RoPE from the (cos, sin) table (the expressions of
+        // vv_rope_append_kernel / vv_attn_fused_kernel: feature i pairs with i + 64 = accumulator tiles i and i + 4 of the same
+        // lane), then q -> fp32 rows (scaled), k / v -> bf16 into the cache's tile layouts.  Replaces the fp32 qkv round trip
+        // and the vv_rope_append launch of the prompt pass (modeling_vibevoice_inference.py:467-482 through HF Qwen2Attention).
+        const VVRow rw = a.rows[0];
+        const int hh = (ft0 * 16 + wf * 128) >> 7;
+        if (hh >= a.Hq + 2 * a.Hkv) return;
+        const int nb0 = hh * 128 + fq * 4;
+        float4 bs[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bs[i] = a.bias ? *reinterpret_cast<const float4*>(a.bias + nb0 + i * 16) : float4{0.f, 0.f, 0.f, 0.f};
+        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = (tt0 + wr * 4 + j) * 16 + frow;
+            if (t >= a.T) continue;
+            const int pos = rw.pos + t;
+            if (hh < a.Hq + a.Hkv) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float2* tp = a.rope_tab + (int64_t)pos * 64 + i * 16 + fq * 4;
+                    const float4 t0 = *reinterpret_cast<const float4*>(tp), t1 = *reinterpret_cast<const float4*>(tp + 2);
+                    const float cs[4] = {t0.x, t0.z, t1.x, t1.z}, sn[4] = {t0.y, t0.w, t1.y, t1.w};
+                    const float b1[4] = {bs[i].x, bs[i].y, bs[i].z, bs[i].w}, b2[4] = {bs[i + 4].x, bs[i + 4].y, bs[i + 4].z, bs[i + 4].w};
+                    float o1[4], o2[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float x1 = acc[i][j][r] + b1[r], x2 = acc[i + 4][j][r] + b2[r];
+                        o1[r] = x1 * cs[r] - x2 * sn[r];
+                        o2[r] = x2 * cs[r] + x1 * sn[r];
+                    }
+                    const int d = i * 16 + fq * 4;                    // rotation index = feature inside the head (first half)
+                    if (hh < a.Hq) {
+                        float* qp = a.q_out + ((int64_t)t * a.Hq + hh) * 128 + d;
+                        *reinterpret_cast<float4*>(qp) = float4{o1[0] * a.q_scale, o1[1] * a.q_scale, o1[2] * a.q_scale, o1[3] * a.q_scale};
+                        *reinterpret_cast<float4*>(qp + 64) = float4{o2[0] * a.q_scale, o2[1] * a.q_scale, o2[2] * a.q_scale, o2[3] * a.q_scale};
+                    } else {
+                        // K tile layout: element (pos, d) -> tile (pos >> 4) * 4 + (d >> 5), lane (pos & 15) + 16 * ((d & 31) >> 3), slot d & 7
+                        __bf16* kb = a.kc + (int64_t)rw.cache * a.cache_stride + (int64_t)(hh - a.Hq) * a.head_stride;
+#pragma unroll
+                        for (int w = 0; w < 2; ++w) {
+                            const int dd = d + w * 64;
+                            bf16x4 v;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = (__bf16)(w ? o2[r] : o1[r]);
+                            const int64_t tile = (int64_t)(pos >> 4) * 4 + (dd >> 5);
+                            const int ln = (pos & 15) + 16 * ((dd & 31) >> 3);
+                            *reinterpret_cast<uint2*>(kb + (tile * 64 + ln) * 8 + (dd & 7)) = __builtin_bit_cast(uint2, v);
+                        }
+                    }
+                }
+            } else {
+                // V tile layout: element (pos, d) -> block pos >> 5, tile blk * 8 + (d >> 4), lane (d & 15) + 16 * ((pos & 15) >> 2),
+                // slot ((pos >> 4) & 1) * 4 + (pos & 3)
+                __bf16* vb = a.vc + (int64_t)rw.cache * a.cache_stride + (int64_t)(hh - a.Hq - a.Hkv) * a.head_stride;
+                const int blk = pos >> 5, pp = pos & 15;
+                const int jj = ((pos >> 4) & 1) * 4 + (pp & 3), q4 = pp >> 2;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float bb[4] = {bs[i].x, bs[i].y, bs[i].z, bs[i].w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int dd = i * 16 + fq * 4 + r;
+                        const int64_t tile = (int64_t)blk * 8 + (dd >> 4);
+                        vb[(tile * 64 + (dd & 15) + 16 * q4) * 8 + jj] = (__bf16)(acc[i][j][r] + bb[r]);
+                    }
+                }
+            }
+        }
+        return;
+    }
     if constexpr (DUAL) {
         const int KTo = (a.N + 31) >> 5;
 #pragma unroll
@@ -648,7 +728,7 @@ template <int D>
 __global__ __launch_bounds__(512) void vv_attn_prefill4_kernel(
     const float* __restrict__ q, const VVRow* __restrict__ rows, const __bf16* __restrict__ kc,
     const __bf16* __restrict__ vc, int R, int Hq, int Hkv, int64_t cache_stride, int64_t head_stride,
-    float* __restrict__ out) {
+    float* __restrict__ out, u32x4* __restrict__ out_packed) {
     constexpr int RT = 2;
     constexpr int KT = D / 32, DT = D / 16;
     constexpr int KF = 2 * KT;                       // K fragments of a 32-position block (2 position tiles x KT)
@@ -865,17 +945,52 @@ __global__ __launch_bounds__(512) void vv_attn_prefill4_kernel(
             const int row = rw0 + rt * 16 + col;
             if (row < R) {
                 const float inv = 1.0f / ol[rt][0];
-                float* orow = out + ((int64_t)row * Hq + h) * D + qg * 4;
+                if (out_packed) {
+                    // straight into the o-projection's B operand (vv_pack_rows_kernel's layout, K = Hq * D): element (t, k) lives in
+                    // tile (t >> 4, k >> 5), lane (t & 15) + 16 * ((k & 31) >> 3), slot k & 7; this lane holds 4 consecutive k
+                    const int KTo = (Hq * D) >> 5;
+                    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
-                    *reinterpret_cast<float4*>(orow + dt * 16) =
-                        float4{o[rt][dt][0] * inv, o[rt][dt][1] * inv, o[rt][dt][2] * inv, o[rt][dt][3] * inv};
+                    for (int dt = 0; dt < DT; ++dt) {
+                        const int k0 = h * D + dt * 16 + qg * 4;
+                        bf16x4 v;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = (__bf16)(o[rt][dt][r] * inv);
+                        const int64_t tile = (int64_t)(row >> 4) * KTo + (k0 >> 5);
+                        const int ol_ = (row & 15) + 16 * ((k0 & 31) >> 3);
+                        unsigned char* dst = reinterpret_cast<unsigned char*>(out_packed) + ((tile * 64 + ol_) * 16 + (k0 & 7) * 2);
+                        *reinterpret_cast<uint2*>(dst) = __builtin_bit_cast(uint2, v);
+                    }
+                } else {
+                    float* orow = out + ((int64_t)row * Hq + h) * D + qg * 4;
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt)
+                        *reinterpret_cast<float4*>(orow + dt * 16) =
+                            float4{o[rt][dt][0] * inv, o[rt][dt][1] * inv, o[rt][dt][2] * inv, o[rt][dt][3] * inv};
+                }
             }
         }
     }
 }
 
 }  // namespace
+
+// the K-split of the partial last round (see vv_gemm3_launch): fills a.full_idx / a.split / workspace pointers, updates the grid size
+static void g4_split_plan(VVGemm3& a, const VVGemmWs* ws, int K, unsigned& n_wgs) {
+    if (!(ws && ws->partials && ws->flags && ws->err)) return;
+    const int total = a.n_blocks * a.t_blocks, q = total >> 3, r = total & 7;
+    const int full_idx = (total / 256) * 32;
+    const int max_rem = q + (r ? 1 : 0) - full_idx;           // 0..32 tiles per XCD in the partial round
+    const int n_steps = ((K + 31) / 32 + 1) / 2;
+    int split = max_rem > 0 ? 32 / max_rem : 1;
+    if (split > 8) split = 8;
+    if (split > n_steps / 8) split = n_steps / 8;             // a part keeps >= 8 of the 64-wide steps
+    if (split == 2 && n_steps < 256) split = 1;               // halves of a short K do not pay (see vv_gemm3_launch)
+    if (split > 1) {
+        a.full_idx = full_idx; a.split = split; a.ws = ws->partials; a.flags = ws->flags; a.err = ws->err;
+        n_wgs = (unsigned)(8 * full_idx + 8 * max_rem * split);
+    }
+}
 
 extern "C" {
 
@@ -927,20 +1042,7 @@ int vv_gemm3_launch(const void* W, const void* W2, const void* Xp, float* Y, voi
         // (o: +6 %; gate/up: neutral) -- a partial round is not a lost round on this chip: the package is at its power limit
         // under these kernels and the clock rises when fewer CUs compute -- so those launches stay whole.
         unsigned n_wgs = (unsigned)(a.n_blocks * a.t_blocks);
-        if (ws && ws->partials && ws->flags && ws->err) {
-            const int total = a.n_blocks * a.t_blocks, q = total >> 3, r = total & 7;
-            const int full_idx = (total / 256) * 32;
-            const int max_rem = q + (r ? 1 : 0) - full_idx;           // 0..32 tiles per XCD in the partial round
-            const int n_steps = ((K + 31) / 32 + 1) / 2;
-            int split = max_rem > 0 ? 32 / max_rem : 1;
-            if (split > 8) split = 8;
-            if (split > n_steps / 8) split = n_steps / 8;             // a part keeps >= 8 of the 64-wide steps
-            if (split == 2 && n_steps < 256) split = 1;               // halves of a short K: see above
-            if (split > 1) {
-                a.full_idx = full_idx; a.split = split; a.ws = ws->partials; a.flags = ws->flags; a.err = ws->err;
-                n_wgs = (unsigned)(8 * full_idx + 8 * max_rem * split);
-            }
-        }
+        g4_split_plan(a, ws, K, n_wgs);
         const dim3 grid4(n_wgs);
         static bool attr4 = false;
         if (!attr4) {
@@ -980,9 +1082,39 @@ int vv_gemm3_launch(const void* W, const void* W2, const void* Xp, float* Y, voi
 }
 
 // causal prefill attention of R consecutive rows of one cache (64 query rows x the GQA group of one kv head per workgroup)
+// The QKV projection of a prompt pass with RoPE + KV-cache append in the epilogue (head_dim 128, vv_gemm4 shapes only).
+// Returns 1 when the fused kernel was launched, 0 when the shape does not qualify (the caller runs the plain GEMM + vv_rope_append),
+// < 0 on error.  rows_dev[0] = (cache, first position): read on the device, so a captured graph replays at other positions.
+int vv_gemm_qkv_rope_launch(const void* W, const void* Xp, const float* bias, int T, int K, int D, int Hq, int Hkv, const VVRow* rows_dev,
+                            const void* rope_tab, float* q_out, void* kc, void* vc, int64_t cache_stride, int64_t head_stride,
+                            const VVGemmWs* ws, hipStream_t s) {
+    const int N = (Hq + 2 * Hkv) * D;
+    if (D != 128 || T < 1 || K < 32 || !rows_dev || !rope_tab || !q_out || !kc || !vc) return 0;
+    const int n_blocks = N / 256, t_blocks = (T + 255) / 256;
+    if ((N & 255) || (int64_t)n_blocks * t_blocks < 256) return 0;
+    VVGemm3 a;
+    memset(&a, 0, sizeof(a));
+    a.W = (const u32x4*)W; a.Xp = (const u32x4*)Xp; a.bias = bias;
+    a.T = T; a.N = N; a.K = K; a.ldy = N;
+    a.n_blocks = n_blocks; a.t_blocks = t_blocks; a.sfw = 4; a.split = 1;
+    a.rows = rows_dev; a.rope_tab = (const float2*)rope_tab; a.q_out = q_out; a.kc = (__bf16*)kc; a.vc = (__bf16*)vc;
+    a.cache_stride = cache_stride; a.head_stride = head_stride; a.Hq = Hq; a.Hkv = Hkv; a.q_scale = 1.0f / sqrtf((float)D);
+    unsigned n_wgs = (unsigned)(n_blocks * t_blocks);
+    g4_split_plan(a, ws, K, n_wgs);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_gemm4_kernel<VV_EPI_QKV_ROPE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL((vv_gemm4_kernel<VV_EPI_QKV_ROPE>), dim3(n_wgs), dim3(512), (size_t)4 * 32 * 1024, s, a);
+    return hipGetLastError() == hipSuccess ? 1 : -2;
+}
+
+// out_packed != null: the result goes out as packed bf16 B fragments [R][Hq * D] (the o-projection GEMM's operand) instead of fp32 rows
 int vv_attn_prefill4_launch(int D, const float* q, const VVRow* rows, const void* kc, const void* vc, int R, int Hq, int Hkv,
-                            int64_t cache_stride, int64_t head_stride, float* out, hipStream_t s) {
+                            int64_t cache_stride, int64_t head_stride, float* out, void* out_packed, hipStream_t s) {
     if (Hq % Hkv != 0 || (D != 128 && D != 64)) return -1;
+    if (out_packed && ((Hq * D) & 31)) return -1;
     const int G = Hq / Hkv;
     const dim3 grid((R + 63) / 64, Hkv, (G + 3) / 4);
     static bool attr = false;
@@ -992,8 +1124,8 @@ int vv_attn_prefill4_launch(int D, const float* q, const VVRow* rows, const void
         attr = true;
     }
     const int sm = 4 * 2 * (2 * (D / 32) + D / 16) * 1024;          // 4 stages of K + V fragments
-    if (D == 128) hipLaunchKernelGGL((vv_attn_prefill4_kernel<128>), grid, dim3(512), sm, s, q, rows, (const __bf16*)kc, (const __bf16*)vc, R, Hq, Hkv, cache_stride, head_stride, out);
-    else hipLaunchKernelGGL((vv_attn_prefill4_kernel<64>), grid, dim3(512), sm, s, q, rows, (const __bf16*)kc, (const __bf16*)vc, R, Hq, Hkv, cache_stride, head_stride, out);
+    if (D == 128) hipLaunchKernelGGL((vv_attn_prefill4_kernel<128>), grid, dim3(512), sm, s, q, rows, (const __bf16*)kc, (const __bf16*)vc, R, Hq, Hkv, cache_stride, head_stride, out, (u32x4*)out_packed);
+    else hipLaunchKernelGGL((vv_attn_prefill4_kernel<64>), grid, dim3(512), sm, s, q, rows, (const __bf16*)kc, (const __bf16*)vc, R, Hq, Hkv, cache_stride, head_stride, out, (u32x4*)out_packed);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

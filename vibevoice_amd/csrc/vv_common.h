@@ -38,7 +38,8 @@ struct VVGemmWs {
 // Y[t][n] (op)= sum_k f(X[t][k]) * W[n][k]
 enum { VV_PRO_NONE = 0, VV_PRO_RMS = 1, VV_PRO_RMS_MOD = 2, VV_PRO_ADD_SILU = 3 };
 enum { VV_EPI_STORE = 0, VV_EPI_BIAS = 1, VV_EPI_BIAS_GELU = 2, VV_EPI_SWIGLU = 3,
-       VV_EPI_RESID = 4, VV_EPI_GATED_RESID = 5, VV_EPI_CFG_DPM = 6 };
+       VV_EPI_RESID = 4, VV_EPI_GATED_RESID = 5, VV_EPI_CFG_DPM = 6,
+       VV_EPI_QKV_ROPE = 7 };   // prefill.hip only: bias + RoPE + KV-cache append in the QKV GEMM's epilogue
 
 struct VVGemm {
     const u32x4* W;        // packed tiles
