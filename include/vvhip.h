@@ -119,6 +119,10 @@ int vv_embed(vv_ctx* ctx, void* stream, int n, const int* ids, float* out_dev);
 /* logits restricted to the valid ids: replaces lm_head + constraint mask (:241-242,488-490).
  * logits_out_dev [n][n_valid] fp32 in the order given to vv_set_valid_tokens. */
 int vv_lm_logits(vv_ctx* ctx, void* stream, int n, const float* hidden_dev, float* logits_out_dev);
+/* lm_head over the whole vocabulary (:241-242, `outputs.logits[:, -1, :]` of :486): logits_out_dev [n][lm_vocab] fp32, 1 <= n <= 16.
+ * Needed only when a full-vocabulary logits processor is requested (top-k / top-p / min-p / repetition penalty run before the
+ * valid-id constraint in the reference's processor list, :310-319); the default path evaluates the valid rows only. */
+int vv_lm_logits_full(vv_ctx* ctx, void* stream, int n, const float* hidden_dev, float* logits_out_dev);
 
 /* sample_speech_tokens (:697-710): cond_dev [2n][H] = n positive then n negative
  * conditions, noise_dev [n][latent], -> latent_out_dev [n][latent] */

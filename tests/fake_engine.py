@@ -87,6 +87,11 @@ class FakeEngine:
         nv = len(self.valid)
         out.reshape(-1)[:n * nv].copy_(F.linear(hidden[:n], self.om.lm_head)[:, self.valid].reshape(-1))
 
+    def lm_logits_full(self, n, hidden, out):
+        # [n][lm_vocab] over the whole table (include/vvhip.h, vv_lm_logits_full)
+        V = self.om.lm_head.shape[0]
+        out.reshape(-1)[:n * V].copy_(F.linear(hidden[:n].float(), self.om.lm_head).reshape(-1))
+
     # ---- diffusion ----
     def diffusion_sample(self, n, cond, noise, cfg_scale, latent_out, step_noise=None):
         om = self.om

@@ -330,7 +330,7 @@ def gen_generate():
             # NOTE: finished_flags deliberately left untouched -- the reference's own streamer sets them, which makes
             # generate() stop at the first finished sample (:443-447); here the whole batch is recorded.
 
-    def run(name, B, plans, seed, max_new_tokens=None, do_sample=False, wav_len=3 * 3200, streamer=False, sde=False):
+    def run(name, B, plans, seed, max_new_tokens=None, do_sample=False, wav_len=3 * 3200, streamer=False, sde=False, gen_cfg=None):
         g = synth.Gen(seed)
         lens = [21, 17][:B]
         L0 = max(lens)
@@ -387,7 +387,8 @@ def gen_generate():
             out = m.generate(input_ids=ids, attention_mask=mask, tokenizer=T(), cfg_scale=1.3, max_new_tokens=max_new_tokens,
                              # top_k=0: HF's default top-50 warper runs BEFORE the reference's valid-token constraint; with random
                              # weights the 4 valid ids can all fall outside the top 50 (all -inf -> NaN probabilities)
-                             generation_config=({"do_sample": True, "top_k": 0} if do_sample else {"do_sample": False}),
+                             generation_config=(gen_cfg if gen_cfg is not None else
+                                                {"do_sample": True, "top_k": 0} if do_sample else {"do_sample": False}),
                              show_progress_bar=False, return_speech=True, audio_streamer=rec,
                              speech_tensors=speech, speech_masks=smask, speech_input_mask=sim)
         finally:
@@ -413,6 +414,26 @@ def gen_generate():
     run("generate_greedy_b1.npz", 1, None, seed=31, max_new_tokens=10)
     # multinomial token sampling from the CPU global RNG, interleaved with the noise draws: pins the RNG consumption order
     run("generate_sampled_b1.npz", 1, None, seed=47, max_new_tokens=14, do_sample=True)
+    # the full-vocabulary logits processors in front of the valid-token constraint (HF's list, :310-319): repetition penalty,
+    # temperature, top-k, top-p, min-p over all 320 ids of the toy vocabulary, then the constraint, then multinomial
+    # (with random weights a step whose valid ids are ALL filtered makes the reference fail in torch.multinomial -- NaN
+    # probabilities; the first seed of the list that runs through is used, and recorded in the file)
+    def run_first_ok(name, seeds, *a, **k):
+        for sd in seeds:
+            try:
+                run(name, *a, seed=sd, **k)
+                return
+            except RuntimeError as ex:
+                if "probability tensor" not in str(ex):
+                    raise
+        raise RuntimeError(f"{name}: no seed in {list(seeds)} survives the filters")
+    run_first_ok("generate_sampled_warped_b1.npz", range(59, 99), 1, None, max_new_tokens=14,
+                 gen_cfg={"do_sample": True, "top_k": 300, "top_p": 0.995, "min_p": 0.0001, "temperature": 0.8, "repetition_penalty": 1.15})
+    # the same processors in a batch of two (left-padded prompts: the pad id counts as seen for the repetition penalty)
+    run_first_ok("generate_sampled_warped_b2.npz", range(161, 199), 2, None, max_new_tokens=12,
+                 gen_cfg={"do_sample": True, "top_k": 310, "top_p": 0.998, "temperature": 1.3, "repetition_penalty": 1.05})
+    # greedy decoding with a repetition penalty (a processor, not a warper: it also acts without sampling)
+    run("generate_greedy_reppen_b1.npz", 1, None, seed=31, max_new_tokens=10, gen_cfg={"do_sample": False, "repetition_penalty": 4.0})
     # voice sample that is not a whole number of 3200-sample frames (2.5 frames; the prompt reserves ceil = 3 positions)
     run("generate_ragged_voice_b1.npz", 1, [[D, D, X]], seed=53, wav_len=8000)
     # length cap: the forced plan would go on, max_new_tokens stops it (reach_max_step_sample bookkeeping, :523-539)

@@ -122,7 +122,7 @@ def test_reference_demo_call_sequence(product, capsys):
     assert outputs.reach_max_step_sample.shape == (1,)
     # seeded sampling run == the reference's own generate() (tests/golden/generate_sampled_b1.npz)
     torch.manual_seed(int(z["seed"]))
-    out2 = model.generate(**inputs, max_new_tokens=14, cfg_scale=1.3, tokenizer=TOK, generation_config={"do_sample": True},
+    out2 = model.generate(**inputs, max_new_tokens=14, cfg_scale=1.3, tokenizer=TOK, generation_config={"do_sample": True, "top_k": 0},
                           verbose=False, is_prefill=True, show_progress_bar=False)
     assert torch.equal(out2.sequences.cpu(), torch.from_numpy(z["sequences"]))
     ref = torch.from_numpy(z["audio_0"])
@@ -133,12 +133,20 @@ def test_reference_demo_call_sequence(product, capsys):
 def test_generation_config_forms(product):
     modeling, path = product
     m = modeling.VibeVoiceForConditionalGenerationInference
-    assert m._generation_options(None) == (False, 1.0)
-    assert m._generation_options({"do_sample": True, "temperature": 0.7}) == (True, 0.7)
+    assert m._generation_options(None) == (False, 1.0, None)
+    assert m._generation_options({"do_sample": True, "temperature": 0.7, "top_k": 0}) == (True, 0.7, None)
+    # transformers==4.51.3 (the reference's pin): do_sample alone means top-50 over the whole vocabulary
+    assert m._generation_options({"do_sample": True}) == (True, 1.0, dict(top_k=50, top_p=1.0, min_p=0.0, repetition_penalty=1.0))
+    assert m._generation_options({"do_sample": True, "top_k": 10, "top_p": 0.9})[2] == dict(top_k=10, top_p=0.9, min_p=0.0, repetition_penalty=1.0)
+    assert m._generation_options({"do_sample": False, "repetition_penalty": 1.2})[2] == dict(top_k=0, top_p=1.0, min_p=0.0, repetition_penalty=1.2)
+    assert m._generation_options({"do_sample": False, "top_k": 10}) == (False, 1.0, None)        # warpers only act with sampling
     from transformers import GenerationConfig
-    assert m._generation_options(GenerationConfig(do_sample=True, temperature=0.5)) == (True, 0.5)      # an object, not a dict
-    with pytest.raises(NotImplementedError):
-        m._generation_options({"do_sample": True, "top_k": 10})
+    assert m._generation_options(GenerationConfig(do_sample=True, temperature=0.5, top_k=0)) == (True, 0.5, None)      # an object, not a dict
+    for bad in ({"do_sample": True, "typical_p": 0.5}, {"num_beams": 4}, {"no_repeat_ngram_size": 3}):
+        with pytest.raises(NotImplementedError):
+            m._generation_options(bad)
+    with pytest.raises(ValueError):
+        m._generation_options({"do_sample": True, "top_p": 1.5})
     with pytest.raises(TypeError):
         m._generation_options(3)
 

@@ -366,8 +366,11 @@ def test_graph_cache_is_bounded(monkeypatch):
         s.eng.close()
 
 
-def test_sampling_path_at_vanishing_temperature_equals_greedy_batch2(sm):
-    """do_sample=True on the engine for a desynchronised batch of TWO: the sampling branch builds full-vocabulary rows from the
+@pytest.mark.parametrize("extra", [{"top_k": 0}, {"top_k": 319}], ids=["valid-rows", "full-vocabulary"])
+def test_sampling_path_at_vanishing_temperature_equals_greedy_batch2(sm, extra):
+    """(ids = "full-vocabulary": the same through vv_lm_logits_full and the full-vocabulary processors -- top-k 319 of the toy
+    vocabulary's 320 removes nothing that matters -- then the valid-token constraint.)
+    do_sample=True on the engine for a desynchronised batch of TWO: the sampling branch builds full-vocabulary rows from the
     dense [n][n_valid] logits block (vibevoice_amd/modeling.py: the branch of ADVICE r1's row-stride finding that no GPU test
     reached -- the reference draws on the device generator, so a seeded run cannot be compared with the CPU oracle).  At
     temperature 1e-3 the categorical draw is the argmax (the tiny model's logit gaps are ~1e-1), so the sampled run must
@@ -395,7 +398,7 @@ def test_sampling_path_at_vanishing_temperature_equals_greedy_batch2(sm):
                                 bos_token_id=None, pad_token_id=TOK.pad_token_id)
     torch.manual_seed(5)
     out = m.generate(input_ids=ids, attention_mask=mask, speech_tensors=st, speech_masks=smk, speech_input_mask=sim, cfg_scale=1.3,
-                     tokenizer=tok, max_new_tokens=10, generation_config={"do_sample": True, "temperature": 1e-3},
+                     tokenizer=tok, max_new_tokens=10, generation_config={"do_sample": True, "temperature": 1e-3, **extra},
                      _noise_fn=noise_fn, _prefill_noise=pre, show_progress_bar=False)
     greedy = h[0]
     assert torch.equal(out.sequences.cpu(), greedy.sequences.cpu())

@@ -605,3 +605,51 @@ def test_lora_merge_reaches_the_engine(tmp_path):
         assert rel_err(hid, ref) <= 5e-4, rel_err(hid, ref)
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("n", [1, 5, 16])
+def test_lm_logits_over_the_whole_vocabulary_and_the_logits_processors(sm, n):
+    """vv_lm_logits_full (one wave per vocabulary row, fp32 products of the bf16 table) against the fp32 matmul, and the product's
+    full-vocabulary processors (vibevoice_amd/modeling.py::_full_vocab_scores) against HF's own classes -- the ones the reference
+    gets from GenerationMixin._get_logits_processor (modeling_vibevoice_inference.py:310-319): repetition penalty, temperature,
+    top-k, top-p, min-p, in that order."""
+    import types as _types
+    from transformers.generation.logits_process import (MinPLogitsWarper, RepetitionPenaltyLogitsProcessor, TemperatureLogitsWarper,
+                                                        TopKLogitsWarper, TopPLogitsWarper)
+    from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference
+    eng = sm.eng
+    H, V = sm.lmcfg.hidden, sm.lmcfg.vocab
+    g = synth.Gen(9100 + n)
+    hid = g.normal((n, H), 2.0, mat=False)
+    table = sm.lm_head if getattr(sm, "lm_head", None) is not None else sm.lm_w["embed_tokens.weight"]
+    ref = hid @ table.float().t()
+    out = eng.new(16 * V)
+    with torch.cuda.stream(eng.stream):
+        eng.lm_logits_full(n, dev(hid, eng), out)
+    eng.sync()
+    got = out[:n * V].view(n, V).cpu()
+    assert rel_err(got, ref) <= 1e-5, rel_err(got, ref)
+    # processors
+    cfgd = {"decoder_config": {"max_position_embeddings": sm.lmcfg.max_pos}, "diffusion_head_config": {"ddpm_num_inference_steps": 5},
+            "acoustic_tokenizer_config": {"fix_std": 0.5, "std_dist_type": "gaussian"}}
+    m = VibeVoiceForConditionalGenerationInference(cfgd, eng, model_dtype=torch.float32)
+    order = []
+    for i in range(n):
+        ids = [int(t) for t in g.rng.integers(0, V, (9 + i,))]
+        order.append(_types.SimpleNamespace(ids=ids, tokens=[int(t) for t in g.rng.integers(0, V, (3,))], seq_len0=30, init_len=len(ids)))
+    warp = dict(top_k=200, top_p=0.93, min_p=0.002, repetition_penalty=1.3)
+    S = dict(warp=warp, do_sample=True, temperature=0.7, pad_id=V - 1)
+    with torch.cuda.stream(eng.stream):
+        sc = m._full_vocab_scores(dev(hid, eng), order, S)
+    eng.sync()
+    sc = sc.cpu()
+    want = ref.clone()
+    for i, u in enumerate(order):
+        row_ids = torch.tensor([[V - 1] + u.ids + u.tokens])
+        want[i:i + 1] = RepetitionPenaltyLogitsProcessor(1.3)(row_ids, want[i:i + 1])
+    for proc in (TemperatureLogitsWarper(0.7), TopKLogitsWarper(200), TopPLogitsWarper(0.93), MinPLogitsWarper(0.002)):
+        want = proc(None, want)
+    keep_w, keep_g = torch.isfinite(want), torch.isfinite(sc)
+    assert int((keep_w != keep_g).sum()) <= n            # a token exactly at a filter's boundary may fall on either side
+    both = keep_w & keep_g
+    assert float((sc[both] - want[both]).abs().max()) <= 1e-4 * float(want[both].abs().max())

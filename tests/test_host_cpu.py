@@ -468,12 +468,79 @@ def test_host_generate_sampling_keeps_the_reference_rng_stream(monkeypatch):
         out = m.generate(input_ids=torch.from_numpy(z["input_ids"]), attention_mask=torch.from_numpy(z["attention_mask"]),
                          speech_tensors=torch.from_numpy(z["speech_tensors"]), speech_masks=torch.from_numpy(z["speech_masks"]),
                          speech_input_mask=torch.from_numpy(z["speech_input_mask"]), cfg_scale=1.3, tokenizer=tok,
-                         max_new_tokens=14, generation_config={"do_sample": True}, show_progress_bar=False)
+                         max_new_tokens=14, generation_config={"do_sample": True, "top_k": 0}, show_progress_bar=False)
     assert torch.equal(out.sequences.cpu(), torch.from_numpy(z["sequences"]))
     ref = torch.from_numpy(z["audio_0"])
     got = out.speech_outputs[0].reshape(-1)
     assert got.shape == ref.shape
     assert float((got - ref).norm() / ref.norm()) <= 1e-4
+
+
+@pytest.mark.parametrize("name,gen_cfg,max_new", [
+    ("generate_sampled_warped_b1.npz", {"do_sample": True, "top_k": 300, "top_p": 0.995, "min_p": 0.0001, "temperature": 0.8,
+                                        "repetition_penalty": 1.15}, 14),
+    ("generate_sampled_warped_b2.npz", {"do_sample": True, "top_k": 310, "top_p": 0.998, "temperature": 1.3, "repetition_penalty": 1.05}, 12),
+    ("generate_greedy_reppen_b1.npz", {"do_sample": False, "repetition_penalty": 4.0}, 10),
+])
+def test_host_generate_full_vocabulary_processors_match_the_reference(monkeypatch, name, gen_cfg, max_new):
+    """The reference's generate() with HF's full-vocabulary logits processors in front of its valid-token constraint (repetition
+    penalty; with do_sample: temperature, top-k, top-p, min-p -- modeling_vibevoice_inference.py:310-319,416-419,488-496), seeded
+    and recorded by tests/golden/make_golden.py.  The product routes such calls through vv_lm_logits_full (here: the fake engine's
+    fp32 lm_head) and its own implementation of the processors: identical token sequences (the multinomial draws see the same
+    distributions on the same generator) and waveforms, for one utterance and for a left-padded batch of two."""
+    import types as _types
+    import fake_engine
+    from test_oracle_golden import G as GOLD, _oracle_small
+    from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference
+    z = np.load(os.path.join(GOLD, name))
+    B = z["input_ids"].shape[0]
+    with fake_engine.cpu_cuda_shims(monkeypatch):
+        eng = fake_engine.FakeEngine(_oracle_small(), n_slots=B)
+        cfgd = {"decoder_config": {"max_position_embeddings": 4096}, "diffusion_head_config": {"ddpm_num_inference_steps": 5},
+                "acoustic_tokenizer_config": {"fix_std": 0.5, "std_dist_type": "gaussian"}}
+        m = VibeVoiceForConditionalGenerationInference(cfgd, eng, model_dtype=torch.float32)
+        m.set_speech_factors(0.2, -0.05)
+        m.set_ddpm_inference_steps(5)
+        tok = _types.SimpleNamespace(speech_start_id=301, speech_end_id=302, speech_diffusion_id=303, eos_token_id=304,
+                                     bos_token_id=None, pad_token_id=305)
+        torch.manual_seed(int(z["seed"]))
+        out = m.generate(input_ids=torch.from_numpy(z["input_ids"]), attention_mask=torch.from_numpy(z["attention_mask"]),
+                         speech_tensors=torch.from_numpy(z["speech_tensors"]), speech_masks=torch.from_numpy(z["speech_masks"]),
+                         speech_input_mask=torch.from_numpy(z["speech_input_mask"]), cfg_scale=1.3, tokenizer=tok,
+                         max_new_tokens=max_new, generation_config=gen_cfg, show_progress_bar=False)
+    assert torch.equal(out.sequences.cpu(), torch.from_numpy(z["sequences"])), (out.sequences.tolist(), z["sequences"].tolist())
+    for b in range(B):
+        ref = torch.from_numpy(z[f"audio_{b}"])
+        if ref.numel() == 0:
+            assert out.speech_outputs[b] is None or out.speech_outputs[b].numel() == 0
+            continue
+        got = out.speech_outputs[b].reshape(-1)
+        assert got.shape == ref.shape
+        assert float((got - ref).norm() / ref.norm()) <= 1e-4
+
+
+def test_host_generate_reports_a_row_whose_valid_tokens_were_all_filtered(monkeypatch):
+    """top_k = 1 over the toy vocabulary keeps one id per row -- with random weights not a speech token: the reference dies in
+    torch.multinomial on NaN probabilities (tests/golden/make_golden.py walks its seed list for that reason); the product says why."""
+    import types as _types
+    import fake_engine
+    from test_oracle_golden import G as GOLD, _oracle_small
+    from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference
+    z = np.load(os.path.join(GOLD, "generate_sampled_b1.npz"))
+    with fake_engine.cpu_cuda_shims(monkeypatch):
+        eng = fake_engine.FakeEngine(_oracle_small(), n_slots=1)
+        cfgd = {"decoder_config": {"max_position_embeddings": 4096}, "diffusion_head_config": {"ddpm_num_inference_steps": 5},
+                "acoustic_tokenizer_config": {"fix_std": 0.5, "std_dist_type": "gaussian"}}
+        m = VibeVoiceForConditionalGenerationInference(cfgd, eng, model_dtype=torch.float32)
+        m.set_speech_factors(0.2, -0.05)
+        m.set_ddpm_inference_steps(5)
+        tok = _types.SimpleNamespace(speech_start_id=301, speech_end_id=302, speech_diffusion_id=303, eos_token_id=304,
+                                     bos_token_id=None, pad_token_id=305)
+        with pytest.raises(RuntimeError, match="removed every valid speech token"):
+            m.generate(input_ids=torch.from_numpy(z["input_ids"]), attention_mask=torch.from_numpy(z["attention_mask"]),
+                       speech_tensors=torch.from_numpy(z["speech_tensors"]), speech_masks=torch.from_numpy(z["speech_masks"]),
+                       speech_input_mask=torch.from_numpy(z["speech_input_mask"]), cfg_scale=1.3, tokenizer=tok,
+                       max_new_tokens=14, generation_config={"do_sample": True, "top_k": 1}, show_progress_bar=False)
 
 
 def test_recorded_bench_line_keeps_the_driver_contract():

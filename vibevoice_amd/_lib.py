@@ -44,6 +44,7 @@ _SIGS = {
     "vv_eos_logit": (C.c_int, [_P, _P, C.c_int, _P, _P]),
     "vv_embed": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int), _P]),
     "vv_lm_logits": (C.c_int, [_P, _P, C.c_int, _P, _P]),
+    "vv_lm_logits_full": (C.c_int, [_P, _P, C.c_int, _P, _P]),
     "vv_diffusion_sample": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_float, _P]),
     "vv_diffusion_sample_sde": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, C.c_float, _P]),
     "vv_head_forward": (C.c_int, [_P, _P, C.c_int, _P, C.POINTER(C.c_float), _P, _P]),

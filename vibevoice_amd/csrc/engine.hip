@@ -30,6 +30,7 @@ int vv_attn_launch(int D, int xs, const float* q, const VVRow* rows, const void*
                    int Hkv, int64_t cache_stride, int64_t head_stride, int S, float* pm, float* pl, float* po,
                    float* out, hipStream_t s);
 int vv_embed_launch(const void* table, const int* ids, float* out, int n, int H, hipStream_t s);
+int vv_logits_full_launch(const void* table, const float* hidden, float* out, int n, int V, int H, hipStream_t s);
 int vv_rmsnorm_rows_launch(const float* x, int ldx, float* y, int ldy, const float* w, int T, int C, float eps, hipStream_t s);
 int vv_dwconv_res_launch(const float* nb, const float* x, float* xo, const float* w, const float* b, const float* gamma, int T, int C, hipStream_t s);
 int vv_normdw_sliced_ok(int T, int C);
@@ -1347,6 +1348,14 @@ extern "C" int vv_embed(vv_ctx* ctx, void* stream, int n, const int* ids, float*
     return 0;
 }
 
+extern "C" int vv_lm_logits_full(vv_ctx* ctx, void* stream, int n, const float* hidden_dev, float* logits_out_dev) {
+    const void* table = ctx->lm_head_loaded ? ctx->lm_head : ctx->embed;
+    if (!table) return fail(ctx, "vv_lm_logits_full: no lm_head / embedding table has been uploaded");
+    if (n < 1 || n > 16) return fail(ctx, "vv_lm_logits_full: n must be in [1,16]");
+    if (ctx->H & 7) return fail(ctx, "vv_lm_logits_full: hidden size %d is not a multiple of 8", ctx->H);
+    VVCHK(vv_logits_full_launch(table, hidden_dev, logits_out_dev, n, ctx->c.lm_vocab, ctx->H, (hipStream_t)stream));
+    return 0;
+}
 extern "C" int vv_lm_logits(vv_ctx* ctx, void* stream, int n, const float* hidden_dev, float* logits_out_dev) {
     hipStream_t st = (hipStream_t)stream;
     if (!ctx->valid_w) return fail(ctx, "vv_set_valid_tokens has not been called");

@@ -473,12 +473,57 @@ __global__ void vv_dw_transpose_kernel(const float* __restrict__ s, float* __res
     if (i < C * 7) { const int c = i / 7, j = i - c * 7; d[j * C + c] = s[i]; }
 }
 
+// lm_head over the WHOLE vocabulary for n hidden rows (n <= 16): logits[r][v] = sum_k hidden[r][k] * W[v][k], W row-major bf16 (the
+// embedding / lm_head table as uploaded).  Only the full-vocabulary logits processors need it (top-k / top-p / min-p /
+// repetition penalty act on every token before the valid-id constraint, modeling_vibevoice_inference.py:310-319,488-496); the
+// greedy / plain-sampling path evaluates the <= 16 valid rows with vv_lm_logits.  One wave per vocabulary row: the row is read
+// once from HBM (8 bf16 per lane and step, fp32 products and sums), the n hidden rows come from L2; HBM-bound (2 V H bytes).
+__global__ __launch_bounds__(256) void vv_logits_full_kernel(const __bf16* __restrict__ table, const float* __restrict__ hidden,
+                                                             float* __restrict__ out, int n, int V, int H) {
+    const int lane = threadIdx.x & 63;
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= V) return;
+    const __bf16* wrow = table + (int64_t)v * H;
+    float acc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int k = lane * 8; k < H; k += 512) {           // H % 8 == 0 is a launch precondition
+        const u32x4 wv = *reinterpret_cast<const u32x4*>(wrow + k);
+        const bf16x8 w8 = __builtin_bit_cast(bf16x8, wv);
+        float wf[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wf[j] = (float)w8[j];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (r < n) {
+                const float4 a = *reinterpret_cast<const float4*>(hidden + (int64_t)r * H + k);
+                const float4 b = *reinterpret_cast<const float4*>(hidden + (int64_t)r * H + k + 4);
+                acc[r] += a.x * wf[0] + a.y * wf[1] + a.z * wf[2] + a.w * wf[3] + b.x * wf[4] + b.y * wf[5] + b.z * wf[6] + b.w * wf[7];
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        if (r < n) {
+            float t = acc[r];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+            if (lane == 0) out[(int64_t)r * V + v] = t;
+        }
+    }
+}
+
 }  // namespace
 
 static inline int okk() { return hipGetLastError() == hipSuccess ? 0 : -2; }
 
 extern "C" {
 
+int vv_logits_full_launch(const void* table, const float* hidden, float* out, int n, int V, int H, hipStream_t s) {
+    if (n < 1 || n > 16 || V < 1 || (H & 7)) return -1;
+    hipLaunchKernelGGL(vv_logits_full_kernel, dim3((V + 3) / 4), dim3(256), 0, s, (const __bf16*)table, hidden, out, n, V, H);
+    return okk();
+}
 int vv_embed_launch(const void* table, const int* ids, float* out, int n, int H, hipStream_t s) {
     hipLaunchKernelGGL(vv_embed_kernel, dim3(n), dim3(256), 0, s, (const __bf16*)table, ids, out, H);
     return okk();

@@ -307,6 +307,11 @@ class Engine:
     def lm_logits(self, n: int, hidden: torch.Tensor, logits_out: torch.Tensor):
         self._chk(self.lib.vv_lm_logits(self._ctx, self._s, n, self._p(hidden), self._p(logits_out)), "vv_lm_logits")
 
+    def lm_logits_full(self, n: int, hidden: torch.Tensor, logits_out: torch.Tensor):
+        """logits over the whole vocabulary, [n, lm_vocab] fp32 (the full-vocabulary logits processors' input)"""
+        assert logits_out.dtype == torch.float32 and logits_out.is_contiguous() and logits_out.numel() >= n * self.cfg.lm_vocab
+        self._chk(self.lib.vv_lm_logits_full(self._ctx, self._s, n, self._p(hidden), self._p(logits_out)), "vv_lm_logits_full")
+
     def diffusion_sample(self, n: int, cond: torch.Tensor, noise: torch.Tensor, cfg_scale: float, latent_out: torch.Tensor,
                          step_noise: Optional[torch.Tensor] = None):
         """step_noise [n_steps, n, latent] fp32 (contiguous, on the device): the per-step variance noise of the stochastic solver."""

@@ -599,14 +599,79 @@ class VibeVoiceForConditionalGenerationInference:
             raise TypeError(f"generation_config must be a dict, None or have to_dict(); got {type(generation_config).__name__}")
         do_sample = bool(gc.get("do_sample", False))
         temperature = float(gc.get("temperature", 1.0) or 1.0)
-        # warpers that act on the FULL-vocabulary distribution before the constraint mask cannot be reproduced from the <=5
-        # logits this path evaluates: refuse them instead of silently sampling from something else
-        for k in ("top_k", "top_p", "min_p", "typical_p", "repetition_penalty", "no_repeat_ngram_size", "bad_words_ids", "num_beams"):
+        # processors this path does not implement: refuse them instead of silently decoding from something else
+        for k in ("typical_p", "epsilon_cutoff", "eta_cutoff", "top_h", "no_repeat_ngram_size", "encoder_no_repeat_ngram_size",
+                  "bad_words_ids", "num_beams", "num_beam_groups", "penalty_alpha", "diversity_penalty", "sequence_bias",
+                  "suppress_tokens", "begin_suppress_tokens", "forced_bos_token_id", "forced_eos_token_id", "min_length",
+                  "min_new_tokens", "exponential_decay_length_penalty", "guidance_scale"):
             v = gc.get(k)
-            if do_sample and v not in (None, 0, 0.0, 1, 1.0, [], ()):
-                raise NotImplementedError(f"generation_config[{k!r}]={v!r}: full-vocabulary logits processors are not available on the "
-                                          "HIP path (the lm_head is evaluated on the valid speech tokens only)")
-        return do_sample, temperature
+            if v not in (None, 0, 0.0, 1, 1.0, [], ()):
+                raise NotImplementedError(f"generation_config[{k!r}]={v!r} is not implemented on the HIP path")
+        # The processors that act on the FULL vocabulary in front of the valid-token constraint (HF's list, :310-319, then the
+        # constraint appended at :416-419): repetition penalty (also without sampling), and with do_sample the warpers
+        # temperature -> top-k -> top-p -> min-p.  transformers==4.51.3 (the reference's pin) defaults top_k to 50 whenever
+        # do_sample is set: an absent top_k means 50 here too; top_k=0 / None switches it off.  Any of them routes the token
+        # choice through vv_lm_logits_full (one pass over the whole lm_head per step) instead of the <= 16 valid rows.
+        rep = float(gc.get("repetition_penalty") or 1.0)
+        warp = None
+        if do_sample:
+            top_k = int((gc["top_k"] if "top_k" in gc else 50) or 0)
+            top_p = float(gc["top_p"]) if gc.get("top_p") is not None else 1.0
+            min_p = float(gc.get("min_p") or 0.0)
+            if top_k < 0 or not (0.0 <= top_p <= 1.0) or not (0.0 <= min_p <= 1.0):
+                raise ValueError(f"top_k={top_k}, top_p={top_p}, min_p={min_p}: out of range")
+            if top_k > 0 or top_p < 1.0 or min_p > 0.0 or rep != 1.0:
+                warp = dict(top_k=top_k, top_p=top_p, min_p=min_p, repetition_penalty=rep)
+        elif rep != 1.0:
+            warp = dict(top_k=0, top_p=1.0, min_p=0.0, repetition_penalty=rep)
+        if rep <= 0.0:
+            raise ValueError(f"repetition_penalty={rep} must be > 0")
+        return do_sample, temperature, warp
+
+    def _full_vocab_scores(self, hidden: torch.Tensor, order, S) -> torch.Tensor:
+        """[n, lm_vocab] scores of the given positive rows after the reference's full-vocabulary logits processors, in HF's order
+        (generation/utils.py `_get_logits_processor`): repetition penalty over the row's input_ids (left padding, prompt and
+        generated tokens), then -- with do_sample -- temperature, top-k, top-p, min-p (min_tokens_to_keep = 1).  The valid-token
+        constraint comes after them (the caller)."""
+        e, w = self.engine, S["warp"]
+        n, V = hidden.shape[0], e.cfg.lm_vocab
+        if getattr(self, "_full_logits", None) is None or self._full_logits.numel() < 16 * V:
+            self._full_logits = torch.empty(16 * V, dtype=torch.float32, device=self.device)
+        hidden = hidden.to(torch.float32).contiguous()
+        parts = []
+        for i0 in range(0, n, 16):
+            k = min(16, n - i0)
+            e.lm_logits_full(k, hidden[i0:i0 + k], self._full_logits)
+            parts.append(self._full_logits[:k * V].view(k, V).clone())
+        scores = torch.cat(parts)                    # (the step loop runs under torch.cuda.stream(engine.stream): one ordered stream)
+        if w["repetition_penalty"] != 1.0:
+            pen = w["repetition_penalty"]
+            for i, u in enumerate(order):
+                seen = list(u.ids) + list(u.tokens)
+                if u.seq_len0 > u.init_len and S["pad_id"] is not None:
+                    seen.append(S["pad_id"])
+                ids = torch.tensor(sorted(set(int(t) for t in seen if 0 <= int(t) < V)), dtype=torch.long, device=scores.device)
+                sc = scores[i, ids]
+                scores[i, ids] = torch.where(sc < 0, sc * pen, sc / pen)
+        if S["do_sample"]:
+            if S["temperature"] != 1.0:
+                scores = scores / S["temperature"]
+            if w["top_k"] > 0:
+                kth = torch.topk(scores, min(w["top_k"], V))[0][..., -1, None]
+                scores = scores.masked_fill(scores < kth, float("-inf"))
+            if w["top_p"] < 1.0:
+                srt, idx = torch.sort(scores, descending=False)
+                remove = srt.softmax(dim=-1).cumsum(dim=-1) <= (1.0 - w["top_p"])
+                remove[..., -1:] = False
+                scores = scores.masked_fill(remove.scatter(1, idx, remove), float("-inf"))
+            if w["min_p"] > 0.0:
+                probs = torch.softmax(scores, dim=-1)
+                remove = probs < w["min_p"] * probs.amax(dim=-1, keepdim=True)
+                idx = torch.argsort(scores, descending=True, dim=-1)
+                srt_remove = torch.gather(remove, dim=-1, index=idx)
+                srt_remove[..., :1] = False
+                scores = scores.masked_fill(srt_remove.scatter(1, idx, srt_remove), float("-inf"))
+        return scores
 
     # ------------------------------------------------------------------ prompt prefill of one utterance
     def _prefill(self, u: _Utt, ids: List[int], speech_rows: Optional[torch.Tensor], speech_pos: Optional[torch.Tensor],
@@ -729,7 +794,7 @@ class VibeVoiceForConditionalGenerationInference:
             for u in order:
                 f = u.forced if u.forced is not None else S["forced"][u.idx]
                 u.last = int(f[u.step]) if u.step < len(f) else eos_id
-        elif do_sample:
+        elif do_sample or S["warp"] is not None:
             # the reference samples torch.multinomial(softmax(scores)) over the FULL vocabulary rows of the WHOLE batch (-inf
             # outside the valid ids, :490-496; finished rows included, their draw is overwritten by eos, :499) on the model's
             # device.  One-sample multinomial spends one exponential variate per (row, category), so the same call on the
@@ -738,10 +803,23 @@ class VibeVoiceForConditionalGenerationInference:
             full = torch.full((len(rows_of), e.cfg.lm_vocab), float("-inf"), device=self.device, dtype=torch.float32)
             vt = valid_t.to(self.device)
             full[:, vt] = 0.0                              # finished rows: any proper distribution, the draw is discarded
-            lg = self._logits[:nA * nv].view(nA, nv).float() / S["temperature"]
+            if S["warp"] is None:
+                lg = self._logits[:nA * nv].view(nA, nv).float() / S["temperature"]
+            else:
+                # full-vocabulary processors, then the constraint: what survives of the valid ids (-inf where a filter removed one;
+                # a row that loses ALL its valid ids has NaN probabilities in the reference too -- torch.multinomial raises)
+                scores = self._full_vocab_scores(torch.cat([pos_hidden(i) for i in range(nA)]), order, S)
+                lg = scores[:, vt]
+                if not bool(torch.isfinite(lg).any(dim=-1).all()):
+                    raise RuntimeError("the full-vocabulary logits processors (top_k / top_p / min_p) removed every valid speech token "
+                                       "of a row: nothing is left to sample from (the reference fails in torch.multinomial here: "
+                                       "'probability tensor contains either `inf`, `nan` or element < 0')")
             for i, u in enumerate(order):
                 full[rows_of.index(u.idx), vt] = lg[i]
-            pick_ids = torch.multinomial(torch.softmax(full, dim=-1), num_samples=1).squeeze(1).cpu()
+            if do_sample:
+                pick_ids = torch.multinomial(torch.softmax(full, dim=-1), num_samples=1).squeeze(1).cpu()
+            else:
+                pick_ids = torch.argmax(full, dim=-1).cpu()
             for u in order:
                 u.last = int(pick_ids[rows_of.index(u.idx)])
         else:
@@ -910,7 +988,7 @@ class VibeVoiceForConditionalGenerationInference:
             raise ValueError("generate() needs tokenizer= (speech_start_id / speech_end_id / speech_diffusion_id / eos_token_id)")
         if not kwargs.get("refresh_negative", True):
             raise NotImplementedError("refresh_negative=False is not supported by the HIP path")
-        do_sample, temperature = self._generation_options(generation_config)
+        do_sample, temperature, warp = self._generation_options(generation_config)
         start_id, end_id, diff_id = tokenizer.speech_start_id, tokenizer.speech_end_id, tokenizer.speech_diffusion_id
         eos_id = tokenizer.eos_token_id
         bos_id = getattr(tokenizer, "bos_token_id", None)
@@ -922,7 +1000,8 @@ class VibeVoiceForConditionalGenerationInference:
         e.set_num_steps(self.ddpm_inference_steps, t_cast_bf16=(self.dtype == torch.bfloat16 and kwargs.get("_t_cast", True)),
                         **({} if algo == "dpmsolver++" else {"algorithm_type": algo}))
         return dict(sde=(algo == "sde-dpmsolver++"), sde_noise_fn=kwargs.pop("_sde_noise_fn", None), nv=len(valid), valid_t=torch.tensor(valid, dtype=torch.long), start_id=start_id, end_id=end_id, diff_id=diff_id,
-                    eos_id=eos_id, cfg_scale=cfg_scale, do_sample=do_sample, temperature=temperature,
+                    eos_id=eos_id, cfg_scale=cfg_scale, do_sample=do_sample, temperature=temperature, warp=warp,
+                    pad_id=getattr(tokenizer, "pad_token_id", None),
                     trace=kwargs.pop("_trace", None), audio_streamer=audio_streamer, verbose=kwargs.get("verbose", False),
                     forced=kwargs.pop("_forced_tokens", None), noise_fn=kwargs.pop("_noise_fn", None), n_rows=n_rows,
                     teacher=kwargs.pop("_teacher_embeds", None),
