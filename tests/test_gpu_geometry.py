@@ -7,7 +7,7 @@
   * decode attention over a LONG cache: 32,768 positions at the 7B geometry, 65,536 at the 1.5B geometry (12 / 2 x 128),
     8,192 at the 0.5B geometry -- random bf16 K/V placed with vv_kv_import(_at), every flash-decoding split and the
     last-arriver ticket merge of vv_attn_fused_kernel, against the oracle's eager attention (oracle/lm.py);
-  * prefill attention over >= 4K positions against the oracle in 512-row chunks: vv_attn_prefill3_kernel in the bf16 mode; in the
+  * prefill attention over >= 4K positions against the oracle in 512-row chunks: vv_attn_prefill4_kernel in the bf16 mode; in the
     exact modes the chunk's rows go through the split + merge attention pair, 64 rows per launch.
 
 One layer keeps the CPU oracle to seconds; every kernel runs at its real per-layer shape.  Weights are bf16-representable
@@ -168,7 +168,7 @@ def test_decode_attention_over_the_full_context(tag, L, xs, tol):
 @pytest.mark.parametrize("xs,tol", [(3, 5e-4), (2, 1e-3), (1, 4e-2)])
 def test_prefill_attention_over_4k_positions(xs, tol):
     """A 4,200-token prompt through one layer in 512-row chunks against the oracle's full causal attention: xs = 1 runs the
-    packed-activation GEMMs + vv_attn_prefill3_kernel; xs = 2, 3 the tile / general GEMMs and, per chunk, eight 64-row launches of
+    packed-activation GEMMs + vv_attn_prefill4_kernel; xs = 2, 3 the tile / general GEMMs and, per chunk, eight 64-row launches of
     the split + merge attention pair (every row attends its own causal prefix)."""
     c = synth.LMCfg(hidden=512, layers=1, heads=4, kv_heads=2, inter=512, vocab=64, max_pos=8192)
     s = build_fast(c, xsplit=xs, max_ctx=4352, max_rows=512, head_layers=1)

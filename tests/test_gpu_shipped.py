@@ -8,7 +8,7 @@
       of 6, EOS landing INSIDE a speech window (modeling_vibevoice_streaming_inference.py:568-694), teacher-forced per step and
       free-running;
   (c) one 7B-width layer prefilled in ONE pass of 10,922 rows (the pass bench.py times) against oracle/lm.py, row by row;
-  (d) the bf16-mode-only kernels (vv_gemm3 / vv_gemm4, vv_attn_prefill3, vv_gemv16p, the 16-row sampler forms) against a
+  (d) the bf16-mode-only kernels (vv_gemm3 / vv_gemm4, vv_attn_prefill4, vv_gemv16p, the 16-row sampler forms) against a
       reference whose matrix-unit INPUTS are rounded to bf16 (oracle mfma_in_bf16): what is left is summation order, so the
       bounds are ~1e-3, not the ~3e-2 the fp32 reference allows -- a wrong k-tile in a hundred fails;
   (e) SURVEY 8d's bf16-vs-bf16 tolerance: the HIP bf16 mode against the oracle loop run as PyTorch-ROCm eager ops in bf16 on
@@ -204,7 +204,7 @@ def test_streaming_generate_in_the_timed_mode_at_0p5b_widths():
 # ---------------------------------------------------------------------------------------------- (c) one-pass 10,922-row prefill
 def test_one_pass_prefill_of_10922_rows_at_7b_widths():
     """The pass bench.py times: 10,922 prompt rows x (28 q / 4 kv heads x 128, hidden 3584, MLP 18944) through ONE call --
-    vv_pack_rows, vv_gemm4 (QKV / o / gate-up / down), vv_rope_append, vv_attn_prefill3 with 171 stages per workgroup -- then
+    vv_pack_rows, vv_gemm4 (QKV with RoPE + append in its epilogue / o / gate-up / down), vv_attn_prefill4 with 171 stages per workgroup -- then
     one decode step on top of the cache it wrote.  Row by row against oracle/lm.py: its fp32 form (bf16-mode bound) and its
     bf16-input form (what is left is summation order and the online-softmax rescaling)."""
     L0 = 10922
@@ -346,7 +346,7 @@ def test_prefill_gemm4_k_split_round(epi, T, N, K):
 # ---------------------------------------------------------------------------------------------- (d) bf16-input references
 @pytest.mark.parametrize("L0,chunk,heads,kv_heads,hd", [(4180, 512, 4, 2, 128), (1000, 1024, 7, 1, 128), (1555, 1024, 14, 2, 64), (90, 128, 4, 2, 128)])
 def test_prefill_attention_v3_against_the_bf16_input_oracle(L0, chunk, heads, kv_heads, hd):
-    """vv_attn_prefill3 (+ the packed-activation GEMMs around it) ROW BY ROW against the oracle with bf16 matrix-unit inputs: one
+    """vv_attn_prefill4 (+ the packed-activation GEMMs around it) ROW BY ROW against the oracle with bf16 matrix-unit inputs: one
     softmax update per 64-position stage, v_permlane16/32_swap row exchange (a clang quirk reads the wrong element of the builtin's
     result unless it goes through unsigned temporaries -- this test is what pins it), mask-free path below the diagonal.  A masking
     or tail-stage slip is an O(1) error in single rows, which a whole-tensor norm hides.  Shapes: ragged tails with 1..32 and
@@ -361,7 +361,7 @@ def test_prefill_attention_v3_against_the_bf16_input_oracle(L0, chunk, heads, kv
     with _Threads(), torch.no_grad():
         ref = m.forward(x, m.new_cache())
     e, r = rel_err(got, ref), row_err(got, ref)
-    print(f"[attn3 vs bf16-input oracle] L0={L0} chunk={chunk} heads={heads}/{kv_heads}x{hd}: rel-L2 {e:.3e}, worst row {r:.3e}")
+    print(f"[prefill attention vs bf16-input oracle] L0={L0} chunk={chunk} heads={heads}/{kv_heads}x{hd}: rel-L2 {e:.3e}, worst row {r:.3e}")
     assert e <= 3e-3 and r <= 5e-3, (e, r)
 
 

@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 from vibevoice_amd import build as vbuild  # noqa: E402
 
 FAMILIES = ("vv_gemv_kernel", "vv_gemv16p_kernel", "vv_attn_fused_kernel", "vv_attn_merge2_kernel", "vv_gemm4_kernel",
-            "vv_gemm3_kernel", "vv_attn_prefill3_kernel")
+            "vv_gemm3_kernel", "vv_attn_prefill4_kernel")
 
 
 def main():

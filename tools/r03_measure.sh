@@ -16,7 +16,7 @@ timeout 600 python bench.py $B7 > $O/${TAG}_7b_4spk_batch8_32k.json 2>/dev/null
 timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 5 --skip-extra --no-cpu-baseline --no-eager-baseline > $O/${TAG}_torchrun_n1.json 2> $O/torchrun_n1.err
 NS="--skip-extra --no-cpu-baseline --no-eager-baseline --steps 20 --warmup 5"
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/p_ns -o ns -- python bench.py $NS > $O/${TAG}_bench_under_rocprof.json 2> $O/rocprof_ns.err
-python tools/rocprof_summary.py $O/p_ns/ns_results.db $O/${TAG}_7b_northstar --around vv_attn_prefill3 40 > $O/${TAG}_7b_northstar_top.txt 2>&1; rm -rf $O/p_ns
+python tools/rocprof_summary.py $O/p_ns/ns_results.db $O/${TAG}_7b_northstar --around vv_attn_prefill4 40 > $O/${TAG}_7b_northstar_top.txt 2>&1; rm -rf $O/p_ns
 bash tools/pmc_refresh.sh $TAG $O > $O/pmc_refresh.log 2>&1; tail -5 $O/pmc_refresh.log
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES -d $O/p_mfma -o m -- python bench.py --skip-extra --no-cpu-baseline --no-eager-baseline --no-roofline --steps 2 --warmup 1 > /dev/null 2> $O/pmc_mfma.err
 python tools/rocprof_summary.py $O/p_mfma/m_results.db $O/${TAG}_7b_pmc_mfma --pmc > $O/${TAG}_7b_pmc_mfma_top.txt 2>&1; rm -rf $O/p_mfma

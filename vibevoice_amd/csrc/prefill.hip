@@ -14,11 +14,15 @@
 //                           conflicts on the ds_read_b128 that follow); epilogues bias / residual / SwiGLU, the SwiGLU one
 //                           writing its result as packed bf16 fragments for the down projection.  Workgroup ids are mapped
 //                           so that one XCD (own L2) owns a contiguous range of feature blocks.
-//   vv_attn_prefill3_kernel causal attention for a chunk of consecutive positions: a workgroup owns 64 query rows x 4 query
-//                           heads of one kv head, streams the causal prefix ONCE, 64 positions per stage, through a
-//                           double-buffered LDS stage (global_load_lds); 8 waves = 4 query heads x 2 row halves, one
-//                           online-softmax update per stage (K / V fragments read from LDS once per block, reused for the
-//                           row tiles): 16 x fewer K/V reads per query row than a 16-row-per-workgroup kernel.
+//   vv_gemm4_kernel         the long-prompt form: 256 x 256 tile, 4-slot ring of 32-wide K stages, the two wave halves in
+//                           anti-phase (one computes while the other loads), strip-ordered tiles (an XCD's L2 serves 4 weight
+//                           blocks x 8 row blocks at a time), the partial last round split along K; one more epilogue: bias +
+//                           RoPE + KV-cache append for the QKV projection.
+//   vv_attn_prefill4_kernel causal attention for a chunk of consecutive positions: a workgroup owns 64 query rows x 4 query
+//                           heads of one kv head, streams the causal prefix ONCE, 64 positions per stage through a 4-slot LDS
+//                           ring; 8 waves = 4 query heads x 2 row halves in anti-phase (matrix segment / softmax segment), one
+//                           lazy-rescaled softmax step per stage, row sums through the matrix pipe; the result leaves as the
+//                           o-projection's packed operand.
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
