@@ -519,6 +519,45 @@ def test_host_generate_full_vocabulary_processors_match_the_reference(monkeypatc
         assert float((got - ref).norm() / ref.norm()) <= 1e-4
 
 
+def test_full_vocabulary_processors_equal_the_transformers_classes(monkeypatch):
+    """vibevoice_amd/modeling.py::_full_vocab_scores against the classes the reference gets from
+    GenerationMixin._get_logits_processor (repetition penalty, temperature, top-k, top-p, min-p, in that order), on the fake
+    engine's fp32 lm_head: the same kept / filtered pattern and the same surviving scores for 7 rows with different histories."""
+    import types as _types
+    import fake_engine
+    from test_oracle_golden import _oracle_small
+    from transformers.generation.logits_process import (MinPLogitsWarper, RepetitionPenaltyLogitsProcessor, TemperatureLogitsWarper,
+                                                        TopKLogitsWarper, TopPLogitsWarper)
+    from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference
+    om = _oracle_small()
+    with fake_engine.cpu_cuda_shims(monkeypatch):
+        eng = fake_engine.FakeEngine(om, n_slots=1)
+        cfgd = {"decoder_config": {"max_position_embeddings": 4096}, "diffusion_head_config": {"ddpm_num_inference_steps": 5},
+                "acoustic_tokenizer_config": {"fix_std": 0.5, "std_dist_type": "gaussian"}}
+        m = VibeVoiceForConditionalGenerationInference(cfgd, eng, model_dtype=torch.float32)
+        V, H = om.lm_head.shape
+        g = torch.Generator().manual_seed(77)
+        n = 7
+        hid = torch.randn(n, H, generator=g) * 2.0
+        order = []
+        for i in range(n):
+            ids = torch.randint(0, V, (8 + i,), generator=g).tolist()
+            order.append(_types.SimpleNamespace(ids=ids, tokens=torch.randint(0, V, (4,), generator=g).tolist(),
+                                                seq_len0=40 if i % 2 else len(ids), init_len=len(ids)))
+        warp = dict(top_k=180, top_p=0.9, min_p=0.003, repetition_penalty=1.25)
+        got = m._full_vocab_scores(hid, order, dict(warp=warp, do_sample=True, temperature=0.6, pad_id=V - 2))
+    want = torch.nn.functional.linear(hid, om.lm_head)
+    for i, u in enumerate(order):
+        row = ([V - 2] if u.seq_len0 > u.init_len else []) + u.ids + u.tokens
+        want[i:i + 1] = RepetitionPenaltyLogitsProcessor(1.25)(torch.tensor([row]), want[i:i + 1])
+    for proc in (TemperatureLogitsWarper(0.6), TopKLogitsWarper(180), TopPLogitsWarper(0.9), MinPLogitsWarper(0.003)):
+        want = proc(None, want)
+    assert torch.equal(torch.isfinite(got), torch.isfinite(want))
+    keep = torch.isfinite(want)
+    assert torch.allclose(got[keep], want[keep], rtol=1e-6, atol=1e-6)
+    assert int(keep.sum(dim=-1).min()) >= 1 and int(keep.sum()) < n * V // 2       # the filters bite, and keep at least one id per row
+
+
 def test_host_generate_reports_a_row_whose_valid_tokens_were_all_filtered(monkeypatch):
     """top_k = 1 over the toy vocabulary keeps one id per row -- with random weights not a speech token: the reference dies in
     torch.multinomial on NaN probabilities (tests/golden/make_golden.py walks its seed list for that reason); the product says why."""
