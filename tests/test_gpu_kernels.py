@@ -636,7 +636,7 @@ def test_lm_logits_over_the_whole_vocabulary_and_the_logits_processors(sm, n):
     order = []
     for i in range(n):
         ids = [int(t) for t in g.rng.integers(0, V, (9 + i,))]
-        order.append(_types.SimpleNamespace(ids=ids, tokens=[int(t) for t in g.rng.integers(0, V, (3,))], seq_len0=30, init_len=len(ids)))
+        order.append(_types.SimpleNamespace(idx=i, ids=ids, tokens=[int(t) for t in g.rng.integers(0, V, (3,))], seq_len0=30, init_len=len(ids)))
     warp = dict(top_k=200, top_p=0.93, min_p=0.002, repetition_penalty=1.3)
     S = dict(warp=warp, do_sample=True, temperature=0.7, pad_id=V - 1)
     with torch.cuda.stream(eng.stream):

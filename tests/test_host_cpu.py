@@ -542,7 +542,7 @@ def test_full_vocabulary_processors_equal_the_transformers_classes(monkeypatch):
         order = []
         for i in range(n):
             ids = torch.randint(0, V, (8 + i,), generator=g).tolist()
-            order.append(_types.SimpleNamespace(ids=ids, tokens=torch.randint(0, V, (4,), generator=g).tolist(),
+            order.append(_types.SimpleNamespace(idx=i, ids=ids, tokens=torch.randint(0, V, (4,), generator=g).tolist(),
                                                 seq_len0=40 if i % 2 else len(ids), init_len=len(ids)))
         warp = dict(top_k=180, top_p=0.9, min_p=0.003, repetition_penalty=1.25)
         got = m._full_vocab_scores(hid, order, dict(warp=warp, do_sample=True, temperature=0.6, pad_id=V - 2))

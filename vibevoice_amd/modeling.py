@@ -645,14 +645,24 @@ class VibeVoiceForConditionalGenerationInference:
             parts.append(self._full_logits[:k * V].view(k, V).clone())
         scores = torch.cat(parts)                    # (the step loop runs under torch.cuda.stream(engine.stream): one ordered stream)
         if w["repetition_penalty"] != 1.0:
+            # RepetitionPenaltyLogitsProcessor: every id present in the row's input_ids (left padding, prompt, generated tokens) is
+            # penalised once.  The row's "seen" set is a [V] mask kept on the device for the session and extended by the tokens
+            # generated since the last step: O(1) per step, not O(history) (a 90-minute utterance has ~40 K of them).
             pen = w["repetition_penalty"]
+            seen = S.setdefault("_seen", {})
             for i, u in enumerate(order):
-                seen = list(u.ids) + list(u.tokens)
-                if u.seq_len0 > u.init_len and S["pad_id"] is not None:
-                    seen.append(S["pad_id"])
-                ids = torch.tensor(sorted(set(int(t) for t in seen if 0 <= int(t) < V)), dtype=torch.long, device=scores.device)
-                sc = scores[i, ids]
-                scores[i, ids] = torch.where(sc < 0, sc * pen, sc / pen)
+                ent = seen.get(u.idx)
+                if ent is None:
+                    base = list(u.ids) + ([S["pad_id"]] if (u.seq_len0 > u.init_len and S["pad_id"] is not None) else [])
+                    mask = torch.zeros(V, dtype=torch.bool, device=scores.device)
+                    mask[torch.tensor([int(t) for t in base if 0 <= int(t) < V], dtype=torch.long, device=scores.device)] = True
+                    ent = seen[u.idx] = [mask, 0]
+                fresh_tok = [int(t) for t in u.tokens[ent[1]:] if 0 <= int(t) < V]
+                if fresh_tok:
+                    ent[0][torch.tensor(fresh_tok, dtype=torch.long, device=scores.device)] = True
+                ent[1] = len(u.tokens)
+                sc = scores[i]
+                scores[i] = torch.where(ent[0], torch.where(sc < 0, sc * pen, sc / pen), sc)
         if S["do_sample"]:
             if S["temperature"] != 1.0:
                 scores = scores / S["temperature"]
