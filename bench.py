@@ -790,7 +790,8 @@ def cpu_baseline(cfg, cpu_sd, n_solver, cfg_scale, n_frames, model_key):
     """Times oracle/ (the CPU restatement of the reference loop) on this host: `n_frames` decode
     frames after a short prompt, fp32, a bounded number of host threads.  kind = "port"."""
     # the GPU box advertises hundreds of logical CPUs but the job may be cgroup-limited; a modest
-    # thread count keeps torch's intra-op pool from thrashing (256 threads measured 200 s/frame)
+    # thread count keeps torch's intra-op pool from thrashing.  Measured on the box, ms per 7B frame: 16 threads 3150-3635,
+    # 32 threads 3657, 64 threads 5958, 256 threads ~200,000: 16 is at the optimum, more cores do not make this baseline faster
     host_cpus = os.cpu_count() or 1
     ncpu = min(int(os.environ.get("VVHIP_CPU_THREADS", "16")), host_cpus)
     torch.set_num_threads(ncpu)
