@@ -97,6 +97,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eager-baseline", action="store_true", help="skip the PyTorch-ROCm eager (oracle loop on the GPU, bf16) leg")
+    ap.add_argument("--no-parity", action="store_true", help="skip the full-depth parity leg (HIP engine vs the oracle legs, teacher-forced)")
     ap.add_argument("--no-roofline", action="store_true", help="skip the GEMV launch-duration passes (for rocprof --pmc runs)")
     ap.add_argument("--skip-extra", action="store_true", help="main workload only (no extra.configs lines)")
     ap.add_argument("--cpu-frames", type=int, default=3)
@@ -273,7 +274,8 @@ def main():
     if "streaming" in spec["model"]:
         res = bench_streaming(args, spec, ctx)
     else:
-        res = bench_decode(args, spec, ctx, with_cpu=(world == 1 and not args.no_cpu_baseline), with_roofline=not args.no_roofline)
+        res = bench_decode(args, spec, ctx, with_cpu=(world == 1 and not args.no_cpu_baseline), with_roofline=not args.no_roofline,
+                           with_parity=(world == 1 and not args.no_cpu_baseline and args.batch == 1 and not args.continuous))
         if rank == 0 and world == 1 and not args.skip_extra and args.workload == "north-star" and args.batch == 1 and not args.continuous:
             # the other single-GPU BASELINE configs, same run, same code
             extra = {}
@@ -287,12 +289,16 @@ def main():
                         r = bench_streaming(a2, sp, ctx)
                     else:
                         a2.steps, a2.warmup = 60, 10
-                        r = bench_decode(a2, sp, ctx, with_cpu=False, with_roofline=not args.no_roofline)
+                        a2.no_parity = args.no_parity or args.no_cpu_baseline
+                        r = bench_decode(a2, sp, ctx, with_cpu=False, with_roofline=not args.no_roofline, with_parity=True)
                     keep = {k: r[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup")}
+                    if r.get("parity"):
+                        keep["parity"] = r["parity"]
+                        keep["gpu_eager_baseline"] = r.get("gpu_eager_baseline")
                     keep["workload"] = r["config"]["workload"]
                     if r.get("roofline"):
                         keep["roofline"] = {k: r["roofline"].get(k) for k in ("kernel", "achieved", "peak", "frac", "avg_launch_us", "launches_per_step",
-                                                                            "bytes_per_launch", "whole_step_frac", "traffic", "attention")}
+                                                                            "bytes_per_launch", "whole_step_frac", "whole_step_achieved_frac", "traffic", "attention")}
                     for k in ("p50_first_audio_ms", "p90_first_audio_ms", "p50_first_chunk_on_device_ms", "prefill_plus_first_frame_s", "first_audio"):
                         if k in r.get("extra", {}):
                             keep[k] = r["extra"][k]
@@ -307,8 +313,12 @@ def main():
         dist.destroy_process_group()
 
 
-def bench_decode(args, spec, ctx, with_cpu, with_roofline):
-    """One multi-speaker model workload: prefill, W warm-up steps, K timed steps; returns the JSON-line dict (rank 0)."""
+def bench_decode(args, spec, ctx, with_cpu, with_roofline, with_parity=False):
+    """One multi-speaker model workload: prefill, W warm-up steps, K timed steps; returns the JSON-line dict (rank 0).
+    with_cpu: the two oracle baselines (fp32 on the host cores, bf16 eager on this GPU); with_parity: the HIP engine of THIS run
+    (full depth, xsplit / hipGraph as timed) is fed the prompt, forced schedule and noise of those oracle runs, teacher-forced
+    per step, and the line carries the worst per-step differences (oracle/parity.py; SURVEY 8d's tolerances).  with_parity
+    without with_cpu runs the bf16 eager leg only (no CPU minute)."""
     import torch.distributed as dist
     from vibevoice_amd import parallel, synthetic
     from vibevoice_amd.configs import CONFIGS
@@ -339,7 +349,8 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline):
     t_load0 = time.time()
     eng = Engine(ecfg, device)
     exp = eng.expected_weights()
-    keep_cpu = rank == 0 and with_cpu
+    with_parity = with_parity and rank == 0 and world == 1 and not args.no_parity
+    keep_cpu = rank == 0 and (with_cpu or with_parity)
     cpu_sd = {}
     # rank 0 draws the weights; ONE packed-blob broadcast over RCCL/xGMI at start-up, no collective later
     gen = torch.Generator(device=device)
@@ -526,7 +537,8 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline):
                                "GBps": round(by_o / 1e9 / (ms_o / 1e3), 1) if ms_o > 0 else None},
                 "formula_bytes_per_step": round(formula, 1), "formula_kv_bytes_per_utterance": round(kv_only, 1),
                 "whole_step_GBps": round(formula / 1e9 / (wall_max / K), 1),
-                "whole_step_frac": round(formula / 1e9 / (wall_max / K) / HBM_PEAK_GBS, 4)}
+                "whole_step_frac": round(formula / 1e9 / (wall_max / K) / HBM_PEAK_GBS, 4),
+                "whole_step_frac_basis": "SURVEY 8(d) formula bytes per step (every head weight incl. the adaLN matrices once per solver step) / step time / 8 TB/s"}
         # the other timed kernel families of the same window, each replayed as its own dependent chain
         def family(fid, name):
             n_f, ms_f, by_f = eng.profile_replay(reps=3, family=fid)
@@ -539,6 +551,12 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline):
                     "bytes_per_launch": round(by_f / n_f, 1), "traffic": tr, "traffic_source": tsrc}
         roof["attention"] = family(2, "vv_attn_fused_kernel (+ vv_attn_merge2_kernel): one unit per layer, KV bytes of every row")
         p16 = family(1, "vv_gemv16p_kernel")
+        # bytes the implementation actually moves per step (the adaLN matrices are hoisted out of the solver loop, so this is
+        # below the formula): every recorded weight-streaming launch's own byte count + the attention units' KV bytes
+        moved = (by + by_o) / kprof + sum((f["bytes_per_launch"] * f["launches_per_step"]) for f in (roof["attention"], p16) if f)
+        roof["whole_step_moved_bytes"] = round(moved, 1)
+        roof["whole_step_achieved_GBps"] = round(moved / 1e9 / (wall_max / K), 1)
+        roof["whole_step_achieved_frac"] = round(moved / 1e9 / (wall_max / K) / HBM_PEAK_GBS, 4)
         if p16 is not None:
             # batch decode (5..16 rows): the LM / head projections run in vv_gemv16p_kernel (pre-packed activations) -- THAT is the
             # dominant kernel of the step; the vv_gemv_kernel figures (the remaining 16-row tokenizer / sampler launches) move aside
@@ -550,19 +568,39 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline):
     # ---- CPU baseline: the oracle loop on the host cores, bounded sample ----
     cpu = None
     eager = None
+    parity = None
+    legs = {}
     if keep_cpu and not args.no_eager_baseline:
         try:
-            eager = gpu_eager_baseline(cfg, cpu_sd, NS, args.cfg_scale, 8, model_key, device)
+            legs["vs_bf16_eager"], eager = gpu_eager_baseline(cfg, cpu_sd, NS, args.cfg_scale, 8, model_key, device)
             eager["speedup_of_this_path"] = round(value / world / eager["value"], 2) if eager["value"] else None
         except Exception as ex:   # a reported number, never the product path
             eager = {"value": None, "error": repr(ex)[:200]}
         torch.cuda.empty_cache()
-    if keep_cpu:
+    if keep_cpu and with_cpu:
         try:
-            cpu = cpu_baseline(cfg, cpu_sd, NS, args.cfg_scale, args.cpu_frames, model_key)
+            legs["vs_fp32_cpu"], cpu = cpu_baseline(cfg, cpu_sd, NS, args.cfg_scale, args.cpu_frames, model_key)
         except Exception as ex:   # the baseline is a reported number, never the product path
             cpu = {"value": None, "error": repr(ex)[:200]}
-        cpu_sd.clear()
+    cpu_sd.clear()
+    if with_parity and legs:
+        # ---- full-depth parity of the engine that was just timed (same weights, same execution mode) against the oracle legs ----
+        from oracle import parity as oparity
+        parity = {"model": f"VibeVoice-{model_key}", "lm_layers": d["num_hidden_layers"], "head_layers": cfg["diffusion_head_config"].get("head_layers", 4),
+                  "solver_steps": NS, "engine_mode": {"xsplit": args.xsplit, "hipgraph": not args.no_graph, "dtype": "bf16"},
+                  "prompt_tokens": 48, "weights": "the timed run's (synthetic, seeded)" if not ckpt else "checkpoint",
+                  "definition": "HIP engine vs the oracle loop (oracle/generate.py, the restatement of the reference's generate()) on the same prompt, "
+                                "forced <speech_diffusion> schedule and noise, teacher-forced per step; worst step; rel-L2 unless marked dB; "
+                                "bounds = SURVEY 8(d)"}
+        for kind, leg in legs.items():
+            try:
+                parity[kind] = oparity.verdict(kind, oparity.compare_engine(model, leg, synthetic.TOKENS))
+                parity[kind]["oracle"] = f"{leg.dtype} on {leg.device}".replace("torch.", "")
+            except Exception as ex:
+                parity[kind] = {"error": repr(ex)[:300]}
+        parity["within_bounds"] = all(isinstance(v, dict) and v.get("within_bounds") for k, v in parity.items() if k.startswith("vs_"))
+        model.set_ddpm_inference_steps(NS)
+    legs.clear()
     res = {
         "metric": "audio-sec/wall-sec", "value": round(value, 3), "unit": "audio-s/wall-s", "n_gpus": world,
         "steps": K, "warmup": W, "ms_per_step": round((marks[W + K] - marks[W]) / K * 1e3, 4), "higher_is_better": True,
@@ -576,7 +614,7 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline):
                    "model": f"VibeVoice-{model_key}", "solver_steps": NS, "prompt_tokens": L0, "speakers": spec["speakers"],
                    "xsplit": args.xsplit, "hipgraph": not args.no_graph, "kv_len_timed": max(L0, kv_target) + W,
                    "parallelism": f"utterance-dp{world}"},
-        "roofline": roof, "cpu_baseline": cpu, "gpu_eager_baseline": eager,
+        "roofline": roof, "cpu_baseline": cpu, "gpu_eager_baseline": eager, "parity": parity,
         "extra": {"frames_timed": frames, "weights_load_s": round(load_s, 2), "libvvhip_build_id": _build_id(),
                   "weights_broadcast": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in bc.items()},
                   "weights_source": (f"checkpoint {ckpt}" if ckpt else "synthetic (seeded N(0, 0.02^2) at the config's shapes)"),
@@ -732,58 +770,12 @@ def bench_streaming(args, spec, ctx):
 
 def _oracle_leg(cfg, sd, n_solver, cfg_scale, n_frames, device, dtype, t_budget):
     """`n_frames` decode frames of oracle/ (the restatement of the reference loop, plain PyTorch ops) after a 48-token text-only
-    prompt, on `device` in `dtype`, weights from the state dict `sd`.  Returns (seconds per frame, frames timed)."""
-    from oracle import generate as ogen
-    from oracle import lm as olm
+    prompt, on `device` in `dtype`, weights from the state dict `sd` (oracle/parity.py).  Returns the leg: seconds per frame,
+    frames timed AND the trace (hidden states, latents, next-step embeddings, decoded frames) the parity check compares the
+    HIP engine against."""
+    from oracle import parity
     from vibevoice_amd import synthetic
-    d = cfg["decoder_config"]
-    H = d["hidden_size"]
-    on_gpu = torch.device(device).type == "cuda"
-
-    def sub(prefix):
-        return {k[len(prefix):]: v.to(device=device, dtype=dtype) for k, v in sd.items() if k.startswith(prefix)}
-    with torch.device(device):                   # the oracle's own factory calls (arange / zeros / tensor) land on `device`
-        lm_w = sub("model.language_model.")
-        lm = olm.Qwen2Oracle(lm_w, d["num_hidden_layers"], d["num_attention_heads"], d["num_key_value_heads"],
-                             H // d["num_attention_heads"], d.get("rope_theta", 1e6), d.get("rms_norm_eps", 1e-6))
-        depths = [int(x) for x in cfg["acoustic_tokenizer_config"]["encoder_depths"].split("-")]
-        m = ogen.OracleModel(
-            lm=lm, lm_head=sd["lm_head.weight"].to(device=device, dtype=dtype) if "lm_head.weight" in sd else lm_w["embed_tokens.weight"],
-            head_w=sub("model.prediction_head."), head_layers=cfg["diffusion_head_config"]["head_layers"],
-            ac_w=sub("model.acoustic_tokenizer."), sem_w=sub("model.semantic_tokenizer."),
-            ac_conn=sub("model.acoustic_connector."), sem_conn=sub("model.semantic_connector."),
-            ratios=cfg["acoustic_tokenizer_config"]["encoder_ratios"], enc_depths=depths,
-            dec_depths=list(reversed(depths)), sem_depths=depths, scaling=0.2, bias=-0.05,
-            max_position_embeddings=d["max_position_embeddings"])
-        T = synthetic.TOKENS
-        tok = ogen.TokenIds(T.speech_start_id, T.speech_end_id, T.speech_diffusion_id, T.eos_token_id, None, T.pad_token_id)
-        g = torch.Generator(device="cpu").manual_seed(7)
-        ids = torch.randint(0, 151000, (1, 48), generator=g, device="cpu")
-        ids[0, -1] = T.speech_start_id
-        ids = ids.to(device)
-        stamps = []
-
-        class _Budget(Exception):
-            pass
-
-        def noise_fn(step, n2):
-            if on_gpu:
-                torch.cuda.synchronize()
-            stamps.append(time.perf_counter())
-            if len(stamps) >= 3 and stamps[-1] - stamps[0] > t_budget:       # at least two whole frames, then the time budget
-                raise _Budget()
-            return torch.randn(n2, 64, generator=g, device="cpu").to(device=device, dtype=dtype)
-        forced = [[T.speech_diffusion_id] * (n_frames + 1)]
-        try:
-            with torch.no_grad():
-                ogen.oracle_generate(m, tok, ids, torch.ones_like(ids), cfg_scale=cfg_scale, num_steps=n_solver,
-                                     max_new_tokens=n_frames + 1, noise_fn=noise_fn, forced_tokens=forced)
-        except _Budget:
-            pass
-    # the first interval carries one-off costs on a GPU (kernel selection, allocator growth): drop it when there are enough
-    first = 1 if (on_gpu and len(stamps) >= 4) else 0
-    n = len(stamps) - 1 - first
-    return (stamps[-1] - stamps[first]) / max(1, n), n
+    return parity.oracle_leg(cfg, sd, synthetic.TOKENS, n_solver, cfg_scale, n_frames, device, dtype, t_budget)
 
 
 def cpu_baseline(cfg, cpu_sd, n_solver, cfg_scale, n_frames, model_key):
@@ -796,8 +788,9 @@ def cpu_baseline(cfg, cpu_sd, n_solver, cfg_scale, n_frames, model_key):
     ncpu = min(int(os.environ.get("VVHIP_CPU_THREADS", "16")), host_cpus)
     torch.set_num_threads(ncpu)
     t_budget = float(os.environ.get("VVHIP_CPU_BUDGET_S", "30"))
-    per_frame, n = _oracle_leg(cfg, cpu_sd, n_solver, cfg_scale, n_frames, "cpu", torch.float32, t_budget)
-    return {"value": round(FRAME_SEC / per_frame, 4), "unit": "audio-s/wall-s", "cores": ncpu, "kind": "port",
+    leg = _oracle_leg(cfg, cpu_sd, n_solver, cfg_scale, n_frames, "cpu", torch.float32, t_budget)
+    per_frame, n = leg.per_frame_s, leg.frames_timed
+    return leg, {"value": round(FRAME_SEC / per_frame, 4), "unit": "audio-s/wall-s", "cores": ncpu, "kind": "port",
             "host_logical_cpus": host_cpus,
             "sample": f"{n} decode frames of the same model shapes and weights (VibeVoice-{model_key}, fp32 = the reference's CPU "
                       f"dtype, {n_solver} solver steps, CFG pos+neg passes) after a 48-token text-only prompt -- the GPU leg's 32K-token context is "
@@ -816,9 +809,10 @@ def gpu_eager_baseline(cfg, dev_sd, n_solver, cfg_scale, n_frames, model_key, de
     # shapes to the BLAS libraries, and in the first process of a fresh box each of them pulls code objects from a cold disk:
     # measured 212 ms/frame for the first pass against 104 for the same pass repeated (a second process in the same box also
     # runs at 104).  The warm figure is the honest "GPU before".
-    cold, _ = _oracle_leg(cfg, dev_sd, n_solver, cfg_scale, n_frames, device, torch.bfloat16, t_budget)
-    per_frame, n = _oracle_leg(cfg, dev_sd, n_solver, cfg_scale, n_frames, device, torch.bfloat16, t_budget)
-    return {"value": round(FRAME_SEC / per_frame, 4), "unit": "audio-s/wall-s", "kind": "port, PyTorch-ROCm eager bf16, same GPU",
+    cold = _oracle_leg(cfg, dev_sd, n_solver, cfg_scale, n_frames, device, torch.bfloat16, t_budget).per_frame_s
+    leg = _oracle_leg(cfg, dev_sd, n_solver, cfg_scale, n_frames, device, torch.bfloat16, t_budget)
+    per_frame, n = leg.per_frame_s, leg.frames_timed
+    return leg, {"value": round(FRAME_SEC / per_frame, 4), "unit": "audio-s/wall-s", "kind": "port, PyTorch-ROCm eager bf16, same GPU",
             "sample": f"{n} decode frames (after one untimed frame) of the same model shapes and weights (VibeVoice-{model_key}, bf16, "
                       f"{n_solver} solver steps, CFG pos+neg passes) after a 48-token text-only prompt, the second of two identical "
                       f"passes (the first one, which also loads the libraries' code objects: {cold * 1e3:.0f} ms/frame): the timed leg's "

@@ -79,6 +79,8 @@ class Trace:
     semantic: list = field(default_factory=list)
     next_embeds: list = field(default_factory=list)
     tokens: list = field(default_factory=list)
+    logits: list = field(default_factory=list)      # [B, n_valid] per step: the lm_head scores of the valid ids, in `valid` order
+    audio: list = field(default_factory=list)       # [n, 3200] per diffusion step: the decoded frames of that step's rows
 
 
 def process_speech_inputs(m: OracleModel, speech_tensors, speech_masks, prefill_noise):
@@ -164,6 +166,7 @@ def oracle_generate(m: OracleModel, tok: TokenIds, input_ids, attention_mask,
         if trace is not None:
             trace.pos_hidden.append(hidden.clone())
             trace.tokens.append(nxt.clone())
+            trace.logits.append(logits[:, valid].clone())
         # ---- bookkeeping (:518-539) ----
         finished = finished | (nxt == tok.eos_token_id)
         hit = (step >= max_step_per_sample) & ~finished
@@ -212,6 +215,7 @@ def oracle_generate(m: OracleModel, tok: TokenIds, input_ids, attention_mask,
                 trace.neg_hidden.append(neg_hidden.clone())
                 trace.latents.append(lat.clone())
                 trace.semantic.append(sem_feat.clone())
+                trace.audio.append(torch.stack([audio_chunks[b][-1].reshape(-1) for b in diff]))
         if trace is not None:
             trace.next_embeds.append(next_embeds.clone())
         inputs_embeds = next_embeds

@@ -1,0 +1,173 @@
+"""ORACLE (test infrastructure) -- full-depth parity harness: the oracle loop at a model's REAL shape and depth on a
+short prompt, and the comparison of a HIP-path model against it, teacher-forced per step.
+
+Used by bench.py's two baseline legs (the oracle runs it times -- fp32 on the host cores, bf16 eager PyTorch-ROCm on the
+same GPU -- are kept instead of thrown away and the HIP engine is fed the same prompt, forced schedule and noise) and by
+tests/test_gpu_fulldepth.py.  Nothing under vibevoice_amd/ imports this module; `compare_engine` drives a model object
+handed to it through the reference's own generate() surface.
+
+What is restated: the loop is oracle/generate.py (modeling_vibevoice_inference.py:432-675, :697-710); the tolerances are
+SURVEY.md 8(d)'s -- bf16 HIP vs bf16 PyTorch-ROCm eager, teacher-forced per step: latent / hidden-state rel-L2 <= 2e-2,
+token decisions identical; bf16 HIP vs the fp32 oracle: latent rel-L2 <= 5e-2, decoded frame RMS within +-0.5 dB.
+"""
+import math
+import time
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import torch
+
+from . import generate as ogen
+from . import lm as olm
+
+BOUNDS = {"vs_bf16_eager": {"latent": 2e-2, "pos_hidden": 2e-2, "neg_hidden": 2e-2},
+          "vs_fp32_cpu": {"latent": 5e-2, "frame_rms_db": 0.5}}
+
+
+@dataclass
+class Leg:
+    """one run of the oracle loop: timing + everything a comparison needs"""
+    per_frame_s: float
+    frames_timed: int
+    frames: int                         # complete frames in the trace
+    trace: ogen.Trace
+    ids: torch.Tensor                   # [1, prompt] (cpu)
+    noise: List[torch.Tensor] = field(default_factory=list)     # per step, [2, 64] fp32 cpu, as the loop consumed it (rounded to `dtype`)
+    n_solver: int = 20
+    cfg_scale: float = 1.3
+    dtype: torch.dtype = torch.float32
+    device: str = "cpu"
+
+
+def oracle_model(cfg, sd, device, dtype, scaling=0.2, bias=-0.05):
+    """OracleModel over the reference-keyed state dict `sd` (any device / dtype) on `device` in `dtype`."""
+    d = cfg["decoder_config"]
+    H = d["hidden_size"]
+
+    def sub(prefix):
+        return {k[len(prefix):]: v.to(device=device, dtype=dtype) for k, v in sd.items() if k.startswith(prefix)}
+    lm_w = sub("model.language_model.")
+    lm = olm.Qwen2Oracle(lm_w, d["num_hidden_layers"], d["num_attention_heads"], d["num_key_value_heads"],
+                         H // d["num_attention_heads"], d.get("rope_theta", 1e6), d.get("rms_norm_eps", 1e-6))
+    dp = cfg["acoustic_tokenizer_config"]["encoder_depths"]
+    depths = [int(x) for x in dp.split("-")] if isinstance(dp, str) else list(dp)
+    return ogen.OracleModel(
+        lm=lm, lm_head=sd["lm_head.weight"].to(device=device, dtype=dtype) if "lm_head.weight" in sd else lm_w["embed_tokens.weight"],
+        head_w=sub("model.prediction_head."), head_layers=cfg["diffusion_head_config"].get("head_layers", 4),
+        ac_w=sub("model.acoustic_tokenizer."), sem_w=sub("model.semantic_tokenizer."),
+        ac_conn=sub("model.acoustic_connector."), sem_conn=sub("model.semantic_connector."),
+        ratios=cfg["acoustic_tokenizer_config"]["encoder_ratios"], enc_depths=depths,
+        dec_depths=list(reversed(depths)), sem_depths=depths, scaling=scaling, bias=bias,
+        max_position_embeddings=d["max_position_embeddings"])
+
+
+def oracle_leg(cfg, sd, tokens, n_solver, cfg_scale, n_frames, device, dtype, t_budget, prompt_len=48, seed=7,
+               t_cast_bf16=True) -> Leg:
+    """`n_frames` decode frames of the oracle loop after a `prompt_len`-token text-only prompt ending in <speech_start>, on
+    `device` in `dtype`, every step forced to <speech_diffusion>; stops early once `t_budget` seconds are spent (after at
+    least two whole frames).  t_cast_bf16: the timestep fed to the head is rounded to bf16 (999 -> 1000), what the reference's
+    bf16 GPU path does (`t.repeat(..).to(combined)`, modeling_vibevoice_inference.py:705) and what the HIP bf16 mode
+    reproduces -- a bf16 leg rounds by construction, the fp32 leg rounds so that both sides evaluate the head at the same t."""
+    on_gpu = torch.device(device).type == "cuda"
+    T = tokens
+    with torch.device(device):                   # the oracle's own factory calls (arange / zeros / tensor) land on `device`
+        m = oracle_model(cfg, sd, device, dtype)
+        if t_cast_bf16:
+            m.t_cast_dtype = torch.bfloat16
+        tok = ogen.TokenIds(T.speech_start_id, T.speech_end_id, T.speech_diffusion_id, T.eos_token_id, None, T.pad_token_id)
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        ids = torch.randint(0, 151000 if cfg["decoder_config"]["vocab_size"] > 151000 else cfg["decoder_config"]["vocab_size"] - 64,
+                            (1, prompt_len), generator=g, device="cpu")
+        ids[0, -1] = T.speech_start_id
+        stamps, noise = [], []
+        trace = ogen.Trace()
+
+        class _Budget(Exception):
+            pass
+
+        def noise_fn(step, n2):
+            if on_gpu:
+                torch.cuda.synchronize()
+            stamps.append(time.perf_counter())
+            if len(stamps) >= 3 and stamps[-1] - stamps[0] > t_budget:       # at least two whole frames, then the time budget
+                raise _Budget()
+            nz = torch.randn(n2, 64, generator=g, device="cpu").to(device=device, dtype=dtype)
+            noise.append(nz.detach().float().cpu())
+            return nz
+        forced = [[T.speech_diffusion_id] * (n_frames + 1)]
+        ids_d = ids.to(device)
+        try:
+            with torch.no_grad():
+                ogen.oracle_generate(m, tok, ids_d, torch.ones_like(ids_d), cfg_scale=cfg_scale, num_steps=n_solver,
+                                     max_new_tokens=n_frames + 1, noise_fn=noise_fn, forced_tokens=forced, trace=trace)
+        except _Budget:
+            pass
+        if on_gpu:
+            torch.cuda.synchronize()
+    # the first interval carries one-off costs on a GPU (kernel selection, allocator growth): drop it when there are enough
+    first = 1 if (on_gpu and len(stamps) >= 4) else 0
+    n = len(stamps) - 1 - first
+    per_frame = (stamps[-1] - stamps[first]) / max(1, n)
+    frames = min(len(trace.latents), len(trace.next_embeds), len(trace.audio))
+    del m
+    return Leg(per_frame, n, frames, trace, ids, noise, n_solver, cfg_scale, dtype, str(device))
+
+
+def _rel(a, b):
+    a = a.detach().float().cpu().reshape(-1)
+    b = b.detach().float().cpu().reshape(-1)
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def compare_engine(model, leg: Leg, tokens, frames: Optional[int] = None) -> dict:
+    """Run `model` (the HIP-path class; its engine's own execution mode -- xsplit, hipGraph -- is what gets checked) on the
+    leg's prompt, forced schedule and noise, TEACHER-FORCED per step with the embeddings the oracle fed its LM at that step
+    (so the autoregressive feedback cannot compound a rounding difference), and compare step by step.  Returns the worst
+    per-step figures:  latent / pos_hidden / neg_hidden rel-L2, frame RMS difference in dB, frame SNR in dB, whether the
+    token the HIP path's own logits would pick equals the oracle's pick on every step (and the smallest top-2 logit margin
+    of the oracle, the context of that statement)."""
+    n = leg.frames if frames is None else min(frames, leg.frames)
+    if n < 1:
+        return {"frames": 0, "error": "the oracle leg completed no frame"}
+    otr = leg.trace
+    D, X = tokens.speech_diffusion_id, tokens.eos_token_id
+    htr = ogen.Trace()
+    model.set_ddpm_inference_steps(leg.n_solver)
+    out = model.generate(input_ids=leg.ids, attention_mask=torch.ones_like(leg.ids), tokenizer=tokens, cfg_scale=leg.cfg_scale,
+                         generation_config={"do_sample": False}, max_new_tokens=n, show_progress_bar=False,
+                         _forced_tokens=[[D] * n + [X]], _noise_fn=lambda step, n2: leg.noise[step][:n2],
+                         _trace=htr, _teacher_embeds=lambda step, rows: otr.next_embeds[step][rows].float())
+    seq_ok = out.sequences.shape[1] == leg.ids.shape[1] + n and bool((out.sequences[0, leg.ids.shape[1]:].cpu() == D).all())
+    w = {"latent": 0.0, "pos_hidden": 0.0, "neg_hidden": 0.0}
+    for a, b in zip(htr.latents[:n], otr.latents[:n]):
+        w["latent"] = max(w["latent"], _rel(a, b))
+    for a, b in zip(htr.pos_hidden[:n], otr.pos_hidden[:n]):
+        w["pos_hidden"] = max(w["pos_hidden"], _rel(a, b))
+    for a, b in zip(htr.neg_hidden[:n], otr.neg_hidden[:n]):
+        w["neg_hidden"] = max(w["neg_hidden"], _rel(a, b))
+    # the token each side's logits pick (argmax over the valid ids, the reference's constrained greedy decision)
+    pick_ok, margin = True, float("inf")
+    for a, b in zip(htr.logits[:n], otr.logits[:n]):
+        a, b = a.float().cpu().reshape(-1), b.float().cpu().reshape(-1)[:a.numel()]
+        top = torch.topk(b, 2).values
+        margin = min(margin, float(top[0] - top[1]))
+        pick_ok = pick_ok and int(a.argmax()) == int(b.argmax())
+    wav = out.speech_outputs[0].float().cpu().reshape(-1)
+    db, snr = 0.0, float("inf")
+    for i in range(min(n, wav.numel() // 3200, len(otr.audio))):
+        h = wav[i * 3200:(i + 1) * 3200]
+        o = otr.audio[i].float().cpu().reshape(-1)
+        rh, ro = float(h.pow(2).mean().sqrt()), float(o.pow(2).mean().sqrt())
+        db = max(db, abs(20.0 * math.log10(max(rh, 1e-30) / max(ro, 1e-30))))
+        snr = min(snr, 20.0 * math.log10(max(float(o.norm()), 1e-30) / max(float((h - o).norm()), 1e-30)))
+    return {"frames": n, "latent": round(w["latent"], 6), "pos_hidden": round(w["pos_hidden"], 6), "neg_hidden": round(w["neg_hidden"], 6),
+            "frame_rms_db": round(db, 4), "frame_snr_db": round(snr, 2), "tokens_equal": bool(seq_ok),
+            "greedy_pick_equal": bool(pick_ok), "oracle_min_top2_margin": round(margin, 5),
+            "mode": "teacher-forced per step (next LM input = the oracle's embedding of that step)"}
+
+
+def verdict(kind: str, res: dict) -> dict:
+    """attach SURVEY 8(d)'s bounds and whether they hold"""
+    b = BOUNDS[kind]
+    ok = all(res.get(k, float("inf")) <= v for k, v in b.items()) and res.get("tokens_equal", False)
+    return dict(res, bounds=b, within_bounds=bool(ok))

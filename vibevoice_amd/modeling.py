@@ -799,6 +799,8 @@ class VibeVoiceForConditionalGenerationInference:
         logits = self._logits_pin[:nA * nv].view(nA, nv).clone()
         if trace is not None:
             trace.pos_hidden.append(torch.cat([pos_hidden(i) for i in range(nA)]).cpu())
+            if hasattr(trace, "logits"):
+                trace.logits.append(logits.clone())               # [rows, n_valid]: the scores the token decision is taken from
         # ---------------- token selection (:488-501) ----------------
         if S["forced"] is not None or any(u.forced is not None for u in order):
             for u in order:
