@@ -105,6 +105,8 @@ def parse_args(argv=None):
                     "diffusion-head weight pass)")
     ap.add_argument("--continuous", type=int, default=0, help="queue this many utterances through generate_continuous() "
                     "(slots = --batch) instead of one synchronous batch")
+    ap.add_argument("--host-delay-us", type=float, default=0.0, help="diagnostic: busy-wait this long on the HOST at the top of every step; the "
+                    "largest delay that leaves ms_per_step unchanged is the host's slack per step (how far off the critical path it is)")
     ap.add_argument("--max-ctx", type=int, default=0)
     ap.add_argument("--enc-frames", type=int, default=75, help="voice-prompt frames per acoustic-encoder pass (the engine default)")
     return ap.parse_args(argv)
@@ -413,6 +415,10 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline, with_parity=False):
         if step == 1:
             eng.sync()
             marks["prefill_done"] = time.perf_counter()
+        if args.host_delay_us > 0 and step > W:
+            t_end = time.perf_counter() + args.host_delay_us * 1e-6
+            while time.perf_counter() < t_end:
+                pass
 
     os.environ.setdefault("VVHIP_TIME_PREFILL", "1")        # sync + time the two prefill phases (outside the timed region)
     if not os.environ.get("VVHIP_COLD_PREFILL"):
@@ -570,6 +576,11 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline, with_parity=False):
     eager = None
     parity = None
     legs = {}
+    if keep_cpu and with_cpu:
+        try:
+            legs["vs_fp32"], cpu = cpu_baseline(cfg, cpu_sd, NS, args.cfg_scale, args.cpu_frames, model_key)
+        except Exception as ex:   # the baseline is a reported number, never the product path
+            cpu = {"value": None, "error": repr(ex)[:200]}
     if keep_cpu and not args.no_eager_baseline:
         try:
             legs["vs_bf16_eager"], eager = gpu_eager_baseline(cfg, cpu_sd, NS, args.cfg_scale, 8, model_key, device)
@@ -577,12 +588,6 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline, with_parity=False):
         except Exception as ex:   # a reported number, never the product path
             eager = {"value": None, "error": repr(ex)[:200]}
         torch.cuda.empty_cache()
-    if keep_cpu and with_cpu:
-        try:
-            legs["vs_fp32_cpu"], cpu = cpu_baseline(cfg, cpu_sd, NS, args.cfg_scale, args.cpu_frames, model_key)
-        except Exception as ex:   # the baseline is a reported number, never the product path
-            cpu = {"value": None, "error": repr(ex)[:200]}
-    cpu_sd.clear()
     if with_parity and legs:
         # ---- full-depth parity of the engine that was just timed (same weights, same execution mode) against the oracle legs ----
         from oracle import parity as oparity
@@ -591,16 +596,37 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline, with_parity=False):
                   "prompt_tokens": 48, "weights": "the timed run's (synthetic, seeded)" if not ckpt else "checkpoint",
                   "definition": "HIP engine vs the oracle loop (oracle/generate.py, the restatement of the reference's generate()) on the same prompt, "
                                 "forced <speech_diffusion> schedule and noise, teacher-forced per step; worst step; rel-L2 unless marked dB; "
-                                "bounds = SURVEY 8(d)"}
+                                "bounds = SURVEY 8(d).  reference_bf16_vs_fp32 = the oracle's OWN bf16 eager run against the same fp32 run, teacher-forced "
+                                "the same way: the reference path's rounding noise at this depth"}
+        try:
+            if "vs_fp32" not in legs:      # no CPU leg in this run (the extra configs): the fp32 oracle as eager ops on this GPU
+                legs["vs_fp32"] = oparity.oracle_leg(cfg, cpu_sd, synthetic.TOKENS, NS, args.cfg_scale, 4, device, torch.float32, 20.0)
+            if "vs_bf16_eager" in legs:
+                floor_leg = oparity.oracle_leg(cfg, cpu_sd, synthetic.TOKENS, NS, args.cfg_scale, 8, device, torch.bfloat16, 20.0,
+                                               teacher=legs["vs_fp32"])
+                parity["reference_bf16_vs_fp32"] = oparity.compare_legs(floor_leg, legs["vs_fp32"])
+                del floor_leg
+        except Exception as ex:
+            parity["reference_bf16_vs_fp32"] = {"error": repr(ex)[:300]}
+        raw = {}
         for kind, leg in legs.items():
             try:
-                parity[kind] = oparity.verdict(kind, oparity.compare_engine(model, leg, synthetic.TOKENS))
-                parity[kind]["oracle"] = f"{leg.dtype} on {leg.device}".replace("torch.", "")
+                raw[kind] = oparity.compare_engine(model, leg, synthetic.TOKENS)
             except Exception as ex:
                 parity[kind] = {"error": repr(ex)[:300]}
-        parity["within_bounds"] = all(isinstance(v, dict) and v.get("within_bounds") for k, v in parity.items() if k.startswith("vs_"))
+        fl = parity.get("reference_bf16_vs_fp32") or {}
+        for kind, r in raw.items():
+            parity[kind] = oparity.verdict(kind, r, floor=fl if "latent" in fl else None, vs_fp32=raw.get("vs_fp32"))
+            parity[kind]["oracle"] = f"{legs[kind].dtype} on {legs[kind].device}".replace("torch.", "")
+        hf = parity.get("vs_fp32") or {}
+        if "latent" in fl and "latent" in hf:
+            # the engine's bf16 mode (fp32 residual stream, bf16 only at the matrix-unit inputs) against the reference's bf16 path
+            parity["engine_at_least_as_close_to_fp32_as_reference_bf16"] = {k: bool(hf[k] <= 1.1 * fl[k] + 1e-3) for k in ("latent", "pos_hidden", "neg_hidden")}
+        parity["within_bounds"] = bool(all(isinstance(parity.get(k), dict) and parity[k].get("within_bounds") for k in legs)
+                                       and all((parity.get("engine_at_least_as_close_to_fp32_as_reference_bf16") or {"x": True}).values()))
         model.set_ddpm_inference_steps(NS)
     legs.clear()
+    cpu_sd.clear()
     res = {
         "metric": "audio-sec/wall-sec", "value": round(value, 3), "unit": "audio-s/wall-s", "n_gpus": world,
         "steps": K, "warmup": W, "ms_per_step": round((marks[W + K] - marks[W]) / K * 1e3, 4), "higher_is_better": True,
@@ -613,6 +639,7 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline, with_parity=False):
                                + (f" ({n_utt} queued, continuous admission)" if args.continuous else "") + ", forced token schedule",
                    "model": f"VibeVoice-{model_key}", "solver_steps": NS, "prompt_tokens": L0, "speakers": spec["speakers"],
                    "xsplit": args.xsplit, "hipgraph": not args.no_graph, "kv_len_timed": max(L0, kv_target) + W,
+                   **({"host_delay_us": args.host_delay_us} if args.host_delay_us > 0 else {}),
                    "parallelism": f"utterance-dp{world}"},
         "roofline": roof, "cpu_baseline": cpu, "gpu_eager_baseline": eager, "parity": parity,
         "extra": {"frames_timed": frames, "weights_load_s": round(load_s, 2), "libvvhip_build_id": _build_id(),

@@ -103,10 +103,13 @@ def oracle_generate(m: OracleModel, tok: TokenIds, input_ids, attention_mask,
                     noise_fn: Callable = None, prefill_noise=None,
                     forced_tokens: Optional[List[List[int]]] = None,
                     do_sample=False, trace: Optional[Trace] = None,
-                    algorithm_type="dpmsolver++", sde_noise_fn: Callable = None):
+                    algorithm_type="dpmsolver++", sde_noise_fn: Callable = None,
+                    teacher_embeds: Callable = None):
     """Returns (sequences [B, L0+steps], speech_outputs list, reach_max_step_sample).
     algorithm_type "sde-dpmsolver++": the scheduler demo/gradio_demo.py:142-146 installs; sde_noise_fn(step, N, 2n) ->
-    [N, 2n, 64], the variance noise scheduler.step() draws per solver step (dpm_solver.py:994-997)."""
+    [N, 2n, 64], the variance noise scheduler.step() draws per solver step (dpm_solver.py:994-997).
+    teacher_embeds(step) -> [B, H] or None: test hook (SURVEY 8d "teacher-forced per step") -- the NEXT positive pass consumes these
+    embeddings instead of the loop's own, so two implementations are compared step by step on identical inputs."""
     B, L0 = input_ids.shape
     if max_new_tokens is None:
         max_new_tokens = m.max_position_embeddings - L0
@@ -219,6 +222,10 @@ def oracle_generate(m: OracleModel, tok: TokenIds, input_ids, attention_mask,
         if trace is not None:
             trace.next_embeds.append(next_embeds.clone())
         inputs_embeds = next_embeds
+        if teacher_embeds is not None:
+            te = teacher_embeds(step)
+            if te is not None:
+                inputs_embeds = te.to(next_embeds)
 
     outs = [torch.cat(c, dim=-1) if c else None for c in audio_chunks]
     return seq, outs, reach_max

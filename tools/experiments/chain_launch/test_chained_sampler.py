@@ -8,6 +8,7 @@ from oracle import dpm, head
 from test_gpu_geometry import GEOM, build_fast, dev
 
 # ---------------------------------------------------------------------------------------------- chained launches (chain.hip)
+@pytest.mark.gpu
 @pytest.mark.parametrize("tag", ["tiny", "7b", "1.5b", "0.5b"])
 def test_chained_sampler_equals_the_launch_per_op_sampler(tag, monkeypatch):
     """vv_diffusion_sample for one utterance as ONE chained launch (VVHIP_CHAIN=1: every GEMV of every solver step a phase of one

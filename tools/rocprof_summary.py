@@ -76,6 +76,10 @@ def timeline(db, out):
         nonlocal span, busy, n_bursts
         if len(burst) < 50:          # a stray launch between phases
             return
+        # a DECODE burst is made of the step loop's kernels; weight upload / re-packing, KV fills and the oracle's eager legs
+        # (memsets, copies, torch kernels back to back) are bursts too and used to be counted as idle decode time
+        if sum(1 for n_, _, _ in burst if "vv_gemv" in n_ or "vv_attn_fused" in n_) < 0.3 * len(burst):
+            return
         n_bursts += 1
         kept.extend(burst)
         span += max(e for _, _, e in burst) - burst[0][1]
@@ -119,6 +123,56 @@ def timeline(db, out):
             f.write(f"  {c:28s} {k:8d} dispatches {ns / 1e6:10.2f} ms  {100.0 * ns / span:5.1f} % of the bursts\n")
 
 
+def gap_report(db, out, min_burst=50):
+    """Where the idle time inside the decode bursts sits: every pause between the end of the latest-ending kernel so far and the
+    start of the next one, keyed by (kernel before -> kernel after), summed.  Kernel boundaries inside one hipGraph show as
+    ~0 (a kernel's recorded interval runs to its successor's start); what shows here are the seams between graph launches /
+    eager launches / copies, and the stalls where the stream waits for the host."""
+    cur = db.cursor()
+    rows = cur.execute("select name, start, end from kernels order by start").fetchall()
+    PREFILL = ("vv_gemm4", "vv_gemm3", "vv_attn_prefill", "vv_pack_rows", "vv_rope_append", "vv_pack_kernel", "vv_kv_import",
+               "distribution_elementwise", "vv_cvt_kernel")
+    gaps = {}
+    hist = [0] * 8            # <1, <2, <5, <10, <20, <50, <100, >=100 us
+    edges = [1, 2, 5, 10, 20, 50, 100]
+    tot_gap = tot_span = 0
+    burst_n, burst_s, last_end, last_name = 0, None, None, None
+    burst_gemv = 0
+    pend = []
+    def flush():
+        nonlocal tot_gap, tot_span
+        if burst_n >= min_burst and burst_gemv >= 0.3 * burst_n:
+            for k, g in pend:
+                gaps.setdefault(k, [0, 0])
+                gaps[k][0] += g; gaps[k][1] += 1
+                tot_gap += g
+                us = g / 1e3
+                hist[sum(1 for e in edges if us >= e)] += 1
+            tot_span += last_end - burst_s
+    for n, s_, e in rows:
+        if any(p in n for p in PREFILL) or (last_end is not None and s_ - last_end > 300000):
+            flush()
+            pend, burst_n, burst_s, last_end, last_name, burst_gemv = [], 0, None, None, None, 0
+            if any(p in n for p in PREFILL):
+                continue
+        if burst_s is None:
+            burst_s = s_
+        elif s_ > last_end:
+            pend.append(((short(last_name)[:48], short(n)[:48]), s_ - last_end))
+        burst_n += 1
+        if "vv_gemv" in n or "vv_attn_fused" in n:
+            burst_gemv += 1
+        if last_end is None or e > last_end:
+            last_end, last_name = e, n
+    flush()
+    with open(out + "_gaps.txt", "w") as f:
+        f.write(f"idle inside the decode bursts: {tot_gap / 1e6:.3f} ms of {tot_span / 1e6:.3f} ms = {100.0 * tot_gap / max(1, tot_span):.2f} %\n")
+        f.write("gap length histogram (us): " + ", ".join(f"{lbl}: {c}" for lbl, c in zip(["<1", "1-2", "2-5", "5-10", "10-20", "20-50", "50-100", ">=100"], hist)) + "\n")
+        f.write("largest contributors (kernel whose end precedes the gap -> kernel that follows): total us, count, mean us\n")
+        for k, (g, c) in sorted(gaps.items(), key=lambda kv: -kv[1][0])[:40]:
+            f.write(f"  {g / 1e3:10.1f} us  {c:6d} x {g / 1e3 / c:7.2f} us   {k[0]}  ->  {k[1]}\n")
+
+
 def dump_around(db, out, pattern, occurrence, count=14):
     """per-dispatch listing (start offset, duration, gap after the previous kernel's end) around the `occurrence`-th dispatch
     whose name matches `pattern`: where the time between two kernels of a chain goes"""
@@ -157,6 +211,7 @@ if __name__ == "__main__":
     else:
         rows, tot = kernel_stats(db, sys.argv[2])
         timeline(db, sys.argv[2])
+        gap_report(db, sys.argv[2])
         if "--around" in sys.argv:
             k = sys.argv.index("--around")
             dump_around(db, sys.argv[2], sys.argv[k + 1], int(sys.argv[k + 2]))

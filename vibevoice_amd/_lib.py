@@ -67,6 +67,7 @@ _SIGS = {
     "vv_profile_replay_family": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "vv_stat": (C.c_int64, [_P, C.c_int]),
     "vv_build_id": (C.c_char_p, []),
+    "vv_check": (C.c_int, [_P, _P]),
 }
 
 EXPORTS = tuple(_SIGS)

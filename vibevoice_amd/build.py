@@ -79,11 +79,21 @@ def _object_key(src, flags, build_id):
     return h.hexdigest()[:16]
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, _locked=False):
     """One object per source (compiled in parallel, cached under csrc/.obj by content hash), then one link: a change to one kernel
     file recompiles that file only (the whole library in one hipcc command took 2.5 minutes)."""
     if not force and not stale():
         return LIB
+    if not _locked:                       # a plain `python -m vibevoice_amd.build` beside a build_locked() rank: same lock, one builder
+        import fcntl
+        with open(LIB + ".lock", "w") as lk:
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            try:
+                if not force and not stale():
+                    return LIB
+                return build(force=force, verbose=verbose, _locked=True)
+            finally:
+                fcntl.flock(lk, fcntl.LOCK_UN)
     from concurrent.futures import ThreadPoolExecutor
     hipcc = _hipcc()
     bid = source_id()
@@ -117,7 +127,7 @@ def build(force=False, verbose=True):
             except OSError:
                 pass
     tmp = f"{LIB}.tmp{os.getpid()}"            # unique per process: concurrent ranks never share a half-written file
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + _extra_flags() + objs + ["-o", tmp]
     if verbose:
         print("[vibevoice_amd] linking libvvhip.so", file=sys.stderr)
     subprocess.run(cmd, check=True)
@@ -133,7 +143,7 @@ def build_locked():
         fcntl.flock(lk, fcntl.LOCK_EX)
         try:
             if stale():
-                build(force=True, verbose=False)
+                build(force=True, verbose=False, _locked=True)
         finally:
             fcntl.flock(lk, fcntl.LOCK_UN)
     return LIB

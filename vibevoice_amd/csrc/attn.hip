@@ -283,11 +283,7 @@ __global__ __launch_bounds__(WAVES * 64) void vv_attn_fused_kernel(
     // K/V fragments of the next 32-position block are requested before the current one is consumed; the FIRST block's loads go
     // out here, before the q / RoPE work: they depend on nothing but the row table
     u32x4 nka[KT], nkb[KT], nvt[DT];
-#ifdef VV_ATTN_NT
-#define VV_KVLD(p) __builtin_nontemporal_load(p)
-#else
-#define VV_KVLD(p) (*(p))
-#endif
+#define VV_KVLD(p) (*(p))       // cacheable: a short context's K/V is re-read from L2 / MALL frame after frame (nt measured slower)
     auto kv_load = [&](int p0) {
         const int64_t t0 = (int64_t)(p0 >> 4) * KT;
 #pragma unroll

@@ -872,7 +872,8 @@ extern "C" int vv_create(const vv_config* cfg, vv_ctx** out) {
         ctx->xp = dalloc(ctx, (size_t)vv_packed_elems(R, std::max(H, Hq * D)) * 2);
         ctx->actp = dalloc(ctx, (size_t)vv_packed_elems(R, I) * 2);
         ctx->tile3_ok = c.xsplit == 1;
-        if (ctx->tile3_ok && R >= 1024) {              // prompts long enough for the 256 x 256 GEMM: its partial round is split along K
+        const char* no_ks = getenv("VVHIP_NO_KSPLIT");  // opt-out: every tile of the partial round computed whole (no inter-workgroup hand-off)
+        if (ctx->tile3_ok && R >= 1024 && !(no_ks && no_ks[0] == '1')) {   // prompts long enough for the 256 x 256 GEMM: its partial round is split along K
             ctx->gws.partials = (float*)dalloc(ctx, (size_t)256 * 32 * 512 * 16, false);
             ctx->gws.flags = (unsigned*)dalloc(ctx, 256 * sizeof(unsigned));
             if (hipHostMalloc((void**)&ctx->gws.err, sizeof(unsigned), hipHostMallocMapped) == hipSuccess && ctx->gws.err) *ctx->gws.err = 0u;
@@ -1242,6 +1243,24 @@ static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float*
 
 extern "C" int vv_lm_forward_range(vv_ctx* ctx, void* stream, int n_rows, const vv_row* rows, const float* x_in_dev,
                                    float* hidden_out_dev, int l0, int l1, int final_norm);
+// The prefill GEMM's K-split hand-off (prefill.hip g4_finish) reports a lost producer through a host-mapped word instead of
+// hanging the GPU; the affected tile is left unwritten and the arrival words untouched.  Recovery, done here at the next
+// enqueue / vv_check: wait for the stream (nothing of that launch is in flight any more), re-zero the arrival words, clear the
+// word and fail THIS call -- the caller knows the output of the prompt pass in flight is invalid and can retry; the context
+// stays usable.
+static int ksplit_check(vv_ctx* ctx, hipStream_t st) {
+    if (!(ctx->gws.err && *ctx->gws.err)) return 0;
+    hipStreamSynchronize(st);
+    hipDeviceSynchronize();
+    if (ctx->gws.flags) { hipMemset(ctx->gws.flags, 0, 256 * sizeof(unsigned)); hipDeviceSynchronize(); }
+    *ctx->gws.err = 0u;
+    return fail(ctx, "prefill GEMM: a K-split hand-off timed out (lost producer workgroup); the prompt pass that was in flight is invalid -- "
+                     "the arrival words were re-armed, retry the pass (VVHIP_NO_KSPLIT=1 disables the split)");
+}
+extern "C" int vv_check(vv_ctx* ctx, void* stream) {
+    if (!ctx) return -1;
+    return ksplit_check(ctx, (hipStream_t)stream);
+}
 extern "C" int vv_lm_forward(vv_ctx* ctx, void* stream, int n_rows, const vv_row* rows, const float* x_in_dev, float* hidden_out_dev) {
     return vv_lm_forward_range(ctx, stream, n_rows, rows, x_in_dev, hidden_out_dev, 0, ctx->c.lm_layers, 1);
 }
@@ -1250,7 +1269,7 @@ extern "C" int vv_lm_forward_range(vv_ctx* ctx, void* stream, int n_rows, const 
     hipStream_t st = (hipStream_t)stream;
     if (l0 < 0 || l1 > ctx->c.lm_layers || l0 >= l1) return fail(ctx, "layer range [%d,%d) invalid", l0, l1);
     if (n_rows < 1 || n_rows > ctx->c.max_rows) return fail(ctx, "n_rows %d out of range [1,%d]", n_rows, ctx->c.max_rows);
-    if (ctx->gws.err && *ctx->gws.err) return fail(ctx, "prefill GEMM: a K-split hand-off timed out earlier (device state is suspect)");
+    if (ksplit_check(ctx, st)) return -1;
     for (int i = 0; i < n_rows; ++i) {
         if (rows[i].cache < 0 || rows[i].cache >= 2 * ctx->c.n_slots) return fail(ctx, "row %d: cache id %d out of range", i, rows[i].cache);
         if (rows[i].pos < 0 || rows[i].pos >= ctx->c.max_ctx) return fail(ctx, "row %d: position %d exceeds max_ctx %d", i, rows[i].pos, ctx->c.max_ctx);
@@ -1692,7 +1711,7 @@ extern "C" int vv_gemm_raw(void* stream, const void* w, const void* w2, const fl
 extern "C" int vv_gemm3_raw(vv_ctx* ctx, void* stream, const void* w, const void* w2, const float* x_dev, int T, int N, int K, int epi,
                             const float* nw_dev, float eps, const float* bias_dev, float* y_dev, void* xp_scratch, void* yp_scratch) {
     hipStream_t st = (hipStream_t)stream;
-    if (ctx && ctx->gws.err && *ctx->gws.err) return fail(ctx, "prefill GEMM: a K-split hand-off timed out earlier (device state is suspect)");
+    if (ctx && ksplit_check(ctx, st)) return -1;
     int r = vv_pack_rows_launch(x_dev, K, nw_dev, eps, xp_scratch, T, K, st);
     if (r) return r;
     r = vv_gemm3_launch(w, w2, xp_scratch, y_dev, yp_scratch, bias_dev, T, N, K, N, epi, ctx ? &ctx->gws : nullptr, st);

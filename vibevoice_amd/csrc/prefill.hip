@@ -382,21 +382,37 @@ __device__ __forceinline__ void g4_finish(const VVGemm3& a, f32x4 (&acc)[8][4], 
             }
             return;
         }
+        // (the flag lives in the first word of the stage ring -- dynamic LDS, every wave is out of the k loop after this barrier;
+        // a static __shared__ word would push the kernel past the 160 KiB the dynamic-size attribute is set to)
+        extern __shared__ __attribute__((aligned(16))) unsigned char g4_lds[];
+        int* const g4_to = reinterpret_cast<int*>(g4_lds);
+        __syncthreads();
+        if (tid == 0) *g4_to = 0;
+        __syncthreads();
         if (tid < 64) {
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            for (int p = 0; p < split - 1; ++p) {
+            bool lost = false;
+            for (int p = 0; p < split - 1 && !lost; ++p) {
                 for (;;) {
                     if (__hip_atomic_load(a.flags + slot0 + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
                     __builtin_amdgcn_s_sleep(16);
-                    if ((unsigned long long)(__builtin_amdgcn_s_memrealtime() - t0) > 20000000ull) {      // 200 ms of the 100 MHz clock
-                        if (tid == 0) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        break;
-                    }
+                    // 2 s of the 100 MHz wall clock (it keeps running while the queue is preempted by another process or a
+                    // profiler): far beyond any producer's running time; only a lost producer gets here
+                    if ((unsigned long long)(__builtin_amdgcn_s_memrealtime() - t0) > 200000000ull) { lost = true; break; }
                 }
+            }
+            if (lost && tid == 0) {
+                *g4_to = 1;
+                __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
+        // a hand-over that timed out: this tile is NOT written (no sum over slots that may be unwritten, no epilogue, no cache
+        // append) and the arrival words are left as they are -- a late producer must not find a word this launch re-armed.  The
+        // host sees the error word at the next sync / enqueue, re-zeroes the words behind a stream sync and reports the call
+        // as failed (engine.hip: ksplit_check)
+        if (__builtin_amdgcn_readfirstlane(*g4_to)) return;
 #pragma unroll 1
         for (int p = 0; p < split - 1; ++p) {
             const char* sbase = reinterpret_cast<const char*>(a.ws + (size_t)(slot0 + p) * SLOT);        // wave-uniform

@@ -153,7 +153,11 @@ class Engine:
             pass
 
     def sync(self):
+        """wait for the engine stream, then surface asynchronous device-side errors (vv_check: the prefill GEMM's K-split
+        hand-off reports a lost producer through a host word instead of hanging)"""
         self.stream.synchronize()
+        if self._ctx:
+            self._chk(self.lib.vv_check(self._ctx, self._s), "vv_check")
 
     def new(self, *shape, dtype=torch.float32):
         """zero tensor whose fill is ordered on the engine stream"""

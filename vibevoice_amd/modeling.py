@@ -401,7 +401,11 @@ class VibeVoiceForConditionalGenerationInference:
         m = cls.from_state_dict(config, it(), torch_dtype or torch.bfloat16, device, attn_implementation=attn_implementation, **runtime)
         m.source_path = path
         if do_warm and hasattr(m.engine, "acoustic_encode") and getattr(m.engine, "lib", None) is not None:
-            m.warmup()
+            try:
+                m.warmup()
+            except Exception as ex:         # a failed warm-up costs the first request its latency, never the model load
+                import warnings
+                warnings.warn(f"vibevoice_amd: warm-up failed ({ex!r}); the first generate() will pay the cold-start costs")
 
         def base_tensor(key):          # lazy access to the checkpoint's own tensors (LoRA merge: vibevoice_amd/lora.py)
             for fn in files:
@@ -482,10 +486,11 @@ class VibeVoiceForConditionalGenerationInference:
         e = self.engine
         H, hop, L = e.cfg.lm_hidden, e.cfg.hop, e.cfg.latent_dim
         R = e.cfg.max_rows
-        cap = max(8, min(R, e.max_ctx - 16))
+        cap = max(1, min(R, e.max_ctx - 16))                    # never more rows than one LM launch takes (max_rows may be 2..7)
         if prompt_rows is None:
-            prompt_rows = sorted({cap, max(8, cap // 3 + 5)}, reverse=True)
+            prompt_rows = sorted({cap, max(1, min(cap, cap // 3 + 5))}, reverse=True)
         rng = torch.cuda.get_rng_state(self.device)
+        saved_valid, saved_stats = getattr(e, "_valid_ids", None), dict(self.last_stats)
         try:
             with torch.cuda.stream(e.stream):
                 for n in prompt_rows:
@@ -501,7 +506,7 @@ class VibeVoiceForConditionalGenerationInference:
             has_voice = bool(getattr(e.cfg, "has_acoustic_encoder", False)) and voice_frames > 0
             vf = voice_frames if has_voice else 0
             n_prompt = int(min(cap, e.max_ctx - 16, vf + 24))
-            vf = min(vf, n_prompt - 8)
+            vf = max(0, min(vf, n_prompt - 8))
             tok = types.SimpleNamespace(speech_start_id=0, speech_end_id=1, speech_diffusion_id=2, eos_token_id=3, bos_token_id=None)
             ids = torch.full((1, n_prompt), 4 % e.cfg.lm_vocab, dtype=torch.long)
             sim = torch.zeros(1, n_prompt, dtype=torch.bool)
@@ -525,6 +530,11 @@ class VibeVoiceForConditionalGenerationInference:
             self._valid_key = None
         finally:
             torch.cuda.set_rng_state(rng, self.device)
+            if saved_valid:                                       # the synthetic request's control-token ids must not outlive it
+                e.set_valid_tokens(saved_valid)
+            elif hasattr(e, "_valid_ids"):
+                e._valid_ids = None
+            self.last_stats = saved_stats
         e.sync()
 
     # ------------------------------------------------------------------ helpers
@@ -603,7 +613,8 @@ class VibeVoiceForConditionalGenerationInference:
         for k in ("typical_p", "epsilon_cutoff", "eta_cutoff", "top_h", "no_repeat_ngram_size", "encoder_no_repeat_ngram_size",
                   "bad_words_ids", "num_beams", "num_beam_groups", "penalty_alpha", "diversity_penalty", "sequence_bias",
                   "suppress_tokens", "begin_suppress_tokens", "forced_bos_token_id", "forced_eos_token_id", "min_length",
-                  "min_new_tokens", "exponential_decay_length_penalty", "guidance_scale"):
+                  "min_new_tokens", "exponential_decay_length_penalty", "guidance_scale", "encoder_repetition_penalty",
+                  "renormalize_logits", "watermarking_config"):
             v = gc.get(k)
             if v not in (None, 0, 0.0, 1, 1.0, [], ()):
                 raise NotImplementedError(f"generation_config[{k!r}]={v!r} is not implemented on the HIP path")
@@ -862,6 +873,10 @@ class VibeVoiceForConditionalGenerationInference:
                 print(f"Samples {sorted(u.idx for u in hit)} reached max generation length at step {hit[0].step + 1}.", flush=True)
             if audio_streamer is not None:
                 audio_streamer.end(torch.tensor(sorted(u.idx for u in hit)))
+        if S.get("_seen"):
+            for u in order:
+                if u.finished:
+                    S["_seen"].pop(u.idx, None)       # the repetition-penalty mask of a finished utterance ([V] bools on the device)
         for u in order:
             if u.last == end_id:
                 e.codec_reset(u.slot)

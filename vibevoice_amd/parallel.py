@@ -131,9 +131,12 @@ def _gather_rows(rows: List[torch.Tensor], dtype, device, gather_to):
     rank, world = world_info()
     n_max = torch.tensor([len(rows)], dtype=torch.int64, device=device)
     dist.all_reduce(n_max, op=dist.ReduceOp.MAX)
-    lens = torch.zeros(int(n_max), dtype=torch.int64, device=device)
+    if int(n_max) == 0:                 # nothing anywhere (an empty request list): no zero-length collective
+        return [[] for _ in range(world)] if (gather_to is None or rank == gather_to) else None
+    lens_cpu = torch.zeros(int(n_max), dtype=torch.int64)
     for j, r in enumerate(rows):
-        lens[j] = r.numel()
+        lens_cpu[j] = r.numel()
+    lens = lens_cpu.to(device)         # one copy, not one tiny device write per row
     all_lens = [torch.zeros_like(lens) for _ in range(world)]
     dist.all_gather(all_lens, lens)
     width = max(1, max(int(l.sum()) for l in all_lens))
