@@ -107,6 +107,9 @@ def parse_args(argv=None):
                     "(slots = --batch) instead of one synchronous batch")
     ap.add_argument("--host-delay-us", type=float, default=0.0, help="diagnostic: busy-wait this long on the HOST at the top of every step; the "
                     "largest delay that leaves ms_per_step unchanged is the host's slack per step (how far off the critical path it is)")
+    ap.add_argument("--full-utterance", action="store_true", help="one whole utterance of the workload, KV really growing; the metric over the "
+                    "wall clock of the whole generate() (prefill and voice encode included)")
+    ap.add_argument("--utterance-frames", type=int, default=0, help="--full-utterance: cap the generated tokens (0: the reference's own cap, 2 x prompt)")
     ap.add_argument("--max-ctx", type=int, default=0)
     ap.add_argument("--enc-frames", type=int, default=75, help="voice-prompt frames per acoustic-encoder pass (the engine default)")
     return ap.parse_args(argv)
@@ -275,6 +278,10 @@ def main():
     ctx = dict(rank=rank, world=world, device=device, use_dist=use_dist)
     if "streaming" in spec["model"]:
         res = bench_streaming(args, spec, ctx)
+    elif args.full_utterance:
+        if world != 1:
+            raise SystemExit("--full-utterance is a one-GPU measurement")
+        res = bench_full_utterance(args, spec, ctx)
     else:
         res = bench_decode(args, spec, ctx, with_cpu=(world == 1 and not args.no_cpu_baseline), with_roofline=not args.no_roofline,
                            with_parity=(world == 1 and not args.no_cpu_baseline and args.batch == 1 and not args.continuous))
@@ -663,6 +670,125 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline, with_parity=False):
     eng.close()
     del model, eng
     torch.cuda.empty_cache()
+    return res
+
+
+def bench_full_utterance(args, spec, ctx):
+    """SURVEY 8(d)'s metric on ONE WHOLE UTTERANCE of the workload (default: BASELINE configs[2]): generate() from the prompt to the
+    reference's own length cap (max_length_times = 2 -> 2 * L0 generated tokens, modeling_vibevoice_inference.py:421; --utterance-frames
+    caps it lower), the KV cache REALLY growing step by step (no imported K/V), the forced schedule's speaker turns included.
+    value = audio seconds / wall(generate()) with the wall clock around the whole call: voice-prompt encode + prompt prefill + every
+    decode step + output assembly -- the reference demo's own figure (demo/inference_from_file.py:388-410, inverted).  Also reports
+    ms/step in windows at several context lengths against the 8(d) bytes of that length, the device memory in use, and the size
+    of the hipGraph cache (the attention geometry, hence the step graph, changes every 1024 positions)."""
+    from vibevoice_amd import synthetic
+    from vibevoice_amd.configs import CONFIGS
+    from vibevoice_amd.engine import Engine, map_param_name
+    from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference, engine_config_from_reference
+    device = ctx["device"]
+    model_key = spec["model"]
+    cfg = CONFIGS[model_key]
+    ckpt = find_checkpoint(model_key)
+    if ckpt:
+        with open(os.path.join(ckpt, "config.json")) as f:
+            cfg = json.load(f)
+    NS = spec["solver_steps"]
+    inputs = synthetic.synthetic_inputs(cfg, n_speakers=spec["speakers"], text_tokens=spec["text_tokens"],
+                                        voice_frames=spec["voice_frames"], seed=100, batch=1)
+    L0 = inputs["input_ids"].shape[1]
+    d = cfg["decoder_config"]
+    model_ctx = d.get("max_position_embeddings", 32768)
+    cap = min(model_ctx - L0, 2 * L0)                              # :421 -- the loop's own length
+    n_steps = min(cap, args.utterance_frames) if args.utterance_frames else cap
+    max_ctx = (L0 + n_steps + 256 + 127) // 128 * 128
+    free0, total_mem = torch.cuda.mem_get_info(device)
+    ecfg = engine_config_from_reference(cfg, n_slots=1, max_ctx=max_ctx, xsplit=args.xsplit, use_graph=not args.no_graph,
+                                        enc_frames=args.enc_frames, max_rows=max(2, spec["prefill_rows"]))
+    eng = Engine(ecfg, device)
+    exp = eng.expected_weights()
+    gen = torch.Generator(device=device)
+    gen.manual_seed(0)
+    scaling, sbias = 0.2, -0.05
+    source = checkpoint_tensors(ckpt) if ckpt else ((k, synthetic.random_tensor(k, shp, gen, device, torch.bfloat16))
+                                                     for k, shp in synthetic.param_shapes(cfg).items())
+    for k, t in source:
+        if k == "model.speech_scaling_factor":
+            scaling = float(t)
+        elif k == "model.speech_bias_factor":
+            sbias = float(t)
+        else:
+            name = map_param_name(k)
+            if name in exp:
+                eng.upload(name, t)
+        del t
+    model = VibeVoiceForConditionalGenerationInference(cfg, eng, model_dtype=torch.bfloat16)
+    model.set_speech_factors(scaling, sbias)
+    model.set_ddpm_inference_steps(NS)
+    T = synthetic.TOKENS
+    forced = [synthetic.forced_schedule(n_steps - 1, turn=150) + [T.eos_token_id]]
+    n_frames_plan = sum(1 for t in forced[0] if t == T.speech_diffusion_id)
+    g = torch.Generator(device=device)
+    g.manual_seed(1234)
+    noise_bank = torch.randn(n_steps + 1, 2, cfg["acoustic_vae_dim"], generator=g, device=device)
+    n_prompt = int(inputs["attention_mask"][0].sum())
+    model.warmup(prompt_rows=[min(n_prompt, eng.cfg.max_rows)], voice_frames=spec["voice_frames"])
+    os.environ.pop("VVHIP_TIME_PREFILL", None)                     # no extra syncs inside the measured call
+    # ms/step in windows of WIN steps starting at these KV lengths (those the utterance reaches)
+    WIN = 200
+    targets = [L for L in (L0 + 64, 16384, 22000, 28000, L0 + n_steps - WIN - 8) if L0 + 8 <= L <= L0 + n_steps - WIN - 4]
+    edges = {}
+    for L in targets:
+        edges[L - L0] = ("a", L)
+        edges[L - L0 + WIN] = ("b", L)
+    stamps = {}
+
+    def step_cb(step):
+        if step in edges:
+            eng.sync()
+            stamps[(edges[step][0], edges[step][1])] = time.perf_counter()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = model.generate(tokenizer=T, cfg_scale=args.cfg_scale, generation_config={"do_sample": False}, max_new_tokens=n_steps,
+                         show_progress_bar=False, _forced_tokens=forced, _noise_fn=lambda step, n2: noise_bank[step],
+                         _step_callback=step_cb, **inputs)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    audio_s = out.speech_outputs[0].shape[-1] / 24000.0
+    free1, _ = torch.cuda.mem_get_info(device)
+    run_stats = dict(model.last_stats)                              # of THIS call (the first-audio trials below overwrite it)
+    n_graphs, n_launch_last = eng.stat(1), eng.stat(0)
+    blocks_kept = len([b for b in model._audio_blocks if b is not None])
+    windows = []
+    for L in targets:
+        if ("a", L) in stamps and ("b", L) in stamps:
+            ms = (stamps[("b", L)] - stamps[("a", L)]) / WIN * 1e3
+            by = algorithmic_bytes_per_frame(cfg, NS, L + WIN // 2, 75)
+            windows.append({"kv_len": L, "steps": WIN, "ms_per_step": round(ms, 4), "formula_bytes_per_step": round(by, 1),
+                            "whole_step_frac_of_8TBps": round(by / 1e9 / (ms / 1e3) / HBM_PEAK_GBS, 4)})
+    # first-audio latency of the same request (warm process), as in the default line
+    lat = first_audio_trials(lambda st: model.generate(
+        tokenizer=T, cfg_scale=args.cfg_scale, generation_config={"do_sample": False}, max_new_tokens=3, show_progress_bar=False,
+        _forced_tokens=forced, _noise_fn=lambda step, n2: noise_bank[step], audio_streamer=st, **inputs), 3)
+    res = {"metric": "audio-sec/wall-sec", "value": round(audio_s / wall, 3), "unit": "audio-s/wall-s", "n_gpus": 1,
+           "steps": int(run_stats.get("steps", n_steps)), "warmup": 0, "ms_per_step": round(wall / max(1, run_stats.get("steps", n_steps)) * 1e3, 4),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": f"BASELINE {spec.get('baseline_config', '?')}, ONE WHOLE UTTERANCE: VibeVoice-{model_key.upper()} shapes, {spec['speakers']} speaker(s), "
+                                  f"{L0}-token prompt, {n_steps} generated tokens ({n_frames_plan} speech frames, turns of 150), KV grows {L0} -> {L0 + n_steps}, "
+                                  f"{NS} solver steps, cfg {args.cfg_scale}; wall = whole generate() incl. voice-prompt encode + prompt prefill",
+                      "model": f"VibeVoice-{model_key}", "solver_steps": NS, "prompt_tokens": L0, "generated_tokens": n_steps,
+                      "xsplit": args.xsplit, "hipgraph": not args.no_graph},
+           "roofline": None, "cpu_baseline": None,
+           "extra": {"utterance_audio_s": round(audio_s, 2), "utterance_wall_s": round(wall, 3), "frames": int(run_stats.get("frames", 0)),
+                     "ms_per_step_by_context": windows,
+                     "first_audio_ms": [round(x, 2) for x in lat],
+                     "device_memory_in_use_GB": round((total_mem - free1) / 2 ** 30, 2),
+                     "device_memory_before_engine_GB": round((total_mem - free0) / 2 ** 30, 2),
+                     "torch_peak_allocated_GB": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2),
+                     "kv_cache_GB": round(2 * 2 * d["num_hidden_layers"] * d["num_key_value_heads"] * (d["hidden_size"] // d["num_attention_heads"]) * 2 * max_ctx / 2 ** 30, 2),
+                     "hipgraph_cache_entries": n_graphs, "launches_last_engine_call": n_launch_last,
+                     "frame_store_blocks_kept_after_the_call": blocks_kept,
+                     "reach_max_step_sample": bool(out.reach_max_step_sample[0]), "libvvhip_build_id": _build_id()}}
+    eng.close()
     return res
 
 

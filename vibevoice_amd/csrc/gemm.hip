@@ -484,7 +484,11 @@ extern "C" int vv_gemv_launch(VVGemm a, int xs, hipStream_t s);
 extern "C" int vv_tile_ok(const VVGemm* a, int xs);
 extern "C" int vv_tile_launch(VVGemm a, int xs, hipStream_t s);
 extern "C" int vv_gemm_launch(VVGemm a, int xs, hipStream_t s) {
-    if (a.sl_n > 0) {                  // slot-batched rows exist only in the 16-row GEMV form
+    if (a.sl_n > 0) {                  // slot-batched rows: the MFMA tile form for tall row sets, else the 16-row GEMV form
+        if (vv_tile_ok(&a, xs)) {
+            const int r = vv_tile_launch(a, xs, s);
+            if (r != -3) return r;
+        }
         if (xs > 2 || !vv_gemv_ok(&a)) return -4;
         const int r = vv_gemv_launch(a, xs, s);
         return r == -3 ? -4 : r;

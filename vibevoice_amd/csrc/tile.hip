@@ -82,6 +82,18 @@ __global__ __launch_bounds__(256) void vv_gemm_tile_kernel(const u32x4* __restri
     const unsigned st_off = ((kk >> 5) * 4 + ((kk & 31) >> 3)) * (BM * 16 + 16) + (kk & 7) * 2;
 
     // ---- staging: wave w owns rows t0 + w*16 .. +15 ----
+    // row offsets (wave-uniform), once.  Slot-batched rows (VVGemm::sl_*, the batched tokenizer chains): logical row t belongs to
+    // utterance slot j = t / sl_T, local row t % sl_T of that slot's streaming buffer (a side with stride 0 is a dense scratch)
+    size_t xoff[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int t = t0 + wave * 16 + r;
+        if (t >= pT) t = pT - 1;                                    // clamped: legal address, never stored
+        if (a.sl_n > 0 && a.sl_x) {
+            const int j = t / a.sl_T, tt = t - j * a.sl_T;
+            xoff[r] = (size_t)vv_slot_id(a.sl_id, j) * a.sl_x + (size_t)tt * pldx;
+        } else xoff[r] = (size_t)t * pldx;
+    }
     float4 xr[16];
     float4 nwv;
     float ssq[16];
@@ -93,11 +105,7 @@ __global__ __launch_bounds__(256) void vv_gemm_tile_kernel(const u32x4* __restri
         if (!kin) k = 0;
         nwv = (PRO == VV_PRO_RMS && pnw) ? *reinterpret_cast<const float4*>(pnw + k) : float4{1.f, 1.f, 1.f, 1.f};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int t = t0 + wave * 16 + r;
-            if (t >= pT) t = pT - 1;                                // clamped: legal address, never stored
-            xr[r] = *reinterpret_cast<const float4*>(pX + (size_t)t * pldx + k);
-        }
+        for (int r = 0; r < 16; ++r) xr[r] = *reinterpret_cast<const float4*>(pX + xoff[r] + k);
     };
     auto x_stage = [&](int c, unsigned char* buf) {
         const float msk = (c * KC + kk < (unsigned)pK) ? 1.f : 0.f;
@@ -202,7 +210,12 @@ __global__ __launch_bounds__(256) void vv_gemm_tile_kernel(const u32x4* __restri
             if (t >= pT) continue;
             const float rs = (PRO == VV_PRO_RMS) ? rs_sh[rt * 16 + frow] : 1.0f;
             float o[4] = {acc[i][rt][0] * rs, acc[i][rt][1] * rs, acc[i][rt][2] * rs, acc[i][rt][3] * rs};
-            float* yp = pY + (size_t)t * pldy + n0;
+            size_t yo = (size_t)t * pldy;
+            if (a.sl_n > 0 && a.sl_y) {
+                const int j = t / a.sl_T, tt = t - j * a.sl_T;
+                yo = (size_t)vv_slot_id(a.sl_id, j) * a.sl_y + (size_t)tt * pldy;
+            }
+            float* yp = pY + yo + n0;
             if constexpr (EPI == VV_EPI_BIAS) {
                 o[0] += pb.x; o[1] += pb.y; o[2] += pb.z; o[3] += pb.w;
             } else if constexpr (EPI == VV_EPI_BIAS_GELU) {
@@ -233,8 +246,16 @@ extern "C" int vv_tile_ok(const VVGemm* a, int xs) {
     {   // enough workgroups to occupy the chip; smaller problems (tokenizer stages at decode) stay on the row-tiled GEMV
         const int per_wg = 4 * (a->epi == VV_EPI_SWIGLU ? 1 : 2);
         const int64_t wgs = (int64_t)(((a->N + 15) / 16 + per_wg - 1) / per_wg) * ((a->T + BM - 1) / BM);
-        constexpr int min_wgs = 48;
+        static int min_sl = -1;
+        if (min_sl < 0) { const char* e = getenv("VVHIP_TILE_MIN_WGS_SLOTS"); min_sl = e ? atoi(e) : 40; }
+        // slot-batched tokenizer stages (several utterances' frames in one launch): the 16-row GEMV form re-normalises and
+        // re-stages its 16 rows in every one of its (feature tiles x row tiles) workgroups -- 87 us for the C = 256 FFN1 of eight
+        // utterances (1600 rows x 1024 features x 256: 0.8 GFLOP) -- so the tile form takes over much earlier there
+        const int min_wgs = a->sl_n > 0 ? min_sl : 48;
         if (wgs < min_wgs) return 0;
+    }
+    if (a->sl_n > 0) {
+        if (a->sl_n > 8 || a->sl_T < 1 || a->T != a->sl_n * a->sl_T || a->sl_x < 0 || a->sl_y < 0 || (a->sl_x & 3) || (a->sl_y & 3)) return 0;
     }
     if ((a->K & 3) || (a->ldx & 3) || (a->N & 3) || (a->ldy & 3)) return 0;
     if ((((uintptr_t)a->X) | ((uintptr_t)a->Y)) & 15) return 0;
