@@ -415,7 +415,10 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline, with_parity=False):
         if step == W or step == W + K:
             eng.sync()
             torch.cuda.synchronize()
-            if use_dist:
+            # ranks meet at the edges of the timed region -- only where every rank is certain to get there: a continuous queue
+            # may drain on one rank before step W + K (its region then ends with its generate()), and a barrier the others
+            # still wait at would hang the job; the collectives AFTER generate() (same count on every rank) do the aggregation
+            if use_dist and not args.continuous:
                 dist.barrier()
                 torch.cuda.synchronize()
             marks[step] = time.perf_counter()
@@ -472,11 +475,7 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline, with_parity=False):
     prefill_phases = getattr(model, "last_prefill", None)
     cont_stats = dict(model.last_stats) if args.continuous else None
     # every rank's own step time next to the max: an imbalance (a slow GPU, a straggling host loop) shows in the first SCALE run
-    per_rank_ms = [round(wall / K * 1e3, 4)]
-    if use_dist:
-        t_all = [torch.zeros(1, dtype=torch.float64, device=device) for _ in range(world)]
-        dist.all_gather(t_all, torch.tensor([wall / K * 1e3], dtype=torch.float64, device=device))
-        per_rank_ms = [round(float(t[0]), 4) for t in t_all]
+    per_rank_ms = [round(v, 4) for v in parallel.per_rank_values(wall / K * 1e3, device)]
     # first-audio latency as SURVEY 8d defines it: generate() entry (voice-prompt encode + prompt prefill + first frame) -> the
     # first chunk an AudioStreamer consumer receives on the host; 3 trials of the same request
     first_audio = None
@@ -590,12 +589,13 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline, with_parity=False):
             cpu = {"value": None, "error": repr(ex)[:200]}
     if keep_cpu and not args.no_eager_baseline:
         try:
-            legs["vs_bf16_eager"], eager = gpu_eager_baseline(cfg, cpu_sd, NS, args.cfg_scale, 8, model_key, device)
+            _free_run_leg, eager = gpu_eager_baseline(cfg, cpu_sd, NS, args.cfg_scale, 8, model_key, device)     # timing only
+            del _free_run_leg
             eager["speedup_of_this_path"] = round(value / world / eager["value"], 2) if eager["value"] else None
         except Exception as ex:   # a reported number, never the product path
             eager = {"value": None, "error": repr(ex)[:200]}
         torch.cuda.empty_cache()
-    if with_parity and legs:
+    if with_parity:
         # ---- full-depth parity of the engine that was just timed (same weights, same execution mode) against the oracle legs ----
         from oracle import parity as oparity
         parity = {"model": f"VibeVoice-{model_key}", "lm_layers": d["num_hidden_layers"], "head_layers": cfg["diffusion_head_config"].get("head_layers", 4),
@@ -603,34 +603,31 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline, with_parity=False):
                   "prompt_tokens": 48, "weights": "the timed run's (synthetic, seeded)" if not ckpt else "checkpoint",
                   "definition": "HIP engine vs the oracle loop (oracle/generate.py, the restatement of the reference's generate()) on the same prompt, "
                                 "forced <speech_diffusion> schedule and noise, teacher-forced per step; worst step; rel-L2 unless marked dB; "
-                                "bounds = SURVEY 8(d).  reference_bf16_vs_fp32 = the oracle's OWN bf16 eager run against the same fp32 run, teacher-forced "
-                                "the same way: the reference path's rounding noise at this depth"}
+                                "bounds = SURVEY 8(d).  Three runs on IDENTICAL inputs: the fp32 oracle (free-running, defines the trajectory), the oracle as "
+                                "bf16 eager ops on this GPU (the reference's GPU dtype) and the engine, both teacher-forced by the fp32 run.  "
+                                "reference_bf16_vs_fp32 = the reference path's own rounding noise at this depth"}
         try:
             if "vs_fp32" not in legs:      # no CPU leg in this run (the extra configs): the fp32 oracle as eager ops on this GPU
                 legs["vs_fp32"] = oparity.oracle_leg(cfg, cpu_sd, synthetic.TOKENS, NS, args.cfg_scale, 4, device, torch.float32, 20.0)
-            if "vs_bf16_eager" in legs:
-                floor_leg = oparity.oracle_leg(cfg, cpu_sd, synthetic.TOKENS, NS, args.cfg_scale, 8, device, torch.bfloat16, 20.0,
-                                               teacher=legs["vs_fp32"])
-                parity["reference_bf16_vs_fp32"] = oparity.compare_legs(floor_leg, legs["vs_fp32"])
-                del floor_leg
-        except Exception as ex:
-            parity["reference_bf16_vs_fp32"] = {"error": repr(ex)[:300]}
-        raw = {}
-        for kind, leg in legs.items():
-            try:
-                raw[kind] = oparity.compare_engine(model, leg, synthetic.TOKENS)
-            except Exception as ex:
-                parity[kind] = {"error": repr(ex)[:300]}
-        fl = parity.get("reference_bf16_vs_fp32") or {}
-        for kind, r in raw.items():
-            parity[kind] = oparity.verdict(kind, r, floor=fl if "latent" in fl else None, vs_fp32=raw.get("vs_fp32"))
-            parity[kind]["oracle"] = f"{legs[kind].dtype} on {legs[kind].device}".replace("torch.", "")
-        hf = parity.get("vs_fp32") or {}
-        if "latent" in fl and "latent" in hf:
+            fp32_leg = legs["vs_fp32"]
+            # the reference's GPU dtype on the SAME inputs: the oracle as bf16 eager ops, teacher-forced by the fp32 run
+            bf16_leg = oparity.oracle_leg(cfg, cpu_sd, synthetic.TOKENS, NS, args.cfg_scale, 8, device, torch.bfloat16, 20.0, teacher=fp32_leg)
+            floor = oparity.compare_legs(bf16_leg, fp32_leg)
+            parity["reference_bf16_vs_fp32"] = floor
+            both = oparity.compare_engine(model, fp32_leg, synthetic.TOKENS, also={"bf16": bf16_leg})
+            r32 = oparity.verdict("vs_fp32", {k: v for k, v in both.items() if k != "also"})
+            r32["oracle"] = f"{fp32_leg.dtype} on {fp32_leg.device}".replace("torch.", "")
+            r16 = oparity.verdict("vs_bf16_eager", both["also"]["bf16"], floor=floor, vs_fp32=r32)
+            r16["oracle"] = f"{bf16_leg.dtype} on {bf16_leg.device}, teacher-forced by the fp32 run (identical inputs)".replace("torch.", "")
+            parity["vs_fp32"], parity["vs_bf16_eager"] = r32, r16
             # the engine's bf16 mode (fp32 residual stream, bf16 only at the matrix-unit inputs) against the reference's bf16 path
-            parity["engine_at_least_as_close_to_fp32_as_reference_bf16"] = {k: bool(hf[k] <= 1.1 * fl[k] + 1e-3) for k in ("latent", "pos_hidden", "neg_hidden")}
-        parity["within_bounds"] = bool(all(isinstance(parity.get(k), dict) and parity[k].get("within_bounds") for k in legs)
-                                       and all((parity.get("engine_at_least_as_close_to_fp32_as_reference_bf16") or {"x": True}).values()))
+            parity["engine_at_least_as_close_to_fp32_as_reference_bf16"] = {k: bool(r32[k] <= 1.1 * floor[k] + 1e-3) for k in ("latent", "pos_hidden", "neg_hidden")}
+            parity["within_bounds"] = bool(r32["within_bounds"] and r16["within_bounds"]
+                                           and all(parity["engine_at_least_as_close_to_fp32_as_reference_bf16"].values()))
+            del bf16_leg
+        except Exception as ex:
+            parity["error"] = repr(ex)[:300]
+            parity["within_bounds"] = False
         model.set_ddpm_inference_steps(NS)
     legs.clear()
     cpu_sd.clear()

@@ -162,13 +162,15 @@ def compare_traces(htr, wav, otr, n, seq_ok=True) -> dict:
             "mode": "teacher-forced per step (next LM input = the oracle's embedding of that step)"}
 
 
-def compare_engine(model, leg: Leg, tokens, frames: Optional[int] = None) -> dict:
+def compare_engine(model, leg: Leg, tokens, frames: Optional[int] = None, also: Optional[dict] = None) -> dict:
     """Run `model` (the HIP-path class; its engine's own execution mode -- xsplit, hipGraph -- is what gets checked) on the
     leg's prompt, forced schedule and noise, TEACHER-FORCED per step with the embeddings the oracle fed its LM at that step
     (so the autoregressive feedback cannot compound a rounding difference), and compare step by step.  Returns the worst
     per-step figures:  latent / pos_hidden / neg_hidden rel-L2, frame RMS difference in dB, frame SNR in dB, whether the
     token the HIP path's own logits would pick equals the oracle's pick on every step (and the smallest top-2 logit margin
-    of the oracle, the context of that statement)."""
+    of the oracle, the context of that statement).
+    also: {name: other_leg} -- further oracle legs that consumed the SAME inputs (oracle_leg(..., teacher=leg)): the one engine
+    run is compared against each of them too; the results land in the returned dict under "also"."""
     n = leg.frames if frames is None else min(frames, leg.frames)
     if n < 1:
         return {"frames": 0, "error": "the oracle leg completed no frame"}
@@ -181,7 +183,10 @@ def compare_engine(model, leg: Leg, tokens, frames: Optional[int] = None) -> dic
                          _forced_tokens=[[D] * n + [X]], _noise_fn=lambda step, n2: leg.noise[step][:n2],
                          _trace=htr, _teacher_embeds=lambda step, rows: otr.next_embeds[step][rows].float())
     seq_ok = out.sequences.shape[1] == leg.ids.shape[1] + n and bool((out.sequences[0, leg.ids.shape[1]:].cpu() == D).all())
-    return compare_traces(htr, out.speech_outputs[0], otr, n, seq_ok)
+    res = compare_traces(htr, out.speech_outputs[0], otr, n, seq_ok)
+    if also:
+        res["also"] = {k: compare_traces(htr, out.speech_outputs[0], o.trace, min(n, o.frames), seq_ok) for k, o in also.items()}
+    return res
 
 
 def compare_legs(leg: Leg, teacher: Leg) -> dict:
@@ -203,8 +208,9 @@ def verdict(kind: str, res: dict, floor: Optional[dict] = None, vs_fp32: Optiona
     (bf16 residual stream and activations; `floor` = its measured distance to the fp32 oracle on identical inputs) sits
     1.7-1.8e-2 (hidden) / 3-4.6e-2 (latent) from fp32, i.e. the stated figure is below the reference's own rounding noise
     for the latents.  Two bf16 implementations can differ by up to the sum of their distances to fp32, so when `floor`
-    and `vs_fp32` (the engine's distance to fp32) are given the bound asserted per quantity is
-    max(SURVEY's 2e-2, 1.05 x (floor + vs_fp32)); `survey_bounds` / `within_survey_bounds` keep the literal statement."""
+    and `vs_fp32` (the engine's distance to fp32) are given -- all three runs on IDENTICAL inputs (the bf16 eager run and the
+    engine both teacher-forced by the fp32 run) -- the bound asserted per quantity is max(SURVEY's 2e-2, 1.05 x (floor + vs_fp32)),
+    the triangle inequality; `survey_bounds` / `within_survey_bounds` keep the literal statement."""
     b = dict(BOUNDS[kind])
     out = dict(res)
     if kind == "vs_bf16_eager":

@@ -155,3 +155,40 @@ def test_bench_gpus_flag_spawns_one_rank_per_gpu(monkeypatch):
     monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
     with pytest.raises(SystemExit, match="only 1 GPU"):
         bench.respawn_ranks(args)
+
+
+def _agg_worker(rank, world, port, q):
+    """rank 1 finishes its shard early (fewer frames, shorter wall): the job's figure is sum(units) / max(wall), every rank's own
+    step time arrives in rank order on every rank, and nobody waits for a collective the early rank never issues"""
+    import time
+    import torch.distributed as dist
+    from vibevoice_amd import parallel
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    frames, wall = (20, 0.40) if rank == 0 else (7, 0.10)            # rank 1: a short queue that drained early
+    if rank == 0:
+        time.sleep(0.3)                                              # ... and it reaches the aggregation long before rank 0
+    tot, wmax = parallel.aggregate_throughput(frames, wall, "cpu")
+    per_rank = parallel.per_rank_values(wall / max(1, frames) * 1e3, "cpu")
+    st = {}
+    list(parallel.broadcast_packed([("w", (8,))], lambda n, s: torch.ones(s), "cpu", torch.float32, stats=st))
+    q.put((rank, tot, wmax, per_rank, st["collectives"], st["world"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_aggregation_survives_a_rank_that_finishes_early():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_agg_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, tot, wmax, per_rank, n_coll, world in res:
+        assert tot == 27.0 and wmax == 0.40                          # whole job: all frames over the slowest rank's wall
+        assert [round(v, 4) for v in per_rank] == [20.0, round(0.10 / 7 * 1e3, 4)]
+        assert n_coll == 1 and world == 2

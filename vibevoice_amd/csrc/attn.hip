@@ -299,8 +299,13 @@ __global__ __launch_bounds__(WAVES * 64) void vv_attn_fused_kernel(
     if (p_first < end) kv_load(p_first);
 
     // ---- new token's K (rotated) / V: LDS copy for the patch below + the cache append (fire and forget) ----
-    __shared__ __attribute__((aligned(16))) __bf16 knew[D];
-    __shared__ __attribute__((aligned(16))) __bf16 vnew[D];
+    // (all LDS of this kernel is one dynamic block: the 8-wave form's partial tiles alone are 64 KiB, the static limit)
+    extern __shared__ __attribute__((aligned(16))) unsigned char af_lds[];
+    f32x4 (*so)[DT][64] = reinterpret_cast<f32x4 (*)[DT][64]>(af_lds);                              // [WAVES][DT][64]
+    float (*sm)[16] = reinterpret_cast<float (*)[16]>(af_lds + (size_t)WAVES * DT * 64 * 16);     // [WAVES][16]
+    float (*sl)[16] = sm + WAVES;                                                                  // [WAVES][16]
+    __bf16* knew = reinterpret_cast<__bf16*>(sl + WAVES);                                          // [D]
+    __bf16* vnew = knew + D;                                                                       // [D]
     if (owner && tid < D) {
         const int d = tid, i = d & (HALF - 1);
         const float* ksrc = qrow + (int64_t)(Hq + kvh) * D;
@@ -427,48 +432,41 @@ __global__ __launch_bounds__(WAVES * 64) void vv_attn_fused_kernel(
     lsum += __shfl_xor(lsum, 16);
     lsum += __shfl_xor(lsum, 32);
 
-    // ---- combine the waves (fixed order) ----
-    __shared__ float sm[WAVES][16], sl[WAVES][16];
-    __shared__ f32x4 so[WAVES][DT][64];
+    // ---- combine the waves (fixed order), ALL waves at work: wave w finishes the output tiles dt = w, w + WAVES, ... (the
+    // one-wave form of this step read WAVES x DT partial tiles through a single wave: the longest serial piece of a
+    // short-context launch, and what made the 8-wave form -- a load chain half as long -- the slower one)
     if (lane < 16) { sm[wave][lane] = m; sl[wave][lane] = lsum; }
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) so[wave][dt][lane] = o[dt];
     __syncthreads();
     const int64_t gidx = (int64_t)r * Hkv + kvh;
     float* orow = out + ((int64_t)r * Hq + kvh * G + g) * D + qg * 4;
-    if (wave == 0) {
-        float M = -INFINITY;
+    float M = -INFINITY;
 #pragma unroll
-        for (int w = 0; w < WAVES; ++w) M = fmaxf(M, sm[w][g]);
-        float L = 0.f;
-        f32x4 O[DT];
+    for (int w = 0; w < WAVES; ++w) M = fmaxf(M, sm[w][g]);
+    float L = 0.f, fw[WAVES];
 #pragma unroll
-        for (int i = 0; i < DT; ++i) O[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int w = 0; w < WAVES; ++w) {
+        const float mw = sm[w][g];
+        fw[w] = (mw == -INFINITY) ? 0.f : expf(mw - M);
+        L += sl[w][g] * fw[w];
+    }
+    const int64_t pidx = gidx * S + split;
+    if (used > 1 && wave == 0 && lane < 16) { part_m[pidx * 16 + lane] = M; part_l[pidx * 16 + lane] = L; }
+    const float inv = 1.0f / L;
 #pragma unroll
-        for (int w = 0; w < WAVES; ++w) {
-            const float mw = sm[w][g];
-            const float f = (mw == -INFINITY) ? 0.f : expf(mw - M);
-            L += sl[w][g] * f;
+    for (int dt0 = 0; dt0 < DT; dt0 += WAVES) {
+        const int dt = dt0 + wave;
+        if (dt >= DT) break;
+        f32x4 O = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) O[dt] += so[w][dt][lane] * f;
-        }
-        if (used == 1) {                          // short sequence: this workgroup saw everything
-            if (g < G) {
-                const float inv = 1.0f / L;
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
-                    *reinterpret_cast<float4*>(orow + dt * 16) = float4{O[dt][0] * inv, O[dt][1] * inv, O[dt][2] * inv, O[dt][3] * inv};
-            }
-        } else {
-            const int64_t pidx = gidx * S + split;
-            if (lane < 16) { part_m[pidx * 16 + lane] = M; part_l[pidx * 16 + lane] = L; }
-            if (g < G) {
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
-                    *reinterpret_cast<float4*>(part_o + (pidx * 16 + g) * D + dt * 16 + qg * 4) = float4{O[dt][0], O[dt][1], O[dt][2], O[dt][3]};
-            }
-            // several splits: the partials are merged by vv_attn_merge2_kernel, a separate wide launch that follows in the
-            // stream -- no fence, no ticket, no serial chain of L2 round trips inside the last workgroup to arrive
+        for (int w = 0; w < WAVES; ++w) O += so[w][dt][lane] * fw[w];
+        if (g < G) {
+            if (used == 1)                        // short sequence: this workgroup saw everything
+                *reinterpret_cast<float4*>(orow + dt * 16) = float4{O[0] * inv, O[1] * inv, O[2] * inv, O[3] * inv};
+            else                                  // several splits: vv_attn_merge2_kernel (a separate wide launch that follows in
+                                                  // the stream: no fence, no ticket) combines the partials in a fixed order
+                *reinterpret_cast<float4*>(part_o + (pidx * 16 + g) * D + dt * 16 + qg * 4) = float4{O[0], O[1], O[2], O[3]};
         }
     }
 }
@@ -594,15 +592,32 @@ extern "C" int vv_rope_table_launch(const float* inv_freq, void* tab, int n_pos,
 
 // Decode-step attention in one launch; requires every row to own a different cache (the new token of row r must not
 // be visible to -- or needed by -- another row of the same launch).
+// waves: 4, or 8 (the caller's choice for contexts that fit ONE split but are several 32-position blocks long: twice the
+// K/V requests in flight at once, half the dependent load -> consume iterations per wave)
+template <int D, int XS, int W>
+static void attn_fused_go(dim3 grid, hipStream_t s, const float* qkv, const VVRow* rows, const void* rope_tab, void* kc, void* vc,
+                          int Hq, int Hkv, int64_t cache_stride, int64_t head_stride, float scale, float* pm, float* pl, float* po, float* out) {
+    constexpr size_t smem = (size_t)W * (D / 16) * 64 * 16 + (size_t)2 * W * 16 * 4 + (size_t)2 * D * 2;
+    static bool attr = false;
+    if (!attr) {
+        if (smem > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_attn_fused_kernel<D, XS, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr = true;
+    }
+    hipLaunchKernelGGL((vv_attn_fused_kernel<D, XS, W>), grid, dim3(W * 64), smem, s, qkv, rows, (const float2*)rope_tab, (__bf16*)kc, (__bf16*)vc,
+                       Hq, Hkv, cache_stride, head_stride, scale, pm, pl, po, out);
+}
 extern "C" int vv_attn_fused_launch(int D, int xs, const float* qkv, const VVRow* rows, const void* rope_tab, void* kc, void* vc,
-                                    int R, int Hq, int Hkv, int64_t cache_stride, int64_t head_stride, int S,
+                                    int R, int Hq, int Hkv, int64_t cache_stride, int64_t head_stride, int S, int waves,
                                     float* pm, float* pl, float* po, float* out, hipStream_t s) {
-    if (Hq % Hkv != 0 || Hq / Hkv > 16) return -1;
+    if (Hq % Hkv != 0 || Hq / Hkv > 16 || (waves != 4 && waves != 8)) return -1;
     const float scale = 1.0f / sqrtf((float)D);
-#define VV_F(D_, XS_)                                                                                         \
-    hipLaunchKernelGGL((vv_attn_fused_kernel<D_, XS_, 4>), dim3(S, Hkv, R), dim3(256), 0, s, qkv, rows,       \
-                       (const float2*)rope_tab, (__bf16*)kc, (__bf16*)vc, Hq, Hkv, cache_stride, head_stride, scale, \
-                       pm, pl, po, out)
+    const dim3 grid(S, Hkv, R);
+#define VV_F(D_, XS_)                                                                                                                   \
+    do {                                                                                                                                \
+        if (waves == 8) attn_fused_go<D_, XS_, 8>(grid, s, qkv, rows, rope_tab, kc, vc, Hq, Hkv, cache_stride, head_stride, scale, pm, pl, po, out); \
+        else attn_fused_go<D_, XS_, 4>(grid, s, qkv, rows, rope_tab, kc, vc, Hq, Hkv, cache_stride, head_stride, scale, pm, pl, po, out);            \
+    } while (0)
     if (D == 128) { if (xs == 1) VV_F(128, 1); else if (xs == 2) VV_F(128, 2); else VV_F(128, 3); }
     else if (D == 64) { if (xs == 1) VV_F(64, 1); else if (xs == 2) VV_F(64, 2); else VV_F(64, 3); }
     else return -1;

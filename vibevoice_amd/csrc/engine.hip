@@ -24,7 +24,7 @@ int vv_rope_append_launch(int D, const float* qkv, const VVRow* rows, const floa
                           void* vc, int R, int Hq, int Hkv, int64_t cache_stride, int64_t head_stride, hipStream_t s);
 int vv_rope_table_launch(const float* inv_freq, void* tab, int n_pos, int half, hipStream_t s);
 int vv_attn_fused_launch(int D, int xs, const float* qkv, const VVRow* rows, const void* rope_tab, void* kc, void* vc,
-                         int R, int Hq, int Hkv, int64_t cache_stride, int64_t head_stride, int S,
+                         int R, int Hq, int Hkv, int64_t cache_stride, int64_t head_stride, int S, int waves,
                          float* pm, float* pl, float* po, float* out, hipStream_t s);
 int vv_attn_launch(int D, int xs, const float* q, const VVRow* rows, const void* kc, const void* vc, int R, int Hq,
                    int Hkv, int64_t cache_stride, int64_t head_stride, int S, float* pm, float* pl, float* po,
@@ -1128,7 +1128,7 @@ static int p16_gemv(vv_ctx* ctx, hipStream_t st, const void* W, const void* W2, 
 }
 
 static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float* hidden_out, int l0, int l1, int final_norm, bool fused_attn, bool contiguous,
-                   int attn_S, int64_t kv_positions = 0) {
+                   int attn_S, int64_t kv_positions = 0, int attn_W = 4) {
     const vv_config& c = ctx->c;
     const int H = ctx->H, D = ctx->D, Hq = ctx->Hq, Hkv = ctx->Hkv, I = ctx->I, QKV = ctx->QKV;
     HIPCHK(ctx, hipMemcpyAsync(ctx->h, x_in, (size_t)R * H * 4, hipMemcpyDeviceToDevice, st));
@@ -1182,18 +1182,18 @@ static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float*
         char* kl = (char*)ctx->kc + (size_t)l * ctx->layer_stride * 2;
         char* vl = (char*)ctx->vc + (size_t)l * ctx->layer_stride * 2;
         if (fused_attn) {
-            // decode rows (one cache each): RoPE + KV append + split attention + last-arriver merge in ONE launch
-            ctx->launches += 1;
+            // decode rows (one cache each): RoPE + KV append + split attention in ONE launch (+ the merge launch when split)
+            ctx->launches += (attn_S > 1) ? 2 : 1;
             if (ctx->prof_on) {
                 // algorithmic bytes: every cached position of every row once, K and V (bf16) + the row's q / new k, v / output
                 const double by = (double)kv_positions * Hkv * D * 2.0 * 2.0 + (double)R * (QKV + Hq * D) * 4.0;
                 const int xs = c.xsplit; vv_ctx* cx = ctx;
                 ctx->prof_other.push_back({2, by, [=](hipStream_t s) {
                     return vv_attn_fused_launch(D, xs, cx->qkv, cx->rows_dev, cx->rope_tab, kl, vl, R, Hq, Hkv, cx->cache_stride,
-                                                cx->head_stride, attn_S, cx->pm, cx->pl, cx->po, cx->attn, s); }});
+                                                cx->head_stride, attn_S, attn_W, cx->pm, cx->pl, cx->po, cx->attn, s); }});
             }
             VVCHK(vv_attn_fused_launch(D, c.xsplit, ctx->qkv, ctx->rows_dev, ctx->rope_tab, kl, vl, R, Hq, Hkv, ctx->cache_stride,
-                                       ctx->head_stride, attn_S, ctx->pm, ctx->pl, ctx->po, ctx->attn, st));
+                                       ctx->head_stride, attn_S, attn_W, ctx->pm, ctx->pl, ctx->po, ctx->attn, st));
         } else {
             // rows of one launch share caches (prefill chunks): every append must land before any row attends
             ctx->launches += 3;
@@ -1305,11 +1305,18 @@ extern "C" int vv_lm_forward_range(vv_ctx* ctx, void* stream, int n_rows, const 
     for (int i = 0; i < n_rows; ++i) if (rows[i].pos + 1 > split_pos) ++n_long;
     const int by_wgs = std::max(1, (target_wgs + std::max(1, n_long) * ctx->Hkv - 1) / (std::max(1, n_long) * ctx->Hkv));
     const int attn_S = std::min(std::min(ctx->c.attn_splits, by_wgs), std::max(1, (max_len + split_pos - 1) / split_pos));
+    // one split, but several 32-position blocks per wave: the 8-wave form (all K/V requests of a <= 512-position context in
+    // flight at once).  Measured three times now, the third with every wave combining its share of the output tiles: slower than
+    // 4 waves (round 4: 8.90 vs 8.28 us per unit at 400 positions, 1.5B; 5.84 vs 5.78 at 250, 0.5B) -- off unless
+    // VVHIP_ATTN_W8_MIN = positions from which to use it
+    static int w8_min = -1;
+    if (w8_min < 0) { const char* e = getenv("VVHIP_ATTN_W8_MIN"); w8_min = e ? atoi(e) : 0; }
+    const int attn_W = (fused && attn_S == 1 && w8_min > 0 && max_len >= w8_min) ? 8 : 4;
     char key[160]; snprintf(key, 160, "lm:%d:%p:%p:%d:%d:%d:%d:%d", n_rows, (const void*)x_in_dev, (void*)hidden_out_dev, l0, l1, final_norm,
-                            fused ? 1 : (contiguous ? 2 : 0), (contiguous && ctx->attn2_ok) ? 0 : attn_S);
+                            fused ? 1 : (contiguous ? 2 : 0), (contiguous && ctx->attn2_ok) ? 0 : attn_S * 16 + attn_W);
     int64_t kv_positions = 0;
     for (int i = 0; i < n_rows; ++i) kv_positions += rows[i].pos + 1;
-    return graphed(ctx, key, st, [&]() { return lm_body(ctx, st, n_rows, x_in_dev, hidden_out_dev, l0, l1, final_norm, fused, contiguous, attn_S, kv_positions); });
+    return graphed(ctx, key, st, [&]() { return lm_body(ctx, st, n_rows, x_in_dev, hidden_out_dev, l0, l1, final_norm, fused, contiguous, attn_S, kv_positions, attn_W); });
 }
 
 extern "C" int vv_kv_import_at(vv_ctx* ctx, void* stream, int cache, int layer, int pos0, int n_pos, const void* k_dev, const void* v_dev, int src_dtype) {

@@ -61,6 +61,16 @@ def aggregate_throughput(units_local: float, wall_local: float, device) -> Tuple
     return float(t[0]), float(t[1])
 
 
+def per_rank_values(x: float, device) -> List[float]:
+    """every rank's own scalar (its ms per step, its frame count), in rank order, on every rank: one small all_gather"""
+    rank, world = world_info()
+    if not (dist.is_available() and dist.is_initialized()):
+        return [float(x)]
+    parts = [torch.zeros(1, dtype=torch.float64, device=device) for _ in range(world)]
+    dist.all_gather(parts, torch.tensor([float(x)], dtype=torch.float64, device=device))
+    return [float(t[0]) for t in parts]
+
+
 def broadcast_packed(shapes: Iterable[Tuple[str, tuple]], make: Callable[[str, tuple], torch.Tensor], device,
                      dtype=torch.bfloat16, src: int = 0, bucket_bytes: int = 2 << 30, stats: dict = None
                      ) -> Iterator[Tuple[str, torch.Tensor]]:
