@@ -197,6 +197,7 @@ struct vv_ctx {
     void *xp = nullptr, *actp = nullptr;               // prefill (prefill.hip): activations as packed bf16 MFMA fragments
     bool tile3_ok = false, attn2_ok = false;
     VVGemmWs gws = {nullptr, nullptr, nullptr};         // K-split workspace of the long-prompt GEMM (null: never split)
+    bool fold_normdw = true;      // one-row tokenizer stages: norm + depthwise conv inside FFN1's prologue (VVHIP_FOLD_NORMDW=0: separate launch)
     // batch decode (5..16 rows, bf16 mode): activations packed once per op into one 16-row fragment tile (gemv16p.hip)
     void *p16_x = nullptr, *p16_act = nullptr; bool p16_ok = false;
     float *pm = nullptr, *pl = nullptr, *po = nullptr;
@@ -618,6 +619,22 @@ static int run_codec(vv_ctx* ctx, CodecNet& net, int sl, int F, float* out, hipS
         }
         float* xo = s.pp ? s.xs2 + (size_t)s.hist * s.C : x;       // pp stages: each block's norm+conv writes the other buffer
         for (auto& b : s.blocks) {
+            if (s.pp && T == 1 && ctx->fold_normdw && vv_normdw_sliced_ok(T, s.C)) {
+                // one-row stages (C = 2048: 8 blocks per net): the block's norm + depthwise conv + layer scale + residual run in
+                // FFN1's prologue (VV_PRO_NORMDW) -- one launch less per block on a chain where every launch is a latency link
+                VVGemm g1 = mk_gemm(b.w1, x, net.u[sl], T, 4 * s.C, s.C, s.C, 4 * s.C);
+                g1.pro = VV_PRO_NORMDW; g1.nw = b.ffn_norm_w; g1.eps = eps; g1.epi = VV_EPI_BIAS_GELU; g1.bias = b.b1; g1.nt = stream_w;
+                g1.dw_hist = b.nb; g1.dw_w = b.dw_w; g1.dw_b = b.dw_b; g1.dw_gamma = b.gamma; g1.dw_nw = b.norm_w;
+                g1.dw_xout = xo; g1.dw_hnew = b.nb + 6 * (size_t)s.C;
+                if (vv_gemv_ok(&g1)) {
+                    GEMM(g1);
+                    VVGemm g2 = mk_gemm(b.w2, net.u[sl], xo, T, s.C, 4 * s.C, 4 * s.C, s.C);
+                    g2.epi = VV_EPI_RESID; g2.bias = b.b2; g2.nscale = b.ffn_gamma; g2.nt = stream_w;
+                    GEMM(g2);
+                    std::swap(x, xo);
+                    continue;
+                }
+            }
             if (s.pp && vv_normdw_sliced_ok(T, s.C)) {
                 ctx->launches += 1;
                 VVCHK(vv_normdw_sliced_launch(x, xo, b.nb, b.norm_w, b.dw_w, b.dw_b, b.gamma, T, s.C, eps, st));
@@ -796,6 +813,7 @@ extern "C" const char* vv_build_id() { return "VVHIP_BUILD_ID=" VV_BUILD_ID; }
 extern "C" int vv_create(const vv_config* cfg, vv_ctx** out) {
     vv_ctx* ctx = new vv_ctx();
     ctx->c = *cfg; ctx->err[0] = 0;
+    { const char* e = getenv("VVHIP_FOLD_NORMDW"); if (e && e[0] == '0') ctx->fold_normdw = false; }
     vv_config& c = ctx->c;
     if (c.max_rows < 1 || c.max_rows > 16384) { delete ctx; return fail(nullptr, "max_rows must be in [1,16384]"); }
     if (c.lm_head_dim != 64 && c.lm_head_dim != 128) { delete ctx; return fail(nullptr, "head_dim must be 64 or 128"); }

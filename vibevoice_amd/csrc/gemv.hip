@@ -102,6 +102,7 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const u32x4* __restri
     __shared__ __attribute__((aligned(16))) unsigned char stg_all[WPB * NOP * XS * U * 4 * GSB];
     __shared__ f32x4 red[WPB][NM * NOP][64];
     __shared__ float ssq_sh[WPB][MR];
+    __shared__ float ssq1_sh[PRO == VV_PRO_NORMDW ? WPB : 1];
     // Pull every kernel argument into SGPRs with ONE batch of s_loads: left alone the compiler fetches
     // them lazily behind branches, i.e. 3-4 dependent ~600-cycle round trips on a launch's critical path.
     asm volatile("" ::"s"(a.mod_scale), "s"(a.mod_shift), "s"(a.addvec), "s"(a.bias), "s"(a.nscale), "s"(a.gate));
@@ -148,12 +149,23 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const u32x4* __restri
     constexpr int MODR = (PRO == VV_PRO_RMS_MOD) ? MR : 1;
     constexpr int ADDR = (PRO == VV_PRO_ADD_SILU) ? MR : 1;
     constexpr int PR = (PARTS == 1) ? MR : 1;
-    struct XR { float4 x[MR]; float4 p0[PR]; float4 p1[PR]; float4 sc[MODR]; float4 sh[MODR]; float4 addv[ADDR]; float4 nwv; };
+    constexpr int DWH = (PRO == VV_PRO_NORMDW) ? 6 : 1, DWT = (PRO == VV_PRO_NORMDW) ? 7 : 1;
+    struct XR { float4 x[MR]; float4 p0[PR]; float4 p1[PR]; float4 sc[MODR]; float4 sh[MODR]; float4 addv[ADDR]; float4 nwv;
+                float4 dh[DWH]; float4 dt[DWT]; float4 db, dg, dn; };
     auto x_load = [&](unsigned ktb, XR& R) {
         unsigned k = ktb * 32 + kk;
         const bool kin = k < min(kt1 * 32, (unsigned)pK);
         if (!kin) k = 0;                                   // clamped: always a legal address, masked later
         R.nwv = pnw ? *reinterpret_cast<const float4*>(pnw + k) : float4{1.f, 1.f, 1.f, 1.f};
+        if constexpr (PRO == VV_PRO_NORMDW) {          // one row: history rows, taps, bias, layer scale, first norm's weight
+#pragma unroll
+            for (int j = 0; j < 6; ++j) R.dh[j] = *reinterpret_cast<const float4*>(a.dw_hist + (unsigned)(j * pK) + k);
+#pragma unroll
+            for (int j = 0; j < 7; ++j) R.dt[j] = *reinterpret_cast<const float4*>(a.dw_w + (unsigned)(j * pK) + k);
+            R.db = *reinterpret_cast<const float4*>(a.dw_b + k);
+            R.dg = *reinterpret_cast<const float4*>(a.dw_gamma + k);
+            R.dn = *reinterpret_cast<const float4*>(a.dw_nw + k);
+        }
 #pragma unroll
         for (int r = 0; r < MR; ++r) {
             if (r < T) {
@@ -190,6 +202,26 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const u32x4* __restri
     if (has_k) { x_load(kt0, R); w_load(kt0, wA); }      // x first: its wait must not drag the weight stream along
     __builtin_amdgcn_sched_barrier(0);
     VV_STAMP(1);
+    // PRO_NORMDW: 1/rms of the INPUT row is needed before anything can be staged (it sits inside the conv's newest tap): every
+    // wave sums its own k-range of x (L2-resident, two loads per lane at C = 2048), one barrier -- under the first weight batch
+    float rs1 = 1.0f;
+    if constexpr (PRO == VV_PRO_NORMDW) {
+        float s1 = 0.f;
+        for (unsigned ktb = kt0; ktb < kt1; ktb += U) {
+            const unsigned k = ktb * 32 + kk;
+            if (k < min(kt1 * 32, (unsigned)pK)) {
+                const float4 v = *reinterpret_cast<const float4*>(pX + k);
+                s1 += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            }
+        }
+        s1 = wave_sum_dpp(s1);
+        if (lane == 0) ssq1_sh[wave] = s1;
+        __syncthreads();
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < WPB; ++w) tot += ssq1_sh[w];
+        rs1 = rsqrtf(tot / (float)pK + a.eps);
+    }
 
     // ---- epilogue operands: requested now, consumed ~one weight stream later (wave 0 only) ----
     const int n0 = tile * 16 + fq * 4;
@@ -240,6 +272,28 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const u32x4* __restri
                 if constexpr (PRO == VV_PRO_RMS) {
                     ssq[r] += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
                     v[0] *= R.nwv.x; v[1] *= R.nwv.y; v[2] *= R.nwv.z; v[3] *= R.nwv.w;
+                } else if constexpr (PRO == VV_PRO_NORMDW) {
+                    if (r == 0) {
+                        const float xn[4] = {R.dn.x, R.dn.y, R.dn.z, R.dn.w}, bb[4] = {R.db.x, R.db.y, R.db.z, R.db.w};
+                        const float gg[4] = {R.dg.x, R.dg.y, R.dg.z, R.dg.w}, n2[4] = {R.nwv.x, R.nwv.y, R.nwv.z, R.nwv.w};
+                        float hn[4], xo[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            hn[e] = v[e] * rs1 * xn[e];                    // the new normed row (the conv's newest input)
+                            float acc = bb[e];
+#pragma unroll
+                            for (int j = 0; j < 6; ++j) acc += reinterpret_cast<const float*>(&R.dt[j])[e] * reinterpret_cast<const float*>(&R.dh[j])[e];
+                            acc += reinterpret_cast<const float*>(&R.dt[6])[e] * hn[e];
+                            xo[e] = (v[e] + gg[e] * acc) * msk;
+                        }
+                        if (tile == 0 && msk != 0.f) {                     // one workgroup publishes the block's intermediate rows
+                            *reinterpret_cast<float4*>(a.dw_xout + k) = float4{xo[0], xo[1], xo[2], xo[3]};
+                            *reinterpret_cast<float4*>(a.dw_hnew + k) = float4{hn[0], hn[1], hn[2], hn[3]};
+                        }
+                        ssq[r] += xo[0] * xo[0] + xo[1] * xo[1] + xo[2] * xo[2] + xo[3] * xo[3];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = xo[e] * n2[e];
+                    }
                 } else if constexpr (PRO == VV_PRO_RMS_MOD) {
                     ssq[r] += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
                     v[0] = (v[0] * R.nwv.x) * (1.f + R.sc[r].x); v[1] = (v[1] * R.nwv.y) * (1.f + R.sc[r].y);
@@ -320,7 +374,7 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const u32x4* __restri
     // ---- split-K partials -> LDS, one barrier, wave 0 finishes ----
 #pragma unroll
     for (int i = 0; i < NM * NOP; ++i) red[wave][i][lane] = acc[i];
-    if constexpr (PRO == VV_PRO_RMS || PRO == VV_PRO_RMS_MOD) {
+    if constexpr (PRO == VV_PRO_RMS || PRO == VV_PRO_RMS_MOD || PRO == VV_PRO_NORMDW) {
 #pragma unroll
         for (int r = 0; r < MR; ++r) {
             const float s = (r < T) ? wave_sum_dpp(ssq[r]) : 0.f;
@@ -337,7 +391,7 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const u32x4* __restri
         for (int i = 0; i < NM * NOP; ++i) acc[i] += red[w][i][lane];
     if (!epi_lane) return;
     float rs = 1.0f;
-    if constexpr (PRO == VV_PRO_RMS || PRO == VV_PRO_RMS_MOD) {
+    if constexpr (PRO == VV_PRO_RMS || PRO == VV_PRO_RMS_MOD || PRO == VV_PRO_NORMDW) {
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < WPB; ++w) s += ssq_sh[w][frow];
@@ -420,6 +474,13 @@ extern "C" int vv_gemv_ok(const VVGemm* a) {
                 (int64_t)a->sl_id[j] * a->sl_y + (int64_t)a->sl_T * a->ldy >= (1LL << 30)) return 0;
     }
     if ((a->x_row_mod > 0 || a->add_rows_per_vec > 0) && a->pro != VV_PRO_ADD_SILU) return 0;
+    if (a->pro == VV_PRO_NORMDW) {     // one row, whole K inside every workgroup, every operand present and 16-B aligned
+        if (a->T != 1 || a->sl_n > 0 || a->kgrid > 1 || a->n_xa || a->n_ya || !a->dw_hist || !a->dw_w || !a->dw_b || !a->dw_gamma ||
+            !a->dw_nw || !a->dw_xout || !a->dw_hnew || a->dw_xout == a->X) return 0;
+        if ((((uintptr_t)a->dw_hist) | ((uintptr_t)a->dw_w) | ((uintptr_t)a->dw_b) | ((uintptr_t)a->dw_gamma) | ((uintptr_t)a->dw_nw) |
+             ((uintptr_t)a->dw_xout) | ((uintptr_t)a->dw_hnew)) & 15) return 0;
+        if ((int64_t)7 * a->K >= (1LL << 30)) return 0;
+    }
     if ((a->K & 3) || (a->ldx & 3) || (((uintptr_t)a->X) & 15)) return 0;
     if (a->pro == VV_PRO_RMS_MOD && (a->ld_mod & 3)) return 0;
     if (a->nw && (((uintptr_t)a->nw) & 15)) return 0;
@@ -445,7 +506,7 @@ extern "C" int vv_gemv_ok(const VVGemm* a) {
     X(VV_PRO_NONE, VV_EPI_GATED_RESID) X(VV_PRO_RMS, VV_EPI_BIAS) X(VV_PRO_RMS, VV_EPI_BIAS_GELU) \
     X(VV_PRO_RMS, VV_EPI_SWIGLU) X(VV_PRO_RMS, VV_EPI_RESID) X(VV_PRO_RMS, VV_EPI_STORE)       \
     X(VV_PRO_RMS_MOD, VV_EPI_SWIGLU) X(VV_PRO_RMS_MOD, VV_EPI_CFG_DPM) X(VV_PRO_RMS_MOD, VV_EPI_STORE) \
-    X(VV_PRO_ADD_SILU, VV_EPI_STORE)
+    X(VV_PRO_ADD_SILU, VV_EPI_STORE) X(VV_PRO_NORMDW, VV_EPI_BIAS_GELU)
 // pairs that also exist in the 16-row form (prefill chunks, batched adaLN, T = 8 codec stage, connectors)
 #define VV_GEMV_WIDE(X)                                                                        \
     X(VV_PRO_NONE, VV_EPI_STORE) X(VV_PRO_NONE, VV_EPI_BIAS) X(VV_PRO_NONE, VV_EPI_RESID)      \
@@ -468,7 +529,8 @@ static bool gemv_combo_ok(int pro, int epi, bool wide) {
 // pairs with a 4-wave form (wide outputs) and a 16-wave form (few tiles, long K); bench mode (xs == 1) only
 #define VV_GEMV_W4(X)                                                                          \
     X(VV_PRO_RMS, VV_EPI_SWIGLU) X(VV_PRO_RMS_MOD, VV_EPI_SWIGLU) X(VV_PRO_RMS, VV_EPI_BIAS_GELU) \
-    X(VV_PRO_RMS, VV_EPI_BIAS) X(VV_PRO_NONE, VV_EPI_STORE) X(VV_PRO_NONE, VV_EPI_BIAS) X(VV_PRO_ADD_SILU, VV_EPI_STORE)
+    X(VV_PRO_RMS, VV_EPI_BIAS) X(VV_PRO_NONE, VV_EPI_STORE) X(VV_PRO_NONE, VV_EPI_BIAS) X(VV_PRO_ADD_SILU, VV_EPI_STORE) \
+    X(VV_PRO_NORMDW, VV_EPI_BIAS_GELU)
 #define VV_GEMV_W16(X)                                                                         \
     X(VV_PRO_NONE, VV_EPI_RESID) X(VV_PRO_NONE, VV_EPI_GATED_RESID) X(VV_PRO_NONE, VV_EPI_BIAS) X(VV_PRO_NONE, VV_EPI_STORE)
 

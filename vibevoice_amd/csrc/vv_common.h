@@ -36,7 +36,8 @@ struct VVGemmWs {
 
 // ---- generic skinny GEMM -----------------------------------------------------
 // Y[t][n] (op)= sum_k f(X[t][k]) * W[n][k]
-enum { VV_PRO_NONE = 0, VV_PRO_RMS = 1, VV_PRO_RMS_MOD = 2, VV_PRO_ADD_SILU = 3 };
+enum { VV_PRO_NONE = 0, VV_PRO_RMS = 1, VV_PRO_RMS_MOD = 2, VV_PRO_ADD_SILU = 3,
+       VV_PRO_NORMDW = 4 };   // gemv.hip only, one row: Block1D's norm + causal depthwise conv + layer scale + residual, then RMSNorm (see VVGemm::dw_*)
 enum { VV_EPI_STORE = 0, VV_EPI_BIAS = 1, VV_EPI_BIAS_GELU = 2, VV_EPI_SWIGLU = 3,
        VV_EPI_RESID = 4, VV_EPI_GATED_RESID = 5, VV_EPI_CFG_DPM = 6,
        VV_EPI_QKV_ROPE = 7 };   // prefill.hip only: bias + RoPE + KV-cache append in the QKV GEMM's epilogue
@@ -86,6 +87,18 @@ struct VVGemm {
     // a side with stride 0 is a dense [rows][ld] scratch tensor.  sl_n = 0: off.
     int sl_n, sl_T, sl_x, sl_y;
     int sl_id[8];
+    // PRO_NORMDW (T = 1 tokenizer stages, modular_vibevoice_tokenizer.py:620-684 Block1D up to FFN1): X is the block's INPUT row
+    // x [K]; the prologue forms  h = RMSNorm(x) * dw_nw,  xo = x + dw_gamma * (dw_b + sum_{j<6} dw_w[j] * dw_hist[j] + dw_w[6] * h)
+    // (the causal k = 7 depthwise conv over the six cached normed rows and the new one), then feeds RMSNorm(xo) * nw to the
+    // product like PRO_RMS.  The workgroup of tile 0 also writes xo -> dw_xout (FFN2's residual, the next block's input) and
+    // h -> dw_hnew (the conv history's new row).  Replaces the separate vv_normdw_sliced launch in front of FFN1.
+    const float* dw_hist;  // [6][K] normed history rows
+    const float* dw_w;     // [7][K] taps
+    const float* dw_b;     // [K]
+    const float* dw_gamma; // [K]
+    const float* dw_nw;    // [K] weight of the block's first norm
+    float* dw_xout;        // [K]
+    float* dw_hnew;        // [K]
 };
 
 // up to 8 utterance slots of one launch (per-utterance kernels take the slot from blockIdx.y / .z)
