@@ -318,16 +318,53 @@ def test_continuous_length_capped_utterance_leaves_the_others_intact(monkeypatch
         assert float(d) <= 1e-5, float(d)
 
 
-def test_batch_limit_is_checked_at_entry(monkeypatch):
+def test_batch_above_eight_rows_goes_through_the_queue(monkeypatch):
+    """The reference's batch is unbounded (modeling_vibevoice_inference.py:393-394); one engine pass carries 8 utterances.  A
+    10-row generate() is decoded through the continuous-admission queue (2 slots here) and comes back in the batched call's own
+    form: every row's tokens and waveform are what generate() gives that row alone (left-padded to the batch's width), the
+    sequences are eos-padded to the longest row, reach_max_step_sample has one entry per row."""
     from test_oracle_golden import _oracle_small
     from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference
     cfgd = {"decoder_config": {"max_position_embeddings": 4096}, "diffusion_head_config": {"ddpm_num_inference_steps": 5},
             "acoustic_tokenizer_config": {"fix_std": 0.5, "std_dist_type": "gaussian"}}
+    reqs = _requests(10, 5)
+    L0 = max(r["input_ids"].shape[1] for r in reqs)
+    ids = torch.full((10, L0), TOK.pad_token_id, dtype=torch.long)
+    mask = torch.zeros((10, L0), dtype=torch.long)
+    for b, r in enumerate(reqs):                                   # left padding, as the processor pads (vibevoice_processor.py:349-353)
+        n = r["input_ids"].shape[1]
+        ids[b, L0 - n:] = r["input_ids"][0]
+        mask[b, L0 - n:] = 1
+    forced = [r["_forced_tokens"] for r in reqs]
+    bank = {}
+
+    def noise_fn(step, n2):                                        # the same draw for every row at its own step: rows are comparable
+        return bank.setdefault(step, synth.Gen(7000 + step).normal((2, 64), 1.0, mat=False))[:n2]
+
+    def new_model(n_slots):
+        m = VibeVoiceForConditionalGenerationInference(cfgd, fake_engine.FakeEngine(_oracle_small(), n_slots=n_slots), model_dtype=torch.float32)
+        m.set_speech_factors(0.2, -0.05)
+        m.set_ddpm_inference_steps(5)
+        m.concurrent_codecs = False
+        return m
     with fake_engine.cpu_cuda_shims(monkeypatch):
-        m = VibeVoiceForConditionalGenerationInference(cfgd, fake_engine.FakeEngine(_oracle_small(), n_slots=16, max_rows=64), model_dtype=torch.float32)
-        ids = torch.full((9, 4), 301, dtype=torch.long)
-        with pytest.raises(ValueError, match="exceeds 8"):
-            m.generate(input_ids=ids, tokenizer=TOK, cfg_scale=1.3, max_new_tokens=2)
+        solo = [new_model(1).generate(input_ids=ids[b:b + 1], attention_mask=mask[b:b + 1], cfg_scale=1.3, tokenizer=TOK,
+                                      generation_config={"do_sample": False}, _forced_tokens=[forced[b]], _noise_fn=noise_fn,
+                                      show_progress_bar=False) for b in range(10)]
+        out = new_model(2).generate(input_ids=ids, attention_mask=mask, cfg_scale=1.3, tokenizer=TOK, generation_config={"do_sample": False},
+                                    _forced_tokens=forced, _noise_fn=noise_fn, show_progress_bar=False)
+    assert out.sequences.shape[0] == 10 and len(out.speech_outputs) == 10 and out.reach_max_step_sample.shape == (10,)
+    width = out.sequences.shape[1]
+    assert width == max(o.sequences.shape[1] for o in solo)
+    for b, o in enumerate(solo):
+        n = o.sequences.shape[1]
+        assert torch.equal(out.sequences[b, :n].cpu(), o.sequences[0].cpu())
+        assert bool((out.sequences[b, n:] == TOK.eos_token_id).all())
+        a, r = out.speech_outputs[b], o.speech_outputs[0]
+        assert (a is None) == (r is None)
+        if a is not None:
+            assert a.shape == r.shape and float((a.float() - r.float()).norm() / (r.float().norm() + 1e-30)) <= 1e-5
+        assert bool(out.reach_max_step_sample[b]) == bool(o.reach_max_step_sample[0])
 
 
 def test_greedy_batch2_dense_logits_layout(monkeypatch):

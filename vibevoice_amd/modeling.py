@@ -1060,8 +1060,11 @@ class VibeVoiceForConditionalGenerationInference:
         attention_mask = attention_mask.cpu()
         B, L0 = input_ids.shape
         if B > MAX_BATCH:
-            raise ValueError(f"batch {B} exceeds {MAX_BATCH} utterances per generate() call (one diffusion-head pass carries 2 rows "
-                             "per utterance); use generate_continuous() to queue more")
+            # the reference's batch is unbounded (:393-394); one engine pass carries MAX_BATCH utterances, so a larger batch is
+            # decoded through the continuous-admission queue and handed back in the batch's own output form
+            return self._generate_queued(input_ids, attention_mask, tokenizer, generation_config, cfg_scale, audio_streamer,
+                                         speech_tensors, speech_masks, speech_input_mask, is_prefill, return_speech, stop_check_fn,
+                                         max_length_times, prefill_noise, step_cb, kwargs)
         if B > e.cfg.n_slots:
             raise ValueError(f"batch {B} exceeds the engine's n_slots={e.cfg.n_slots}")
         if 2 * B > e.cfg.max_rows:
@@ -1150,6 +1153,66 @@ class VibeVoiceForConditionalGenerationInference:
         return VibeVoiceGenerationOutput(
             sequences=seq.to(self.device), speech_outputs=outs if return_speech else None,
             reach_max_step_sample=torch.tensor([u.reach_max for u in utts], dtype=torch.bool).to(self.device))
+
+    def _generate_queued(self, input_ids, attention_mask, tokenizer, generation_config, cfg_scale, audio_streamer, speech_tensors,
+                         speech_masks, speech_input_mask, is_prefill, return_speech, stop_check_fn, max_length_times, prefill_noise,
+                         step_cb, kwargs):
+        """generate() for a batch of more than MAX_BATCH rows (the reference's batch is unbounded, :393-394): every row becomes a
+        one-utterance request of generate_continuous() -- up to n_slots of them in flight, a finished row's slot refilled at once --
+        and the results are assembled into ONE VibeVoiceGenerationOutput as the batched loop returns it (sequences [B, L0 + steps]
+        padded with eos after a row's end, :499; speech_outputs one entry per row; reach_max_step_sample [B]).  Rows are
+        independent in the reference's loop (no cross-sample arithmetic, :393-394,549,573,594), so under greedy / forced decoding
+        each row is exactly what the batched call gives it; RNG-dependent draws (diffusion noise, do_sample) are consumed in queue
+        order instead of the batch's lock-step order.  Loop lengths follow the batch: every row's cap uses the batch's padded
+        width L0 (:421-422)."""
+        B, L0 = input_ids.shape
+        if prefill_noise is not None:
+            raise NotImplementedError("_prefill_noise (test hook) is per call; not supported for batches above MAX_BATCH")
+        forced = kwargs.pop("_forced_tokens", None)
+        noise_fn = kwargs.pop("_noise_fn", None)
+        # voice-prompt rows: speaker i of speech_tensors contributes speech_masks[i].sum() frames; the rows' speech positions
+        # consume those frames in row-major order (_process_speech_inputs + the masked scatter, :149-163,470-474)
+        spk_of_row = [[] for _ in range(B)]
+        if is_prefill and speech_tensors is not None and speech_masks is not None and speech_input_mask is not None:
+            need = [int((speech_input_mask[b].cpu() & attention_mask[b].bool()).sum()) for b in range(B)]
+            have = [int(speech_masks[i].sum()) for i in range(speech_masks.shape[0])]
+            i = 0
+            for b in range(B):
+                got = 0
+                while got < need[b]:
+                    if i >= len(have):
+                        raise ValueError("speech_masks hold fewer frames than speech_input_mask marks")
+                    spk_of_row[b].append(i)
+                    got += have[i]
+                    i += 1
+                if got != need[b]:
+                    raise ValueError("a voice prompt spans two batch rows: the rows' speech positions must consume whole speakers")
+        reqs = []
+        for b in range(B):
+            r = {"input_ids": input_ids[b:b + 1], "attention_mask": attention_mask[b:b + 1]}
+            if spk_of_row[b]:
+                idx = torch.tensor(spk_of_row[b], dtype=torch.long)
+                r["speech_tensors"] = speech_tensors[idx]
+                r["speech_masks"] = speech_masks[idx]
+                r["speech_input_mask"] = speech_input_mask[b:b + 1]
+            if forced is not None:
+                r["_forced_tokens"] = forced[b]
+            if noise_fn is not None:
+                r["_noise_fn"] = noise_fn                # per utterance here: noise_fn(its own step, 2) -> [2, latent]
+            reqs.append(r)
+        kw = {k: v for k, v in kwargs.items() if k in ("verbose", "refresh_negative", "_trace", "_teacher_embeds", "_t_cast", "_sde_noise_fn")}
+        outs = self.generate_continuous(reqs, tokenizer=tokenizer, generation_config=generation_config, cfg_scale=cfg_scale,
+                                        audio_streamer=audio_streamer, is_prefill=is_prefill, return_speech=return_speech,
+                                        max_new_tokens=kwargs.get("max_new_tokens"), max_length_times=max_length_times,
+                                        stop_check_fn=stop_check_fn, _step_callback=step_cb, **kw)
+        eos = tokenizer.eos_token_id
+        width = max(int(o.sequences.shape[1]) for o in outs)
+        seq = torch.full((B, width), eos, dtype=torch.long, device=self.device)
+        for b, o in enumerate(outs):
+            seq[b, :o.sequences.shape[1]] = o.sequences[0]
+        speech = [o.speech_outputs[0] if o.speech_outputs else None for o in outs] if return_speech else None
+        return VibeVoiceGenerationOutput(sequences=seq, speech_outputs=speech,
+                                         reach_max_step_sample=torch.cat([o.reach_max_step_sample.reshape(1) for o in outs]).to(self.device))
 
     # ------------------------------------------------------------------ continuous batching (SURVEY 8f rank 2)
     @torch.no_grad()
