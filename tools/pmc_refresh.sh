@@ -1,5 +1,5 @@
 #!/bin/bash
-# FETCH_SIZE pass of the binary at HEAD for the three single-GPU configs -> profiles/r03_*_pmc_fetch_pmc_by_kernel.csv and
+# FETCH_SIZE pass of the binary at HEAD for the three single-GPU configs -> profiles/r0N_*_pmc_fetch_pmc_by_kernel.csv and
 # profiles/pmc_traffic.json (tools/pmc_refresh.py).  Run on the GPU box through gpurun; counters in their own pass (no --stats,
 # no other trace domain).  $1 = tag (r03), $2 = directory with the bench JSON lines of the same build (optional).
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc; mkdir -p $O; cd $R; export TMPDIR=/tmp
