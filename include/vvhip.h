@@ -60,8 +60,8 @@ const char* vv_last_error(vv_ctx* ctx);
 const char* vv_build_id(void);
 /* Asynchronous device-side errors, checked on the host: today the one inter-workgroup hand-off on the path (the K-split of the
  * long-prompt GEMM's partial round, prefill.hip) reports a lost producer through a host-mapped word instead of spinning.  Waits
- * for `stream`, and if the word is set: re-arms the hand-off state, clears it and returns <0 (vv_last_error says which prompt
- * pass is invalid; the context stays usable).  The same check runs at the head of every vv_lm_forward*.  Callers: after the
+ * for `stream`, and if the word is set: re-arms the hand-off state, clears it and returns <0 (the prompt pass that was in flight
+ * produced a wrong tile and must be repeated; the context stays usable).  The same check runs at the head of every vv_lm_forward*.  Callers: after the
  * stream sync that ends a prompt prefill.  New surface (the reference has no native code); its closest counterpart is the
  * CUDA error a torch.cuda.synchronize() raises after modeling_vibevoice_inference.py:467-482. */
 int vv_check(vv_ctx* ctx, void* stream);

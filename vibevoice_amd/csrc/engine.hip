@@ -1262,7 +1262,7 @@ static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float*
 extern "C" int vv_lm_forward_range(vv_ctx* ctx, void* stream, int n_rows, const vv_row* rows, const float* x_in_dev,
                                    float* hidden_out_dev, int l0, int l1, int final_norm);
 // The prefill GEMM's K-split hand-off (prefill.hip g4_finish) reports a lost producer through a host-mapped word instead of
-// hanging the GPU; the affected tile is left unwritten and the arrival words untouched.  Recovery, done here at the next
+// hanging the GPU; the affected tile is wrong (summed from incomplete partials) and the arrival words are left untouched.  Recovery, done here at the next
 // enqueue / vv_check: wait for the stream (nothing of that launch is in flight any more), re-zero the arrival words, clear the
 // word and fail THIS call -- the caller knows the output of the prompt pass in flight is invalid and can retry; the context
 // stays usable.

@@ -382,37 +382,26 @@ __device__ __forceinline__ void g4_finish(const VVGemm3& a, f32x4 (&acc)[8][4], 
             }
             return;
         }
-        // (the flag lives in the first word of the stage ring -- dynamic LDS, every wave is out of the k loop after this barrier;
-        // a static __shared__ word would push the kernel past the 160 KiB the dynamic-size attribute is set to)
-        extern __shared__ __attribute__((aligned(16))) unsigned char g4_lds[];
-        int* const g4_to = reinterpret_cast<int*>(g4_lds);
-        __syncthreads();
-        if (tid == 0) *g4_to = 0;
-        __syncthreads();
+        // A hand-over that times out (a lost producer; the 100 MHz wall clock keeps running while the queue is preempted by
+        // another process or a profiler, hence 2 s: far beyond any producer's running time) marks the host-mapped error word
+        // and LEAVES THE ARRIVAL WORDS ALONE -- a late producer must never find a word this launch re-armed and the next launch
+        // must not consume stale partials.  The tile itself is then summed from whatever the slots hold and is wrong; the host
+        // sees the word at the next sync / enqueue (engine.hip: ksplit_check), re-zeroes the words behind a stream sync and
+        // reports the prompt pass as failed.  (Skipping the epilogue instead cost the QKV form 200 B of scratch per lane.)
+        bool lost = false;                          // meaningful in wave 0, whose lanes also re-arm the words below
         if (tid < 64) {
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            bool lost = false;
             for (int p = 0; p < split - 1 && !lost; ++p) {
                 for (;;) {
                     if (__hip_atomic_load(a.flags + slot0 + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
                     __builtin_amdgcn_s_sleep(16);
-                    // 2 s of the 100 MHz wall clock (it keeps running while the queue is preempted by another process or a
-                    // profiler): far beyond any producer's running time; only a lost producer gets here
                     if ((unsigned long long)(__builtin_amdgcn_s_memrealtime() - t0) > 200000000ull) { lost = true; break; }
                 }
             }
-            if (lost && tid == 0) {
-                *g4_to = 1;
-                __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
+            if (lost && tid == 0) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
-        // a hand-over that timed out: this tile is NOT written (no sum over slots that may be unwritten, no epilogue, no cache
-        // append) and the arrival words are left as they are -- a late producer must not find a word this launch re-armed.  The
-        // host sees the error word at the next sync / enqueue, re-zeroes the words behind a stream sync and reports the call
-        // as failed (engine.hip: ksplit_check)
-        if (__builtin_amdgcn_readfirstlane(*g4_to)) return;
 #pragma unroll 1
         for (int p = 0; p < split - 1; ++p) {
             const char* sbase = reinterpret_cast<const char*>(a.ws + (size_t)(slot0 + p) * SLOT);        // wave-uniform
@@ -427,7 +416,7 @@ __device__ __forceinline__ void g4_finish(const VVGemm3& a, f32x4 (&acc)[8][4], 
                 for (int j = 0; j < 4; ++j) acc[i][j] += v[j];
             }
         }
-        if (tid < split - 1) __hip_atomic_store(a.flags + slot0 + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        if (tid < split - 1 && !lost) __hip_atomic_store(a.flags + slot0 + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     }
     // ---- epilogue: lane holds D[n = tile*16 + fq*4 + r][t = ttile*16 + frow] ----
     if constexpr (EPI == VV_EPI_QKV_ROPE) {
