@@ -24,10 +24,10 @@ SHAPES = {"1.5b": (1536, 4608), "7b": (3584, 10752), "test": (1024, 3072)}
 
 
 def build_lib():
-    so = os.path.join(HERE, "liblc.so")
+    so = os.path.join(HERE, os.environ.get("LC_SO", "liblc.so"))
     src = os.path.join(HERE, "lc.hip")
     if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", src, "-o", so], check=True)
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC"] + os.environ.get("LC_CFLAGS", "").split() + [src, "-o", so], check=True)
     lib = C.CDLL(so)
     lib.lc_run.restype = C.c_int
     lib.lc_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -74,6 +74,21 @@ def main():
         return xa.clone()
     ref1 = run_chain_eager(1)
     refS = run_chain_eager(S)
+
+    def torch_ref(steps, layers=L):
+        """the chain in plain torch ops (fp32 accumulate, bf16-rounded matrix inputs as both arms round them)"""
+        x = x0.clone()
+        for _ in range(steps):
+            for l in range(layers):
+                xb = x.to(torch.bfloat16).float()
+                rs = torch.rsqrt((x * x).mean(-1, keepdim=True) + eps)
+                gg = (xb @ Wg[l].float().T) * rs
+                uu = (xb @ Wu[l].float().T) * rs
+                u = (torch.nn.functional.silu(gg) * uu).to(torch.bfloat16).float()
+                x = x + u @ Wd[l].float().T
+        return x
+    t1 = torch_ref(1)
+    res["launch_chain_vs_torch_after_1_step"] = ((ref1 - t1).norm() / t1.norm()).item()
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.stream(eng.stream):
         xa.copy_(x0)
@@ -113,6 +128,9 @@ def main():
         per_layer.append(torch.cat([a, b], dim=1))
     wstream = torch.cat(per_layer, dim=1).contiguous()           # [256][L * per-layer elements] bf16
     assert (wstream.shape[1] * 2) % 1024 == 0
+    pad = (-wstream.shape[1] * 2) % 16384                        # one solver step = whole 16 KiB ring slots
+    if pad:
+        wstream = torch.cat([wstream, torch.zeros(256, pad // 2, dtype=wstream.dtype, device=dev)], dim=1).contiguous()
     xg = torch.zeros(H, dtype=torch.int64, device=dev)
     ug = torch.zeros(F, dtype=torch.int64, device=dev)
     xo = torch.zeros(2, H, device=dev)
@@ -130,6 +148,25 @@ def main():
     eng.sync()
     res["abort_word_first_call"] = int(ab.item())
     d1 = ((xo - ref1).norm() / ref1.norm()).item()
+    res["persistent_vs_torch_after_1_step"] = ((xo - t1).norm() / t1.norm()).item()
+    # timeline of one call (S steps): consumer wave 0 of CU 0 / CU 131 stamps every op (gather start, own gather done, all
+    # waves' gather done, compute done; 100 MHz wall clock); the loader reports its total / ring-full / vmcnt-wait time
+    dbg = torch.zeros(64 + 128 * 4, dtype=torch.int64, device=dev)
+    with torch.cuda.stream(eng.stream):
+        rc = lib.lc_run(st, H, F, C.c_void_p(wstream.data_ptr()), C.c_void_p(xg.data_ptr()), C.c_void_p(ug.data_ptr()),
+                        C.c_void_p(x0.data_ptr()), C.c_void_p(xo.data_ptr()), C.c_void_p(ab.data_ptr()), C.c_void_p(dbg.data_ptr()), L, min(S, 8), eps)
+    eng.sync()
+    d = dbg.cpu().numpy()
+    tl = {}
+    for name, off, lo in (("cu0", 64, 0), ("cu131", 64 + 64 * 4, 8)):
+        ops = d[off:off + 64 * 4].reshape(64, 4)[8:min(64, 2 * L * min(S, 8))]      # skip the first layers (cold)
+        A, B = ops[0::2], ops[1::2]
+        f = lambda x: round(float(x.mean()) * 0.01, 2)
+        tl[name] = {"A_gather_own_us": f(A[:, 1] - A[:, 0]), "A_gather_wait_others_us": f(A[:, 2] - A[:, 1]), "A_compute_us": f(A[:, 3] - A[:, 2]),
+                    "B_gather_own_us": f(B[:, 1] - B[:, 0]), "B_gather_wait_others_us": f(B[:, 2] - B[:, 1]), "B_compute_us": f(B[:, 3] - B[:, 2]),
+                    "loader_total_us": round(float(d[lo]) * 0.01, 1), "loader_ring_full_us": round(float(d[lo + 1]) * 0.01, 1),
+                    "loader_vmcnt_wait_us": round(float(d[lo + 2]) * 0.01, 1), "loader_slots": int(d[lo + 3])}
+    res["timeline"] = tl
     with torch.cuda.stream(eng.stream):
         run_lc(S)
     eng.sync()

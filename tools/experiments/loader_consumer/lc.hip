@@ -17,6 +17,7 @@
 //   every spin is bounded; a timeout sets a global abort word and the wave leaves.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -56,13 +57,29 @@ __device__ __forceinline__ float wave_sum(float v) {
     const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 48));
     return (r0 + r1) + (r2 + r3);
 }
+__device__ __forceinline__ float bf_lo_(unsigned v) { return __builtin_bit_cast(float, v << 16); }
+__device__ __forceinline__ float bf_hi_(unsigned v) { return __builtin_bit_cast(float, v & 0xFFFF0000u); }
+#ifdef LC_FMA
 __device__ __forceinline__ float dot8(const u32x4 w, const u32x4 a, float c) {
-    c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, w.x), __builtin_bit_cast(bf16x2, a.x), c, false);
-    c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, w.y), __builtin_bit_cast(bf16x2, a.y), c, false);
-    c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, w.z), __builtin_bit_cast(bf16x2, a.z), c, false);
-    c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, w.w), __builtin_bit_cast(bf16x2, a.w), c, false);
+    c += bf_lo_(w.x) * bf_lo_(a.x) + bf_hi_(w.x) * bf_hi_(a.x);
+    c += bf_lo_(w.y) * bf_lo_(a.y) + bf_hi_(w.y) * bf_hi_(a.y);
+    c += bf_lo_(w.z) * bf_lo_(a.z) + bf_hi_(w.z) * bf_hi_(a.z);
+    c += bf_lo_(w.w) * bf_lo_(a.w) + bf_hi_(w.w) * bf_hi_(a.w);
     return c;
 }
+#else
+__device__ __forceinline__ float dot2(unsigned w, unsigned a, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, w), __builtin_bit_cast(bf16x2, a), c, false);
+}
+__device__ __forceinline__ float dot8(const u32x4 w, const u32x4 a, float c) {
+    // NB: the elements go through `unsigned` temporaries: __builtin_bit_cast(bf16x2, w.y) applied to a vector ELEMENT directly reads
+    // element 0 (clang, ROCm 7.2 -- the ISA showed four v_dot2c on the same registers; same quirk as DESIGN.md section 8 notes for
+    // the permlane swap's result)
+    const unsigned w0 = w.x, w1 = w.y, w2 = w.z, w3 = w.w, a0 = a.x, a1 = a.y, a2 = a.z, a3 = a.w;
+    c = dot2(w0, a0, c); c = dot2(w1, a1, c); c = dot2(w2, a2, c); c = dot2(w3, a3, c);
+    return c;
+}
+#endif
 __device__ __forceinline__ unsigned pack2(float lo, float hi) {
     const __bf16 a = (__bf16)lo, b = (__bf16)hi;
     return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
@@ -76,6 +93,7 @@ struct Ctrl {                       // LDS control block
     volatile unsigned slot_cnt[8];  // chunks consumed from each ring slot, cumulative
     volatile unsigned gather_cnt;   // consumer waves that finished a gather, cumulative
     volatile unsigned abort_l;
+    volatile unsigned gathering;    // consumer waves inside a gather (the loader thins itself meanwhile)
     float ssq[3][2];
 };
 
@@ -96,14 +114,15 @@ __global__ __launch_bounds__(256, 1) void lc_chain_kernel(const LCParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cu = blockIdx.x;
     if (tid == 0) {
-        ct->landed = 0; ct->gather_cnt = 0; ct->abort_l = 0;
+        ct->landed = 0; ct->gather_cnt = 0; ct->abort_l = 0; ct->gathering = 0;
         for (int i = 0; i < 8; ++i) ct->slot_cnt[i] = 0;
         for (int i = 0; i < 3; ++i) { ct->ssq[i][0] = 0.f; ct->ssq[i][1] = 0.f; }
     }
     __syncthreads();
     const int n_ops = p.S * p.L * 2;
-    const long total_chunks = (long)p.S * p.L * CPL;
-    const int total_slots = (int)((total_chunks + 15) / 16);
+    // the per-CU stream of ONE solver step is padded to whole ring slots (16 chunks): the loader never wraps inside a slot
+    const int step_chunks = p.L * CPL, step_slots = (step_chunks + 15) / 16, step_pad = step_slots * 16 - step_chunks;
+    const int total_slots = p.S * step_slots;
 
     auto fail = [&](unsigned code) {
         ct->abort_l = code;
@@ -112,12 +131,15 @@ __global__ __launch_bounds__(256, 1) void lc_chain_kernel(const LCParams p) {
 
     if (wave == 0) {
         // ------------------------------------------------------------------ LOADER
-        const unsigned char* base = p.wstream + (size_t)cu * ((size_t)p.L * CPL * 1024);
-        const long per_step = (long)p.L * CPL;
+        const unsigned char* base = p.wstream + (size_t)cu * ((size_t)step_slots * 16384) + lane * 16;
         unsigned pub = 0;                               // slots published as landed (monotonic)
+        u64 t_space = 0, t_vm = 0;
+        const u64 t_begin = __builtin_amdgcn_s_memrealtime();
+        int ks = 0;                                     // slot inside the step
         for (int k = 0; k < total_slots; ++k) {
             const int slot = k % NSLOT;
             const unsigned need = 16u * (unsigned)(k / NSLOT);
+            const u64 ts0 = __builtin_amdgcn_s_memrealtime();
             for (unsigned spins = 0; ct->slot_cnt[slot] < need; ++spins) {
                 if (spins == 0) {                      // blocked on ring space anyway: everything issued so far may as well be published
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -127,18 +149,31 @@ __global__ __launch_bounds__(256, 1) void lc_chain_kernel(const LCParams p) {
                 if (ct->abort_l) return;
                 if (spins > SPIN_LIMIT) { if (lane == 0) fail(0x100u + (unsigned)slot); return; }
             }
+            const u64 ts1 = __builtin_amdgcn_s_memrealtime();
+            t_space += ts1 - ts0;
+            // 16 straight-line 1 KiB copies (no per-load bookkeeping: the first version's 64-bit modulo per load, then a compare and
+            // branch per load, made the LOADER the bottleneck -- 7.5 and 13 GB/s per CU)
+            const unsigned char* src = base + (size_t)ks * 16384;
+            unsigned char* dst = ring + slot * 16384;
 #pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                long ci = (long)k * 16 + c;
-                if (ci >= total_chunks) ci = total_chunks - 1;          // keep 16 loads per slot (vmcnt bookkeeping)
-                const unsigned char* src = base + (size_t)(ci % per_step) * 1024 + lane * 16;
-                __builtin_amdgcn_global_load_lds((gvoid_t*)src, (lvoid_t*)(ring + slot * 16384 + c * 1024), 16, 0, 2);
+            for (int c = 0; c < 16; ++c)
+                __builtin_amdgcn_global_load_lds((gvoid_t*)(src + c * 1024), (lvoid_t*)(dst + c * 1024), 16, 0, 2);
+            if (++ks == step_slots) {                   // the step's last slot: its padding chunks are nobody's to consume
+                ks = 0;
+                if (step_pad && lane == 0) atomicAdd((unsigned*)&ct->slot_cnt[slot], (unsigned)step_pad);
             }
-            asm volatile("s_waitcnt vmcnt(32)" ::: "memory");           // slot k-2 has landed
-            if (k >= 2 && (unsigned)(k - 1) > pub) { pub = (unsigned)(k - 1); if (lane == 0) ct->landed = pub; }
+            const u64 ts2 = __builtin_amdgcn_s_memrealtime();
+            if (ct->gathering) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this CU's consumers are sweeping granules: one fill in flight
+            asm volatile("s_waitcnt vmcnt(47)" ::: "memory");           // at most 47 copies outstanding: slot k-3 has landed
+            t_vm += __builtin_amdgcn_s_memrealtime() - ts2;
+            if (k >= 3 && (unsigned)(k - 2) > pub) { pub = (unsigned)(k - 2); if (lane == 0) ct->landed = pub; }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) ct->landed = (unsigned)total_slots;
+        if (p.stamps && lane == 0 && (cu == 0 || cu == 131)) {
+            u64* q = p.stamps + (cu == 0 ? 0 : 8);
+            q[0] = __builtin_amdgcn_s_memrealtime() - t_begin; q[1] = t_space; q[2] = t_vm; q[3] = (u64)total_slots;
+        }
         return;
     }
 
@@ -153,39 +188,63 @@ __global__ __launch_bounds__(256, 1) void lc_chain_kernel(const LCParams p) {
             __hip_atomic_store(p.xg + lane * (H / 2) + (h >> 1), ((u64)1 << 32) | pack2(a, b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    long chunk_base = 0;                               // first chunk of the current op in this CU's stream
+    long chunk_base = 0;                               // first chunk of the current op in this CU's (padded) stream
     for (int op = 0; op < n_ops; ++op) {
         const bool isA = (op & 1) == 0;
         const unsigned epoch_in = (unsigned)op + 1u, epoch_out = (unsigned)op + 2u;
+        const bool stamp = p.stamps && cw == 0 && lane == 0 && (cu == 0 || cu == 131) && op < 64;
+        u64* stp = p.stamps + 64 + ((cu == 0 ? 0 : 64) + op) * 4;
+        if (stamp) stp[0] = __builtin_amdgcn_s_memrealtime();
         // ---- gather the op's input vector: x (H) for A, u (F) for B ----
         {
             const int NG = isA ? H : F;                 // granules = pairs x 2 rows
             u64* g = isA ? p.xg : p.ug;
             unsigned* act = isA ? actx : actu;
             float ss0 = 0.f, ss1 = 0.f;
-            for (int b = cw; b < NG / 512; b += 3) {
-                unsigned v[8];
-                for (unsigned spins = 0;; ++spins) {
-                    bool ok = true;
+#ifndef LC_NO_THIN
+            if (lane == 0) atomicAdd((unsigned*)&ct->gathering, 1u);
+#endif
+            // this wave's batches (512 granules each): b = cw, cw + 3, ...  ALL of them are requested in every pass (one latency
+            // per pass, not one per batch); a batch whose 512 tags all match is written to LDS and leaves the pending set
+            constexpr int NBW = ((F > H ? F : H) / 512 + 2) / 3;          // batches per wave, at most
+            const int nb_tot = NG / 512;
+            unsigned pending = 0;
+            for (int i = 0; i < NBW; ++i) if (cw + 3 * i < nb_tot) pending |= 1u << i;
+            for (unsigned spins = 0; pending; ++spins) {
+                u64 gv[NBW][8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const u64 x = __hip_atomic_load(g + b * 512 + j * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        v[j] = (unsigned)x;
-                        ok &= (unsigned)(x >> 32) == epoch_in;
+                for (int i = 0; i < NBW; ++i) {
+                    if (pending & (1u << i)) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            gv[i][j] = __hip_atomic_load(g + (cw + 3 * i) * 512 + j * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
-                    if (__all(ok)) break;
+                }
+#pragma unroll
+                for (int i = 0; i < NBW; ++i) {
+                    if (pending & (1u << i)) {
+                        bool ok = true;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) ok &= (unsigned)(gv[i][j] >> 32) == epoch_in;
+                        if (__all(ok)) {
+                            pending &= ~(1u << i);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const int idx = (cw + 3 * i) * 512 + j * 64 + lane;
+                                const unsigned v = (unsigned)gv[i][j];
+                                act[idx] = v;
+                                if (isA) {
+                                    const float lo = bf_lo(v), hi = bf_hi(v);
+                                    if (idx < NG / 2) ss0 += lo * lo + hi * hi; else ss1 += lo * lo + hi * hi;
+                                }
+                            }
+                        }
+                    }
+                }
+                if (pending) {
                     __builtin_amdgcn_s_sleep(1);
                     if (ct->abort_l) return;
                     if (spins > SPIN_LIMIT) { if (lane == 0) fail(0x200u + (unsigned)op); return; }
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int idx = b * 512 + j * 64 + lane;
-                    act[idx] = v[j];
-                    if (isA) {
-                        const float lo = bf_lo(v[j]), hi = bf_hi(v[j]);
-                        if (idx < NG / 2) ss0 += lo * lo + hi * hi; else ss1 += lo * lo + hi * hi;
-                    }
                 }
             }
             if (isA) {
@@ -193,6 +252,10 @@ __global__ __launch_bounds__(256, 1) void lc_chain_kernel(const LCParams p) {
                 if (lane == 0) { atomicAdd(&ct->ssq[op % 3][0], ss0); atomicAdd(&ct->ssq[op % 3][1], ss1); }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this wave's LDS writes are ordered before its report
+            if (stamp) stp[1] = __builtin_amdgcn_s_memrealtime();
+#ifndef LC_NO_THIN
+            if (lane == 0) atomicSub((unsigned*)&ct->gathering, 1u);
+#endif
             if (lane == 0) atomicAdd((unsigned*)&ct->gather_cnt, 1u);
             const unsigned want = 3u * ((unsigned)op + 1u);
             for (unsigned spins = 0; ct->gather_cnt < want; ++spins) {
@@ -201,6 +264,7 @@ __global__ __launch_bounds__(256, 1) void lc_chain_kernel(const LCParams p) {
                 if (spins > SPIN_LIMIT) { if (lane == 0) fail(0x300u + (unsigned)op); return; }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      // the other waves' activation words / sums are read below
+            if (stamp) stp[2] = __builtin_amdgcn_s_memrealtime();
             if (cw == 0 && lane == 0) { ct->ssq[(op + 2) % 3][0] = 0.f; ct->ssq[(op + 2) % 3][1] = 0.f; }
         }
         float rs0 = 1.f, rs1 = 1.f;
@@ -211,38 +275,61 @@ __global__ __launch_bounds__(256, 1) void lc_chain_kernel(const LCParams p) {
         // ---- compute this wave's feature pairs ----
         const int NP = isA ? PA : PB, RPP = isA ? 4 : 2, CPR = isA ? CA : CB;
         bool dead = false;
-        // one weight row: CPR_ chunks from the ring against both activation rows
-        auto row_dot = [&](long c0, int cpr, const unsigned* act, int K, float& o0, float& o1) {
-            float a0 = 0.f, a1 = 0.f;
-            for (int j = 0; j < cpr; ++j) {
-                const long ci = c0 + j;
-                const unsigned sl = (unsigned)(ci >> 4);
-                for (unsigned spins = 0; ct->landed < sl + 1u; ++spins) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (ct->abort_l) { dead = true; return; }
-                    if (spins > SPIN_LIMIT) { if (lane == 0) fail(0x400u + (unsigned)op); dead = true; return; }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // the slot's bytes (LDS-DMA, published by the loader) are read below
-                const int slot = (int)(sl % NSLOT);
-                const u32x4 w = *reinterpret_cast<const u32x4*>(ring + slot * 16384 + (int)(ci & 15) * 1024 + lane * 16);
+        // one weight row: its CPR_ chunks read from the ring in ONE batch (the row's last chunk has landed -> all of it has), then
+        // the dot products against both activation rows; the ring slots are released after the reads
+        auto row_dot = [&](long c0, auto cpr_c, const unsigned* act, int K, float& o0, float& o1) {
+            constexpr int CPR_ = decltype(cpr_c)::value;
+            const unsigned need = (unsigned)((c0 + CPR_ - 1) >> 4) + 1u;
+            for (unsigned spins = 0; ct->landed < need; ++spins) {
+                __builtin_amdgcn_s_sleep(1);
+                if (ct->abort_l) { dead = true; return; }
+                if (spins > SPIN_LIMIT) { if (lane == 0) fail(0x400u + (unsigned)op); dead = true; return; }
+            }
+            asm volatile("" ::: "memory");       // compiler barrier only: the LDS executes a wave's operations in order, and the loader's
+                                                 // `landed` store follows its own vmcnt wait (a workgroup acquire fence here also waited for this
+                                                 // wave's write-through granule stores: ~1 us per feature pair)
+            u32x4 w[CPR_];
+            const unsigned cb = (unsigned)c0;
+#pragma unroll
+            for (int j = 0; j < CPR_; ++j) {
+                const unsigned ci = cb + (unsigned)j;
+                w[j] = *reinterpret_cast<const u32x4*>(ring + ((ci >> 4) % NSLOT) * 16384 + (ci & 15u) * 1024 + lane * 16);
+            }
+            float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};       // four independent chains per activation row
+#pragma unroll
+            for (int j = 0; j < CPR_; ++j) {
                 const u32x4 x0 = *reinterpret_cast<const u32x4*>(act + j * 256 + lane * 4);
                 const u32x4 x1 = *reinterpret_cast<const u32x4*>(act + K / 2 + j * 256 + lane * 4);
-                a0 = dot8(w, x0, a0);
-                a1 = dot8(w, x1, a1);
-                // release: the reads above are not moved below it (and a wave's LDS operations execute in order)
-                if (lane == 0) __hip_atomic_fetch_add((unsigned*)&ct->slot_cnt[slot], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const unsigned w0 = w[j].x, w1 = w[j].y, w2 = w[j].z, w3 = w[j].w;
+                const unsigned p0 = x0.x, p1 = x0.y, p2 = x0.z, p3 = x0.w, q0 = x1.x, q1 = x1.y, q2 = x1.z, q3 = x1.w;
+                acc[0][0] = dot2(w0, p0, acc[0][0]); acc[1][0] = dot2(w0, q0, acc[1][0]);
+                acc[0][1] = dot2(w1, p1, acc[0][1]); acc[1][1] = dot2(w1, q1, acc[1][1]);
+                acc[0][2] = dot2(w2, p2, acc[0][2]); acc[1][2] = dot2(w2, q2, acc[1][2]);
+                acc[0][3] = dot2(w3, p3, acc[0][3]); acc[1][3] = dot2(w3, q3, acc[1][3]);
             }
-            o0 = wave_sum(a0);
-            o1 = wave_sum(a1);
+            const float a0 = acc[0][0] + acc[0][1], b0 = acc[0][2] + acc[0][3], a1 = acc[1][0] + acc[1][1], b1 = acc[1][2] + acc[1][3];
+            // release the ring slots (after the reads; a wave's LDS operations execute in order): one add per slot touched
+            asm volatile("" ::: "memory");
+            if (lane == 0) {
+                const unsigned cl = cb + CPR_ - 1;
+                for (unsigned sl = cb >> 4; sl <= (cl >> 4); ++sl) {
+                    const unsigned lo = sl * 16 > cb ? sl * 16 : cb, hi = sl * 16 + 15 < cl ? sl * 16 + 15 : cl;
+                    atomicAdd((unsigned*)&ct->slot_cnt[sl % NSLOT], hi - lo + 1);
+                }
+            }
+            o0 = wave_sum(a0 + b0);
+            o1 = wave_sum(a1 + b1);
         };
+        using CA_t = std::integral_constant<int, CA>;
+        using CB_t = std::integral_constant<int, CB>;
         for (int pr = cw; pr < NP; pr += 3) {
             const long c0 = chunk_base + (long)pr * RPP * CPR;
             if (isA) {
                 float g0a, g0b, u0a, u0b, g1a, g1b, u1a, u1b;
-                row_dot(c0, CA, actx, H, g0a, g0b); if (dead) return;
-                row_dot(c0 + CA, CA, actx, H, u0a, u0b); if (dead) return;
-                row_dot(c0 + 2 * CA, CA, actx, H, g1a, g1b); if (dead) return;
-                row_dot(c0 + 3 * CA, CA, actx, H, u1a, u1b); if (dead) return;
+                row_dot(c0, CA_t{}, actx, H, g0a, g0b); if (dead) return;
+                row_dot(c0 + CA, CA_t{}, actx, H, u0a, u0b); if (dead) return;
+                row_dot(c0 + 2 * CA, CA_t{}, actx, H, g1a, g1b); if (dead) return;
+                row_dot(c0 + 3 * CA, CA_t{}, actx, H, u1a, u1b); if (dead) return;
                 const int f = cu * nA + 2 * pr;
                 if (lane < 2) {
                     const float rs = lane == 0 ? rs0 : rs1;
@@ -253,8 +340,8 @@ __global__ __launch_bounds__(256, 1) void lc_chain_kernel(const LCParams p) {
                 }
             } else {
                 float d0a, d0b, d1a, d1b;
-                row_dot(c0, CB, actu, F, d0a, d0b); if (dead) return;
-                row_dot(c0 + CB, CB, actu, F, d1a, d1b); if (dead) return;
+                row_dot(c0, CB_t{}, actu, F, d0a, d0b); if (dead) return;
+                row_dot(c0 + CB, CB_t{}, actu, F, d1a, d1b); if (dead) return;
                 const int h = cu * nB + 2 * pr;
                 if (lane < 2) {
                     const float n0 = xown[lane * nB + 2 * pr] + (lane == 0 ? d0a : d0b);
@@ -265,9 +352,10 @@ __global__ __launch_bounds__(256, 1) void lc_chain_kernel(const LCParams p) {
                 }
             }
         }
+        if (stamp) stp[3] = __builtin_amdgcn_s_memrealtime();
         chunk_base += (long)NP * RPP * CPR;
+        if ((op + 1) % (2 * p.L) == 0) chunk_base += step_pad;          // end of a solver step: skip the slot padding
     }
-    if (p.stamps && lane == 0) p.stamps[cu * 8 + wave] = __builtin_amdgcn_s_memrealtime();
 }
 
 }  // namespace
