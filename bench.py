@@ -332,7 +332,7 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline, with_parity=False):
     from vibevoice_amd import parallel, synthetic
     from vibevoice_amd.configs import CONFIGS
     from vibevoice_amd.engine import Engine, map_param_name
-    from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference, engine_config_from_reference
+    from vibevoice_amd.modeling import BenchHooks, VibeVoiceForConditionalGenerationInference, engine_config_from_reference
     rank, world, device, use_dist = ctx["rank"], ctx["world"], ctx["device"], ctx["use_dist"]
     model_key = spec["model"]
     cfg = CONFIGS[model_key]
@@ -452,13 +452,13 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline, with_parity=False):
             r["_forced_tokens"] = forced[i][:W + K + 1 + 7 * (i % 3)] + [synthetic.TOKENS.eos_token_id]     # staggered ends
             reqs.append(r)
         outs = model.generate_continuous(reqs, tokenizer=synthetic.TOKENS, cfg_scale=args.cfg_scale,
-                                         generation_config={"do_sample": False}, max_concurrent=B, _step_callback=step_cb)
+                                         generation_config={"do_sample": False}, max_concurrent=B, _bench_hooks=BenchHooks(step_callback=step_cb))
         out = outs[0]
     else:
         out = model.generate(tokenizer=synthetic.TOKENS, cfg_scale=args.cfg_scale, generation_config={"do_sample": False},
                              max_new_tokens=total_steps, show_progress_bar=False, _forced_tokens=forced,
-                             _noise_fn=lambda step, n2: noise_bank[step], _step_callback=step_cb,
-                             _kv_start=kv_target, _kv_fill_fn=kv_fill if kv_target else None, **inputs)
+                             _noise_fn=lambda step, n2: noise_bank[step],
+                             _bench_hooks=BenchHooks(step_callback=step_cb, kv_start=kv_target, kv_fill_fn=kv_fill if kv_target else None), **inputs)
     eng.sync()
     t_gen1 = time.perf_counter()
     if W + K not in marks:                         # continuous mode may finish early
@@ -522,8 +522,8 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline, with_parity=False):
         # the window is recorded at the timed KV length (the attention launches' bytes depend on it; the GEMV launches do not)
         model.generate(tokenizer=synthetic.TOKENS, cfg_scale=args.cfg_scale, generation_config={"do_sample": False},
                        max_new_tokens=kprof + 3, show_progress_bar=False, _forced_tokens=forced_p,
-                       _noise_fn=lambda step, n2: noise_bank[step], _step_callback=prof_cb,
-                       _kv_start=kv_target, _kv_fill_fn=kv_fill if kv_target else None, **inp2)
+                       _noise_fn=lambda step, n2: noise_bank[step],
+                       _bench_hooks=BenchHooks(step_callback=prof_cb, kv_start=kv_target, kv_fill_fn=kv_fill if kv_target else None), **inp2)
         (n_l, ms_cal, by), (n_o, ms_o, by_o) = prof["res"]       # [decode GEMV kernel], [other GEMM kernels]
         # (1) launch duration in the execution mode of the timed region: the recorded GEMV launches replayed as ONE dependent
         # hipGraph chain between two events (vv_profile_replay) = start-to-start period of a launch = what rocprofv3
@@ -681,7 +681,7 @@ def bench_full_utterance(args, spec, ctx):
     from vibevoice_amd import synthetic
     from vibevoice_amd.configs import CONFIGS
     from vibevoice_amd.engine import Engine, map_param_name
-    from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference, engine_config_from_reference
+    from vibevoice_amd.modeling import BenchHooks, VibeVoiceForConditionalGenerationInference, engine_config_from_reference
     device = ctx["device"]
     model_key = spec["model"]
     cfg = CONFIGS[model_key]
@@ -747,7 +747,7 @@ def bench_full_utterance(args, spec, ctx):
     t0 = time.perf_counter()
     out = model.generate(tokenizer=T, cfg_scale=args.cfg_scale, generation_config={"do_sample": False}, max_new_tokens=n_steps,
                          show_progress_bar=False, _forced_tokens=forced, _noise_fn=lambda step, n2: noise_bank[step],
-                         _step_callback=step_cb, **inputs)
+                         _bench_hooks=BenchHooks(step_callback=step_cb), **inputs)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     audio_s = out.speech_outputs[0].shape[-1] / 24000.0

@@ -246,7 +246,7 @@ def test_continuous_frame_store_follows_the_audio_in_flight(monkeypatch):
     dropping happens several times inside this 6-utterance queue: every result must stay identical to generate() alone, the store
     must end with at most one block, and it must never hold more than the blocks the two utterances in flight span."""
     from test_oracle_golden import _oracle_small
-    from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference
+    from vibevoice_amd.modeling import BenchHooks, VibeVoiceForConditionalGenerationInference
     cfgd = {"decoder_config": {"max_position_embeddings": 4096}, "diffusion_head_config": {"ddpm_num_inference_steps": 5},
             "acoustic_tokenizer_config": {"fix_std": 0.5, "std_dist_type": "gaussian"}}
     reqs = _requests(6, 5)
@@ -267,7 +267,7 @@ def test_continuous_frame_store_follows_the_audio_in_flight(monkeypatch):
         m.frame_block = 4
         peak = []
         outs = m.generate_continuous(reqs, tokenizer=TOK, generation_config={"do_sample": False}, cfg_scale=1.3,
-                                     _step_callback=lambda it: peak.append(sum(b is not None for b in m._audio_blocks)))
+                                     _bench_hooks=BenchHooks(step_callback=lambda it: peak.append(sum(b is not None for b in m._audio_blocks))))
     frames_total = sum(o.speech_outputs[0].shape[-1] // 3200 for o in outs if o.speech_outputs[0] is not None)
     assert frames_total > 4 * 4                                    # the queue spans several blocks ...
     assert max(peak) <= 3, peak                                    # ... but the store never holds more than the live span

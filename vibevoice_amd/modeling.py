@@ -47,6 +47,18 @@ MAX_BATCH = 8          # rows of one diffusion-head pass (2 per utterance, 16-ro
 
 
 @dataclass
+class BenchHooks:
+    """What a measurement harness (bench.py) may hang on generate() / generate_continuous() through `_bench_hooks=`: nothing
+    in here changes what is computed for the positions generate() itself fills.
+      step_callback(step)      called at the top of every loop iteration (timed-region marks, profiler windows, host-delay probe)
+      kv_start, kv_fill_fn     long-context decode measurement: after the real prompt prefill the positive cache is declared
+                               kv_start positions long and kv_fill_fn(engine, cache, p0, p1) writes the positions in between"""
+    step_callback: Optional[Callable[[int], None]] = None
+    kv_start: int = 0
+    kv_fill_fn: Optional[Callable] = None
+
+
+@dataclass
 class VibeVoiceGenerationOutput:
     """modeling_vibevoice_inference.py:38-51"""
     sequences: torch.LongTensor = None
@@ -1049,9 +1061,8 @@ class VibeVoiceForConditionalGenerationInference:
         kwargs.pop("all_speakers_list", None)
         max_length_times = kwargs.pop("max_length_times", 2)
         prefill_noise = kwargs.pop("_prefill_noise", None)
-        step_cb = kwargs.pop("_step_callback", None)             # bench hook: called at the top of every step
-        kv_start = kwargs.pop("_kv_start", 0)                     # bench hook: long-context decode measurement
-        kv_fill_fn = kwargs.pop("_kv_fill_fn", None)
+        hooks = kwargs.pop("_bench_hooks", None) or BenchHooks()  # measurement harness only (bench.py): see BenchHooks
+        step_cb, kv_start, kv_fill_fn = hooks.step_callback, hooks.kv_start, hooks.kv_fill_fn
         input_ids = kwargs["input_ids"] if inputs is None else inputs
         attention_mask = kwargs.get("attention_mask")
         input_ids = input_ids.cpu()
@@ -1204,7 +1215,7 @@ class VibeVoiceForConditionalGenerationInference:
         outs = self.generate_continuous(reqs, tokenizer=tokenizer, generation_config=generation_config, cfg_scale=cfg_scale,
                                         audio_streamer=audio_streamer, is_prefill=is_prefill, return_speech=return_speech,
                                         max_new_tokens=kwargs.get("max_new_tokens"), max_length_times=max_length_times,
-                                        stop_check_fn=stop_check_fn, _step_callback=step_cb, **kw)
+                                        stop_check_fn=stop_check_fn, _bench_hooks=BenchHooks(step_callback=step_cb), **kw)
         eos = tokenizer.eos_token_id
         width = max(int(o.sequences.shape[1]) for o in outs)
         seq = torch.full((B, width), eos, dtype=torch.long, device=self.device)
@@ -1233,7 +1244,7 @@ class VibeVoiceForConditionalGenerationInference:
         if cap < 1:
             raise ValueError("no engine slot available")
         kwargs = dict(kwargs)
-        step_cb = kwargs.pop("_step_callback", None)
+        step_cb = (kwargs.pop("_bench_hooks", None) or BenchHooks()).step_callback
         S = self._session(tokenizer, generation_config, cfg_scale, kwargs, audio_streamer, n_req)
         S["sample_rows"] = lambda order: [u.idx for u in order]
         self._frame_w = cap
