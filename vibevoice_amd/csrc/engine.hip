@@ -196,7 +196,7 @@ struct vv_ctx {
     float *h_parts = nullptr, *xh_parts = nullptr;     // K-split partial tensors of the residual streams (2 x [rows][H] each)
     void *xp = nullptr, *actp = nullptr;               // prefill (prefill.hip): activations as packed bf16 MFMA fragments
     bool tile3_ok = false, attn2_ok = false;
-    VVGemmWs gws = {nullptr, nullptr, nullptr};         // K-split workspace of the long-prompt GEMM (null: never split)
+    VVGemmWs gws = {nullptr, nullptr, nullptr, nullptr, 0};         // K-split workspace of the long-prompt GEMM (null: never split)
     bool fold_normdw = true;      // one-row tokenizer stages: norm + depthwise conv inside FFN1's prologue (VVHIP_FOLD_NORMDW=0: separate launch)
     // batch decode (5..16 rows, bf16 mode): activations packed once per op into one 16-row fragment tile (gemv16p.hip)
     void *p16_x = nullptr, *p16_act = nullptr; bool p16_ok = false;
@@ -890,6 +890,11 @@ extern "C" int vv_create(const vv_config* cfg, vv_ctx** out) {
         ctx->xp = dalloc(ctx, (size_t)vv_packed_elems(R, std::max(H, Hq * D)) * 2);
         ctx->actp = dalloc(ctx, (size_t)vv_packed_elems(R, I) * 2);
         ctx->tile3_ok = c.xsplit == 1;
+        if (ctx->tile3_ok) {      // short prompts: K parts of the 128 x 128 GEMM (up to 8 dense [rows][features] fp32 tensors, rows <= 1024)
+            ctx->gws.g3_bytes = (size_t)8 * std::min(R, 1024) * std::max(ctx->QKV, H) * 4;
+            ctx->gws.g3_partials = (float*)dalloc(ctx, ctx->gws.g3_bytes, false);
+            if (!ctx->gws.g3_partials) ctx->gws.g3_bytes = 0;
+        }
         const char* no_ks = getenv("VVHIP_NO_KSPLIT");  // opt-out: every tile of the partial round computed whole (no inter-workgroup hand-off)
         if (ctx->tile3_ok && R >= 1024 && !(no_ks && no_ks[0] == '1')) {   // prompts long enough for the 256 x 256 GEMM: its partial round is split along K
             ctx->gws.partials = (float*)dalloc(ctx, (size_t)256 * 32 * 512 * 16, false);

@@ -224,8 +224,11 @@ __global__ __launch_bounds__(256, TR == 8 ? 2 : 4) void vv_gemm3_kernel(const VV
         for (int j = 0; j < TR; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int n_steps = (KT + 1) >> 1;
+    // short prompts: grid.y = K parts (a.split), each writes a dense fp32 partial tensor (vv_gemm3_launch / vv_g3_reduce_kernel)
+    const int ks = (int)gridDim.y, part = (int)blockIdx.y;
+    const int s_lo = (int)((int64_t)part * n_steps / ks), s_hi = (int)((int64_t)(part + 1) * n_steps / ks);
 #pragma unroll 1
-    for (int s = 0; s < n_steps; ++s) {
+    for (int s = s_lo; s < s_hi; ++s) {
         const int kt0 = s * 2;
 #pragma unroll
         for (int i = 0; i < FPW; ++i) {
@@ -299,6 +302,10 @@ __global__ __launch_bounds__(256, TR == 8 ? 2 : 4) void vv_gemm3_kernel(const VV
             for (int j = 0; j < TR; ++j) {
                 const int t = (tt0 + wr * TR + j) * 16 + frow;
                 if (t >= a.T) continue;
+                if (ks > 1) {                                          // K part: the raw sums, bias / residual belong to the reduce
+                    *reinterpret_cast<float4*>(a.ws + ((int64_t)part * a.T + t) * a.N + n0) = float4{acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    continue;
+                }
                 float* yp = a.Y + (int64_t)t * a.ldy + n0;
                 float4 o = {acc[i][j][0] + pb.x, acc[i][j][1] + pb.y, acc[i][j][2] + pb.z, acc[i][j][3] + pb.w};
                 if constexpr (EPI == VV_EPI_RESID) {
@@ -309,6 +316,25 @@ __global__ __launch_bounds__(256, TR == 8 ? 2 : 4) void vv_gemm3_kernel(const VV
             }
         }
     }
+}
+
+// Y[t][n] (+)= bias[n] + sum over the K parts, in part order (deterministic): the second half of a K-split vv_gemm3 launch
+__global__ __launch_bounds__(256) void vv_g3_reduce_kernel(const float* __restrict__ ws, int parts, int T, int N, const float* __restrict__ bias,
+                                                           float* __restrict__ Y, int ldy, int resid) {
+    const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e >= (int64_t)T * N) return;
+    const int t = (int)(e / N), n = (int)(e - (int64_t)t * N);
+    float4 v[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) v[p] = (p < parts) ? *reinterpret_cast<const float4*>(ws + (int64_t)p * T * N + e) : float4{0.f, 0.f, 0.f, 0.f};
+    float* yp = Y + (int64_t)t * ldy + n;
+    float4 o = bias ? *reinterpret_cast<const float4*>(bias + n) : float4{0.f, 0.f, 0.f, 0.f};
+    float4 sum = v[0];
+#pragma unroll
+    for (int p = 1; p < 8; ++p) { sum.x += v[p].x; sum.y += v[p].y; sum.z += v[p].z; sum.w += v[p].w; }
+    o.x += sum.x; o.y += sum.y; o.z += sum.z; o.w += sum.w;
+    if (resid) { const float4 py = *reinterpret_cast<const float4*>(yp); o.x += py.x; o.y += py.y; o.z += py.z; o.w += py.w; }
+    *reinterpret_cast<float4*>(yp) = o;
 }
 
 // workgroup -> (feature block, row block) of the 256 x 256 kernels, XCD-major (see vv_gemm3_kernel), plus the K-split of the
@@ -1071,7 +1097,23 @@ int vv_gemm3_launch(const void* W, const void* W2, const void* Xp, float* Y, voi
     // 256-row workgroups once the problem is tall enough to fill the chip with them
     const int tr = (int64_t)a.n_blocks * ((T + 255) / 256) >= 768 ? 8 : 4;
     a.t_blocks = (T + 32 * tr - 1) / (32 * tr);
-    const dim3 grid((unsigned)(a.n_blocks * a.t_blocks));
+    dim3 grid((unsigned)(a.n_blocks * a.t_blocks));
+    // Short prompts (a 330-token request: 36 tiles for the o / down projections of a 1.5B layer, 48 for QKV): a few dozen workgroups
+    // stream the whole matrix -- 170 us for the 27.5 MB down projection.  K is split over grid.y (each part >= 4 of the 64-wide
+    // steps) until ~192 workgroups pull on HBM; the parts go to dense fp32 tensors and vv_g3_reduce_kernel sums them in part order
+    // with the bias / residual: deterministic, no hand-off inside a launch.  VVHIP_G3_KSPLIT=0 switches it off.
+    int ks = 1;
+    if (epi != VV_EPI_SWIGLU && ws && ws->g3_partials && grid.x < 128 && (N & 3) == 0 && Y) {
+        static int on = -1;
+        if (on < 0) { const char* e = getenv("VVHIP_G3_KSPLIT"); on = (e && e[0] == '0') ? 0 : 1; }
+        const int n_steps = (((K + 31) >> 5) + 1) >> 1;
+        ks = on ? (int)((192 + grid.x - 1) / grid.x) : 1;
+        if (ks > 8) ks = 8;
+        if (ks > n_steps / 4) ks = n_steps / 4;
+        if (ks < 2 || (size_t)ks * T * N * 4 > ws->g3_bytes) ks = 1;
+    }
+    const float* bias_r = bias; const int resid_r = (epi == VV_EPI_RESID) ? 1 : 0;
+    if (ks > 1) { grid.y = (unsigned)ks; a.ws = ws->g3_partials; a.split = ks; }
 #define VV_G3(E_) do { if (tr == 8) hipLaunchKernelGGL((vv_gemm3_kernel<E_, 8>), grid, dim3(256), 0, s, a); \
                        else hipLaunchKernelGGL((vv_gemm3_kernel<E_, 4>), grid, dim3(256), 0, s, a); } while (0)
     if (epi == VV_EPI_SWIGLU) {
@@ -1087,6 +1129,10 @@ int vv_gemm3_launch(const void* W, const void* W2, const void* Xp, float* Y, voi
         return -3;
     }
 #undef VV_G3
+    if (ks > 1) {
+        const int64_t n4 = ((int64_t)T * N + 3) / 4;
+        hipLaunchKernelGGL(vv_g3_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, ws->g3_partials, ks, T, N, bias_r, Y, ldy, resid_r);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -32,6 +32,10 @@ struct VVGemmWs {
     float* partials;     // 256 slots x 256 KiB (a workgroup's 32 accumulators x 512 threads x f32x4)
     unsigned* flags;     // 256 arrival words, zero whenever no launch is in flight
     unsigned* err;       // host-mapped word, set by a wait that timed out
+    // short prompts (vv_gemm3_kernel: a few dozen 128 x 128 tiles): K split over grid.y into dense fp32 partial tensors
+    // [part][T][N], summed in part order (+ bias / residual) by vv_g3_reduce_kernel -- no hand-off inside a launch
+    float* g3_partials;
+    size_t g3_bytes;
 };
 
 // ---- generic skinny GEMM -----------------------------------------------------
