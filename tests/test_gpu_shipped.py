@@ -343,6 +343,47 @@ def test_prefill_gemm4_k_split_round(epi, T, N, K):
         eng.close()
 
 
+@pytest.mark.parametrize("epi", [0, 1, 4])
+@pytest.mark.parametrize("T,N,K", [(330, 1536, 8960), (330, 2048, 1536), (333, 1540, 1056), (75, 896, 4864), (500, 36, 3584)])
+def test_short_prompt_gemm3_k_split_and_reduce(epi, T, N, K):
+    """Short prompts (round 4): vv_gemm3_kernel launches a few dozen 128 x 128 tiles for such shapes (36 for the 1.5B down projection
+    of a 330-token prompt), so K is split over grid.y into dense fp32 partial tensors and vv_g3_reduce_kernel adds them in part order
+    with the bias / residual -- with two LDS stage buffers, the next stage's copies issued before the current stage's MFMAs.
+    Shapes: the 1.5B down / QKV projections at 330 rows, ragged T / N with an odd k-tile count (33), a 75-row voice prompt at 0.5B
+    widths, a one-block problem.  Against the bf16-rounded-activation reference at test_prefill_gemm3's bounds, against the unsplit
+    kernel (no workspace: summation order only), twice (bit-identical repeats)."""
+    s = build_fast(GEOM["0.5b"], xsplit=1, max_ctx=128, max_rows=512, head_layers=1)
+    eng = s.eng
+    try:
+        g = _FastGen(8800 + T + N + K + epi)
+        w = g.normal((N, K), 1.0 / np.sqrt(K))
+        x = g.normal((T, K), 1.0, mat=False)
+        nw = g.vec(K, 0.1, 1.0)
+        bias = g.vec(N, 0.3)
+        y0 = g.normal((T, N), 1.0, mat=False)
+        norm = epi == 1
+        xin = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-5) * nw if norm else x
+        x16 = synth.bf16_round(xin)
+        a16 = (x16.to(eng.device, torch.float64) @ w.to(eng.device, torch.float64).t()).float().cpu()
+        ref16 = {0: a16, 1: a16 + bias, 4: y0 + a16}[epi]
+        wp, xd = eng.pack_matrix(w), dev(x, eng)
+        outs = []
+        for ksplit in (True, True, False):
+            y = dev(y0.clone(), eng)
+            with torch.cuda.stream(eng.stream):
+                eng.gemm3_raw(wp, xd, y, N, K, epi=epi, nw=dev(nw, eng) if norm else None, eps=1e-5,
+                              bias=dev(bias, eng) if epi == 1 else None, ksplit=ksplit)
+            eng.sync()
+            outs.append(y.float().cpu())
+        for y in outs:
+            assert rel_err(y, ref16) <= 2e-4, rel_err(y, ref16)
+            assert float((y - ref16).abs().max()) <= 8e-4 * float(ref16.abs().max()), float((y - ref16).abs().max())
+        assert torch.equal(outs[0], outs[1])                                   # deterministic: fixed part order
+        assert rel_err(outs[0], outs[2]) <= 2e-6, rel_err(outs[0], outs[2])
+    finally:
+        eng.close()
+
+
 # ---------------------------------------------------------------------------------------------- (d) bf16-input references
 @pytest.mark.parametrize("L0,chunk,heads,kv_heads,hd", [(4180, 512, 4, 2, 128), (1000, 1024, 7, 1, 128), (1555, 1024, 14, 2, 64), (90, 128, 4, 2, 128)])
 def test_prefill_attention_v3_against_the_bf16_input_oracle(L0, chunk, heads, kv_heads, hd):

@@ -65,7 +65,22 @@ __global__ __launch_bounds__(256) void vv_pack_rows_kernel(const float* __restri
             float s = 0.f;
             if (t < T) {
                 const float* xr = x + (int64_t)t * ldx;
-                for (int k = lane * 4; k < K; k += 256) {
+                // six loads in flight per trip (H = 1536: one trip; 3584: two + one pair): a row of a short prompt's 21-workgroup
+                // launch is pure load latency otherwise
+                int k = lane * 4;
+                for (; k + 5 * 256 < K; k += 6 * 256) {
+                    float4 v[6];
+#pragma unroll
+                    for (int u = 0; u < 6; ++u) v[u] = *reinterpret_cast<const float4*>(xr + k + u * 256);
+#pragma unroll
+                    for (int u = 0; u < 6; ++u) s += v[u].x * v[u].x + v[u].y * v[u].y + v[u].z * v[u].z + v[u].w * v[u].w;
+                }
+                for (; k + 256 < K; k += 2 * 256) {
+                    const float4 v0 = *reinterpret_cast<const float4*>(xr + k), v1 = *reinterpret_cast<const float4*>(xr + k + 256);
+                    s += v0.x * v0.x + v0.y * v0.y + v0.z * v0.z + v0.w * v0.w;
+                    s += v1.x * v1.x + v1.y * v1.y + v1.z * v1.z + v1.w * v1.w;
+                }
+                for (; k < K; k += 256) {
                     const float4 v = *reinterpret_cast<const float4*>(xr + k);
                     s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
                 }
@@ -169,14 +184,19 @@ __device__ __forceinline__ float g3_silu(float u) { return u / (1.0f + __expf(-u
 
 // TR = row tiles (16 rows each) per wave: the workgroup covers 128 features x 32*TR rows.  TR = 8 (256 rows) doubles the
 // MFMAs per staged byte and per barrier: three such workgroups per CU carry enough arithmetic to cover a stage's load latency.
-template <int EPI, int TR>
-__global__ __launch_bounds__(256, TR == 8 ? 2 : 4) void vv_gemm3_kernel(const VVGemm3 a) {
+// DB = 1: two stage buffers (TR = 4 only), the next stage's copies issued before the current stage's MFMAs, one barrier per stage.
+// Launches of at most ~2 workgroups per CU (short prompts: a few hundred tiles) have no neighbour workgroup to hide a stage's
+// load latency behind; with four resident workgroups per CU the single-buffer form overlaps through occupancy and keeps its LDS.
+template <int EPI, int TR, int DB = 0>
+__global__ __launch_bounds__(256, TR == 8 ? 2 : (DB ? 2 : 4)) void vv_gemm3_kernel(const VVGemm3 a) {
     constexpr bool DUAL = (EPI == VV_EPI_SWIGLU);
     constexpr int FT = DUAL ? 4 : 8;              // feature tiles (per matrix) per workgroup
     // LDS stage: 16 A fragments then 4*TR B fragments of one 64-wide K step (2 k-tiles): [frag][64 lanes][16 B]
     constexpr int NFR = 16 + 4 * TR;               // fragments per stage
     constexpr int FPW = NFR / 4;                   // copied by each wave
-    __shared__ __attribute__((aligned(16))) unsigned char stage[NFR * 1024];
+    static_assert(DB == 0 || TR == 4, "two stage buffers: 64 KiB of static LDS, TR = 4 only");
+    __shared__ __attribute__((aligned(16))) unsigned char stage_all[NFR * 1024 * (DB + 1)];
+    unsigned char* stage = stage_all;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 15, fq = lane >> 4;
@@ -227,17 +247,27 @@ __global__ __launch_bounds__(256, TR == 8 ? 2 : 4) void vv_gemm3_kernel(const VV
     // short prompts: grid.y = K parts (a.split), each writes a dense fp32 partial tensor (vv_gemm3_launch / vv_g3_reduce_kernel)
     const int ks = (int)gridDim.y, part = (int)blockIdx.y;
     const int s_lo = (int)((int64_t)part * n_steps / ks), s_hi = (int)((int64_t)(part + 1) * n_steps / ks);
-#pragma unroll 1
-    for (int s = s_lo; s < s_hi; ++s) {
-        const int kt0 = s * 2;
+    auto issue = [&](int s, unsigned char* buf) {
 #pragma unroll
         for (int i = 0; i < FPW; ++i) {
             const int f = wave * FPW + i;
-            int kt = kt0 + (f & 1);
+            int kt = s * 2 + (f & 1);
             if (kt > KT - 1) kt = KT - 1;                              // odd K tail: re-reads the last k-tile, MFMA skipped
-            glds16(src[i] + (int64_t)kt * 64, stage + f * 1024);
+            glds16(src[i] + (int64_t)kt * 64, buf + f * 1024);
         }
-        stage_sync();                                                 // the stage has landed for every wave
+    };
+    if constexpr (DB) { if (s_lo < s_hi) issue(s_lo, stage_all); }
+#pragma unroll 1
+    for (int s = s_lo; s < s_hi; ++s) {
+        const int kt0 = s * 2;
+        if constexpr (DB) {
+            stage = stage_all + ((s - s_lo) & 1) * (NFR * 1024);
+            stage_sync();                                             // stage s has landed for every wave; everyone is done with stage s - 1
+            if (s + 1 < s_hi) issue(s + 1, stage_all + (((s - s_lo) & 1) ^ 1) * (NFR * 1024));
+        } else {
+            issue(s, stage);
+            stage_sync();                                             // the stage has landed for every wave
+        }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             if (kt0 + kk < KT) {
@@ -258,7 +288,7 @@ __global__ __launch_bounds__(256, TR == 8 ? 2 : 4) void vv_gemm3_kernel(const VV
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
             }
         }
-        __syncthreads();                                              // everyone is done reading before the next stage lands
+        if constexpr (!DB) __syncthreads();                           // everyone is done reading before the next stage lands
     }
 
     // ---- epilogue: lane holds D[n = tile*16 + fq*4 + r][t = ttile*16 + frow] ----
@@ -1114,7 +1144,11 @@ int vv_gemm3_launch(const void* W, const void* W2, const void* Xp, float* Y, voi
     }
     const float* bias_r = bias; const int resid_r = (epi == VV_EPI_RESID) ? 1 : 0;
     if (ks > 1) { grid.y = (unsigned)ks; a.ws = ws->g3_partials; a.split = ks; }
+    static int db_on = -1;
+    if (db_on < 0) { const char* e = getenv("VVHIP_G3_DB"); db_on = (e && e[0] == '0') ? 0 : 1; }
+    const bool db = db_on && tr == 4 && (int64_t)grid.x * (ks > 1 ? ks : 1) <= 512;      // at most ~2 workgroups per CU: nothing else hides a stage's latency
 #define VV_G3(E_) do { if (tr == 8) hipLaunchKernelGGL((vv_gemm3_kernel<E_, 8>), grid, dim3(256), 0, s, a); \
+                       else if (db) hipLaunchKernelGGL((vv_gemm3_kernel<E_, 4, 1>), grid, dim3(256), 0, s, a); \
                        else hipLaunchKernelGGL((vv_gemm3_kernel<E_, 4>), grid, dim3(256), 0, s, a); } while (0)
     if (epi == VV_EPI_SWIGLU) {
         if (!W2 || !Yp) return -1;
