@@ -104,12 +104,17 @@ def oracle_generate(m: OracleModel, tok: TokenIds, input_ids, attention_mask,
                     forced_tokens: Optional[List[List[int]]] = None,
                     do_sample=False, trace: Optional[Trace] = None,
                     algorithm_type="dpmsolver++", sde_noise_fn: Callable = None,
-                    teacher_embeds: Callable = None):
+                    teacher_embeds: Callable = None, refresh_negative: bool = True):
     """Returns (sequences [B, L0+steps], speech_outputs list, reach_max_step_sample).
     algorithm_type "sde-dpmsolver++": the scheduler demo/gradio_demo.py:142-146 installs; sde_noise_fn(step, N, 2n) ->
     [N, 2n, 64], the variance noise scheduler.step() draws per solver step (dpm_solver.py:994-997).
     teacher_embeds(step) -> [B, H] or None: test hook (SURVEY 8d "teacher-forced per step") -- the NEXT positive pass consumes these
-    embeddings instead of the loop's own, so two implementations are compared step by step on identical inputs."""
+    embeddings instead of the loop's own, so two implementations are compared step by step on identical inputs.
+    refresh_negative=False (:503-516; the reset of :550-565 and the forward of :576-588 are then skipped): the negative pass runs at
+    EVERY step for every row, right after the token choice, on the embedding the positive pass consumed at this step (the lone
+    <speech_start> prompt token at step 0, where inputs_embeds is still None, :395); it is never reset.  The correction of
+    :590-624 still runs whenever some row diffuses: it shifts the valid part of a non-diffusing live row's negative cache right by
+    one and masks the slot that frees up -- on the compact cache "the entry appended at this step is dropped again"."""
     B, L0 = input_ids.shape
     if max_new_tokens is None:
         max_new_tokens = m.max_position_embeddings - L0
@@ -179,8 +184,15 @@ def oracle_generate(m: OracleModel, tok: TokenIds, input_ids, attention_mask,
         for b in (nxt == tok.speech_end_id).nonzero().flatten().tolist():
             codec.zero_state(ac_state[b])
             codec.zero_state(sem_state[b])
+        neg_all = None
+        if not refresh_negative:
+            # ---- :503-516: negative pass of every row (finished rows too in the reference; their cache is never read again) ----
+            neg_all = {}
+            for b in range(B):
+                e = m.lm.embed(torch.tensor([tok.speech_start_id])) if consumed is None else consumed[b][None]
+                neg_all[b] = m.lm.forward(e, neg_cache[b])[-1]
         # ---- <speech_start>: reset the negative branch (:549-565) ----
-        for b in (~finished & (nxt == tok.speech_start_id)).nonzero().flatten().tolist():
+        for b in (~finished & (nxt == tok.speech_start_id)).nonzero().flatten().tolist() if refresh_negative else []:
             # The reference zeroes the negative attention mask except its LAST slot -- the slot of the token that will be fed
             # next -- and copies K/V[0] into the last *cached* slot, which that mask then hides (:551-560).  Net effect
             # (pinned by tests/golden/generate_forced_*.npz, recorded from the reference's own generate()): the negative
@@ -190,11 +202,16 @@ def oracle_generate(m: OracleModel, tok: TokenIds, input_ids, attention_mask,
         diff = (~finished & (nxt == tok.speech_diffusion_id)).nonzero().flatten().tolist()
         if diff:
             n = len(diff)
-            neg_hidden = []
-            for b in diff:
-                e = m.lm.embed(torch.tensor([tok.speech_start_id])) if consumed is None else consumed[b][None]
-                neg_hidden.append(m.lm.forward(e, neg_cache[b])[-1])
-            neg_hidden = torch.stack(neg_hidden)
+            if refresh_negative:
+                neg_hidden = []
+                for b in diff:
+                    e = m.lm.embed(torch.tensor([tok.speech_start_id])) if consumed is None else consumed[b][None]
+                    neg_hidden.append(m.lm.forward(e, neg_cache[b])[-1])
+                neg_hidden = torch.stack(neg_hidden)
+            else:
+                neg_hidden = torch.stack([neg_all[b] for b in diff])
+                for b in (~finished & (nxt != tok.speech_diffusion_id)).nonzero().flatten().tolist():
+                    neg_cache[b].truncate(neg_cache[b].length - 1)          # :590-624
             pos_cond = hidden[diff]
             noise = noise_fn(step, 2 * n)
             sn = sde_noise_fn(step, num_steps, 2 * n) if algorithm_type == "sde-dpmsolver++" else None

@@ -330,7 +330,7 @@ def gen_generate():
             # NOTE: finished_flags deliberately left untouched -- the reference's own streamer sets them, which makes
             # generate() stop at the first finished sample (:443-447); here the whole batch is recorded.
 
-    def run(name, B, plans, seed, max_new_tokens=None, do_sample=False, wav_len=3 * 3200, streamer=False, sde=False, gen_cfg=None):
+    def run(name, B, plans, seed, max_new_tokens=None, do_sample=False, wav_len=3 * 3200, streamer=False, sde=False, gen_cfg=None, **gen_kw):
         g = synth.Gen(seed)
         lens = [21, 17][:B]
         L0 = max(lens)
@@ -390,7 +390,7 @@ def gen_generate():
                              generation_config=(gen_cfg if gen_cfg is not None else
                                                 {"do_sample": True, "top_k": 0} if do_sample else {"do_sample": False}),
                              show_progress_bar=False, return_speech=True, audio_streamer=rec,
-                             speech_tensors=speech, speech_masks=smask, speech_input_mask=sim)
+                             speech_tensors=speech, speech_masks=smask, speech_input_mask=sim, **gen_kw)
         finally:
             torch.randn, torch.randn_like = o_randn, o_like
             Ref._get_logits_processor = orig_glp
@@ -442,6 +442,11 @@ def gen_generate():
     # (per frame: the initial randn(2n, 64), then one randn(2n, 64) per solver step inside scheduler.step())
     run("generate_sde_b1.npz", 1, [[D, D, D, E, S, D, D, X]], seed=67, sde=True)
     run("generate_sde_b2.npz", 2, [[D, D, D, E, S, D, D, X], [D, D, E, S, D, X]], seed=71, sde=True)
+    # refresh_negative=False (:503-516, and the resets of :550-565 / the forward of :576-588 skipped): the negative branch consumes
+    # every step's input and is never reset; in the batch of two the rows that do not diffuse while the other one does go through
+    # the cache correction of :590-624
+    run("generate_norefresh_b1.npz", 1, [[D, D, D, D, E, S, D, D, D, X]], seed=83, refresh_negative=False)
+    run("generate_norefresh_b2.npz", 2, [[D, D, D, E, S, D, D, X], [D, D, E, S, D, X]], seed=89, refresh_negative=False)
 
 
 @torch.no_grad()

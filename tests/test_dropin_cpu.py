@@ -651,3 +651,41 @@ def test_gradio_demo_scheduler_swap_and_generate(product, capsys, name):
                           verbose=False, is_prefill=True, _forced_tokens=forced)
     assert torch.equal(out2.sequences.cpu(), outputs.sequences.cpu())
     assert not torch.allclose(out2.speech_outputs[0].float(), outputs.speech_outputs[0].float())      # a different solver
+
+
+# ---------------------------------------------------------------- refresh_negative=False (modeling_vibevoice_inference.py:503-516)
+@pytest.mark.parametrize("name", ["generate_norefresh_b1", "generate_norefresh_b2"])
+def test_generate_without_negative_refresh_lands_on_the_reference_golden(product, name):
+    """generate(..., refresh_negative=False) of the product loop, seeded like the run that recorded the golden with the REFERENCE's own
+    generate() in that mode: the negative pass runs at every step on the positive pass's input (the lone <speech_start> at step 0),
+    is never reset, and -- batch of two -- a row that does not diffuse while the other does loses the step's entry again
+    (:590-624).  Only the forced token plan is injected; sequences identical, waveform rel-L2 <= 1e-4.  The request queue refuses
+    the mode (it is a rule over the rows of one lock-step batch)."""
+    modeling, path = product
+    model = modeling.VibeVoiceForConditionalGenerationInference.from_pretrained(path, torch_dtype=torch.float32, device_map="cuda")
+    model.eval()
+    model.set_ddpm_inference_steps(num_steps=5)
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    B = z["input_ids"].shape[0]
+    inputs = {"input_ids": torch.from_numpy(z["input_ids"]), "attention_mask": torch.from_numpy(z["attention_mask"]),
+              "speech_tensors": torch.from_numpy(z["speech_tensors"]), "speech_masks": torch.from_numpy(z["speech_masks"]),
+              "speech_input_mask": torch.from_numpy(z["speech_input_mask"])}
+    forced = [z["forced"][b][:int(z["forced_len"][b])].tolist() for b in range(B)]
+    for speculate in (False, True):
+        model.speculate_sampling = speculate
+        torch.manual_seed(int(z["seed"]))
+        outputs = model.generate(**inputs, max_new_tokens=None, cfg_scale=1.3, tokenizer=TOK, generation_config={'do_sample': False},
+                                 verbose=False, refresh_negative=False, is_prefill=True, _forced_tokens=forced)
+        assert torch.equal(outputs.sequences.cpu(), torch.from_numpy(z["sequences"]))
+        assert torch.equal(outputs.reach_max_step_sample.cpu(), torch.from_numpy(z["reach_max"]))
+        for b in range(B):
+            ref = torch.from_numpy(z[f"audio_{b}"])
+            got = outputs.speech_outputs[b].reshape(-1)
+            assert got.shape == ref.shape and float((got - ref).norm() / ref.norm()) <= 1e-4
+    # the refreshed mode on the same seeded call is something else
+    torch.manual_seed(int(z["seed"]))
+    out2 = model.generate(**inputs, max_new_tokens=None, cfg_scale=1.3, tokenizer=TOK, generation_config={'do_sample': False},
+                          verbose=False, is_prefill=True, _forced_tokens=forced)
+    assert not torch.allclose(out2.speech_outputs[0].float(), outputs.speech_outputs[0].float())
+    with pytest.raises(NotImplementedError):
+        model.generate_continuous([{k: v[:1] for k, v in inputs.items()}], tokenizer=TOK, refresh_negative=False)

@@ -52,7 +52,7 @@ def make_inputs(s, B, with_speech, seed):
     return ids, mask, sim, speech_tensors, speech_masks
 
 
-def run_both(s, B, forced, with_speech, cfg=1.3, steps=5, seed=11, max_new_tokens=None):
+def run_both(s, B, forced, with_speech, cfg=1.3, steps=5, seed=11, max_new_tokens=None, **mode):
     from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference
     ids, mask, sim, st, sm = make_inputs(s, B, with_speech, seed)
     g = synth.Gen(seed + 1)
@@ -69,7 +69,7 @@ def run_both(s, B, forced, with_speech, cfg=1.3, steps=5, seed=11, max_new_token
     otr = ogen.Trace()
     oseq, oaud, omax = ogen.oracle_generate(om, TOK, ids, mask, st, sm, sim if with_speech else None, cfg_scale=cfg,
                                             num_steps=steps, max_new_tokens=max_new_tokens, noise_fn=noise_fn,
-                                            prefill_noise=pre, forced_tokens=forced, trace=otr)
+                                            prefill_noise=pre, forced_tokens=forced, trace=otr, **mode)
     cfgd = {"decoder_config": {"max_position_embeddings": s.lmcfg.max_pos},
             "diffusion_head_config": {"ddpm_num_inference_steps": steps},
             "acoustic_tokenizer_config": {"fix_std": 0.5, "std_dist_type": "gaussian"}}
@@ -84,7 +84,7 @@ def run_both(s, B, forced, with_speech, cfg=1.3, steps=5, seed=11, max_new_token
                      speech_input_mask=sim if with_speech else None, cfg_scale=cfg, tokenizer=tok,
                      max_new_tokens=max_new_tokens, generation_config={"do_sample": False},
                      _forced_tokens=forced, _noise_fn=noise_fn, _prefill_noise=pre, _trace=htr,
-                     show_progress_bar=False)
+                     show_progress_bar=False, **mode)
     return (oseq, oaud, omax, otr), (out, htr)
 
 
@@ -127,6 +127,58 @@ def test_generate_forced_batch2_desync(sm):
     forced = [[D, D, D, E, S, D, D, X], [D, D, E, S, D, X]]
     o, h = run_both(sm, 2, forced, with_speech=True, seed=23)
     check(o, h)
+
+
+@pytest.mark.parametrize("B,forced,seed", [(1, [[D, D, D, D, E, S, D, D, D, X]], 83), (2, [[D, D, D, E, S, D, D, X], [D, D, E, S, D, X]], 89),
+                                           (2, [[S, D, D, E, S, D, X], [D, E, E, S, D, D, D, X]], 97)])
+def test_generate_without_negative_refresh(sm, B, forced, seed):
+    """refresh_negative=False (modeling_vibevoice_inference.py:503-516): the negative branch consumes every step's input, is never
+    reset on <speech_start>, and in a batch the rows that do not diffuse while another does lose the step's entry again (:590-624).
+    Engine vs the oracle loop, which tests/test_oracle_golden.py pins to the reference's own generate() in this mode
+    (tests/golden/generate_norefresh_b{1,2}.npz); speculation on (the wrong guesses at <speech_end> are discarded)."""
+    o, h = run_both(sm, B, forced, with_speech=True, seed=seed, refresh_negative=False)
+    check(o, h)
+    # the mode is not a no-op on these plans: the negative conditions differ from the refreshed run's after the first <speech_start>
+    o2, _ = run_both(sm, B, forced, with_speech=True, seed=seed)
+    assert any(rel_err(a, b) > 1e-2 for a, b in zip(o[3].neg_hidden, o2[3].neg_hidden))
+
+
+@pytest.mark.parametrize("name", ["generate_norefresh_b1", "generate_norefresh_b2"])
+def test_generate_without_negative_refresh_against_the_reference_golden(sm, name):
+    """the engine directly against what the REFERENCE's generate(refresh_negative=False) produced on the same tiny seeded model, inputs,
+    forced plan and recorded noise draws (tests/golden/make_golden.py::gen_generate): sequences identical, waveform rel-L2 <= 1e-2
+    (xsplit = 3 against fp32)."""
+    import os
+    import numpy as np
+    from test_oracle_golden import G as GOLD
+    from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    ids = torch.from_numpy(z["input_ids"])
+    B = ids.shape[0]
+    draws = [torch.from_numpy(z[f"draw_{i}"]) for i in range(int(z["n_draws"]))]
+    pre = (draws[0].reshape(B), draws[1].reshape(B, 3, 64))
+    it = iter(draws[2:])
+    forced = [z["forced"][b][:int(z["forced_len"][b])].tolist() for b in range(B)]
+    cfgd = {"decoder_config": {"max_position_embeddings": sm.lmcfg.max_pos}, "diffusion_head_config": {"ddpm_num_inference_steps": 5},
+            "acoustic_tokenizer_config": {"fix_std": 0.5, "std_dist_type": "gaussian"}}
+    m = VibeVoiceForConditionalGenerationInference(cfgd, sm.eng, model_dtype=torch.float32)
+    m.set_speech_factors(sm.scaling, sm.bias)
+    m.set_ddpm_inference_steps(5)
+    m.speculate_sampling = False               # the recorded draws are consumed strictly in order
+    tok = types.SimpleNamespace(speech_start_id=TOK.speech_start_id, speech_end_id=TOK.speech_end_id,
+                                speech_diffusion_id=TOK.speech_diffusion_id, eos_token_id=TOK.eos_token_id,
+                                bos_token_id=None, pad_token_id=TOK.pad_token_id)
+    out = m.generate(input_ids=ids, attention_mask=torch.from_numpy(z["attention_mask"]), speech_tensors=torch.from_numpy(z["speech_tensors"]),
+                     speech_masks=torch.from_numpy(z["speech_masks"]), speech_input_mask=torch.from_numpy(z["speech_input_mask"]),
+                     cfg_scale=1.3, tokenizer=tok, generation_config={"do_sample": False}, _forced_tokens=forced, _prefill_noise=pre,
+                     _noise_fn=lambda step, n2: next(it).reshape(n2, 64), show_progress_bar=False, refresh_negative=False)
+    assert torch.equal(out.sequences.cpu(), torch.from_numpy(z["sequences"]))
+    assert next(it, None) is None
+    for b in range(B):
+        ref = torch.from_numpy(z[f"audio_{b}"])
+        got = out.speech_outputs[b].reshape(-1).float().cpu()
+        assert got.shape == ref.shape
+        assert rel_err(got, ref) <= 1e-2, rel_err(got, ref)
 
 
 def test_generate_greedy_free_running(sm):
@@ -227,8 +279,8 @@ def test_streamer_contract_and_stop_check(sm):
     out3 = m.generate(input_ids=ids, attention_mask=mask, cfg_scale=1.3, tokenizer=tok, audio_streamer=fs3,
                       _forced_tokens=forced, show_progress_bar=False)
     assert fs3.puts == []
-    with pytest.raises(NotImplementedError):
-        m.generate(input_ids=ids, attention_mask=mask, tokenizer=tok, refresh_negative=False)
+    with pytest.raises(NotImplementedError):       # a rule over the rows of ONE lock-step batch: the request queue refuses it
+        m.generate_continuous([dict(input_ids=ids[:1], attention_mask=mask[:1])], tokenizer=tok, refresh_negative=False)
     with pytest.raises(ValueError):
         big = torch.cat([ids, ids, ids], 0)
         m.generate(input_ids=big, attention_mask=torch.ones_like(big), tokenizer=tok)

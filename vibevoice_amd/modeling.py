@@ -798,6 +798,13 @@ class VibeVoiceForConditionalGenerationInference:
                     e.lm_logits(1, self._hid_fresh[u.slot:u.slot + 1], self._logits[(nR + i) * nv:])
         self._logits_pin.copy_(self._logits, non_blocking=True)      # whole (contiguous) buffer: a true async D2H
         self._lg_event.record(e.stream)
+        refresh = S["refresh_negative"]
+        if not refresh:
+            # refresh_negative=False (:503-516): the negative pass runs at EVERY step for every row on the input the positive pass
+            # consumed -- the speculative rows above for `run`; at step 0 (inputs_embeds still None, :395) the lone <speech_start>
+            # prompt token
+            for i, u in enumerate(fresh):
+                e.lm_forward([(2 * u.slot + 1, u.neg_len)], self._start_emb, self._neg_hidden[i:i + 1])
 
         def pos_hidden(i):                      # hidden state of order[i]'s positive row, [1, H]
             return self._hidden[i:i + 1] if i < nR else self._hid_fresh[order[i].slot:order[i].slot + 1]
@@ -892,7 +899,7 @@ class VibeVoiceForConditionalGenerationInference:
         for u in order:
             if u.last == end_id:
                 e.codec_reset(u.slot)
-            if not u.finished and u.last == start_id:
+            if refresh and not u.finished and u.last == start_id:
                 # :549-565 -- the reference masks the whole negative cache and un-masks only the slot of the NEXT token, so the
                 # negative context restarts empty and the next negative pass re-feeds <speech_start> at position 0
                 # (pinned against the reference's generate(): tests/golden/generate_forced_*.npz)
@@ -912,6 +919,12 @@ class VibeVoiceForConditionalGenerationInference:
                 torch.set_rng_state(rng_state)
         cond_used = self._hidden if spec_sample else self._cond
         n = len(diff)
+        if not refresh:
+            # the entry the negative pass appended at this step stays for a live row that does not diffuse, unless some row of the
+            # batch does: then the reference's correction of :590-624 shifts it back out (pinned by generate_norefresh_b2.npz)
+            for u in plain:
+                if not diff:
+                    u.neg_len += 1
         if diff and spec_sample:
             for u in diff:
                 u.neg_len += 1
@@ -922,6 +935,8 @@ class VibeVoiceForConditionalGenerationInference:
                 self._cond[j].copy_(pos_hidden(oi)[0])
                 if u.have_embeds:
                     self._cond[n + j].copy_(self._hidden[nR + oi])
+                elif not refresh:
+                    self._cond[n + j].copy_(self._neg_hidden[oi - nR])
                 else:
                     # first negative step of a fresh utterance: the lone <speech_start> prompt token (:379-386)
                     e.lm_forward([(2 * u.slot + 1, u.neg_len)], self._start_emb, self._neg_hidden[j:j + 1])
@@ -1025,8 +1040,6 @@ class VibeVoiceForConditionalGenerationInference:
         e = self.engine
         if tokenizer is None:
             raise ValueError("generate() needs tokenizer= (speech_start_id / speech_end_id / speech_diffusion_id / eos_token_id)")
-        if not kwargs.get("refresh_negative", True):
-            raise NotImplementedError("refresh_negative=False is not supported by the HIP path")
         do_sample, temperature, warp = self._generation_options(generation_config)
         start_id, end_id, diff_id = tokenizer.speech_start_id, tokenizer.speech_end_id, tokenizer.speech_diffusion_id
         eos_id = tokenizer.eos_token_id
@@ -1043,7 +1056,7 @@ class VibeVoiceForConditionalGenerationInference:
                     pad_id=getattr(tokenizer, "pad_token_id", None),
                     trace=kwargs.pop("_trace", None), audio_streamer=audio_streamer, verbose=kwargs.get("verbose", False),
                     forced=kwargs.pop("_forced_tokens", None), noise_fn=kwargs.pop("_noise_fn", None), n_rows=n_rows,
-                    teacher=kwargs.pop("_teacher_embeds", None),
+                    teacher=kwargs.pop("_teacher_embeds", None), refresh_negative=bool(kwargs.get("refresh_negative", True)),
                     frame_rows=0, n_frames=0, step=0, sample_rows=None)
 
     # ------------------------------------------------------------------ generate
@@ -1245,6 +1258,11 @@ class VibeVoiceForConditionalGenerationInference:
             raise ValueError("no engine slot available")
         kwargs = dict(kwargs)
         step_cb = (kwargs.pop("_bench_hooks", None) or BenchHooks()).step_callback
+        if not kwargs.get("refresh_negative", True):
+            # with refresh_negative=False a row's negative cache depends on whether ANOTHER row of the same batch diffuses at that
+            # step (the correction of :590-624): defined for the lock-step batch of generate(), not for a queue of requests
+            raise NotImplementedError("refresh_negative=False is a rule over the rows of one lock-step batch: use generate() with at "
+                                      f"most {MAX_BATCH} rows (continuous admission / larger batches refuse it)")
         S = self._session(tokenizer, generation_config, cfg_scale, kwargs, audio_streamer, n_req)
         S["sample_rows"] = lambda order: [u.idx for u in order]
         self._frame_w = cap
