@@ -385,14 +385,16 @@ def test_short_prompt_gemm3_k_split_and_reduce(epi, T, N, K):
 
 
 # ---------------------------------------------------------------------------------------------- (d) bf16-input references
-@pytest.mark.parametrize("L0,chunk,heads,kv_heads,hd", [(4180, 512, 4, 2, 128), (1000, 1024, 7, 1, 128), (1555, 1024, 14, 2, 64), (90, 128, 4, 2, 128)])
+@pytest.mark.parametrize("L0,chunk,heads,kv_heads,hd", [(4180, 512, 4, 2, 128), (1000, 1024, 7, 1, 128), (1555, 1024, 14, 2, 64), (90, 128, 4, 2, 128),
+                                                        (1330, 1024, 12, 2, 128), (700, 512, 3, 1, 128), (333, 256, 2, 2, 128), (1100, 1024, 5, 1, 64)])
 def test_prefill_attention_v3_against_the_bf16_input_oracle(L0, chunk, heads, kv_heads, hd):
     """vv_attn_prefill4 (+ the packed-activation GEMMs around it) ROW BY ROW against the oracle with bf16 matrix-unit inputs: one
     softmax update per 64-position stage, v_permlane16/32_swap row exchange (a clang quirk reads the wrong element of the builtin's
     result unless it goes through unsigned temporaries -- this test is what pins it), mask-free path below the diagonal.  A masking
     or tail-stage slip is an O(1) error in single rows, which a whole-tensor norm hides.  Shapes: ragged tails with 1..32 and
-    33..64 live positions in the last stage, passes that start at a non-zero position, GQA groups 2 / 7 (one idle wave pair), both
-    head widths, a prompt shorter than one pass."""
+    33..64 live positions in the last stage, passes that start at a non-zero position, GQA groups 1 / 2 / 3 / 5 / 6 / 7 (a workgroup
+    takes four (row tile, query head) units: groups that are not multiples of 4 make it straddle two row tiles, groups below 4 up to
+    four, and the last workgroup is partly idle), both head widths, a prompt shorter than one pass."""
     from test_gpu_geometry import _prefill_probe
     got, s, x = _prefill_probe(L0, chunk, heads, kv_heads, hd)
     c = s.lmcfg

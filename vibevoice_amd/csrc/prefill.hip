@@ -18,9 +18,9 @@
 //                           anti-phase (one computes while the other loads), strip-ordered tiles (an XCD's L2 serves 4 weight
 //                           blocks x 8 row blocks at a time), the partial last round split along K; one more epilogue: bias +
 //                           RoPE + KV-cache append for the QKV projection.
-//   vv_attn_prefill4_kernel causal attention for a chunk of consecutive positions: a workgroup owns 64 query rows x 4 query
-//                           heads of one kv head, streams the causal prefix ONCE, 64 positions per stage through a 4-slot LDS
-//                           ring; 8 waves = 4 query heads x 2 row halves in anti-phase (matrix segment / softmax segment), one
+//   vv_attn_prefill4_kernel causal attention for a chunk of consecutive positions: a workgroup owns 4 units (64 query rows x 1 query
+//                           head) of one kv head, streams the causal prefix ONCE, 64 positions per stage through a 4-slot LDS
+//                           ring; 8 waves = 4 units x 2 row halves in anti-phase (matrix segment / softmax segment), one
 //                           lazy-rescaled softmax step per stage, row sums through the matrix pipe; the result leaves as the
 //                           o-projection's packed operand.
 #include <cstdlib>
@@ -762,7 +762,7 @@ __device__ __forceinline__ float a3_xrow_max(float v) {
 }
 
 // rows = consecutive positions of ONE cache (rows[0] first); q = the rotated queries (vv_rope_append_kernel), fp32 [R][Hq][D]; the
-// softmax scale is applied here.  A workgroup = 64 query rows x 4 query heads of one kv head, 8 waves = head x row half (two
+// softmax scale is applied here.  A workgroup = 4 units (64 query rows x one query head) of one kv head, 8 waves = unit x row half (two
 // 16-row tiles per wave), the causal prefix streamed ONCE, 64 positions per stage through a 4-slot LDS ring (LDS-DMA).
 // Round 2's form of this kernel (all waves in step: S^T MFMAs -> softmax -> P.V MFMAs between two barriers per stage) ran the
 // matrix pipe 31-33 % busy: both waves of a SIMD contended for it, then both for the VALU.  Here the two waves of a SIMD (w and
@@ -807,18 +807,26 @@ __global__ __launch_bounds__(512) void vv_attn_prefill4_kernel(
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int half = wave >> 2;
-    const int qt = (int)gridDim.x - 1 - (int)blockIdx.x;                        // longest workgroups first
-    const int r0 = qt * 64, kvh = blockIdx.y;
-    const int rw0 = r0 + half * (RT * 16);           // first query row of this wave
+    // The work of one kv head is n_rt x G units (64-row tile, query head of the group), tile-major; a workgroup takes FOUR
+    // consecutive units (a wave pair each).  With 4 heads per workgroup taken from ONE tile a group of 7 left every eighth wave pair
+    // idle (6: every fourth); packed, a workgroup may straddle two adjacent tiles (more when G < 4): it walks the longer
+    // prefix and the earlier tile's rows see the extra stage fully masked (what the ragged diagonal stage already is for them).
     const VVRow rw = rows[0];
     const int G = Hq / Hkv;
-    const int g = (int)blockIdx.z * 4 + (wave & 3);  // this wave's query head inside the group
-    const bool act = g < G;
-    const int h = kvh * G + (act ? g : 0);
+    const int n_rt = (R + 63) >> 6, n_units = n_rt * G;
+    const int b = (int)gridDim.x - 1 - (int)blockIdx.x;                         // longest workgroups first
+    const int u = b * 4 + (wave & 3);                                           // this wave pair's unit
+    const bool act = u < n_units;
+    const int qt_lo = (b * 4) / G, qt_hi = min(b * 4 + 3, n_units - 1) / G;     // tiles this workgroup touches
+    const int qt = act ? u / G : qt_hi;
+    const int g = act ? u - qt * G : 0;                                         // this wave's query head inside the group
+    const int r0 = qt * 64, kvh = blockIdx.y;
+    const int rw0 = r0 + half * (RT * 16);           // first query row of this wave
+    const int h = kvh * G + g;
     const int col = lane & 15, qg = lane >> 4;
-    const int pend = rw.pos + min(r0 + 63, R - 1) + 1;              // positions this tile walks: [0, pend)
+    const int pend = rw.pos + min(qt_hi * 64 + 63, R - 1) + 1;        // positions this workgroup walks: [0, pend)
     const int n = (pend + 63) >> 6;                                   // stages
-    const int first_masked = (rw.pos + r0) >> 6;                      // stages below this one are visible to every query row
+    const int first_masked = (rw.pos + qt_lo * 64) >> 6;              // stages below this one are visible to every query row
     const u32x4* kt_base = reinterpret_cast<const u32x4*>(kc + (int64_t)rw.cache * cache_stride + (int64_t)kvh * head_stride);
     const u32x4* vt_base = reinterpret_cast<const u32x4*>(vc + (int64_t)rw.cache * cache_stride + (int64_t)kvh * head_stride);
     constexpr float LOG2E = 1.4426950408889634f;
@@ -1205,7 +1213,7 @@ int vv_attn_prefill4_launch(int D, const float* q, const VVRow* rows, const void
     if (Hq % Hkv != 0 || (D != 128 && D != 64)) return -1;
     if (out_packed && ((Hq * D) & 31)) return -1;
     const int G = Hq / Hkv;
-    const dim3 grid((R + 63) / 64, Hkv, (G + 3) / 4);
+    const dim3 grid((unsigned)((((int64_t)(R + 63) / 64) * G + 3) / 4), Hkv, 1);     // four (row tile, query head) units per workgroup
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vv_attn_prefill4_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
