@@ -1,7 +1,7 @@
 #!/bin/bash
-# round 4 closing pass on the FINAL build (after the K-split timeout rework): bench lines, FETCH_SIZE passes -> profiles/pmc_traffic.json,
+# round 4 closing pass on the FINAL build: bench lines, FETCH_SIZE passes -> profiles/pmc_traffic.json,
 # the default line again (now with `traffic`), north-star kernel trace + MFMA-busy pass, the GPU suite
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final2; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final3; mkdir -p $O
 cd $R; export TMPDIR=/tmp
 TAG=r04
 Q="--no-cpu-baseline --no-eager-baseline"
