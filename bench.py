@@ -488,14 +488,15 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline, with_parity=False):
     # every rank's own step time next to the max: an imbalance (a slow GPU, a straggling host loop) shows in the first SCALE run
     per_rank_ms = [round(v, 4) for v in parallel.per_rank_values(wall / K * 1e3, device)]
     # first-audio latency as SURVEY 8d defines it: generate() entry (voice-prompt encode + prompt prefill + first frame) -> the
-    # first chunk an AudioStreamer consumer receives on the host; 3 trials of the same request
+    # first chunk an AudioStreamer consumer receives on the host; 5 trials of the same request
     first_audio = None
     if rank == 0 and world == 1 and B == 1 and not args.continuous and not os.environ.get("VVHIP_NO_TTFA"):
         try:
             one_in = {k: v for k, v in inputs.items()}
+            os.environ.pop("VVHIP_TIME_PREFILL", None)          # the phase timer's syncs do not belong in a latency measurement
             lat = first_audio_trials(lambda st: model.generate(
                 tokenizer=synthetic.TOKENS, cfg_scale=args.cfg_scale, generation_config={"do_sample": False}, max_new_tokens=3,
-                show_progress_bar=False, _forced_tokens=forced, _noise_fn=lambda step, n2: noise_bank[step], audio_streamer=st, **one_in), 3)
+                show_progress_bar=False, _forced_tokens=forced, _noise_fn=lambda step, n2: noise_bank[step], audio_streamer=st, **one_in), 5)
             if lat:
                 first_audio = {"p50_ms": round(sorted(lat)[len(lat) // 2], 2), "trials_ms": [round(x, 2) for x in lat],
                                "definition": "generate() entry -> first chunk delivered to an AudioStreamer consumer thread on the host "

@@ -313,6 +313,39 @@ def test_pinned_ring_streamer_delivers_the_generated_audio(sm):
         assert torch.equal(torch.cat(chunks), out.speech_outputs[b].cpu().flatten())
 
 
+def test_streamer_ring_buffers_are_pooled_across_requests():
+    """One AudioStreamer per request: a finished streamer hands its pinned ring buffers to the module's pool and the next one takes
+    them (no pinned allocation in front of the next request's first chunk).  Three streamers in a row, different data each: the
+    consumer reads exactly what was put, the second and third run on buffers the first one allocated."""
+    from vibevoice_amd import streamer as S
+    dev = torch.device("cuda")
+    with S._POOL_LOCK:
+        S._POOL.clear()
+    seen = []
+    for trial in range(3):
+        st = S.AudioStreamer(batch_size=1, timeout=20.0)
+        data = [torch.full((1, 1, 3200), float(trial * 10 + i), device=dev) + torch.arange(3200, device=dev) * 1e-3 for i in range(5)]
+        for d in data:
+            st.put(d, torch.tensor([0]))
+        torch.cuda.synchronize()
+        seen.append({b.data_ptr() for b in st._ring if b is not None})
+        st.end()
+        got = list(st.get_stream(0))
+        assert len(got) == 5
+        for g, d in zip(got, data):
+            assert torch.equal(g.flatten(), d.cpu().flatten())
+        st._thread.join(timeout=10)
+        assert st._ring == [None] * len(st._ring)
+        with S._POOL_LOCK:
+            pooled = {b.data_ptr() for v in S._POOL.values() for b in v}
+        assert seen[-1] <= pooled                      # handed back
+    assert seen[1] <= seen[0] or seen[1] & seen[0]     # the second request ran on the first one's buffers
+    assert seen[2] & (seen[0] | seen[1])
+    # a put() after the stream has closed is dropped, and nothing is written into a buffer that went back to the pool
+    st.put(torch.zeros(1, 1, 3200, device=dev), torch.tensor([0]))
+    assert st._ring == [None] * len(st._ring)
+
+
 def test_generate_greedy_batch2_free_running(sm):
     """Free-running argmax on a desynchronised batch of TWO: vv_lm_logits writes a dense [n][n_valid] block
     and every row must pick from its own logits.  Row 1 of a B=2 run used to read stale data; forced-token tests cannot

@@ -491,7 +491,7 @@ class VibeVoiceForConditionalGenerationInference:
         of `prompt_rows` (default: a full max_rows pass and a ragged remainder) and (b) a REAL generate() on a synthetic
         one-speaker request (`voice_frames`-frame silent voice prompt, short prompt, three forced frames, explicit noise), i.e.
         the request path itself: encoder, connectors, prompt scatter, decode steps under the graph keys generate() uses,
-        sampler, both tokenizers, streamer-free output assembly.  Draws nothing from any RNG (noise is passed in; the device
+        sampler, both tokenizers, the streamer hand-off.  Draws nothing from any RNG (noise is passed in; the device
         generator's state is saved and restored around it) and leaves no state behind: caches are overwritten by the next
         prefill, codec states are zeroed at the start of every generate()."""
         import types
@@ -534,9 +534,16 @@ class VibeVoiceForConditionalGenerationInference:
             if not scaled:
                 self.engine.set_speech_factors(1.0, 0.0)
                 self._scaling, self._bias = 1.0, 0.0
-            self.generate(input_ids=ids, attention_mask=torch.ones_like(ids), tokenizer=tok, cfg_scale=1.3,
-                          generation_config={"do_sample": False}, max_new_tokens=4, show_progress_bar=False,
-                          _forced_tokens=[[D, D, D, tok.eos_token_id]], _noise_fn=lambda step, n2: torch.zeros(n2, L), **kw)
+            # through an AudioStreamer, as a serving request goes: its copy stream exists and its pinned ring buffers sit in the
+            # streamer module's pool afterwards, so the first real request's first chunk does not wait for pinned allocations
+            from .streamer import AudioStreamer
+            st = AudioStreamer(batch_size=1)
+            try:
+                self.generate(input_ids=ids, attention_mask=torch.ones_like(ids), tokenizer=tok, cfg_scale=1.3,
+                              generation_config={"do_sample": False}, max_new_tokens=4, show_progress_bar=False, audio_streamer=st,
+                              _forced_tokens=[[D, D, D, tok.eos_token_id]], _noise_fn=lambda step, n2: torch.zeros(n2, L), **kw)
+            finally:
+                st.close()
             if not scaled:
                 self._scaling = self._bias = float("nan")
             self._valid_key = None
@@ -566,7 +573,10 @@ class VibeVoiceForConditionalGenerationInference:
         self._noise[:n].copy_(pin[:n], non_blocking=True)
 
     def _process_speech_inputs(self, speech_tensors, speech_masks, prefill_noise=None):
-        """_process_speech_inputs (:149-163): encode voice prompts, sample, scale, connect."""
+        """_process_speech_inputs (:149-163): encode voice prompts, sample, scale, connect.
+        Every host -> device copy of the call (waveform, frame selection, explicit noise) goes out BEFORE the encoder is enqueued:
+        a pageable copy blocks the host until the stream has drained, and a boolean-mask gather synchronises to count its rows --
+        behind the encoder either one keeps the prompt pass from being enqueued while the encoder runs."""
         e = self.engine
         hop = e.cfg.hop
         n_spk, S = speech_tensors.shape
@@ -577,6 +587,10 @@ class VibeVoiceForConditionalGenerationInference:
             speech_tensors = torch.nn.functional.pad(speech_tensors, (0, pad))
             frames += 1
         wav = speech_tensors.to(self.device, torch.float32).contiguous()
+        # rows of the [n_spk * frames] encoder output that are real frames (speech_masks is the processor's host data)
+        sel_idx = speech_masks.reshape(-1).to(torch.bool).cpu().nonzero().squeeze(1).to(self.device)
+        if prefill_noise is not None:
+            prefill_noise = tuple(t.to(self.device, torch.float32) for t in prefill_noise)
         mean = e.new(n_spk, frames, e.cfg.latent_dim)
         for i in range(n_spk):
             e.acoustic_encode(frames, wav[i], mean[i])
@@ -589,16 +603,16 @@ class VibeVoiceForConditionalGenerationInference:
                 r1 = torch.randn(n_spk, device=self.device, dtype=torch.float32)
                 r2 = torch.randn_like(torch.empty(n_spk, mean.shape[2], mean.shape[1], device=self.device, dtype=torch.float32).permute(0, 2, 1))
             else:
-                r1, r2 = (t.to(self.device, torch.float32) for t in prefill_noise)
+                r1, r2 = prefill_noise
             lat = mean + (r1 * (self.fix_std / 0.8))[:, None, None] * r2
         elif self.std_dist_type == "fix":
             r2 = (torch.randn_like(torch.empty(n_spk, mean.shape[2], mean.shape[1], device=self.device).permute(0, 2, 1))
-                  if prefill_noise is None else prefill_noise[1].to(self.device))
+                  if prefill_noise is None else prefill_noise[1])
             lat = mean + self.fix_std * r2
         else:
             lat = mean
         feats = ((lat + self._bias) * self._scaling).contiguous()
-        sel = feats[speech_masks.to(self.device)].contiguous()            # [n_valid, 64]
+        sel = feats.reshape(n_spk * frames, -1).index_select(0, sel_idx)   # [n_valid, 64]: feats[speech_masks] without the count sync
         out = e.new(sel.shape[0], e.cfg.lm_hidden)
         e.connect(sel.shape[0], sel, None, out)
         return feats, out
@@ -727,7 +741,10 @@ class VibeVoiceForConditionalGenerationInference:
             hid = e.new(CH, H)
         self._embed_ids(ids, emb)
         if speech_rows is not None and speech_pos is not None and speech_rows.shape[0]:
-            emb[speech_pos] = speech_rows
+            if speech_pos.dtype == torch.bool:
+                emb[speech_pos] = speech_rows                   # boolean mask: counts its rows on the host (a sync)
+            else:
+                emb.index_copy_(0, speech_pos, speech_rows)     # int64 positions, uploaded by the caller ahead of the encoder
         timed = os.environ.get("VVHIP_TIME_PREFILL") is not None
         if timed:                    # split the reported prefill time: embedding + voice-row scatter | LM passes
             e.sync(); torch.cuda.synchronize(self.device); t_emb = time.perf_counter()
@@ -1139,21 +1156,28 @@ class VibeVoiceForConditionalGenerationInference:
                     t_pf = [time.perf_counter()] if time_prefill else None
                     self._t_kv_fill = 0.0
                     self._t_lm_pass = 0.0
-                    if is_prefill and speech_tensors is not None and speech_masks is not None:
+                    with_voice = is_prefill and speech_tensors is not None and speech_masks is not None
+                    # masks are host data (the processor's output): positions and counts on the host (a device-side .sum() costs a
+                    # lazy kernel-module load (~20 ms) on its first use and a sync on every use), uploaded while the stream is
+                    # still idle -- behind the encoder a pageable copy would hold the host until the encoder has finished
+                    sp_pos = {}
+                    if with_voice and speech_input_mask is not None:
+                        for u in utts:
+                            sm_cpu = speech_input_mask[u.idx].cpu()[attention_mask[u.idx].bool().cpu()]
+                            idx = sm_cpu.to(torch.bool).nonzero().squeeze(1)
+                            if idx.numel():
+                                sp_pos[u.idx] = (int(idx.numel()), idx.to(self.device))
+                    if with_voice:
                         _, sp_embeds = self._process_speech_inputs(speech_tensors, speech_masks, prefill_noise)
                     if time_prefill:
                         e.sync(); torch.cuda.synchronize(self.device); t_pf.append(time.perf_counter())
                     sp_off = 0
                     for u in utts:
                         rows = pos = None
-                        if sp_embeds is not None and speech_input_mask is not None:
-                            # masks are host data (the processor's output): count on the host -- a device-side .sum() here costs
-                            # a lazy kernel-module load (~20 ms) on its first use and a sync on every use
-                            sm_cpu = speech_input_mask[u.idx].cpu()[attention_mask[u.idx].bool().cpu()]
-                            cnt = int(sm_cpu.sum())
-                            if cnt:
-                                rows, pos = sp_embeds[sp_off:sp_off + cnt], sm_cpu.to(self.device)
-                                sp_off += cnt
+                        if sp_embeds is not None and u.idx in sp_pos:
+                            cnt, pos = sp_pos[u.idx]
+                            rows = sp_embeds[sp_off:sp_off + cnt]
+                            sp_off += cnt
                         self._prefill(u, u.ids, rows, pos, kv_start, kv_fill_fn)
                     if time_prefill:
                         e.sync(); t_pf.append(time.perf_counter())
@@ -1325,8 +1349,10 @@ class VibeVoiceForConditionalGenerationInference:
                         _, sp = self._process_speech_inputs(r["speech_tensors"], r["speech_masks"], r.get("_prefill_noise"))
                         sim = r.get("speech_input_mask")
                         if sim is not None:
-                            pos = sim[0][am[0].bool()].to(self.device)
-                            rows = sp[:int(pos.sum())]
+                            idx = sim[0].cpu()[am[0].bool().cpu()].to(torch.bool).nonzero().squeeze(1)      # host data: no device count
+                            if idx.numel():
+                                pos = idx.to(self.device)
+                                rows = sp[:int(idx.numel())]
                     self._prefill(u, u.ids, rows, pos)
                     done[ri] = u
                     stats["admissions"].append((it, ri, slot))
