@@ -139,8 +139,10 @@ class AudioStreamer:
 
     def close(self):
         """Stop the drain thread and release the pinned ring (also happens by itself once every sample has ended)."""
-        if not self._closed:
+        with self._lock:                     # under the lock put() queues its copies: every one of them precedes the marker below
+            was_open = not self._closed
             self._closed = True
+        if was_open:
             # a consumer blocked in get_stream() / __iter__ with timeout=None must wake up: every sample that has not ended
             # gets its stop signal (ordered after its pending chunks) before the thread stops
             for idx in range(self.batch_size):
@@ -176,7 +178,18 @@ class AudioStreamer:
                     break
         with self._lock:                                 # no put() is between its closed check and its copy
             self._closed = True
-            _pinned_give(self._ring)                     # every copy into them has completed (their events were waited on above)
+        # a put() that raced with an end() / close() from another thread may have queued its copy behind the marker that ended the
+        # loop: wait for those copies too before the buffers change hands
+        import queue as _q
+        while True:
+            try:
+                item = self._work.get_nowait()
+            except _q.Empty:
+                break
+            if item[0] == "slot":
+                item[3].synchronize()
+        with self._lock:
+            _pinned_give(self._ring)                     # every copy into them has completed (their events have been waited on)
             self._ring = [None] * len(self._ring)
             self._pcm_dev = [None] * len(self._pcm_dev)  # release the device staging
 
