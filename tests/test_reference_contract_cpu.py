@@ -94,3 +94,36 @@ def test_reference_model_exposes_the_parameter_table_the_loader_reads(tag):
     assert set(syn) <= set(ref_sd)
     assert set(ref_eng) - set(syn_eng) <= {map_param_name("lm_head.weight")}
     assert {n: (syn_eng[n], ref_eng[n]) for n in syn_eng if syn_eng[n] != ref_eng[n]} == {}
+
+
+def test_reference_streaming_model_exposes_the_parameter_table_the_loader_reads():
+    """Streaming-0.5B: no config file ships with the reference; the architecture dict of vibevoice_amd.configs goes through the
+    reference's own VibeVoiceStreamingConfig / model classes (full depth: 4 + 20 layers at 896 wide) and every tensor the engine is
+    fed is there with that shape -- the reference model only adds the acoustic tokenizer's ENCODER, which streaming inference never
+    runs (voice prompts arrive as prefilled caches, modeling_vibevoice_streaming_inference.py:412-751)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import refshim
+    RefS = refshim.install_streaming_shims()
+    from vibevoice.modular.configuration_vibevoice_streaming import VibeVoiceStreamingConfig
+    from vibevoice_amd import synthetic
+    from vibevoice_amd.configs import CONFIGS
+    raw = copy.deepcopy(CONFIGS["0.5b-streaming"])
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)
+    tsaved = {n: getattr(torch.Tensor, n) for n in ("normal_", "uniform_", "fill_", "zero_")}
+    try:
+        for n in tsaved:
+            setattr(torch.Tensor, n, lambda self, *a, **k: self)
+        cfg = VibeVoiceStreamingConfig(**raw)
+        refshim.expose_text_config(cfg)
+        model = RefS(cfg)
+        ref_sd = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        del model
+    finally:
+        for n, f in tsaved.items():
+            setattr(torch.Tensor, n, f)
+        torch.set_default_dtype(old)
+    syn = {k: tuple(s) for k, s in synthetic.streaming_param_shapes(raw).items()}
+    assert set(syn) <= set(ref_sd)
+    assert all(k.startswith("model.acoustic_tokenizer.encoder.") for k in set(ref_sd) - set(syn))
+    assert {k: (syn[k], ref_sd[k]) for k in syn if syn[k] != ref_sd[k]} == {}
