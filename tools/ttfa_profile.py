@@ -16,6 +16,25 @@ _orig = bench.first_audio_trials
 
 
 def trials(fn, n_trials):
+    if os.environ.get("TTFA_FIRST"):
+        # the FIRST trial on its own (it is the slow one: 14 vs 10.9 ms at 1.5B), then a later one, side by side
+        for tag in ("first", "third"):
+            if tag == "third":
+                _orig(fn, 1)
+            pr = cProfile.Profile()
+
+            def fn_p(st, pr=pr):
+                pr.enable()
+                try:
+                    return fn(st)
+                finally:
+                    pr.disable()
+            lat1 = _orig(fn_p, 1)
+            s = io.StringIO()
+            pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(14)
+            print(f"[ttfa] {tag} trial {lat1} ms", file=sys.stderr)
+            print(s.getvalue(), file=sys.stderr)
+        return _orig(fn, n_trials)
     lat = _orig(fn, 2)                                   # warm
     pr = cProfile.Profile()
 

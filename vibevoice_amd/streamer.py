@@ -30,6 +30,20 @@ _POOL: dict = {}
 _POOL_CAP = 64
 
 
+# ... and so does the copy stream: a stream's first operations pay for its hardware queue (measured: 2 ms per wait_event on a
+# streamer's fresh stream, in front of the first request's first chunk); one per device, created once, warmed by warmup()
+_COPY_STREAMS: dict = {}
+
+
+def _copy_stream_for(device):
+    key = (device.type, device.index)
+    with _POOL_LOCK:
+        st = _COPY_STREAMS.get(key)
+        if st is None:
+            st = _COPY_STREAMS[key] = torch.cuda.Stream(device=device)
+        return st
+
+
 def _pinned_take(shape, dtype):
     with _POOL_LOCK:
         lst = _POOL.get((tuple(shape), dtype))
@@ -57,7 +71,7 @@ class AudioStreamer:
         self._pcm_engine = pcm16                  # vibevoice_amd.Engine (or None: chunks keep the producer's dtype)
         self._ring = [None] * ring_slots          # pinned host buffers, allocated on first use (shape of the first chunk)
         self._pcm_dev = [None] * ring_slots       # device int16 staging per ring slot (pcm16 mode)
-        self._copy_stream = None                  # D2H copies run here (created on the first device chunk)
+        self._copy_stream = None                  # D2H copies run here: the module's copy stream of the chunks' device
         self._free = Queue()
         for i in range(ring_slots):
             self._free.put(i)
@@ -116,7 +130,7 @@ class AudioStreamer:
         # whenever a new graph key was captured while a chunk was still in flight.)
         prod = torch.cuda.current_stream(audio_chunks.device)
         if self._copy_stream is None:
-            self._copy_stream = torch.cuda.Stream(device=audio_chunks.device)
+            self._copy_stream = _copy_stream_for(audio_chunks.device)
         ready = torch.cuda.Event()
         ready.record(prod)
         self._copy_stream.wait_event(ready)
