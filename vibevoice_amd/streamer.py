@@ -1,8 +1,8 @@
 """AudioStreamer / AsyncAudioStreamer for the HIP path.  Same surface as the reference's
 (vibevoice/modular/streamer.py: batch_size / stop_signal / timeout, put(audio_chunks, sample_indices),
 end(sample_indices=None), finished_flags, audio_queues, iteration, get_stream; AsyncAudioStreamer :150-264) -- but put()
-never blocks the generation loop: the chunk batch is copied into a pinned ring slot with ONE asynchronous D2H copy on the
-producing stream, an event marks it, and a background thread hands finished chunks to the per-sample queues (the
+never blocks the generation loop: the chunk batch is copied into a pinned ring slot with ONE asynchronous D2H copy on a copy
+stream ordered behind the producing stream, an event marks it, and a background thread hands finished chunks to the per-sample queues (the
 reference does `.detach().cpu()` per sample = one stream sync each).
 
 `pcm16=engine` converts each chunk to 16-bit PCM on the device before it leaves (vv_audio_to_pcm16: the arithmetic of the
