@@ -447,6 +447,9 @@ def gen_generate():
     # the cache correction of :590-624
     run("generate_norefresh_b1.npz", 1, [[D, D, D, D, E, S, D, D, D, X]], seed=83, refresh_negative=False)
     run("generate_norefresh_b2.npz", 2, [[D, D, D, E, S, D, D, X], [D, D, E, S, D, X]], seed=89, refresh_negative=False)
+    # max_length_times (:370, :421-422): the loop length follows the PADDED prompt width (int(0.4 * 21) = 8 steps), each row's own cap
+    # its unpadded length (21 -> 8, 17 -> int(6.8) = 6): the shorter row is stopped by reach_max_step_sample while the other goes on
+    run("generate_times_b2.npz", 2, [[D] * 50, [D] * 50], seed=101, max_length_times=0.4)
 
 
 @torch.no_grad()

@@ -689,3 +689,30 @@ def test_generate_without_negative_refresh_lands_on_the_reference_golden(product
     assert not torch.allclose(out2.speech_outputs[0].float(), outputs.speech_outputs[0].float())
     with pytest.raises(NotImplementedError):
         model.generate_continuous([{k: v[:1] for k, v in inputs.items()}], tokenizer=TOK, refresh_negative=False)
+
+
+# ---------------------------------------------------------------- max_length_times (modeling_vibevoice_inference.py:370, :421-422, :523-539)
+def test_generate_with_a_length_factor_lands_on_the_reference_golden(product):
+    """generate(..., max_length_times=0.4) on a left-padded batch of two, seeded like the run that recorded the golden with the REFERENCE's
+    own generate(): the loop runs int(0.4 * padded width) steps, each row's own cap follows its unpadded length -- the shorter row is
+    stopped by reach_max_step_sample (its last token is still recorded, its frame is not) while the longer one runs to the end of the
+    loop unflagged.  Only the forced token plan is injected."""
+    modeling, path = product
+    model = modeling.VibeVoiceForConditionalGenerationInference.from_pretrained(path, torch_dtype=torch.float32, device_map="cuda")
+    model.eval()
+    model.set_ddpm_inference_steps(num_steps=5)
+    z = np.load(os.path.join(GOLD, "generate_times_b2.npz"))
+    inputs = {"input_ids": torch.from_numpy(z["input_ids"]), "attention_mask": torch.from_numpy(z["attention_mask"]),
+              "speech_tensors": torch.from_numpy(z["speech_tensors"]), "speech_masks": torch.from_numpy(z["speech_masks"]),
+              "speech_input_mask": torch.from_numpy(z["speech_input_mask"])}
+    forced = [z["forced"][b][:int(z["forced_len"][b])].tolist() for b in range(2)]
+    torch.manual_seed(int(z["seed"]))
+    out = model.generate(**inputs, max_new_tokens=None, cfg_scale=1.3, tokenizer=TOK, generation_config={'do_sample': False},
+                         verbose=False, is_prefill=True, max_length_times=0.4, _forced_tokens=forced)
+    assert torch.equal(out.sequences.cpu(), torch.from_numpy(z["sequences"]))
+    assert out.reach_max_step_sample.tolist() == [False, True]
+    assert torch.equal(out.reach_max_step_sample.cpu(), torch.from_numpy(z["reach_max"]))
+    for b in range(2):
+        ref = torch.from_numpy(z[f"audio_{b}"])
+        got = out.speech_outputs[b].reshape(-1)
+        assert got.shape == ref.shape and float((got - ref).norm() / ref.norm()) <= 1e-4

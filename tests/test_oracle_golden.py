@@ -179,7 +179,7 @@ def _oracle_small(kv_round_bf16=False):
 
 
 @pytest.mark.parametrize("name", ["generate_forced_b1", "generate_forced_b2", "generate_greedy_b1", "generate_cap_b1", "generate_ragged_voice_b1",
-                                  "generate_norefresh_b1", "generate_norefresh_b2"])
+                                  "generate_norefresh_b1", "generate_norefresh_b2", "generate_times_b2"])
 def test_generate_loop_matches_the_reference_generate(name):
     """Golden = the REFERENCE's own generate() (modeling_vibevoice_inference.py:326-710) run on the tiny seeded model
     (tests/golden/make_golden.py::gen_generate, through oracle/refshim.install_generate_shims).  The oracle loop gets
@@ -187,7 +187,8 @@ def test_generate_loop_matches_the_reference_generate(name):
     rel-L2 <= 1e-4 (fp32 both sides; different summation order only).  Covers voice-prompt prefill, the negative branch's
     reset on <speech_start>, the cache fix-ups for non-diffusing rows of a desynchronised batch, the codec cache reset
     on <speech_end>, EOS / max-length bookkeeping; the two generate_norefresh files are refresh_negative=False runs (negative pass at
-    every step, never reset, :503-516)."""
+    every step, never reset, :503-516); generate_times_b2 runs with max_length_times=0.4 on a left-padded batch of two (the loop length
+    follows the padded width, each row's cap its own length: the shorter row is stopped by reach_max_step_sample, :421-422,523-539)."""
     from oracle import generate as ogen
     z = np.load(os.path.join(G, name + ".npz"))
     tok = ogen.TokenIds(speech_start_id=301, speech_end_id=302, speech_diffusion_id=303, eos_token_id=304,
@@ -210,7 +211,8 @@ def test_generate_loop_matches_the_reference_generate(name):
                                              torch.from_numpy(z["speech_tensors"]), torch.from_numpy(z["speech_masks"]),
                                              torch.from_numpy(z["speech_input_mask"]), cfg_scale=1.3, num_steps=5,
                                              max_new_tokens=mnt, noise_fn=noise_fn, prefill_noise=pre, forced_tokens=forced,
-                                             refresh_negative="norefresh" not in name)
+                                             refresh_negative="norefresh" not in name,
+                                             max_length_times={"generate_times_b2": 0.4}.get(name, 2))
     assert torch.equal(seq, torch.from_numpy(z["sequences"]))
     assert torch.equal(reach, torch.from_numpy(z["reach_max"]))
     assert next(it, None) is None                      # every recorded draw was consumed, in order
