@@ -18,9 +18,9 @@ Negative (CFG) branch, compact form of :379-386, :549-565, :576-624:
     this step (:579-581), or the lone <speech_start> prompt token on step 0;
   * on <speech_start> (:549-565) everything but the first entry is dropped
     (mask := 0 except last; K/V[last] := K/V[0]) -> compact length 1.
-    (Exact whenever an utterance's first negative step is the batch's first
-    negative step, which the processor's prompt guarantees: every prompt ends
-    in <speech_start>, so step 0 emits <speech_diffusion> for every row.)
+    (Pinned also for rows whose first frame comes later than the batch's first:
+    tests/golden/generate_late_start_b2*.npz -- where the reference's tokenizer
+    cache couples the rows, see the decode step.)
 
 PARITY PINNED: the reference's own generate() runs in the build container under transformers 5.15 through the
 API shims of oracle/refshim.install_generate_shims(); tests/golden/make_golden.py::gen_generate recorded it on the
@@ -104,12 +104,14 @@ def oracle_generate(m: OracleModel, tok: TokenIds, input_ids, attention_mask,
                     forced_tokens: Optional[List[List[int]]] = None,
                     do_sample=False, trace: Optional[Trace] = None,
                     algorithm_type="dpmsolver++", sde_noise_fn: Callable = None,
-                    teacher_embeds: Callable = None, refresh_negative: bool = True):
+                    teacher_embeds: Callable = None, refresh_negative: bool = True, batch_cache_quirk: bool = True):
     """Returns (sequences [B, L0+steps], speech_outputs list, reach_max_step_sample).
     algorithm_type "sde-dpmsolver++": the scheduler demo/gradio_demo.py:142-146 installs; sde_noise_fn(step, N, 2n) ->
     [N, 2n, 64], the variance noise scheduler.step() draws per solver step (dpm_solver.py:994-997).
     teacher_embeds(step) -> [B, H] or None: test hook (SURVEY 8d "teacher-forced per step") -- the NEXT positive pass consumes these
     embeddings instead of the loop's own, so two implementations are compared step by step on identical inputs.
+    batch_cache_quirk=False: every row keeps its own tokenizer history whatever the other rows do (what a queue of independent
+    requests computes: generate_continuous) instead of the lock-step batch's behaviour described at the decode step below.
     refresh_negative=False (:503-516; the reset of :550-565 and the forward of :576-588 are then skipped): the negative pass runs at
     EVERY step for every row, right after the token choice, on the embedding the positive pass consumed at this step (the lone
     <speech_start> prompt token at step 0, where inputs_embeds is still None, :395); it is never reset.  The correction of
@@ -220,6 +222,16 @@ def oracle_generate(m: OracleModel, tok: TokenIds, input_ids, attention_mask,
                 pos_cond, neg_hidden, cfg_scale, num_steps, noise, m.t_cast_dtype,
                 algorithm_type=algorithm_type, step_noise=sn)
             scaled = lat / m.scaling - m.bias
+            # VibeVoiceTokenizerStreamingCache.get (modular_vibevoice_tokenizer.py:198-207) returns None -- "no history", i.e. zero
+            # left context for EVERY row of the call -- as soon as ONE of the requested rows has no entry yet.  A row that diffuses
+            # for the first time therefore costs the rows decoded in the same call their conv history for that frame (both
+            # tokenizers; the new states are stored for all of them afterwards).  Every processor-built prompt ends in
+            # <speech_start> and all rows take their first frame together at step 0, where "no history" is the right answer, so the
+            # quirk never fires there; under a forced plan that starts a row late it does (pinned by generate_late_start_b2*.npz).
+            if batch_cache_quirk and any(not ac_state[b] for b in diff) and any(ac_state[b] for b in diff):
+                for b in diff:
+                    codec.zero_state(ac_state[b])
+                    codec.zero_state(sem_state[b])
             sem_list = []
             for j, b in enumerate(diff):
                 chunk = codec.decoder_forward(m.ac_w, scaled[j][None, :, None], m.ratios, m.dec_depths,

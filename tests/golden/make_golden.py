@@ -450,6 +450,12 @@ def gen_generate():
     # max_length_times (:370, :421-422): the loop length follows the PADDED prompt width (int(0.4 * 21) = 8 steps), each row's own cap
     # its unpadded length (21 -> 8, 17 -> int(6.8) = 6): the shorter row is stopped by reach_max_step_sample while the other goes on
     run("generate_times_b2.npz", 2, [[D] * 50, [D] * 50], seed=101, max_length_times=0.4)
+    # a row whose first frame comes LATER than the other row's: VibeVoiceTokenizerStreamingCache.get (modular_vibevoice_tokenizer.py:
+    # 198-207) returns None for the whole call when one requested row has no entry yet, so the row that was already streaming loses its
+    # conv history for that frame (both tokenizers) -- a cross-row coupling of the lock-step batch that processor-built prompts never
+    # trigger (every row diffuses at step 0)
+    run("generate_late_start_b2.npz", 2, [[D, D, D, X], [E, S, D, D, X]], seed=201)
+    run("generate_late_start_b2r.npz", 2, [[S, D, D, X], [D, D, E, S, D, X]], seed=203)
 
 
 @torch.no_grad()

@@ -716,3 +716,35 @@ def test_generate_with_a_length_factor_lands_on_the_reference_golden(product):
         ref = torch.from_numpy(z[f"audio_{b}"])
         got = out.speech_outputs[b].reshape(-1)
         assert got.shape == ref.shape and float((got - ref).norm() / ref.norm()) <= 1e-4
+
+
+# ---------------------------------------------------------------- a row whose first frame comes later than the other row's
+@pytest.mark.parametrize("name", ["generate_late_start_b2", "generate_late_start_b2r"])
+def test_late_starting_row_costs_the_streaming_row_its_conv_history_as_in_the_reference(product, name):
+    """The reference's VibeVoiceTokenizerStreamingCache.get (modular_vibevoice_tokenizer.py:198-207) returns None for a whole decode /
+    encode call as soon as one requested row has no entry yet: in a lock-step batch the row that was already streaming loses its conv
+    history for the frame in which another row diffuses for the first time.  generate() reproduces it (golden recorded from the
+    reference's own generate(); waveform rel-L2 <= 1e-4 on BOTH rows); the request queue does not -- there each request ends as
+    generate() on it alone would, which for the streaming row is a different waveform."""
+    modeling, path = product
+    model = modeling.VibeVoiceForConditionalGenerationInference.from_pretrained(path, torch_dtype=torch.float32, device_map="cuda")
+    model.eval()
+    model.set_ddpm_inference_steps(num_steps=5)
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    inputs = {"input_ids": torch.from_numpy(z["input_ids"]), "attention_mask": torch.from_numpy(z["attention_mask"]),
+              "speech_tensors": torch.from_numpy(z["speech_tensors"]), "speech_masks": torch.from_numpy(z["speech_masks"]),
+              "speech_input_mask": torch.from_numpy(z["speech_input_mask"])}
+    forced = [z["forced"][b][:int(z["forced_len"][b])].tolist() for b in range(2)]
+    errs = {}
+    for speculate in (False, True):
+        model.speculate_sampling = speculate
+        torch.manual_seed(int(z["seed"]))
+        out = model.generate(**inputs, max_new_tokens=None, cfg_scale=1.3, tokenizer=TOK, generation_config={'do_sample': False},
+                             verbose=False, is_prefill=True, _forced_tokens=forced)
+        assert torch.equal(out.sequences.cpu(), torch.from_numpy(z["sequences"]))
+        for b in range(2):
+            ref = torch.from_numpy(z[f"audio_{b}"])
+            got = out.speech_outputs[b].reshape(-1)
+            assert got.shape == ref.shape
+            errs[(speculate, b)] = float((got - ref).norm() / ref.norm())
+    assert max(errs.values()) <= 1e-4, errs

@@ -143,11 +143,13 @@ def test_generate_without_negative_refresh(sm, B, forced, seed):
     assert any(rel_err(a, b) > 1e-2 for a, b in zip(o[3].neg_hidden, o2[3].neg_hidden))
 
 
-@pytest.mark.parametrize("name", ["generate_norefresh_b1", "generate_norefresh_b2"])
-def test_generate_without_negative_refresh_against_the_reference_golden(sm, name):
+@pytest.mark.parametrize("name", ["generate_norefresh_b1", "generate_norefresh_b2", "generate_late_start_b2", "generate_late_start_b2r", "generate_times_b2"])
+def test_generate_against_the_reference_goldens_of_the_rare_modes(sm, name):
     """the engine directly against what the REFERENCE's generate(refresh_negative=False) produced on the same tiny seeded model, inputs,
     forced plan and recorded noise draws (tests/golden/make_golden.py::gen_generate): sequences identical, waveform rel-L2 <= 1e-2
-    (xsplit = 3 against fp32)."""
+    (xsplit = 3 against fp32).  Also, in the default mode: the two late-start files (a row whose first frame comes later than the other
+    row's costs the streaming row its tokenizer conv history for that frame, modular_vibevoice_tokenizer.py:198-207) and the
+    max_length_times=0.4 run (per-row length caps on a left-padded batch)."""
     import os
     import numpy as np
     from test_oracle_golden import G as GOLD
@@ -171,8 +173,10 @@ def test_generate_without_negative_refresh_against_the_reference_golden(sm, name
     out = m.generate(input_ids=ids, attention_mask=torch.from_numpy(z["attention_mask"]), speech_tensors=torch.from_numpy(z["speech_tensors"]),
                      speech_masks=torch.from_numpy(z["speech_masks"]), speech_input_mask=torch.from_numpy(z["speech_input_mask"]),
                      cfg_scale=1.3, tokenizer=tok, generation_config={"do_sample": False}, _forced_tokens=forced, _prefill_noise=pre,
-                     _noise_fn=lambda step, n2: next(it).reshape(n2, 64), show_progress_bar=False, refresh_negative=False)
+                     _noise_fn=lambda step, n2: next(it).reshape(n2, 64), show_progress_bar=False, refresh_negative="norefresh" not in name,
+                     **({"max_length_times": 0.4} if name == "generate_times_b2" else {}))
     assert torch.equal(out.sequences.cpu(), torch.from_numpy(z["sequences"]))
+    assert torch.equal(out.reach_max_step_sample.cpu(), torch.from_numpy(z["reach_max"]))
     assert next(it, None) is None
     for b in range(B):
         ref = torch.from_numpy(z[f"audio_{b}"])

@@ -968,6 +968,17 @@ class VibeVoiceForConditionalGenerationInference:
                 e.diffusion_sample(n, self._cond, self._noise, cfg_scale, self._latent, step_noise=self._sde_draws(S, n))
             else:
                 e.diffusion_sample(n, self._cond, self._noise, cfg_scale, self._latent)
+        if diff and S.get("lockstep", True):
+            # The reference's VibeVoiceTokenizerStreamingCache.get (modular_vibevoice_tokenizer.py:198-207) answers "no history" for
+            # EVERY row of a decode / encode call as soon as ONE of its rows has no entry yet: in a lock-step batch, a row that
+            # diffuses for the first time costs the rows decoded with it their conv history for that frame (both tokenizers).  It
+            # cannot fire on processor-built prompts (every row takes its first frame at step 0); pinned by
+            # tests/golden/generate_late_start_b2*.npz.  A queue of independent requests (generate_continuous) keeps every row's own
+            # history instead -- each request ends as generate() on it alone would.
+            started = [u for u in diff if u.chunks]
+            if started and len(started) < len(diff):
+                for u in started:
+                    e.codec_reset(u.slot)
         if diff:
             # ---- codec decode, semantic encode, connectors (:636-672) ----
             if len(diff) > 1 and self.batched_codecs:
@@ -1209,8 +1220,10 @@ class VibeVoiceForConditionalGenerationInference:
         one-utterance request of generate_continuous() -- up to n_slots of them in flight, a finished row's slot refilled at once --
         and the results are assembled into ONE VibeVoiceGenerationOutput as the batched loop returns it (sequences [B, L0 + steps]
         padded with eos after a row's end, :499; speech_outputs one entry per row; reach_max_step_sample [B]).  Rows are
-        independent in the reference's loop (no cross-sample arithmetic, :393-394,549,573,594), so under greedy / forced decoding
-        each row is exactly what the batched call gives it; RNG-dependent draws (diffusion noise, do_sample) are consumed in queue
+        independent in the reference's loop (no cross-sample arithmetic, :393-394,549,573,594) with ONE exception this path does not
+        reproduce: a row whose first frame comes later than another's costs the rows decoded with it their tokenizer conv history
+        for that frame (the cache quirk described in _iterate; impossible on processor-built prompts, where every row takes its first
+        frame at step 0).  So under greedy / forced decoding each row is exactly what the batched call gives it; RNG-dependent draws (diffusion noise, do_sample) are consumed in queue
         order instead of the batch's lock-step order.  Loop lengths follow the batch: every row's cap uses the batch's padded
         width L0 (:421-422)."""
         B, L0 = input_ids.shape
@@ -1288,6 +1301,7 @@ class VibeVoiceForConditionalGenerationInference:
             raise NotImplementedError("refresh_negative=False is a rule over the rows of one lock-step batch: use generate() with at "
                                       f"most {MAX_BATCH} rows (continuous admission / larger batches refuse it)")
         S = self._session(tokenizer, generation_config, cfg_scale, kwargs, audio_streamer, n_req)
+        S["lockstep"] = False                   # independent requests: no cross-row tokenizer-cache coupling (see _iterate)
         S["sample_rows"] = lambda order: [u.idx for u in order]
         self._frame_w = cap
         self._first_row = {}
