@@ -10,17 +10,11 @@ cache_position) replaced by its arithmetic meaning on *compact per-utterance
 caches* (SURVEY.md 8c): a left-padded row's pads carry no information, position
 ids are cumsum(mask)-1 == index in the compact cache.
 
-Negative (CFG) branch, compact form of :379-386, :549-565, :576-624:
-  * the negative cache of utterance b only ever grows on steps where b emits
-    <speech_diffusion>; the reference forwards all rows and then masks the
-    spurious entry back out (:594-624) -- net effect "nothing appended";
-  * the appended token is the SAME embedding the positive pass consumed at
-    this step (:579-581), or the lone <speech_start> prompt token on step 0;
-  * on <speech_start> (:549-565) everything but the first entry is dropped
-    (mask := 0 except last; K/V[last] := K/V[0]) -> compact length 1.
-    (Pinned also for rows whose first frame comes later than the batch's first:
-    tests/golden/generate_late_start_b2*.npz -- where the reference's tokenizer
-    cache couples the rows, see the decode step.)
+Negative (CFG) branch (:379-386, :503-516, :549-565, :576-624): restated LITERALLY (class NegativeRow below: every entry ever
+appended, the attention mask over them, the correction counter), not in compact form.  An earlier compact form ("the spurious
+entry of a non-diffusing row is dropped; <speech_start> restarts the context empty") is the net effect almost everywhere, and
+exactly wrong in one case the fuzz tool found (tools/fuzz_generate_vs_reference.py): the correction guards its mask shift and its
+K/V shift differently, so a row holding one valid entry keeps the NEW entry and loses the old one.
 
 PARITY PINNED: the reference's own generate() runs in the build container under transformers 5.15 through the
 API shims of oracle/refshim.install_generate_shims(); tests/golden/make_golden.py::gen_generate recorded it on the
@@ -97,6 +91,67 @@ def process_speech_inputs(m: OracleModel, speech_tensors, speech_masks, prefill_
     return feats, connected
 
 
+class NegativeRow:
+    """One row of the reference's negative (CFG) branch, kept the way the reference keeps it: EVERY entry the negative pass ever
+    appended (K/V per layer), an attention mask over them plus the slot of the token fed next (HF extends the mask by one after
+    every forward, _update_model_kwargs_for_generation), and the row's correction counter (correct_cnt, :69).  The three things the
+    loop does to it are restated array operation by array operation, because their net effect is NOT always "drop the spurious
+    entry": the mask and the K/V shifts of the correction have different guards (:603 `start + 1 < seq_len - 1` with seq_len =
+    cache length + 1, :613 `start + 1 < cache length - 1`), so for a row with exactly one valid entry the mask moves and the K/V
+    does not -- the entry appended at this step STAYS and the older one is masked out (found by tools/fuzz_generate_vs_reference.py:
+    a row that emits <speech_diffusion> at step 0 and something else at step 1 while another row diffuses).
+    Position ids are mask-derived (cumsum - 1; what transformers 4.51.3's prepare_inputs_for_generation gives and oracle/refshim
+    restores): the new token sits at position = number of valid entries before it; stored keys keep the rotation they were
+    computed with."""
+
+    def __init__(self, lm):
+        self.lm = lm
+        self.full = lm.new_cache()          # all entries ever appended, masked ones included
+        self.mask = [1]                     # :379-386: the lone <speech_start> prompt token's slot
+        self.cnt = 0                        # correct_cnt[b]
+
+    def forward(self, e):
+        """one negative pass of this row on input embedding e [1, H]; returns the final hidden state [H]"""
+        c = self.full.length
+        assert len(self.mask) == c + 1
+        keep = [i for i in range(c) if self.mask[i]]
+        tmp = self.lm.new_cache()
+        if keep:
+            idx = torch.tensor(keep)
+            for l in range(len(tmp.k)):
+                tmp.k[l], tmp.v[l] = self.full.k[l][:, idx], self.full.v[l][:, idx]
+            tmp.length = len(keep)
+        h = self.lm.forward(e, tmp)[-1]
+        for l in range(len(tmp.k)):
+            nk, nv = tmp.k[l][:, -1:], tmp.v[l][:, -1:]
+            self.full.k[l] = nk if self.full.k[l] is None else torch.cat([self.full.k[l], nk], dim=1)
+            self.full.v[l] = nv if self.full.v[l] is None else torch.cat([self.full.v[l], nv], dim=1)
+        self.full.length = c + 1
+        self.mask.append(1)
+        return h
+
+    def reset_on_speech_start(self):
+        """:551-560: mask := 0 except the next token's slot; K/V[last] := K/V[0] (which that mask hides)"""
+        self.mask = [0] * len(self.mask)
+        self.mask[-1] = 1
+        if self.full.length > 0:
+            for l in range(len(self.full.k)):
+                self.full.k[l][:, -1] = self.full.k[l][:, 0].clone()
+                self.full.v[l][:, -1] = self.full.v[l][:, 0].clone()
+
+    def correct_non_diffusing(self):
+        """:594-624 for a live row that did not diffuse at a step where the negative pass ran"""
+        c, s, n = self.full.length, self.cnt, len(self.mask)
+        if s + 1 < n - 1:
+            self.mask[s + 1:] = self.mask[s:-1]
+        self.mask[s] = 0
+        if s + 1 < c - 1:
+            for l in range(len(self.full.k)):
+                self.full.k[l][:, s + 1:] = self.full.k[l][:, s:-1].clone()
+                self.full.v[l][:, s + 1:] = self.full.v[l][:, s:-1].clone()
+        self.cnt += 1
+
+
 def oracle_generate(m: OracleModel, tok: TokenIds, input_ids, attention_mask,
                     speech_tensors=None, speech_masks=None, speech_input_mask=None,
                     cfg_scale=1.3, num_steps=10, max_new_tokens=None, max_length_times=2,
@@ -131,7 +186,7 @@ def oracle_generate(m: OracleModel, tok: TokenIds, input_ids, attention_mask,
     finished = torch.zeros(B, dtype=torch.bool)
     reach_max = torch.zeros(B, dtype=torch.bool)
     pos_cache = [m.lm.new_cache() for _ in range(B)]
-    neg_cache = [m.lm.new_cache() for _ in range(B)]
+    neg = [NegativeRow(m.lm) for _ in range(B)]
     ac_state = [dict() for _ in range(B)]
     sem_state = [dict() for _ in range(B)]
     audio_chunks = [[] for _ in range(B)]
@@ -186,34 +241,27 @@ def oracle_generate(m: OracleModel, tok: TokenIds, input_ids, attention_mask,
         for b in (nxt == tok.speech_end_id).nonzero().flatten().tolist():
             codec.zero_state(ac_state[b])
             codec.zero_state(sem_state[b])
+        def neg_input(b):                  # :505-508 / :578-581: the embedding the positive pass consumed, or the lone prompt token
+            return m.lm.embed(torch.tensor([tok.speech_start_id])) if consumed is None else consumed[b][None]
         neg_all = None
         if not refresh_negative:
-            # ---- :503-516: negative pass of every row (finished rows too in the reference; their cache is never read again) ----
-            neg_all = {}
-            for b in range(B):
-                e = m.lm.embed(torch.tensor([tok.speech_start_id])) if consumed is None else consumed[b][None]
-                neg_all[b] = m.lm.forward(e, neg_cache[b])[-1]
+            # ---- :503-516: negative pass of every row at every step (finished rows too in the reference; theirs is never read) ----
+            neg_all = {b: neg[b].forward(neg_input(b)) for b in range(B)}
         # ---- <speech_start>: reset the negative branch (:549-565) ----
-        for b in (~finished & (nxt == tok.speech_start_id)).nonzero().flatten().tolist() if refresh_negative else []:
-            # The reference zeroes the negative attention mask except its LAST slot -- the slot of the token that will be fed
-            # next -- and copies K/V[0] into the last *cached* slot, which that mask then hides (:551-560).  Net effect
-            # (pinned by tests/golden/generate_forced_*.npz, recorded from the reference's own generate()): the negative
-            # context restarts EMPTY; the next negative pass consumes the <speech_start> embedding at position 0.
-            neg_cache[b].truncate(0)
+        if refresh_negative:
+            for b in (~finished & (nxt == tok.speech_start_id)).nonzero().flatten().tolist():
+                neg[b].reset_on_speech_start()
         next_embeds = m.lm.embed(nxt)                          # [B, H]
         diff = (~finished & (nxt == tok.speech_diffusion_id)).nonzero().flatten().tolist()
         if diff:
             n = len(diff)
             if refresh_negative:
-                neg_hidden = []
-                for b in diff:
-                    e = m.lm.embed(torch.tensor([tok.speech_start_id])) if consumed is None else consumed[b][None]
-                    neg_hidden.append(m.lm.forward(e, neg_cache[b])[-1])
-                neg_hidden = torch.stack(neg_hidden)
-            else:
-                neg_hidden = torch.stack([neg_all[b] for b in diff])
-                for b in (~finished & (nxt != tok.speech_diffusion_id)).nonzero().flatten().tolist():
-                    neg_cache[b].truncate(neg_cache[b].length - 1)          # :590-624
+                # :576-588: the negative pass runs for EVERY row whenever some row diffuses
+                neg_all = {b: neg[b].forward(neg_input(b)) for b in range(B) if not finished[b] or b in diff}
+            neg_hidden = torch.stack([neg_all[b] for b in diff])
+            # :590-624: the rows that are live and did not diffuse are "corrected"
+            for b in (~finished & (nxt != tok.speech_diffusion_id)).nonzero().flatten().tolist():
+                neg[b].correct_non_diffusing()
             pos_cond = hidden[diff]
             noise = noise_fn(step, 2 * n)
             sn = sde_noise_fn(step, num_steps, 2 * n) if algorithm_type == "sde-dpmsolver++" else None

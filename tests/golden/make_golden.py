@@ -36,11 +36,14 @@ refshim.install()
 import synth  # noqa: E402
 
 
+OUT_DIR = HERE          # tools/fuzz_generate_vs_reference.py points this elsewhere
+
+
 def save(name, **arrs):
     out = {}
     for k, v in arrs.items():
         out[k] = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
-    np.savez_compressed(os.path.join(HERE, name), **out)
+    np.savez_compressed(os.path.join(OUT_DIR, name), **out)
     print("wrote", name, {k: tuple(np.shape(v)) for k, v in out.items()})
 
 
@@ -262,8 +265,10 @@ class _Tok:
 
 
 @torch.no_grad()
-def gen_generate():
-    """Row G: the reference's OWN generate() loop (modeling_vibevoice_inference.py:326-710), tiny seeded weights, CPU
+def gen_generate(custom=None):
+    """custom: [(file name, batch, forced plans as lists of "D" / "E" / "S" / "X", seed, generate() keyword arguments)] -- record
+    THOSE runs instead of the goldens (the fuzz tool); None: the goldens.
+    Row G: the reference's OWN generate() loop (modeling_vibevoice_inference.py:326-710), tiny seeded weights, CPU
     fp32.  The token choice is forced through a LogitsProcessor (random weights would never emit <speech_diffusion>);
     every torch.randn / randn_like draw is recorded so the oracle can be fed the same noise."""
     from transformers import LogitsProcessor, LogitsProcessorList
@@ -332,12 +337,12 @@ def gen_generate():
 
     def run(name, B, plans, seed, max_new_tokens=None, do_sample=False, wav_len=3 * 3200, streamer=False, sde=False, gen_cfg=None, **gen_kw):
         g = synth.Gen(seed)
-        lens = [21, 17][:B]
+        lens = [21, 17, 19, 14][:B]
         L0 = max(lens)
         ids = torch.full((B, L0), T.pad_token_id, dtype=torch.long)
         mask = torch.zeros((B, L0), dtype=torch.long)
         sim = torch.zeros((B, L0), dtype=torch.bool)
-        n_fr = [2, 3]
+        n_fr = [2, 3, 1, 2]
         for b in range(B):
             n = lens[b]
             row = torch.from_numpy(g.rng.integers(0, 300, (n,)))
@@ -409,6 +414,11 @@ def gen_generate():
             arrs[f"audio_{b}"] = a.reshape(-1) if a is not None else torch.zeros(0)
         save(name, **arrs)
 
+    if custom is not None:
+        sym = {"D": D, "E": E, "S": S, "X": X}
+        for name, B, plans, seed, kw in custom:
+            run(name, B, [[sym[t] for t in p] for p in plans], seed=seed, **kw)
+        return
     run("generate_forced_b1.npz", 1, [[D, D, D, D, E, S, D, D, D, X]], seed=11)
     run("generate_forced_b2.npz", 2, [[D, D, D, E, S, D, D, X], [D, D, E, S, D, X]], seed=23, streamer=True)
     run("generate_greedy_b1.npz", 1, None, seed=31, max_new_tokens=10)
@@ -456,6 +466,11 @@ def gen_generate():
     # trigger (every row diffuses at step 0)
     run("generate_late_start_b2.npz", 2, [[D, D, D, X], [E, S, D, D, X]], seed=201)
     run("generate_late_start_b2r.npz", 2, [[S, D, D, X], [D, D, E, S, D, X]], seed=203)
+    # the correction of a non-diffusing row (:594-624) when that row holds exactly ONE valid negative entry (a one-frame segment: D, then
+    # <speech_end> while the other row diffuses): the mask shift is guarded by `start + 1 < seq_len - 1` (:603), the K/V shift by
+    # `start + 1 < cache length - 1` (:613) -- the mask moves, the K/V does not, the entry appended at this step stays and the older
+    # one is masked out
+    run("generate_single_entry_b2.npz", 2, [[D, D, D, S, D, E, D, X], [D, E, D, D, D, D, D, D, E, X]], seed=207)
 
 
 @torch.no_grad()

@@ -179,7 +179,7 @@ def _oracle_small(kv_round_bf16=False):
 
 
 @pytest.mark.parametrize("name", ["generate_forced_b1", "generate_forced_b2", "generate_greedy_b1", "generate_cap_b1", "generate_ragged_voice_b1",
-                                  "generate_norefresh_b1", "generate_norefresh_b2", "generate_times_b2", "generate_late_start_b2", "generate_late_start_b2r"])
+                                  "generate_norefresh_b1", "generate_norefresh_b2", "generate_times_b2", "generate_late_start_b2", "generate_late_start_b2r", "generate_single_entry_b2"])
 def test_generate_loop_matches_the_reference_generate(name):
     """Golden = the REFERENCE's own generate() (modeling_vibevoice_inference.py:326-710) run on the tiny seeded model
     (tests/golden/make_golden.py::gen_generate, through oracle/refshim.install_generate_shims).  The oracle loop gets
@@ -190,7 +190,9 @@ def test_generate_loop_matches_the_reference_generate(name):
     every step, never reset, :503-516); generate_times_b2 runs with max_length_times=0.4 on a left-padded batch of two (the loop length
     follows the padded width, each row's cap its own length: the shorter row is stopped by reach_max_step_sample, :421-422,523-539);
     the two generate_late_start files start one row's first frame later than the other's, where the reference's tokenizer cache drops the
-    streaming row's conv history for that frame (modular_vibevoice_tokenizer.py:198-207)."""
+    streaming row's conv history for that frame (modular_vibevoice_tokenizer.py:198-207); generate_single_entry_b2 has a one-frame segment
+    in one row while the other diffuses: the correction's mask shift happens and its K/V shift does not (:603 vs :613), the entry of
+    THAT step stays and the older one is masked (oracle.generate.NegativeRow restates the arrays literally)."""
     from oracle import generate as ogen
     z = np.load(os.path.join(G, name + ".npz"))
     tok = ogen.TokenIds(speech_start_id=301, speech_end_id=302, speech_diffusion_id=303, eos_token_id=304,

@@ -279,7 +279,7 @@ class _Utt:
     """One utterance in flight: its engine slot (KV caches 2*slot / 2*slot+1, codec states), lengths and outputs."""
     __slots__ = ("idx", "slot", "ids", "seq_len0", "init_len", "max_length", "max_steps", "max_step_sample", "step", "pos_len",
                  "neg_len", "have_embeds", "finished", "reach_max", "tokens", "chunks", "last", "forced", "noise_fn", "req",
-                 "t_admit", "t_done")
+                 "t_admit", "t_done", "neg_book")
 
     def __init__(self, idx, slot, ids, seq_len0, max_length, max_length_times, start_id):
         self.idx, self.slot, self.ids = idx, slot, ids
@@ -296,6 +296,9 @@ class _Utt:
         self.last = ids[-1] if ids else start_id
         self.forced = self.noise_fn = self.req = None
         self.t_admit = self.t_done = None
+        # the reference's bookkeeping of this row's negative cache, without the tensors: [attention mask incl. the next token's slot,
+        # entries ever appended, corrections so far (correct_cnt)] -- only to RECOGNISE the one correction the engine cannot follow
+        self.neg_book = [[1], 0, 0]
 
 
 class VibeVoiceForConditionalGenerationInference:
@@ -936,6 +939,8 @@ class VibeVoiceForConditionalGenerationInference:
                 torch.set_rng_state(rng_state)
         cond_used = self._hidden if spec_sample else self._cond
         n = len(diff)
+        if S.get("lockstep", True) and len(order) > 1:
+            self._negative_bookkeeping(S, order, live, diff, refresh, start_id)
         if not refresh:
             # the entry the negative pass appended at this step stays for a live row that does not diffuse, unless some row of the
             # batch does: then the reference's correction of :590-624 shifts it back out (pinned by generate_norefresh_b2.npz)
@@ -1036,6 +1041,45 @@ class VibeVoiceForConditionalGenerationInference:
         for u in live:
             u.have_embeds = True
         return live
+
+    def _negative_bookkeeping(self, S, order, live, diff, refresh, start_id):
+        """The reference's array bookkeeping of the negative branch (oracle.generate.NegativeRow restates it with the tensors), masks
+        and counters only.  Its correction of a non-diffusing row (:594-624) guards the mask shift and the K/V shift differently
+        (:603 vs :613): for a row holding exactly one valid entry the mask moves and the K/V does not, so the reference KEEPS the entry
+        appended at this step and masks the older one out.  Everywhere else the net effect is "this step's entry is dropped", which
+        is what this path does for every row -- it has no KV-entry move.  Needs a one-frame speech segment (or a non-diffusion token
+        at step 1 with refresh_negative=False) in one row of a batch while another row diffuses; found by
+        tools/fuzz_generate_vs_reference.py, which reports the pattern.  Warned once per generate() when it happens."""
+        def fwd():
+            for u in order:
+                b = u.neg_book
+                b[1] += 1
+                b[0].append(1)
+        if not refresh:
+            fwd()
+        else:
+            for u in live:
+                if u.last == start_id:
+                    u.neg_book[0] = [0] * (len(u.neg_book[0]) - 1) + [1]
+        if not diff:
+            return
+        if refresh:
+            fwd()
+        for u in live:
+            if u in diff:
+                continue
+            mask, c, cnt = u.neg_book
+            if c - cnt == 2 and mask[cnt] == 1 and not S.get("_warned_single_entry"):
+                S["_warned_single_entry"] = True
+                import warnings
+                warnings.warn(f"generate(): row {u.idx} emits a non-diffusion token at step {u.step} while another row of the batch diffuses and "
+                              "its negative (CFG) cache holds exactly one valid entry: the reference keeps THIS step's entry and masks the older "
+                              "one there (modeling_vibevoice_inference.py:603 vs :613); this path drops this step's entry as everywhere else, so "
+                              "the row's negative condition differs from the reference's from its next frame on", RuntimeWarning, stacklevel=3)
+            if cnt + 1 < len(mask) - 1:
+                mask[cnt + 1:] = mask[cnt:-1]
+            mask[cnt] = 0
+            u.neg_book[2] = cnt + 1
 
     def _sde_draws(self, S, n):
         """The variance noise of one frame's solver steps, [N, n, latent] fp32 on the device.  scheduler.step() draws
