@@ -417,7 +417,7 @@ def gen_generate(custom=None):
     if custom is not None:
         sym = {"D": D, "E": E, "S": S, "X": X}
         for name, B, plans, seed, kw in custom:
-            run(name, B, [[sym[t] for t in p] for p in plans], seed=seed, **kw)
+            run(name, B, None if plans is None else [[sym[t] for t in p] for p in plans], seed=seed, **kw)
         return
     run("generate_forced_b1.npz", 1, [[D, D, D, D, E, S, D, D, D, X]], seed=11)
     run("generate_forced_b2.npz", 2, [[D, D, D, E, S, D, D, X], [D, D, E, S, D, X]], seed=23, streamer=True)

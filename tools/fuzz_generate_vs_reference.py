@@ -3,7 +3,9 @@
 through the oracle loop + the product loop (on the oracle-backed CPU engine of tests/fake_engine.py): token sequences, length flags,
 RNG draw counts and waveforms must agree.  Build container only (needs /root/reference); nothing is written into the repository.
 
-    python tools/fuzz_generate_vs_reference.py [n_random_plans] [seed] [--norefresh]
+    python tools/fuzz_generate_vs_reference.py [n_random_plans] [seed] [--norefresh | --sampled]
+
+--sampled: free-running token sampling instead of forced plans (product loop only; pins the RNG consumption order in batches).
 
 This is how round 4 found the reference's cross-row tokenizer-cache coupling: a plan that starts one row's first
 frame later than another's."""
@@ -77,6 +79,13 @@ def main():
     runs += [("fuzz_eos0.npz", 2, [list("X"), list("DDEX")], 1900 + seed, kw),
              ("fuzz_ss.npz", 2, [list("DEESSDX"), list("SSDDX")], 1901 + seed, kw),
              ("fuzz_b3late.npz", 3, [list("DDDDX"), list("ESDDX"), list("SESDX")], 1902 + seed, kw)]
+    sampled = "--sampled" in sys.argv
+    if sampled:
+        # free-running token SAMPLING (do_sample, plain multinomial over the valid ids: top_k=0), batches of 1-3: what is compared is the
+        # product loop only, seeded like the reference's run -- every draw (prefill Gaussians, per-frame noise, one multinomial per
+        # step over the whole batch) must come off the global generator in the reference's order for the tokens to agree at all
+        runs = [(f"fuzz_s{k}.npz", rnd.choice([1, 2, 2, 3]), None, 3000 + seed * 100 + k,
+                 {"max_new_tokens": 12, "do_sample": True}) for k in range(n)]
     import make_golden
     out = tempfile.mkdtemp(prefix="vv_fuzz_")
     make_golden.OUT_DIR = out
@@ -111,8 +120,28 @@ def main():
         model = modeling.VibeVoiceForConditionalGenerationInference.from_pretrained(ck, torch_dtype=torch.float32, device_map="cuda")
         model.eval()
         model.set_ddpm_inference_steps(num_steps=5)
-        for name, B, plans, sd, _ in runs:
+        for name, B, plans, sd, rkw in runs:
             z = np.load(os.path.join(out, name))
+            if sampled:
+                ids = torch.from_numpy(z["input_ids"])
+                inputs = dict(speech_tensors=torch.from_numpy(z["speech_tensors"]), speech_masks=torch.from_numpy(z["speech_masks"]),
+                              speech_input_mask=torch.from_numpy(z["speech_input_mask"]))
+                model.speculate_sampling = True
+                torch.manual_seed(int(z["seed"]))
+                o = model.generate(input_ids=ids, attention_mask=torch.from_numpy(z["attention_mask"]), max_new_tokens=12, cfg_scale=1.3, tokenizer=TOK,
+                                   generation_config={"do_sample": True, "top_k": 0}, verbose=False, is_prefill=True, show_progress_bar=False, **inputs)
+                okp = torch.equal(o.sequences.cpu(), torch.from_numpy(z["sequences"])) and torch.equal(o.reach_max_step_sample.cpu(), torch.from_numpy(z["reach_max"]))
+                e = []
+                for b in range(B):
+                    ref = torch.from_numpy(z[f"audio_{b}"])
+                    got = o.speech_outputs[b].reshape(-1) if o.speech_outputs[b] is not None else torch.zeros(0)
+                    e.append(float((got - ref).norm() / ref.norm()) if got.shape == ref.shape and ref.numel() else (0.0 if got.shape == ref.shape else float("inf")))
+                good = okp and max(e) <= 1e-4
+                bad_pr += 0 if good else 1
+                worst = max(worst, max(e))
+                toks = z["sequences"][:, ids.shape[1]:].tolist()
+                print(f"{'ok  ' if good else 'FAIL'} {name:16s} B={B} sampled tokens {toks}  product loop rel-L2 {max(e):.1e}")
+                continue
             ids = torch.from_numpy(z["input_ids"])
             draws = [torch.from_numpy(z[f"draw_{i}"]) for i in range(int(z["n_draws"]))]
             pre = (draws[0].reshape(B), draws[1].reshape(B, 3, 64))
