@@ -474,8 +474,9 @@ def gen_generate(custom=None):
 
 
 @torch.no_grad()
-def gen_generate_streaming():
-    """Row Z: the reference's Streaming-0.5B generate() (modeling_vibevoice_streaming_inference.py:412-751) on a tiny
+def gen_generate_streaming(custom=None):
+    """custom: [(file name, text tokens, max_new, seed, eos_bias or None)] -- record THOSE runs instead of the goldens (fuzzing).
+    Row Z: the reference's Streaming-0.5B generate() (modeling_vibevoice_streaming_inference.py:412-751) on a tiny
     seeded model.  The four prefilled branches (what demo/voices/streaming_model/*.pt hold) are produced with the
     reference's own forward_lm / forward_tts_lm on a random prompt and stored, so the oracle starts from identical
     caches; every torch.randn draw is recorded."""
@@ -591,6 +592,10 @@ def gen_generate_streaming():
             arrs[f"draw_{i}"] = d
         save(name, **arrs)
 
+    if custom is not None:
+        for name, n_text, max_new, seed, eos_bias in custom:
+            run(name, n_text, max_new, seed=seed, eos_bias=eos_bias)
+        return
     run("streaming_text12_cap40.npz", 12, 40, seed=5)
     run("streaming_text3_cap20.npz", 3, 20, seed=6)
     run("streaming_eos.npz", 12, 60, seed=7, eos_bias=0.35)

@@ -3,7 +3,7 @@
 through the oracle loop + the product loop (on the oracle-backed CPU engine of tests/fake_engine.py): token sequences, length flags,
 RNG draw counts and waveforms must agree.  Build container only (needs /root/reference); nothing is written into the repository.
 
-    python tools/fuzz_generate_vs_reference.py [n_random_plans] [seed] [--norefresh | --sampled]
+    python tools/fuzz_generate_vs_reference.py [n_random_plans] [seed] [--norefresh | --sampled | --streaming]
 
 --sampled: free-running token sampling instead of forced plans (product loop only; pins the RNG consumption order in batches).
 
@@ -64,8 +64,52 @@ def hits_single_entry_pattern(plans, refresh_negative=True):
     return False
 
 
+def streaming_main(n, seed):
+    """--streaming: random (text length, length cap, EOS-classifier bias) triples through the reference's Streaming-0.5B generate()
+    (tiny split model, prefilled branches from its own forward passes) and the oracle's streaming loop: token count, stop reason,
+    RNG draw count, waveform."""
+    import make_golden
+    from oracle import generate_streaming as ogs
+    from test_oracle_golden import _oracle_streaming_small
+    rnd = random.Random(seed)
+    runs = [(f"fuzz_z{k}.npz", rnd.randint(1, 23), rnd.randint(4, 70), 500 + seed * 100 + k, rnd.choice([-1.5, -1.0, -0.5, -0.2, 0.0, 0.1, 0.35]))
+            for k in range(n)]
+    out = tempfile.mkdtemp(prefix="vv_fuzz_z_")
+    make_golden.OUT_DIR = out
+    make_golden.gen_generate_streaming(custom=runs)
+    bad = 0
+    for name, n_text, max_new, sd, eb in runs:
+        z = np.load(os.path.join(out, name))
+        om = _oracle_streaming_small(eos_bias=float(z["eos_bias"]))
+
+        def cache(tag, lm):
+            c = lm.new_cache()
+            for li in range(int(z[f"{tag}_layers"])):
+                c.k[li] = torch.from_numpy(z[f"{tag}_k{li}"]).clone()
+                c.v[li] = torch.from_numpy(z[f"{tag}_v{li}"]).clone()
+            c.length = c.k[0].shape[1]
+            return c
+        preset = ogs.Preset(cache("lm", om.lm), cache("tts", om.tts_lm), cache("neg_tts", om.tts_lm), torch.from_numpy(z["tts_last"]),
+                            torch.from_numpy(z["neg_tts_last"]))
+        draws = iter([torch.from_numpy(z[f"draw_{i}"]) for i in range(int(z["n_draws"]))])
+        n_tok, audio, reach, fin = ogs.oracle_generate_streaming(om, preset, torch.from_numpy(z["text"]), 1.5, 5, lambda frame, n2: next(draws).reshape(n2, 64),
+                                                                 preset.tts_cache.length + int(z["max_new"]))
+        ref = torch.from_numpy(z["audio"])
+        got = audio.reshape(-1) if audio is not None else torch.zeros(0)
+        ok = next(draws, None) is None and n_tok == int(z["n_tokens"]) and bool(reach) == bool(z["reach_max"][0]) and got.shape == ref.shape
+        err = float((got - ref).norm() / ref.norm()) if ok and ref.numel() else (0.0 if ok else float("inf"))
+        good = ok and err <= 1e-4
+        bad += 0 if good else 1
+        print(f"{'ok  ' if good else 'FAIL'} {name:14s} text {n_text:2d}, cap {max_new:2d}, eos bias {eb:+.2f}: {int(z['n_tokens'])} tokens, {ref.numel() // 3200} frames, "
+              f"reach_max {bool(z['reach_max'][0])}; oracle rel-L2 {err:.1e}")
+    print(f"{len(runs)} streaming runs: {bad} mismatches")
+    return 1 if bad else 0
+
+
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    if "--streaming" in sys.argv:
+        return streaming_main(int(args[0]) if args else 8, int(args[1]) if len(args) > 1 else 7)
     n = int(args[0]) if args else 8
     seed = int(args[1]) if len(args) > 1 else 7
     norefresh = "--norefresh" in sys.argv
