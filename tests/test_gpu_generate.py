@@ -69,7 +69,7 @@ def run_both(s, B, forced, with_speech, cfg=1.3, steps=5, seed=11, max_new_token
     otr = ogen.Trace()
     oseq, oaud, omax = ogen.oracle_generate(om, TOK, ids, mask, st, sm, sim if with_speech else None, cfg_scale=cfg,
                                             num_steps=steps, max_new_tokens=max_new_tokens, noise_fn=noise_fn,
-                                            prefill_noise=pre, forced_tokens=forced, trace=otr, **mode)
+                                            prefill_noise=pre, forced_tokens=forced, trace=otr, engine_negative_correction=True, **mode)
     cfgd = {"decoder_config": {"max_position_embeddings": s.lmcfg.max_pos},
             "diffusion_head_config": {"ddpm_num_inference_steps": steps},
             "acoustic_tokenizer_config": {"fix_std": 0.5, "std_dist_type": "gaussian"}}
@@ -423,7 +423,7 @@ def test_generate_batch8_desynchronised():
         om = s.oracle_model(kv_round_bf16=True)
         otr = ogen.Trace()
         oseq, oaud, omax = ogen.oracle_generate(om, TOK, ids, mask, cfg_scale=1.3, num_steps=5, noise_fn=noise_fn,
-                                                forced_tokens=forced, trace=otr)
+                                                forced_tokens=forced, trace=otr, engine_negative_correction=True)
         cfgd = {"decoder_config": {"max_position_embeddings": s.lmcfg.max_pos},
                 "diffusion_head_config": {"ddpm_num_inference_steps": 5},
                 "acoustic_tokenizer_config": {"fix_std": 0.5, "std_dist_type": "gaussian"}}
@@ -549,7 +549,7 @@ def test_generate_under_the_gradio_scheduler(sm):
     otr = ogen.Trace()
     oseq, oaud, omax = ogen.oracle_generate(om, TOK, ids, mask, st, smk, sim, cfg_scale=1.3, num_steps=5, noise_fn=noise_fn,
                                             prefill_noise=pre, forced_tokens=forced, trace=otr,
-                                            algorithm_type="sde-dpmsolver++", sde_noise_fn=sde_fn)
+                                            algorithm_type="sde-dpmsolver++", sde_noise_fn=sde_fn, engine_negative_correction=True)
     cfgd = {"decoder_config": {"max_position_embeddings": sm.lmcfg.max_pos}, "diffusion_head_config": {"ddpm_num_inference_steps": 5},
             "acoustic_tokenizer_config": {"fix_std": 0.5, "std_dist_type": "gaussian"}}
     m = VibeVoiceForConditionalGenerationInference(cfgd, sm.eng, model_dtype=torch.float32)

@@ -493,7 +493,8 @@ def test_bf16_hip_against_bf16_pytorch_rocm_eager():
             with torch.no_grad():
                 oseq, oaud, omax = ogen.oracle_generate(
                     om, tm.TOK, to(ids), to(mask), cfg_scale=1.3, num_steps=steps,
-                    noise_fn=lambda step, n2: noise_fn(step, n2).to(devc, torch.bfloat16), forced_tokens=forced, trace=otr)
+                    noise_fn=lambda step, n2: noise_fn(step, n2).to(devc, torch.bfloat16), forced_tokens=forced, trace=otr,
+                    engine_negative_correction=True)
         torch.cuda.synchronize()
         cfgd = {"decoder_config": {"max_position_embeddings": s.lmcfg.max_pos}, "diffusion_head_config": {"ddpm_num_inference_steps": steps},
                 "acoustic_tokenizer_config": {"fix_std": 0.5, "std_dist_type": "gaussian"}}

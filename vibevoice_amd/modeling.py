@@ -1074,8 +1074,9 @@ class VibeVoiceForConditionalGenerationInference:
                 import warnings
                 warnings.warn(f"generate(): row {u.idx} emits a non-diffusion token at step {u.step} while another row of the batch diffuses and "
                               "its negative (CFG) cache holds exactly one valid entry: the reference keeps THIS step's entry and masks the older "
-                              "one there (modeling_vibevoice_inference.py:603 vs :613); this path drops this step's entry as everywhere else, so "
-                              "the row's negative condition differs from the reference's from its next frame on", RuntimeWarning, stacklevel=3)
+                              "one there (modeling_vibevoice_inference.py:603 vs :613); this path drops this step's entry as everywhere else: if the "
+                              "row diffuses again before its next <speech_start> (which resets the negative context either way), its "
+                              "negative condition differs from the reference's", RuntimeWarning, stacklevel=3)
             if cnt + 1 < len(mask) - 1:
                 mask[cnt + 1:] = mask[cnt:-1]
             mask[cnt] = 0
