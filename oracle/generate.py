@@ -122,7 +122,7 @@ class NegativeRow:
         keep = [i for i in range(c) if self.mask[i]]
         tmp = self.lm.new_cache()
         if keep:
-            idx = torch.tensor(keep)
+            idx = torch.tensor(keep, device=self.full.k[0].device)
             for l in range(len(tmp.k)):
                 tmp.k[l], tmp.v[l] = self.full.k[l][:, idx], self.full.v[l][:, idx]
             tmp.length = len(keep)
