@@ -99,10 +99,52 @@ def streaming_main(n, seed):
         got = audio.reshape(-1) if audio is not None else torch.zeros(0)
         ok = next(draws, None) is None and n_tok == int(z["n_tokens"]) and bool(reach) == bool(z["reach_max"][0]) and got.shape == ref.shape
         err = float((got - ref).norm() / ref.norm()) if ok and ref.numel() else (0.0 if ok else float("inf"))
-        good = ok and err <= 1e-4
+        # ---- the product's streaming class on the oracle-backed CPU engine, as demo/streaming_inference_from_file.py drives it ----
+        import copy
+        import fake_engine
+        from test_dropin_cpu import TOK, tiny_streaming_checkpoint
+        from transformers.modeling_outputs import BaseModelOutputWithPast
+        from vibevoice_amd import modeling_streaming
+        import pathlib
+        ckdir = pathlib.Path(tempfile.mkdtemp(prefix="vv_fuzz_zck_"))
+        path = tiny_streaming_checkpoint(ckdir, float(z["eos_bias"]))
+        pdraws = [torch.from_numpy(z[f"draw_{i}"]).reshape(2, 64) for i in range(int(z["n_draws"]))]
+
+        def branch(tag):
+            kv = [(torch.from_numpy(z[f"{tag}_k{li}"])[None], torch.from_numpy(z[f"{tag}_v{li}"])[None]) for li in range(int(z[f"{tag}_layers"]))]
+            hid = torch.zeros(1, kv[0][0].shape[2], 128)
+            hid[0, -1] = torch.from_numpy(z[f"{tag}_last"])
+            return BaseModelOutputWithPast(last_hidden_state=hid, past_key_values=kv)
+        pre_out = {"lm": branch("lm"), "tts_lm": branch("tts"), "neg_lm": None, "neg_tts_lm": branch("neg_tts")}
+
+        class Patch:
+            def setattr(self, obj, name_, val, raising=True):
+                setattr(obj, name_, val)
+
+            def setenv(self, k, v):
+                os.environ[k] = v
+
+            def delenv(self, k, raising=False):
+                os.environ.pop(k, None)
+        with fake_engine.cpu_cuda_shims(Patch()):
+            modeling_streaming.Engine = fake_engine.LoadableFakeStreamingEngine
+            model = modeling_streaming.VibeVoiceStreamingForConditionalGenerationInference.from_pretrained(path, torch_dtype=torch.float32, device_map="cuda")
+            model.eval()
+            model.set_ddpm_inference_steps(num_steps=5)
+            prompt, text = torch.from_numpy(z["prompt"])[None], torch.from_numpy(z["text"])[None]
+            lm_len = pre_out["lm"]["last_hidden_state"].size(1)
+            o = model.generate(input_ids=torch.zeros(1, lm_len, dtype=torch.long), attention_mask=torch.ones(1, lm_len, dtype=torch.long),
+                               tts_lm_input_ids=prompt, tts_lm_attention_mask=torch.ones_like(prompt), tts_text_ids=text,
+                               speech_input_mask=torch.zeros(1, prompt.shape[1], dtype=torch.bool), speech_tensors=None, speech_masks=None,
+                               max_new_tokens=int(z["max_new"]), cfg_scale=1.5, tokenizer=TOK, generation_config={"do_sample": False}, verbose=False,
+                               all_prefilled_outputs=copy.deepcopy(pre_out), _noise_fn=lambda frame, n2: pdraws[frame])
+        pgot = o.speech_outputs[0].reshape(-1) if (o.speech_outputs and o.speech_outputs[0] is not None) else torch.zeros(0)
+        pok = int(o.sequences.shape[1]) == int(z["n_tokens"]) and bool(o.reach_max_step_sample[0]) == bool(z["reach_max"][0]) and pgot.shape == ref.shape
+        perr = float((pgot - ref).norm() / ref.norm()) if pok and ref.numel() else (0.0 if pok else float("inf"))
+        good = ok and err <= 1e-4 and pok and perr <= 1e-4
         bad += 0 if good else 1
         print(f"{'ok  ' if good else 'FAIL'} {name:14s} text {n_text:2d}, cap {max_new:2d}, eos bias {eb:+.2f}: {int(z['n_tokens'])} tokens, {ref.numel() // 3200} frames, "
-              f"reach_max {bool(z['reach_max'][0])}; oracle rel-L2 {err:.1e}")
+              f"reach_max {bool(z['reach_max'][0])}; oracle rel-L2 {err:.1e}, product streaming loop {perr:.1e}")
     print(f"{len(runs)} streaming runs: {bad} mismatches")
     return 1 if bad else 0
 
