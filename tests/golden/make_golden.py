@@ -335,7 +335,11 @@ def gen_generate(custom=None):
             # NOTE: finished_flags deliberately left untouched -- the reference's own streamer sets them, which makes
             # generate() stop at the first finished sample (:443-447); here the whole batch is recorded.
 
-    def run(name, B, plans, seed, max_new_tokens=None, do_sample=False, wav_len=3 * 3200, streamer=False, sde=False, gen_cfg=None, **gen_kw):
+    def run(name, B, plans, seed, max_new_tokens=None, do_sample=False, wav_len=3 * 3200, streamer=False, sde=False, gen_cfg=None,
+            voices=None, **gen_kw):
+        """voices: per row, the frame counts (1..3) of its voice samples -- several speakers in one prompt, as the processor builds a
+        multi-speaker script (speech_tensors / speech_masks hold ALL samples of the batch, row after row; each sample's placeholder
+        positions follow one another in its row, separated by a text token).  None: one sample per row (2, 3, 1, 2 frames)."""
         g = synth.Gen(seed)
         lens = [21, 17, 19, 14][:B]
         L0 = max(lens)
@@ -350,12 +354,26 @@ def gen_generate(custom=None):
             ids[b, L0 - n:] = row
             mask[b, L0 - n:] = 1
             st0 = L0 - n + 3
-            ids[b, st0:st0 + n_fr[b]] = T.speech_diffusion_id
-            sim[b, st0:st0 + n_fr[b]] = True
-        speech = g.uniform((B, wav_len), -0.5, 0.5)
-        smask = torch.zeros((B, 3), dtype=torch.bool)
-        for b in range(B):
-            smask[b, :n_fr[b]] = True
+            if voices is None:
+                ids[b, st0:st0 + n_fr[b]] = T.speech_diffusion_id
+                sim[b, st0:st0 + n_fr[b]] = True
+            else:
+                for f in voices[b]:
+                    assert st0 + f < L0 - 1, "the row is too short for its voice samples"
+                    ids[b, st0:st0 + f] = T.speech_diffusion_id
+                    sim[b, st0:st0 + f] = True
+                    st0 += f + 1
+        if voices is None:
+            speech = g.uniform((B, wav_len), -0.5, 0.5)
+            smask = torch.zeros((B, 3), dtype=torch.bool)
+            for b in range(B):
+                smask[b, :n_fr[b]] = True
+        else:
+            fr = [f for v in voices for f in v]
+            speech = g.uniform((len(fr), wav_len), -0.5, 0.5)
+            smask = torch.zeros((len(fr), 3), dtype=torch.bool)
+            for i, f in enumerate(fr):
+                smask[i, :f] = True
         force = Force(plans) if plans is not None else None
         orig_glp = Ref._get_logits_processor
 
@@ -471,6 +489,9 @@ def gen_generate(custom=None):
     # `start + 1 < cache length - 1` (:613) -- the mask moves, the K/V does not, the entry appended at this step stays and the older
     # one is masked out
     run("generate_single_entry_b2.npz", 2, [[D, D, D, S, D, E, D, X], [D, E, D, D, D, D, D, D, E, X]], seed=207)
+    # several voice samples in one prompt (a multi-speaker script: BASELINE configs[2] has two speakers, configs[3] four): row 0 carries
+    # two samples (2 and 1 frames), row 1 one (3 frames); speech_tensors / speech_masks hold the three samples row after row
+    run("generate_multivoice_b2.npz", 2, [[D, D, D, E, S, D, X], [D, D, E, X]], seed=602, voices=[[2, 1], [3]])
 
 
 @torch.no_grad()

@@ -720,13 +720,15 @@ def test_generate_with_a_length_factor_lands_on_the_reference_golden(product):
 
 
 # ---------------------------------------------------------------- a row whose first frame comes later than the other row's
-@pytest.mark.parametrize("name", ["generate_late_start_b2", "generate_late_start_b2r"])
+@pytest.mark.parametrize("name", ["generate_late_start_b2", "generate_late_start_b2r", "generate_multivoice_b2"])
 def test_late_starting_row_costs_the_streaming_row_its_conv_history_as_in_the_reference(product, name):
     """The reference's VibeVoiceTokenizerStreamingCache.get (modular_vibevoice_tokenizer.py:198-207) returns None for a whole decode /
     encode call as soon as one requested row has no entry yet: in a lock-step batch the row that was already streaming loses its conv
     history for the frame in which another row diffuses for the first time.  generate() reproduces it (golden recorded from the
     reference's own generate(); waveform rel-L2 <= 1e-4 on BOTH rows); the request queue does not -- there each request ends as
-    generate() on it alone would, which for the streaming row is a different waveform."""
+    generate() on it alone would, which for the streaming row is a different waveform.
+    (generate_multivoice_b2 rides along: several voice samples in one prompt -- three samples for two rows -- seeded, nothing injected
+    but the plan.)"""
     modeling, path = product
     model = modeling.VibeVoiceForConditionalGenerationInference.from_pretrained(path, torch_dtype=torch.float32, device_map="cuda")
     model.eval()

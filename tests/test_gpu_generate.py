@@ -143,13 +143,13 @@ def test_generate_without_negative_refresh(sm, B, forced, seed):
     assert any(rel_err(a, b) > 1e-2 for a, b in zip(o[3].neg_hidden, o2[3].neg_hidden))
 
 
-@pytest.mark.parametrize("name", ["generate_norefresh_b1", "generate_norefresh_b2", "generate_late_start_b2", "generate_late_start_b2r", "generate_times_b2"])
+@pytest.mark.parametrize("name", ["generate_norefresh_b1", "generate_norefresh_b2", "generate_late_start_b2", "generate_late_start_b2r", "generate_times_b2", "generate_multivoice_b2"])
 def test_generate_against_the_reference_goldens_of_the_rare_modes(sm, name):
     """the engine directly against what the REFERENCE's generate(refresh_negative=False) produced on the same tiny seeded model, inputs,
     forced plan and recorded noise draws (tests/golden/make_golden.py::gen_generate): sequences identical, waveform rel-L2 <= 1e-2
     (xsplit = 3 against fp32).  Also, in the default mode: the two late-start files (a row whose first frame comes later than the other
     row's costs the streaming row its tokenizer conv history for that frame, modular_vibevoice_tokenizer.py:198-207) and the
-    max_length_times=0.4 run (per-row length caps on a left-padded batch)."""
+    max_length_times=0.4 run (per-row length caps on a left-padded batch), and a multi-speaker prompt batch (three voice samples for two rows)."""
     import os
     import numpy as np
     from test_oracle_golden import G as GOLD
@@ -158,7 +158,8 @@ def test_generate_against_the_reference_goldens_of_the_rare_modes(sm, name):
     ids = torch.from_numpy(z["input_ids"])
     B = ids.shape[0]
     draws = [torch.from_numpy(z[f"draw_{i}"]) for i in range(int(z["n_draws"]))]
-    pre = (draws[0].reshape(B), draws[1].reshape(B, 3, 64))
+    N = z["speech_tensors"].shape[0]                    # voice samples of the whole batch (generate_multivoice_b2: 3 for 2 rows)
+    pre = (draws[0].reshape(N), draws[1].reshape(N, 3, 64))
     it = iter(draws[2:])
     forced = [z["forced"][b][:int(z["forced_len"][b])].tolist() for b in range(B)]
     cfgd = {"decoder_config": {"max_position_embeddings": sm.lmcfg.max_pos}, "diffusion_head_config": {"ddpm_num_inference_steps": 5},

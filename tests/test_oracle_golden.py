@@ -179,7 +179,7 @@ def _oracle_small(kv_round_bf16=False):
 
 
 @pytest.mark.parametrize("name", ["generate_forced_b1", "generate_forced_b2", "generate_greedy_b1", "generate_cap_b1", "generate_ragged_voice_b1",
-                                  "generate_norefresh_b1", "generate_norefresh_b2", "generate_times_b2", "generate_late_start_b2", "generate_late_start_b2r", "generate_single_entry_b2"])
+                                  "generate_norefresh_b1", "generate_norefresh_b2", "generate_times_b2", "generate_late_start_b2", "generate_late_start_b2r", "generate_single_entry_b2", "generate_multivoice_b2"])
 def test_generate_loop_matches_the_reference_generate(name):
     """Golden = the REFERENCE's own generate() (modeling_vibevoice_inference.py:326-710) run on the tiny seeded model
     (tests/golden/make_golden.py::gen_generate, through oracle/refshim.install_generate_shims).  The oracle loop gets
@@ -192,7 +192,8 @@ def test_generate_loop_matches_the_reference_generate(name):
     the two generate_late_start files start one row's first frame later than the other's, where the reference's tokenizer cache drops the
     streaming row's conv history for that frame (modular_vibevoice_tokenizer.py:198-207); generate_single_entry_b2 has a one-frame segment
     in one row while the other diffuses: the correction's mask shift happens and its K/V shift does not (:603 vs :613), the entry of
-    THAT step stays and the older one is masked (oracle.generate.NegativeRow restates the arrays literally)."""
+    THAT step stays and the older one is masked (oracle.generate.NegativeRow restates the arrays literally); generate_multivoice_b2 carries
+    several voice samples per prompt (a multi-speaker script: three samples for two rows)."""
     from oracle import generate as ogen
     z = np.load(os.path.join(G, name + ".npz"))
     tok = ogen.TokenIds(speech_start_id=301, speech_end_id=302, speech_diffusion_id=303, eos_token_id=304,
@@ -200,7 +201,8 @@ def test_generate_loop_matches_the_reference_generate(name):
     ids = torch.from_numpy(z["input_ids"])
     B = ids.shape[0]
     draws = [torch.from_numpy(z[f"draw_{i}"]) for i in range(int(z["n_draws"]))]
-    pre = (draws[0].reshape(B), draws[1].reshape(B, 3, 64))
+    N = z["speech_tensors"].shape[0]                   # voice samples of the whole batch (generate_multivoice_b2: 3 for 2 rows)
+    pre = (draws[0].reshape(N), draws[1].reshape(N, 3, 64))
     it = iter(draws[2:])
 
     def noise_fn(step, n2):
