@@ -161,7 +161,7 @@ def main():
     rnd = random.Random(seed)
     runs = []
     for k in range(n):
-        B = rnd.choice([1, 2, 2, 3])
+        B = rnd.choice([1, 2, 2, 3, 4])
         plans = [[rnd.choice("DDDES") for _ in range(rnd.randint(3, 9))] + ["X"] for _ in range(B)]
         runs.append((f"fuzz_{k}.npz", B, plans, 1000 + seed * 100 + k, kw))
     runs += [("fuzz_eos0.npz", 2, [list("X"), list("DDEX")], 1900 + seed, kw),
