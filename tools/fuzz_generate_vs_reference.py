@@ -3,9 +3,10 @@
 through the oracle loop + the product loop (on the oracle-backed CPU engine of tests/fake_engine.py): token sequences, length flags,
 RNG draw counts and waveforms must agree.  Build container only (needs /root/reference); nothing is written into the repository.
 
-    python tools/fuzz_generate_vs_reference.py [n_random_plans] [seed] [--norefresh | --sampled | --mixed | --streaming]
+    python tools/fuzz_generate_vs_reference.py [n_random_plans] [seed] [--norefresh | --sampled | --warped | --mixed | --streaming]
 
 --sampled: free-running token sampling instead of forced plans (product loop only; pins the RNG consumption order in batches).
+--warped: random full-vocabulary logits processors (repetition penalty, temperature, top-k / top-p / min-p), product loop only.
 --mixed: batches of 1-4, forced or greedy, length caps, ragged voice samples, the stochastic scheduler (product loop only).
 
 This is how round 4 found the reference's cross-row tokenizer-cache coupling: a plan that starts one row's first
@@ -191,10 +192,42 @@ def main():
                 rkw["wav_len"] = 9600
             runs.append((f"fuzz_m{k}.npz", B, plans, 5000 + seed * 100 + k, rkw))
         sampled = True                        # same comparison code path: product only
+    warped = "--warped" in sys.argv
+    if warped:
+        # the full-vocabulary logits processors in front of the valid-token constraint (HF's list: repetition penalty, temperature,
+        # top-k, top-p, min-p), random settings, batches of 1-2; product loop only, seeded.  A setting that filters EVERY valid id of
+        # some step makes the reference fail in torch.multinomial (NaN probabilities): such runs are skipped.
+        runs = []
+        for k in range(n):
+            gc = {"do_sample": rnd.random() < 0.8}
+            if rnd.random() < 0.7:
+                gc["repetition_penalty"] = round(rnd.uniform(1.0, 1.4), 3)
+            if gc["do_sample"]:
+                gc["top_k"] = rnd.choice([0, 0, 280, 300, 310, 315])
+                if rnd.random() < 0.5:
+                    gc["top_p"] = round(rnd.uniform(0.99, 0.9999), 4)
+                if rnd.random() < 0.5:
+                    gc["temperature"] = round(rnd.uniform(0.6, 1.6), 3)
+                if rnd.random() < 0.4:
+                    gc["min_p"] = round(rnd.uniform(1e-5, 2e-4), 6)
+            runs.append((f"fuzz_w{k}.npz", rnd.choice([1, 2]), None, 7000 + seed * 100 + k, {"max_new_tokens": 10, "gen_cfg": gc}))
+        sampled = True
     import make_golden
     out = tempfile.mkdtemp(prefix="vv_fuzz_")
     make_golden.OUT_DIR = out
-    make_golden.gen_generate(custom=runs)
+    if warped:
+        kept = []
+        for r in runs:
+            try:
+                make_golden.gen_generate(custom=[r])
+                kept.append(r)
+            except RuntimeError as ex:
+                if "probability tensor" not in str(ex):
+                    raise
+                print(f"skip {r[0]:16s} {r[4]['gen_cfg']}: every valid id filtered at some step (the reference fails in torch.multinomial)")
+        runs = kept
+    else:
+        make_golden.gen_generate(custom=runs)
 
     # ---- the oracle loop ----
     from oracle import generate as ogen
@@ -241,6 +274,8 @@ def main():
                     if plans is not None:
                         sym = {"D": 303, "E": 302, "S": 301, "X": 304}
                         gkw["_forced_tokens"] = [[sym[t] for t in p] for p in plans]
+                elif warped:
+                    gkw = dict(max_new_tokens=10, generation_config=dict(rkw["gen_cfg"]))
                 else:
                     gkw = dict(max_new_tokens=12, generation_config={"do_sample": True, "top_k": 0})
                 torch.manual_seed(int(z["seed"]))
@@ -271,7 +306,8 @@ def main():
                     n_known += 1
                 else:
                     worst = max(worst, max(e))
-                what = f"{'forced ' + str([''.join(p) for p in plans]) if plans is not None else 'free-running'} {rkw}" if mixed else f"sampled tokens {toks}"
+                what = (f"{'forced ' + str([''.join(p) for p in plans]) if plans is not None else 'free-running'} {rkw}" if mixed else
+                        (f"{rkw['gen_cfg']} tokens {toks}" if warped else f"sampled tokens {toks}"))
                 print(f"{'ok  ' if good else ('KNWN' if known else 'FAIL')} {name:16s} B={B} {what}  product loop rel-L2 {max(e):.1e}")
                 continue
             ids = torch.from_numpy(z["input_ids"])
