@@ -117,6 +117,11 @@ int vv_kv_import(vv_ctx* ctx, void* stream, int cache, int layer, int n_pos, con
  * utterance from KV state computed elsewhere (and the long-context tests / bench place known K/V at chosen positions). */
 int vv_kv_import_at(vv_ctx* ctx, void* stream, int cache, int layer, int pos0, int n_pos, const void* k_dev,
                     const void* v_dev, int src_dtype);
+/* Cached position src_pos copied onto dst_pos in every layer of `cache` (keys keep the rotation they were computed with).  The one
+ * place the reference re-arranges a row's negative cache so that an entry ends up at another index with its ORIGINAL rotation: the
+ * correction of a non-diffusing batch row that holds exactly one valid entry (modeling_vibevoice_inference.py:594-624: the mask
+ * shifts, :603, and the K/V does not, :613 -- the entry appended at that step stays, the older one is masked out). */
+int vv_kv_move(vv_ctx* ctx, void* stream, int cache, int src_pos, int dst_pos);
 /* y[t][:] = x[t][:] + tts_input_types[type]  (forward_tts_lm, :293) */
 int vv_add_type_embedding(vv_ctx* ctx, void* stream, int n, const float* x_dev, int type, float* out_dev);
 /* tts_eos_classifier: fc2(relu(fc1(h))) -> out_dev[n] logits (BinaryClassifier, modeling_vibevoice_streaming.py:42-53) */
@@ -167,6 +172,11 @@ int vv_codec_chain_batch(vv_ctx* ctx, void* stream, int n, const int* slots, con
 /* acoustic_tokenizer.encode(wav).mean, non-streaming (:154; modular_vibevoice_tokenizer.py:1081-1085):
  * wav_dev [frames*hop] -> mean_out_dev [frames][latent] */
 int vv_acoustic_encode(vv_ctx* ctx, void* stream, int frames, const float* wav_dev, float* mean_out_dev);
+/* The same for a signal that does not fill its last frame: valid_samples in ((frames - 1) * hop, frames * hop], wav_dev zero beyond them.
+ * The reference right-pads PER strided conv layer (SConv1d.forward -> get_extra_padding_for_conv1d, modular_vibevoice_tokenizer.py):
+ * past the end of the signal every strided conv reads zeros, not the activations a zero waveform would produce.  Only the last,
+ * partial frame's latent depends on it (every layer is causal). */
+int vv_acoustic_encode_ragged(vv_ctx* ctx, void* stream, int frames, long long valid_samples, const float* wav_dev, float* mean_out_dev);
 /* Frames the voice-prompt encoder takes per pass, 1..config.enc_frames (the buffers are sized for enc_frames; the default).
  * The reference's non-streaming encode runs the whole prompt as one sequence (modular_vibevoice_tokenizer.py:384-418,
  * 1081-1085); a pass of F frames is that computation on F frames with the causal history carried over, so the result does

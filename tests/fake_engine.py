@@ -82,6 +82,12 @@ class FakeEngine:
             hidden[i] = self.om.lm.forward(x_in[i][None], c)[-1]
             self.calls["lm_rows"] += 1
 
+    def kv_move(self, cache, src_pos, dst_pos):
+        c = self.caches[cache]
+        for l in range(len(c.k)):
+            c.k[l][:, dst_pos] = c.k[l][:, src_pos].clone()
+            c.v[l][:, dst_pos] = c.v[l][:, src_pos].clone()
+
     def lm_logits(self, n, hidden, out):
         # the C ABI's layout: a dense [n][n_valid] block at the start of `out` (include/vvhip.h, vv_lm_logits)
         nv = len(self.valid)
@@ -123,8 +129,10 @@ class FakeEngine:
             if sem_out is not None:
                 self.semantic_encode(sl, audio_out[j], sem_out[j])
 
-    def acoustic_encode(self, frames, wav, mean_out):
+    def acoustic_encode(self, frames, wav, mean_out, valid_samples=None):
         om = self.om
+        if valid_samples is not None:
+            wav = wav[:valid_samples]          # the oracle encoder pads per conv layer, as the reference does
         lat = codec.encoder_forward(om.ac_w, wav[None, None, :], om.ratios, om.enc_depths, state=None, eps=om.codec_eps)
         mean_out.copy_(lat[0].t())
 

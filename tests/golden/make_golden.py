@@ -492,6 +492,10 @@ def gen_generate(custom=None):
     # several voice samples in one prompt (a multi-speaker script: BASELINE configs[2] has two speakers, configs[3] four): row 0 carries
     # two samples (2 and 1 frames), row 1 one (3 frames); speech_tensors / speech_masks hold the three samples row after row
     run("generate_multivoice_b2.npz", 2, [[D, D, D, E, S, D, X], [D, D, E, X]], seed=602, voices=[[2, 1], [3]])
+    # a voice sample that is not a whole number of frames AND whose partial last frame is used (row 1 takes all three frames of the
+    # 2.5-frame batch tensor): SConv1d right-pads per strided conv layer (get_extra_padding_for_conv1d), so past the end of the signal
+    # every strided conv reads zeros -- the partial frame's latent, and through it the whole prompt of that row, depends on it
+    run("generate_ragged_voice_full_b2.npz", 2, [[D, D, D, X], [D, D, E, X]], seed=611, wav_len=8000)
 
 
 @torch.no_grad()

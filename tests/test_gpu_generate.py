@@ -143,7 +143,7 @@ def test_generate_without_negative_refresh(sm, B, forced, seed):
     assert any(rel_err(a, b) > 1e-2 for a, b in zip(o[3].neg_hidden, o2[3].neg_hidden))
 
 
-@pytest.mark.parametrize("name", ["generate_norefresh_b1", "generate_norefresh_b2", "generate_late_start_b2", "generate_late_start_b2r", "generate_times_b2", "generate_multivoice_b2"])
+@pytest.mark.parametrize("name", ["generate_norefresh_b1", "generate_norefresh_b2", "generate_late_start_b2", "generate_late_start_b2r", "generate_times_b2", "generate_multivoice_b2", "generate_ragged_voice_full_b2"])
 def test_generate_against_the_reference_goldens_of_the_rare_modes(sm, name):
     """the engine directly against what the REFERENCE's generate(refresh_negative=False) produced on the same tiny seeded model, inputs,
     forced plan and recorded noise draws (tests/golden/make_golden.py::gen_generate): sequences identical, waveform rel-L2 <= 1e-2

@@ -435,6 +435,69 @@ def test_acoustic_encode_nonstream(sm):
     assert rel_err(out, ref) <= 2e-4, rel_err(out, ref)
 
 
+@pytest.mark.parametrize("samples", [8000, 6500, 12801, 15999, 3201])
+def test_acoustic_encode_ragged_tail(sm, samples):
+    """A signal that does not fill its last frame: the reference right-pads PER strided conv layer (SConv1d.forward ->
+    get_extra_padding_for_conv1d), i.e. past the end of the signal every strided conv reads zeros; vv_acoustic_encode_ragged zeroes
+    those rows in front of each strided conv of the last pass.  Against the oracle encoder on the UNPADDED signal (which pads per
+    layer, as the reference); enc_frames = 2, so the partial frame falls into a pass of one or two frames.  The whole-frame entry point
+    on the zero-padded waveform differs in the last frame only (that is the deviation this entry point removes)."""
+    eng, cc = sm.eng, sm.cc
+    g = synth.Gen(303 + samples)
+    wav = g.uniform((samples,), -0.5, 0.5)
+    nfr = -(-samples // 3200)
+    ref = codec.encoder_forward(sm.ac_w, wav[None, None], cc.ratios, cc.enc_depths, None, cc.eps)[0].t()
+    assert ref.shape[0] == nfr
+    padded = torch.zeros(nfr * 3200)
+    padded[:samples] = wav
+    out, out_whole = eng.new(nfr, 64), eng.new(nfr, 64)
+    with torch.cuda.stream(eng.stream):
+        eng.acoustic_encode(nfr, dev(padded, eng), out, valid_samples=samples)
+        eng.acoustic_encode(nfr, dev(padded, eng), out_whole)
+    eng.sync()
+    assert rel_err(out, ref) <= 2e-4, rel_err(out, ref)
+    for f in range(nfr):
+        assert rel_err(out[f], ref[f]) <= 5e-4, (f, rel_err(out[f], ref[f]))
+    if nfr > 1:
+        assert rel_err(out_whole[:nfr - 1], ref[:nfr - 1]) <= 2e-4            # causal: the frames before the partial one agree either way
+    assert rel_err(out_whole[nfr - 1], ref[nfr - 1]) > 1e-3                    # ... and the partial frame is where the two paddings part
+
+
+def test_kv_move_keeps_the_rotation(sm):
+    """vv_kv_move: cached position src copied onto dst in every layer, keys keeping the rotation they were computed with -- the
+    reference's single-entry negative correction leaves the entry of step 1 (rotated for position 1) as the row's only entry.  Three
+    tokens through one cache of the engine and of the oracle; entry 1 moved onto 0 on both sides; the next token at position 1 must
+    see the same context."""
+    s = build_small(LM_CASES["gqa"], xsplit=3, max_ctx=256)
+    eng = s.eng
+    try:
+        H = s.lmcfg.hidden
+        m = s.oracle_lm(kv_round_bf16=True)
+        g = synth.Gen(611)
+        x = g.normal((3, H), 1.0, mat=False)
+        oc = m.new_cache()
+        m.forward(x[0:1], oc)
+        m.forward(x[1:2], oc)
+        for l in range(len(oc.k)):
+            oc.k[l][:, 0] = oc.k[l][:, 1].clone()
+            oc.v[l][:, 0] = oc.v[l][:, 1].clone()
+        oc.truncate(1)
+        ref = m.forward(x[2:3], oc)                       # position 1, context = the moved entry
+        hid = eng.new(1, H)
+        xd = dev(x, eng)
+        with torch.cuda.stream(eng.stream):
+            eng.lm_forward([(1, 0)], xd[0:1], hid)
+            eng.lm_forward([(1, 1)], xd[1:2], hid)
+            eng.kv_move(1, 1, 0)
+            eng.lm_forward([(1, 1)], xd[2:3], hid)
+        eng.sync()
+        assert rel_err(hid, ref) <= 2e-3, rel_err(hid, ref)
+        with pytest.raises(Exception):
+            eng.kv_move(99, 0, 1)
+    finally:
+        eng.close()
+
+
 LM_CASES = {"d64": synth.LMCfg(), "d128": synth.LMCfg(hidden=256, heads=2, kv_heads=1, inter=384),
             "gqa": synth.LMCfg(hidden=256, heads=4, kv_heads=2, inter=320, layers=3)}
 

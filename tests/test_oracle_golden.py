@@ -179,7 +179,7 @@ def _oracle_small(kv_round_bf16=False):
 
 
 @pytest.mark.parametrize("name", ["generate_forced_b1", "generate_forced_b2", "generate_greedy_b1", "generate_cap_b1", "generate_ragged_voice_b1",
-                                  "generate_norefresh_b1", "generate_norefresh_b2", "generate_times_b2", "generate_late_start_b2", "generate_late_start_b2r", "generate_single_entry_b2", "generate_multivoice_b2"])
+                                  "generate_norefresh_b1", "generate_norefresh_b2", "generate_times_b2", "generate_late_start_b2", "generate_late_start_b2r", "generate_single_entry_b2", "generate_multivoice_b2", "generate_ragged_voice_full_b2"])
 def test_generate_loop_matches_the_reference_generate(name):
     """Golden = the REFERENCE's own generate() (modeling_vibevoice_inference.py:326-710) run on the tiny seeded model
     (tests/golden/make_golden.py::gen_generate, through oracle/refshim.install_generate_shims).  The oracle loop gets

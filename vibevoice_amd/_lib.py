@@ -52,6 +52,8 @@ _SIGS = {
     "vv_semantic_encode": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     "vv_codec_chain_batch": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, C.c_int]),
     "vv_acoustic_encode": (C.c_int, [_P, _P, C.c_int, _P, _P]),
+    "vv_acoustic_encode_ragged": (C.c_int, [_P, _P, C.c_int, C.c_longlong, _P, _P]),
+    "vv_kv_move": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int]),
     "vv_set_enc_pass_frames": (C.c_int, [_P, C.c_int]),
     "vv_audio_to_pcm16": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     "vv_codec_reset": (C.c_int, [_P, _P, C.c_int]),

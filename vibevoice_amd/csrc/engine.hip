@@ -70,6 +70,7 @@ int vv_ada_in_launch(const float* cproj, const float* temb, float* out, int rows
 int vv_add_rows_launch(const float* x, const float* v, float* y, int n, int C, hipStream_t s);
 int vv_relu_launch(float* x, int n, hipStream_t s);
 int vv_kv_import_launch(const void* k, const void* v, int src_bf16, void* kc, void* vc, int L, int Hkv, int D, int64_t head_stride, int pos0, hipStream_t s);
+int vv_kv_move_launch(void* kc, void* vc, int layers, int Hkv, int D, int64_t layer_stride, int64_t head_stride, int src, int dst, hipStream_t s);
 int vv_pcm16_launch(const float* x, short* out, int n, int samples, hipStream_t s);
 int vv_cvt_launch(const void* src, void* dst, int64_t n, int to_bf16, hipStream_t s);
 int vv_dw_transpose_launch(const float* src, float* dst, int C, hipStream_t s);
@@ -581,8 +582,13 @@ extern "C" int vv_timeline_dump(vv_ctx* ctx, unsigned long long* out_host, int* 
 // input rows into net.in_buf[sl] + 6*in_dim.
 // Stages [i0, i1) only (i1 < 0: to the end); `head` / `shift`: run the head conv / the history shift at the end.  The split
 // forms serve vv_codec_chain_batch, where part of the net runs slot-batched (run_codec_batch) and the rest per utterance.
+// tail_valid >= 0 (encoder, last pass of a ragged input): only the first tail_valid rows of stage 0's output are real signal.
+// The reference's non-streaming encoder right-pads with zeros PER strided conv (SConv1d: get_extra_padding_for_conv1d), i.e. the
+// rows past the end of the signal are ZERO at the input of every strided conv -- not conv(0) + bias, which is what the rows past the
+// end hold here when the waveform is zero-padded to whole frames.  Every layer is causal, so zeroing those rows of stage i-1's
+// output right before stage i's incoming conv reproduces the reference exactly; only the last, partial frame's latent changes.
 static int run_codec(vv_ctx* ctx, CodecNet& net, int sl, int F, float* out, hipStream_t st, int i0 = 0, int i1 = -1,
-                     bool head = true, bool shift = true) {
+                     bool head = true, bool shift = true, int tail_valid = -1) {
     const float eps = ctx->c.codec_eps;
     const bool stream_w = (F == 1);      // T=1 stages stream their weights exactly once
     auto& stages = net.st[sl];
@@ -592,6 +598,14 @@ static int run_codec(vv_ctx* ctx, CodecNet& net, int sl, int F, float* out, hipS
         Stage& s = stages[i];
         const int T = s.Tpf * F;
         float* x = s.xs + (size_t)s.hist * s.C;
+        if (tail_valid >= 0 && i > 0) {
+            Stage& pv = stages[i - 1];
+            const int Tp = pv.Tpf * F;
+            if (tail_valid < Tp)
+                HIPCHK(ctx, hipMemsetAsync(pv.xfinal + ((size_t)pv.hist + tail_valid) * pv.C, 0, (size_t)(Tp - tail_valid) * pv.C * 4, st));
+            const int r = pv.Tpf / s.Tpf;                       // this stage's incoming stride
+            tail_valid = (tail_valid + r - 1) / r;
+        }
         {   // incoming conv
             const ConvG& cg = s.in;
             const float* X = (i == 0) ? net.in_buf[sl] : stages[i - 1].xfinal;
@@ -1352,6 +1366,18 @@ extern "C" int vv_kv_import_at(vv_ctx* ctx, void* stream, int cache, int layer, 
     VVCHK(vv_kv_import_launch(k_dev, v_dev, src_dtype, (char*)ctx->kc + off, (char*)ctx->vc + off, n_pos, ctx->Hkv, ctx->D, ctx->head_stride, pos0, st));
     return 0;
 }
+extern "C" int vv_kv_move(vv_ctx* ctx, void* stream, int cache, int src_pos, int dst_pos) {
+    hipStream_t st = (hipStream_t)stream;
+    if (cache < 0 || cache >= 2 * ctx->c.n_slots) return fail(ctx, "cache id %d out of range", cache);
+    if (src_pos < 0 || dst_pos < 0 || src_pos >= ctx->c.max_ctx || dst_pos >= ctx->c.max_ctx)
+        return fail(ctx, "vv_kv_move: positions %d -> %d outside [0, %d)", src_pos, dst_pos, ctx->c.max_ctx);
+    if (src_pos == dst_pos) return 0;
+    const size_t off = (size_t)cache * ctx->cache_stride * 2;
+    ctx->launches++;
+    VVCHK(vv_kv_move_launch((char*)ctx->kc + off, (char*)ctx->vc + off, ctx->c.lm_layers, ctx->Hkv, ctx->D, ctx->layer_stride, ctx->head_stride,
+                            src_pos, dst_pos, st));
+    return 0;
+}
 extern "C" int vv_kv_import(vv_ctx* ctx, void* stream, int cache, int layer, int n_pos, const void* k_dev, const void* v_dev, int src_dtype) {
     return vv_kv_import_at(ctx, stream, cache, layer, 0, n_pos, k_dev, v_dev, src_dtype);
 }
@@ -1670,9 +1696,12 @@ extern "C" int vv_codec_chain_batch(vv_ctx* ctx, void* stream, int n, const int*
     });
 }
 
-extern "C" int vv_acoustic_encode(vv_ctx* ctx, void* stream, int frames, const float* wav_dev, float* mean_out_dev) {
+// valid_samples: samples of real signal in wav_dev [frames * hop] (the rest must be zeros); frames = ceil(valid_samples / hop).
+extern "C" int vv_acoustic_encode_ragged(vv_ctx* ctx, void* stream, int frames, long long valid_samples, const float* wav_dev, float* mean_out_dev) {
     hipStream_t st = (hipStream_t)stream;
     if (!ctx->c.has_acoustic_encoder) return fail(ctx, "no acoustic encoder configured");
+    if (valid_samples <= (int64_t)(frames - 1) * ctx->hop || valid_samples > (int64_t)frames * ctx->hop)
+        return fail(ctx, "vv_acoustic_encode_ragged: %lld valid samples do not end in frame %d of %d", (long long)valid_samples, frames - 1, frames);
     CodecNet& net = ctx->aenc;
     if (zero_codec(ctx, net, 0, st)) return -1;
     const int L = ctx->c.latent_dim;
@@ -1680,9 +1709,15 @@ extern "C" int vv_acoustic_encode(vv_ctx* ctx, void* stream, int frames, const f
     for (int f0 = 0; f0 < frames; f0 += pass) {
         const int F = std::min(pass, frames - f0);
         HIPCHK(ctx, hipMemcpyAsync(net.in_buf[0] + 6, wav_dev + (size_t)f0 * ctx->hop, (size_t)F * ctx->hop * 4, hipMemcpyDeviceToDevice, st));
-        if (run_codec(ctx, net, 0, F, mean_out_dev + (size_t)f0 * L, st)) return -1;
+        const int64_t v = valid_samples - (int64_t)f0 * ctx->hop;            // real samples inside this pass
+        const int tail = (f0 + F == frames && v < (int64_t)F * ctx->hop) ? (int)v : -1;
+        if (run_codec(ctx, net, 0, F, mean_out_dev + (size_t)f0 * L, st, 0, -1, true, true, tail)) return -1;
     }
     return 0;
+}
+
+extern "C" int vv_acoustic_encode(vv_ctx* ctx, void* stream, int frames, const float* wav_dev, float* mean_out_dev) {
+    return vv_acoustic_encode_ragged(ctx, stream, frames, (long long)frames * ctx->hop, wav_dev, mean_out_dev);
 }
 
 extern "C" int vv_set_enc_pass_frames(vv_ctx* ctx, int frames_per_pass) {

@@ -416,6 +416,25 @@ __global__ void vv_kv_import_kernel(const ST* __restrict__ k, const ST* __restri
     }
 }
 
+// one cached position copied onto another, every layer and kv head of one cache: grid (layers, kvh), block D threads
+__global__ void vv_kv_move_kernel(__bf16* __restrict__ kc, __bf16* __restrict__ vc, int D, int64_t layer_stride, int64_t head_stride,
+                                  int src, int dst) {
+    const int d = threadIdx.x;
+    __bf16* kb = kc + (int64_t)blockIdx.x * layer_stride + (int64_t)blockIdx.y * head_stride;
+    __bf16* vb = vc + (int64_t)blockIdx.x * layer_stride + (int64_t)blockIdx.y * head_stride;
+    auto kidx = [&](int pos) {
+        const int64_t tile = (int64_t)(pos >> 4) * (D / 32) + (d >> 5);
+        return (tile * 64 + (pos & 15) + 16 * ((d & 31) >> 3)) * 8 + (d & 7);
+    };
+    auto vidx = [&](int pos) {
+        const int p = pos & 31, half = p >> 4, pp = p & 15, q4 = pp >> 2, rr = pp & 3;
+        const int64_t tile = (int64_t)(pos >> 5) * (D / 16) + (d >> 4);
+        return (tile * 64 + (d & 15) + 16 * q4) * 8 + half * 4 + rr;
+    };
+    kb[kidx(dst)] = kb[kidx(src)];
+    vb[vidx(dst)] = vb[vidx(src)];
+}
+
 // 16-bit PCM of one chunk per workgroup, the arithmetic of the reference's convert_to_16_bit_wav (demo/gradio_demo.py:1058-1073):
 // peak = max|x|; if peak > 1: x /= peak (fp32, IEEE division); (x * 32767) truncated toward zero to int16.
 __global__ __launch_bounds__(256) void vv_pcm16_kernel(const float* __restrict__ x, short* __restrict__ out, int samples) {
@@ -667,6 +686,10 @@ int vv_kv_import_launch(const void* k, const void* v, int src_bf16, void* kc, vo
                         int64_t head_stride, int pos0, hipStream_t s) {
     if (src_bf16) hipLaunchKernelGGL((vv_kv_import_kernel<__bf16>), dim3(L, Hkv), dim3(D), 0, s, (const __bf16*)k, (const __bf16*)v, (__bf16*)kc, (__bf16*)vc, L, D, head_stride, pos0);
     else hipLaunchKernelGGL((vv_kv_import_kernel<float>), dim3(L, Hkv), dim3(D), 0, s, (const float*)k, (const float*)v, (__bf16*)kc, (__bf16*)vc, L, D, head_stride, pos0);
+    return okk();
+}
+int vv_kv_move_launch(void* kc, void* vc, int layers, int Hkv, int D, int64_t layer_stride, int64_t head_stride, int src, int dst, hipStream_t s) {
+    hipLaunchKernelGGL(vv_kv_move_kernel, dim3(layers, Hkv), dim3(D), 0, s, (__bf16*)kc, (__bf16*)vc, D, layer_stride, head_stride, src, dst);
     return okk();
 }
 int vv_pcm16_launch(const float* x, short* out, int n, int samples, hipStream_t s) {

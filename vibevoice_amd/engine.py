@@ -281,6 +281,10 @@ class Engine:
         self._chk(self.lib.vv_kv_import(self._ctx, self._s, cache, layer, k.shape[1], self._p(k), self._p(v),
                                         1 if k.dtype == torch.bfloat16 else 0), "vv_kv_import")
 
+    def kv_move(self, cache: int, src_pos: int, dst_pos: int):
+        """cached position src_pos copied onto dst_pos, every layer of `cache` (keys keep their rotation)"""
+        self._chk(self.lib.vv_kv_move(self._ctx, self._s, int(cache), int(src_pos), int(dst_pos)), "vv_kv_move")
+
     def kv_import_at(self, cache: int, layer: int, pos0: int, k: torch.Tensor, v: torch.Tensor):
         """k, v: [kv_heads, n_pos, head_dim] -> cache positions [pos0, pos0 + n_pos)."""
         assert k.shape == v.shape and k.dim() == 3
@@ -357,9 +361,14 @@ class Engine:
                                                 self._p(sem_out) if sem_out is not None else None, int(apply_speech_factors)),
                   "vv_codec_chain_batch")
 
-    def acoustic_encode(self, frames: int, wav: torch.Tensor, mean_out: torch.Tensor):
-        self._chk(self.lib.vv_acoustic_encode(self._ctx, self._s, frames, self._p(wav), self._p(mean_out)),
-                  "vv_acoustic_encode")
+    def acoustic_encode(self, frames: int, wav: torch.Tensor, mean_out: torch.Tensor, valid_samples: Optional[int] = None):
+        """wav [frames * hop] -> mean_out [frames, latent].  valid_samples: real signal length when it does not fill the last frame (wav is
+        zero beyond it): the reference's per-conv-layer right padding is reproduced (vv_acoustic_encode_ragged)."""
+        if valid_samples is None or valid_samples >= frames * self.cfg.hop:
+            self._chk(self.lib.vv_acoustic_encode(self._ctx, self._s, frames, self._p(wav), self._p(mean_out)), "vv_acoustic_encode")
+        else:
+            self._chk(self.lib.vv_acoustic_encode_ragged(self._ctx, self._s, frames, int(valid_samples), self._p(wav), self._p(mean_out)),
+                      "vv_acoustic_encode_ragged")
 
     def set_enc_pass_frames(self, frames_per_pass: int):
         """frames per voice-prompt encoder pass, 1..cfg.enc_frames"""

@@ -584,11 +584,15 @@ class VibeVoiceForConditionalGenerationInference:
         hop = e.cfg.hop
         n_spk, S = speech_tensors.shape
         frames = S // hop
+        valid = None
         if frames * hop != S:
-            # the reference's non-streaming conv right-pads to a whole number of frames
+            # the batch tensor does not end on a frame: the engine takes whole frames of zero-padded waveform plus the signal length --
+            # the reference right-pads per strided conv LAYER (zeros, not the activations of a zero waveform), which only the last,
+            # partial frame's latent can tell (vv_acoustic_encode_ragged)
             pad = (frames + 1) * hop - S
             speech_tensors = torch.nn.functional.pad(speech_tensors, (0, pad))
             frames += 1
+            valid = S
         wav = speech_tensors.to(self.device, torch.float32).contiguous()
         # rows of the [n_spk * frames] encoder output that are real frames (speech_masks is the processor's host data)
         sel_idx = speech_masks.reshape(-1).to(torch.bool).cpu().nonzero().squeeze(1).to(self.device)
@@ -596,7 +600,7 @@ class VibeVoiceForConditionalGenerationInference:
             prefill_noise = tuple(t.to(self.device, torch.float32) for t in prefill_noise)
         mean = e.new(n_spk, frames, e.cfg.latent_dim)
         for i in range(n_spk):
-            e.acoustic_encode(frames, wav[i], mean[i])
+            e.acoustic_encode(frames, wav[i], mean[i], valid_samples=valid)
         if self.std_dist_type == "gaussian":
             if prefill_noise is None:
                 # VibeVoiceTokenizerEncoderOutput.sample('gaussian'), modular_vibevoice_tokenizer.py:980-989:
@@ -1046,10 +1050,9 @@ class VibeVoiceForConditionalGenerationInference:
         """The reference's array bookkeeping of the negative branch (oracle.generate.NegativeRow restates it with the tensors), masks
         and counters only.  Its correction of a non-diffusing row (:594-624) guards the mask shift and the K/V shift differently
         (:603 vs :613): for a row holding exactly one valid entry the mask moves and the K/V does not, so the reference KEEPS the entry
-        appended at this step and masks the older one out.  Everywhere else the net effect is "this step's entry is dropped", which
-        is what this path does for every row -- it has no KV-entry move.  Needs a one-frame speech segment (or a non-diffusion token
+        appended at this step and masks the older one out.  Everywhere else the net effect is "this step's entry is dropped".  Needs a one-frame speech segment (or a non-diffusion token
         at step 1 with refresh_negative=False) in one row of a batch while another row diffuses; found by
-        tools/fuzz_generate_vs_reference.py, which reports the pattern.  Warned once per generate() when it happens."""
+        tools/fuzz_generate_vs_reference.py.  Followed with vv_kv_move: the entry of this step is moved onto the older one."""
         def fwd():
             for u in order:
                 b = u.neg_book
@@ -1069,14 +1072,11 @@ class VibeVoiceForConditionalGenerationInference:
             if u in diff:
                 continue
             mask, c, cnt = u.neg_book
-            if c - cnt == 2 and mask[cnt] == 1 and not S.get("_warned_single_entry"):
-                S["_warned_single_entry"] = True
-                import warnings
-                warnings.warn(f"generate(): row {u.idx} emits a non-diffusion token at step {u.step} while another row of the batch diffuses and "
-                              "its negative (CFG) cache holds exactly one valid entry: the reference keeps THIS step's entry and masks the older "
-                              "one there (modeling_vibevoice_inference.py:603 vs :613); this path drops this step's entry as everywhere else: if the "
-                              "row diffuses again before its next <speech_start> (which resets the negative context either way), its "
-                              "negative condition differs from the reference's", RuntimeWarning, stacklevel=3)
+            if c - cnt == 2 and mask[cnt] == 1:
+                # the row's one valid entry sits at compact position 0, this step's entry (written by the speculative negative row of
+                # the LM pass above) at position 1: the reference keeps the NEW one.  Position 1 -> 0 with its rotation, length stays 1
+                assert u.neg_len == 1, (u.idx, u.neg_len)
+                self.engine.kv_move(2 * u.slot + 1, 1, 0)
             if cnt + 1 < len(mask) - 1:
                 mask[cnt + 1:] = mask[cnt:-1]
             mask[cnt] = 0
