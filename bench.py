@@ -487,6 +487,29 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline, with_parity=False):
     cont_stats = dict(model.last_stats) if args.continuous else None
     # every rank's own step time next to the max: an imbalance (a slow GPU, a straggling host loop) shows in the first SCALE run
     per_rank_ms = [round(v, 4) for v in parallel.per_rank_values(wall / K * 1e3, device)]
+    # the result phase of an N-GPU job, outside the timed region: every rank's finished utterances -- token sequences and
+    # waveforms of the generate() above -- travel to rank 0 as device tensors through parallel.gather_outputs (RCCL gather; with one
+    # rank under torchrun it is the same collective on a one-rank communicator).  Rank 0 checks what arrived against its own rows.
+    rccl = None
+    if use_dist:
+        from vibevoice_amd.modeling import VibeVoiceGenerationOutput
+        per = list(outs) if args.continuous else [
+            VibeVoiceGenerationOutput(sequences=out.sequences[b:b + 1], speech_outputs=[out.speech_outputs[b]],
+                                      reach_max_step_sample=out.reach_max_step_sample[b:b + 1]) for b in range(out.sequences.shape[0])]
+        n_per = len(per)
+        gst = {}
+        got = parallel.gather_outputs(per, [list(range(r * n_per, (r + 1) * n_per)) for r in range(world)], world * n_per, device,
+                                      torch.bfloat16, gather_to=0, stats=gst)
+        if rank == 0:
+            ok = len(got) == world * n_per and all(g is not None and g.speech_outputs[0] is not None for g in got)
+            ok = ok and all(torch.equal(got[j].sequences, per[j].sequences.cpu()) and
+                            torch.equal(got[j].speech_outputs[0], per[j].speech_outputs[0].reshape(1, -1).float().cpu()) for j in range(n_per))
+            rccl = {"backend": dist.get_backend(), "ranks": world,
+                    "weights_broadcast": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in bc.items()},
+                    "result_gather": gst.get("gather"), "utterances_received_on_rank0": len(got),
+                    "audio_seconds_received": round(sum(g.speech_outputs[0].shape[-1] for g in got if g is not None) / 24000.0, 2),
+                    "rank0_rows_identical_after_the_round_trip": bool(ok),
+                    "collectives_inside_the_step_loop": 0}
     # first-audio latency as SURVEY 8d defines it: generate() entry (voice-prompt encode + prompt prefill + first frame) -> the
     # first chunk an AudioStreamer consumer receives on the host; 5 trials of the same request
     first_audio = None
@@ -661,7 +684,7 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline, with_parity=False):
         "extra": {"frames_timed": frames, "weights_load_s": round(load_s, 2), "libvvhip_build_id": _build_id(),
                   "weights_broadcast": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in bc.items()},
                   "weights_source": (f"checkpoint {ckpt}" if ckpt else "synthetic (seeded N(0, 0.02^2) at the config's shapes)"),
-                  "per_rank_ms_per_step": per_rank_ms, "warmup_s": round(warm_s, 3), "first_audio": first_audio,
+                  "per_rank_ms_per_step": per_rank_ms, "rccl": rccl, "warmup_s": round(warm_s, 3), "first_audio": first_audio,
                   "sharding": parallel.shard_report([L0] * (world * n_utt), [list(range(r * n_utt, (r + 1) * n_utt)) for r in range(world)]),
                   "prefill_plus_first_frame_s": round(marks.get("prefill_done", t_gen0) - t_gen0, 4),
                   "prefill_phases": prefill_phases,

@@ -104,13 +104,8 @@ class NegativeRow:
     restores): the new token sits at position = number of valid entries before it; stored keys keep the rotation they were
     computed with."""
 
-    def __init__(self, lm, engine_form=False):
+    def __init__(self, lm):
         self.lm = lm
-        # engine_form: the K/V shift of the correction takes the MASK shift's guard -- the net effect is then "this step's entry is
-        # dropped" in every case, which is what the HIP engine computes (it has no KV-entry move yet: DESIGN.md section 4, the known
-        # deviation).  Tests that hold the ENGINE to the oracle on batched forced plans use this form; tests against the reference's
-        # goldens use the literal one.
-        self.engine_form = engine_form
         self.full = lm.new_cache()          # all entries ever appended, masked ones included
         self.mask = [1]                     # :379-386: the lone <speech_start> prompt token's slot
         self.cnt = 0                        # correct_cnt[b]
@@ -150,7 +145,7 @@ class NegativeRow:
         if s + 1 < n - 1:
             self.mask[s + 1:] = self.mask[s:-1]
         self.mask[s] = 0
-        if s + 1 < (c if self.engine_form else c - 1):
+        if s + 1 < c - 1:
             for l in range(len(self.full.k)):
                 self.full.k[l][:, s + 1:] = self.full.k[l][:, s:-1].clone()
                 self.full.v[l][:, s + 1:] = self.full.v[l][:, s:-1].clone()
@@ -164,15 +159,12 @@ def oracle_generate(m: OracleModel, tok: TokenIds, input_ids, attention_mask,
                     forced_tokens: Optional[List[List[int]]] = None,
                     do_sample=False, trace: Optional[Trace] = None,
                     algorithm_type="dpmsolver++", sde_noise_fn: Callable = None,
-                    teacher_embeds: Callable = None, refresh_negative: bool = True, batch_cache_quirk: bool = True,
-                    engine_negative_correction: bool = False):
+                    teacher_embeds: Callable = None, refresh_negative: bool = True, batch_cache_quirk: bool = True):
     """Returns (sequences [B, L0+steps], speech_outputs list, reach_max_step_sample).
     algorithm_type "sde-dpmsolver++": the scheduler demo/gradio_demo.py:142-146 installs; sde_noise_fn(step, N, 2n) ->
     [N, 2n, 64], the variance noise scheduler.step() draws per solver step (dpm_solver.py:994-997).
     teacher_embeds(step) -> [B, H] or None: test hook (SURVEY 8d "teacher-forced per step") -- the NEXT positive pass consumes these
     embeddings instead of the loop's own, so two implementations are compared step by step on identical inputs.
-    engine_negative_correction=True: the negative-cache correction in the form the HIP engine computes (see NegativeRow) -- for tests
-    that compare the ENGINE with this loop on batched plans; the default is the reference's literal arithmetic.
     batch_cache_quirk=False: every row keeps its own tokenizer history whatever the other rows do (what a queue of independent
     requests computes: generate_continuous) instead of the lock-step batch's behaviour described at the decode step below.
     refresh_negative=False (:503-516; the reset of :550-565 and the forward of :576-588 are then skipped): the negative pass runs at
@@ -194,7 +186,7 @@ def oracle_generate(m: OracleModel, tok: TokenIds, input_ids, attention_mask,
     finished = torch.zeros(B, dtype=torch.bool)
     reach_max = torch.zeros(B, dtype=torch.bool)
     pos_cache = [m.lm.new_cache() for _ in range(B)]
-    neg = [NegativeRow(m.lm, engine_form=engine_negative_correction) for _ in range(B)]
+    neg = [NegativeRow(m.lm) for _ in range(B)]
     ac_state = [dict() for _ in range(B)]
     sem_state = [dict() for _ in range(B)]
     audio_chunks = [[] for _ in range(B)]

@@ -37,6 +37,9 @@ class Leg:
     cfg_scale: float = 1.3
     dtype: torch.dtype = torch.float32
     device: str = "cpu"
+    inputs: Optional[dict] = None       # processor-shaped request the leg ran (cpu tensors): input_ids, attention_mask, speech_*
+    prefill_noise: Optional[tuple] = None   # the two draws of the voice-prompt sampling (fp32 cpu), as the loop consumed them
+    prompt_s: float = 0.0               # wall time of everything before the first solver draw (voice-prompt encode + prompt pass)
 
 
 def oracle_model(cfg, sd, device, dtype, scaling=0.2, bias=-0.05):
@@ -62,7 +65,7 @@ def oracle_model(cfg, sd, device, dtype, scaling=0.2, bias=-0.05):
 
 
 def oracle_leg(cfg, sd, tokens, n_solver, cfg_scale, n_frames, device, dtype, t_budget, prompt_len=48, seed=7,
-               t_cast_bf16=True, teacher: Optional[Leg] = None) -> Leg:
+               t_cast_bf16=True, teacher: Optional[Leg] = None, inputs: Optional[dict] = None, attn_rows: Optional[int] = None) -> Leg:
     """`n_frames` decode frames of the oracle loop after a `prompt_len`-token text-only prompt ending in <speech_start>, on
     `device` in `dtype`, every step forced to <speech_diffusion>; stops early once `t_budget` seconds are spent (after at
     least two whole frames).  t_cast_bf16: the timestep fed to the head is rounded to bf16 (999 -> 1000), what the reference's
@@ -70,9 +73,16 @@ def oracle_leg(cfg, sd, tokens, n_solver, cfg_scale, n_frames, device, dtype, t_
     reproduces -- a bf16 leg rounds by construction, the fp32 leg rounds so that both sides evaluate the head at the same t.
     teacher: another leg of the same prompt -- this run consumes ITS noise (rounded to `dtype`, as the reference's `.to(condition)`
     does) and is teacher-forced per step with ITS next-step embeddings, for as many frames as it completed: the two legs then
-    differ by their arithmetic only (compare_legs)."""
+    differ by their arithmetic only (compare_legs).
+    inputs: a whole processor-shaped request of ONE utterance instead of the short text-only prompt (input_ids [1, L0], attention_mask,
+    speech_tensors [n_spk, S], speech_masks, speech_input_mask): the voice prompts go through the oracle's non-streaming encoder and
+    connector, the L0-token prompt through all layers in one pass (modeling_vibevoice_inference.py:149-163, :467-482) -- the trace's
+    step 0 then holds the hidden state at the prompt's last position.  The two voice-prompt sampling draws are seeded here (or taken
+    from the teacher).  attn_rows: query rows per attention block of the oracle's prompt pass (bounds the fp32 score matrix: 28 heads
+    x 10,922^2 fp32 would be 13 GB per layer)."""
     if teacher is not None:
         n_frames = min(n_frames, teacher.frames)
+        inputs = teacher.inputs if inputs is None else inputs
     on_gpu = torch.device(device).type == "cuda"
     T = tokens
     with torch.device(device):                   # the oracle's own factory calls (arange / zeros / tensor) land on `device`
@@ -80,11 +90,29 @@ def oracle_leg(cfg, sd, tokens, n_solver, cfg_scale, n_frames, device, dtype, t_
         if t_cast_bf16:
             m.t_cast_dtype = torch.bfloat16
         tok = ogen.TokenIds(T.speech_start_id, T.speech_end_id, T.speech_diffusion_id, T.eos_token_id, None, T.pad_token_id)
+        m.lm.attn_rows = attn_rows
         g = torch.Generator(device="cpu").manual_seed(seed)
-        ids = torch.randint(0, 151000 if cfg["decoder_config"]["vocab_size"] > 151000 else cfg["decoder_config"]["vocab_size"] - 64,
-                            (1, prompt_len), generator=g, device="cpu")
-        ids[0, -1] = T.speech_start_id
+        speech_kw, pre = {}, None
+        if inputs is None:
+            ids = torch.randint(0, 151000 if cfg["decoder_config"]["vocab_size"] > 151000 else cfg["decoder_config"]["vocab_size"] - 64,
+                                (1, prompt_len), generator=g, device="cpu")
+            ids[0, -1] = T.speech_start_id
+        else:
+            inputs = {k: v.detach().cpu() for k, v in inputs.items()}
+            ids = inputs["input_ids"]
+            assert ids.shape[0] == 1 and bool(inputs["attention_mask"].all()), "one unpadded utterance"
+            if inputs.get("speech_tensors") is not None:
+                n_spk, n_fr = inputs["speech_masks"].shape
+                if teacher is not None:
+                    pre = teacher.prefill_noise
+                else:
+                    gp = torch.Generator(device="cpu").manual_seed(seed + 1)
+                    pre = (torch.randn(n_spk, generator=gp), torch.randn(n_spk, n_fr, 64, generator=gp))
+                speech_kw = dict(speech_tensors=inputs["speech_tensors"].to(device=device, dtype=dtype),
+                                 speech_masks=inputs["speech_masks"].to(device), speech_input_mask=inputs["speech_input_mask"].to(device),
+                                 prefill_noise=tuple(t.to(device=device, dtype=dtype) for t in pre))
         stamps, noise = [], []
+        t_begin = time.perf_counter()
         trace = ogen.Trace()
 
         class _Budget(Exception):
@@ -111,7 +139,7 @@ def oracle_leg(cfg, sd, tokens, n_solver, cfg_scale, n_frames, device, dtype, t_
             with torch.no_grad():
                 ogen.oracle_generate(m, tok, ids_d, torch.ones_like(ids_d), cfg_scale=cfg_scale, num_steps=n_solver,
                                      max_new_tokens=len(forced[0]), noise_fn=noise_fn, forced_tokens=forced, trace=trace,
-                                     teacher_embeds=te_fn)
+                                     teacher_embeds=te_fn, **speech_kw)
         except _Budget:
             pass
         if on_gpu:
@@ -122,7 +150,8 @@ def oracle_leg(cfg, sd, tokens, n_solver, cfg_scale, n_frames, device, dtype, t_
     per_frame = (stamps[-1] - stamps[first]) / max(1, n)
     frames = min(len(trace.latents), len(trace.next_embeds), len(trace.audio))
     del m
-    return Leg(per_frame, n, frames, trace, ids, noise, n_solver, cfg_scale, dtype, str(device))
+    return Leg(per_frame, n, frames, trace, ids, noise, n_solver, cfg_scale, dtype, str(device), inputs=inputs, prefill_noise=pre,
+               prompt_s=(stamps[0] - t_begin) if stamps else 0.0)
 
 
 def _rel(a, b):
@@ -178,10 +207,14 @@ def compare_engine(model, leg: Leg, tokens, frames: Optional[int] = None, also: 
     D, X = tokens.speech_diffusion_id, tokens.eos_token_id
     htr = ogen.Trace()
     model.set_ddpm_inference_steps(leg.n_solver)
-    out = model.generate(input_ids=leg.ids, attention_mask=torch.ones_like(leg.ids), tokenizer=tokens, cfg_scale=leg.cfg_scale,
+    req = dict(input_ids=leg.ids, attention_mask=torch.ones_like(leg.ids))
+    if leg.inputs is not None and leg.inputs.get("speech_tensors") is not None:
+        req.update(speech_tensors=leg.inputs["speech_tensors"], speech_masks=leg.inputs["speech_masks"],
+                   speech_input_mask=leg.inputs["speech_input_mask"], _prefill_noise=leg.prefill_noise)
+    out = model.generate(tokenizer=tokens, cfg_scale=leg.cfg_scale,
                          generation_config={"do_sample": False}, max_new_tokens=n, show_progress_bar=False,
                          _forced_tokens=[[D] * n + [X]], _noise_fn=lambda step, n2: leg.noise[step][:n2],
-                         _trace=htr, _teacher_embeds=lambda step, rows: otr.next_embeds[step][rows].float())
+                         _trace=htr, _teacher_embeds=lambda step, rows: otr.next_embeds[step][rows].float(), **req)
     seq_ok = out.sequences.shape[1] == leg.ids.shape[1] + n and bool((out.sequences[0, leg.ids.shape[1]:].cpu() == D).all())
     res = compare_traces(htr, out.speech_outputs[0], otr, n, seq_ok)
     if also:

@@ -381,8 +381,7 @@ def test_greedy_batch2_dense_logits_layout(monkeypatch):
     def noise_fn(step, n2):
         return noise.setdefault((step, n2), synth.Gen(77 * step + n2).normal((n2, 64), 1.0, mat=False))
     tok = ogen.TokenIds(301, 302, 303, 304, None, 305)
-    oseq, oaud, omax = ogen.oracle_generate(_oracle_small(), tok, ids, mask, cfg_scale=1.3, num_steps=5, max_new_tokens=12, noise_fn=noise_fn,
-                                            engine_negative_correction=True)
+    oseq, oaud, omax = ogen.oracle_generate(_oracle_small(), tok, ids, mask, cfg_scale=1.3, num_steps=5, max_new_tokens=12, noise_fn=noise_fn)
     cfgd = {"decoder_config": {"max_position_embeddings": 4096}, "diffusion_head_config": {"ddpm_num_inference_steps": 5},
             "acoustic_tokenizer_config": {"fix_std": 0.5, "std_dist_type": "gaussian"}}
     with fake_engine.cpu_cuda_shims(monkeypatch):

@@ -103,6 +103,52 @@ def test_voice_prompt_encoder_at_the_shipped_pass_sizes(xs, tol_ref, tol_pair):
         eng.close()
 
 
+@pytest.mark.parametrize("xs,tol", [(1, 1.5e-2), (3, 1e-5)])
+def test_voice_prompt_encoder_ragged_at_real_widths(xs, tol):
+    """What every real wav hits: a 10-s voice prompt plus 1,234 stray samples (76 frames by the processor's ceil,
+    vibevoice_processor.py:491) beside a shorter speaker (47 frames + 777 samples) that the processor zero-pads to the batch
+    tensor's width.  The reference encodes the [2, 1, S] tensor non-streaming and right-pads PER strided conv layer
+    (modular_vibevoice_tokenizer.py:127-134, 384-418); the product goes through _process_speech_inputs' path: whole frames of
+    zero-padded waveform plus valid_samples = S for every row (vv_acoustic_encode_ragged).  Against the oracle's one-sequence
+    non-streaming encode of the unpadded batch tensor, EVERY frame including the last, partial one; pass sizes 76 (one pass) and
+    25 (the partial frame falls into a one-frame last pass)."""
+    S = 75 * 3200 + 1234
+    n_b = 47 * 3200 + 777
+    nfr = -(-S // 3200)
+    g = torch.Generator().manual_seed(76)
+    wav = torch.zeros(2, S)
+    wav[0] = torch.rand(S, generator=g) * 0.2 - 0.1
+    wav[1, :n_b] = torch.rand(n_b, generator=g) * 0.2 - 0.1
+    model, ac_w = _tokenizer_model(xs, nfr)
+    eng = model.engine
+    try:
+        depths, ratios = [3, 3, 3, 3, 3, 3, 8], [8, 5, 5, 4, 2, 2]
+        with _Threads(), torch.no_grad():
+            ref = codec.encoder_forward(ac_w, wav[:, None], ratios, depths, None, 1e-5).permute(0, 2, 1)      # [2, 76, 64]
+        assert ref.shape[1] == nfr
+        padded = torch.zeros(2, nfr * 3200)
+        padded[:, :S] = wav
+        wd = padded.to(eng.device)
+        for F in (nfr, 25):
+            eng.set_enc_pass_frames(F)
+            out, whole = eng.new(2, nfr, 64), eng.new(2, nfr, 64)
+            with torch.cuda.stream(eng.stream):
+                for i in range(2):
+                    eng.acoustic_encode(nfr, wd[i], out[i], valid_samples=S)
+                    eng.acoustic_encode(nfr, wd[i], whole[i])
+            eng.sync()
+            for i in range(2):
+                e_ref, e_row, e_last = rel_err(out[i], ref[i]), row_err(out[i], ref[i]), rel_err(out[i, -1], ref[i, -1])
+                e_whole_last = rel_err(whole[i, -1], ref[i, -1])
+                print(f"[ragged encoder xsplit={xs}] speaker {i}, {F} frames/pass: rel-L2 {e_ref:.3e}, worst frame {e_row:.3e}, partial frame "
+                      f"{e_last:.3e} (whole-frame padding: {e_whole_last:.3e})")
+                assert e_ref <= tol and e_row <= 2 * tol and e_last <= 2 * tol, (xs, F, i, e_ref, e_row, e_last)
+                assert rel_err(whole[i, :-1], ref[i, :-1]) <= tol            # causal: only the partial frame can tell the two paddings apart
+            assert rel_err(whole[0, -1], ref[0, -1]) > 10 * rel_err(out[0, -1], ref[0, -1])   # ... and it does, where the signal ends in it
+    finally:
+        eng.close()
+
+
 # ---------------------------------------------------------------------------------------------- (b) Streaming-0.5B, timed mode
 def _streaming_inputs(om, seed, n_text):
     g = synth.Gen(seed)
@@ -493,8 +539,7 @@ def test_bf16_hip_against_bf16_pytorch_rocm_eager():
             with torch.no_grad():
                 oseq, oaud, omax = ogen.oracle_generate(
                     om, tm.TOK, to(ids), to(mask), cfg_scale=1.3, num_steps=steps,
-                    noise_fn=lambda step, n2: noise_fn(step, n2).to(devc, torch.bfloat16), forced_tokens=forced, trace=otr,
-                    engine_negative_correction=True)
+                    noise_fn=lambda step, n2: noise_fn(step, n2).to(devc, torch.bfloat16), forced_tokens=forced, trace=otr)
         torch.cuda.synchronize()
         cfgd = {"decoder_config": {"max_position_embeddings": s.lmcfg.max_pos}, "diffusion_head_config": {"ddpm_num_inference_steps": steps},
                 "acoustic_tokenizer_config": {"fix_std": 0.5, "std_dist_type": "gaussian"}}
@@ -607,16 +652,41 @@ def test_generate_sharded_over_an_rccl_process_group():
         kw = dict(tokenizer=tok, generation_config={"do_sample": False}, cfg_scale=1.3)
         solo = m.generate_continuous(reqs, **kw)
         st = {}
-        got = parallel.generate_sharded(m, reqs, gather_to=0, stats=st, **kw)
+        calls = {"gather": [], "all_gather": []}
+        o_gather, o_all = dist.gather, dist.all_gather
+
+        def c_gather(t, gl=None, dst=0, **k):
+            calls["gather"].append((t.dtype, t.device.type, t.numel()))
+            return o_gather(t, gl, dst=dst, **k)
+
+        def c_all(lst, t, **k):
+            calls["all_gather"].append((t.dtype, t.device.type, t.numel()))
+            return o_all(lst, t, **k)
+        dist.gather, dist.all_gather = c_gather, c_all
+        try:
+            got = parallel.generate_sharded(m, reqs, gather_to=0, stats=st, **kw)
+        finally:
+            dist.gather, dist.all_gather = o_gather, o_all
         assert st["utterances_per_rank"] == [4] and st["imbalance_max_over_mean"] == 1.0
+        # the one-rank group took the collective path: three payload gathers (sequences, flags, waveforms) of DEVICE tensors over RCCL,
+        # the waveforms in the model dtype, plus the three length all_gathers
+        assert [c[0] for c in calls["gather"]] == [torch.int64, torch.int64, torch.bfloat16], calls
+        assert all(c[1] == "cuda" for c in calls["gather"] + calls["all_gather"]) and len(calls["all_gather"]) == 3, calls
+        assert calls["gather"][2][2] == sum(o.speech_outputs[0].numel() for o in solo)
+        assert st["gather"]["backend"] == "nccl" and st["gather"]["on_device"] and st["gather"]["audio_dtype"] == "bfloat16"
+        assert st["gather"]["payload_bytes_this_rank"] > 0 and st["gather"]["seconds"] > 0
+        print(f"[rccl gather] {st['gather']}")
         assert len(got) == 4
         for a, b in zip(got, solo):
             assert torch.equal(a.sequences.cpu(), b.sequences.cpu())
             assert bool(a.reach_max_step_sample[0]) == bool(b.reach_max_step_sample[0])
             assert a.speech_outputs[0].shape == b.speech_outputs[0].shape
             assert torch.equal(a.speech_outputs[0].float().cpu(), b.speech_outputs[0].float().cpu())     # bf16 waveforms travel unchanged
-        every = parallel.generate_sharded(m, reqs, gather_to=None, **kw)                                      # the all_gather form
+        st2 = {}
+        every = parallel.generate_sharded(m, reqs, gather_to=None, stats=st2, **kw)                           # the all_gather form
+        assert st2["gather"]["collective"] == "all_gather"
         assert all(torch.equal(a.sequences, b.sequences) for a, b in zip(every, got))
+        assert all(torch.equal(a.speech_outputs[0], b.speech_outputs[0]) for a, b in zip(every, got))
     finally:
         dist.destroy_process_group()
         sm.eng.close()

@@ -50,7 +50,7 @@ def run(s, forced, teacher, seed=5, steps=5):
     om.t_cast_dtype = torch.bfloat16
     otr = ogen.Trace()
     oseq, oaud, omax = ogen.oracle_generate(om, TOK, ids, mask, st, sm, sim, cfg_scale=1.3, num_steps=steps, noise_fn=noise_fn,
-                                            prefill_noise=pre, forced_tokens=forced, trace=otr, engine_negative_correction=True)
+                                            prefill_noise=pre, forced_tokens=forced, trace=otr)
     cfgd = {"decoder_config": {"max_position_embeddings": s.lmcfg.max_pos}, "diffusion_head_config": {"ddpm_num_inference_steps": steps},
             "acoustic_tokenizer_config": {"fix_std": 0.5, "std_dist_type": "gaussian"}}
     m = VibeVoiceForConditionalGenerationInference(cfgd, s.eng, model_dtype=torch.bfloat16)      # bf16: timestep cast as the reference
@@ -145,7 +145,7 @@ def test_timed_mode_teacher_forced_batch8():
         om.t_cast_dtype = torch.bfloat16
         otr = ogen.Trace()
         oseq, oaud, omax = ogen.oracle_generate(om, TOK, ids, mask, cfg_scale=1.3, num_steps=5, noise_fn=noise_fn,
-                                                forced_tokens=forced, trace=otr, engine_negative_correction=True)
+                                                forced_tokens=forced, trace=otr)
         cfgd = {"decoder_config": {"max_position_embeddings": s.lmcfg.max_pos}, "diffusion_head_config": {"ddpm_num_inference_steps": 5},
                 "acoustic_tokenizer_config": {"fix_std": 0.5, "std_dist_type": "gaussian"}}
         m = VibeVoiceForConditionalGenerationInference(cfgd, s.eng, model_dtype=torch.bfloat16)

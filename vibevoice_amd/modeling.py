@@ -593,6 +593,11 @@ class VibeVoiceForConditionalGenerationInference:
             speech_tensors = torch.nn.functional.pad(speech_tensors, (0, pad))
             frames += 1
             valid = S
+        if tuple(speech_masks.shape) != (n_spk, frames):
+            # the reference's feats[speech_masks] raises on a mask that does not have the encoder output's shape; a flattened gather
+            # would silently pick other rows
+            raise ValueError(f"speech_masks has shape {tuple(speech_masks.shape)}; {n_spk} voice samples of {S} samples give "
+                             f"({n_spk}, {frames}) frames (ceil(S / {hop}))")
         wav = speech_tensors.to(self.device, torch.float32).contiguous()
         # rows of the [n_spk * frames] encoder output that are real frames (speech_masks is the processor's host data)
         sel_idx = speech_masks.reshape(-1).to(torch.bool).cpu().nonzero().squeeze(1).to(self.device)

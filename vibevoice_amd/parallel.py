@@ -190,27 +190,52 @@ def generate_sharded(model, requests: Sequence[dict], gather_to: int = 0, stats:
         stats.update(shard_report(costs, shards))
     mine = shards[rank]
     outs = model.generate_continuous([requests[i] for i in mine], **gen_kwargs) if mine else []
-    if not (dist.is_available() and dist.is_initialized()) or world == 1:
+    if not (dist.is_available() and dist.is_initialized()):
+        # no process group at all: a plain single-process call.  With a group -- a ONE-rank group included -- the results always go
+        # through the collectives below: the path an 8-GPU job takes is the path every test and every 1-GPU run takes
         res = [None] * len(requests)
         for i, o in zip(mine, outs):
             audio = o.speech_outputs[0] if o.speech_outputs else None
             res[i] = VibeVoiceGenerationOutput(sequences=o.sequences.cpu(), speech_outputs=[None if audio is None else audio.float().cpu()],
                                                reach_max_step_sample=o.reach_max_step_sample.cpu())
         return res
+    return gather_outputs(outs, shards, len(requests), model.device, model.dtype, gather_to=gather_to, stats=stats)
+
+
+def gather_outputs(outs, shards: Sequence[Sequence[int]], n_requests: int, device, model_dtype, gather_to: int = 0, stats: dict = None):
+    """The result phase of generate_sharded, on its own (bench.py --gpus N runs it after the timed region): every rank hands in the
+    VibeVoiceGenerationOutput objects of ITS shard (in shard order); rank `gather_to` (every rank if None) gets the list of all
+    n_requests outputs in request order, the others None.  Three tensor collectives per call -- token sequences (int64), flags (int64),
+    waveforms (the model dtype on RCCL, device to device; fp32 on gloo) -- each preceded by the small all_gather of the row lengths.
+    Requires an initialised process group (a one-rank group included)."""
+    import time
+    from .modeling import VibeVoiceGenerationOutput
+    rank, world = world_info()
     on_gpu = dist.get_backend() == "nccl"
-    device = model.device if on_gpu else torch.device("cpu")
+    device = device if on_gpu else torch.device("cpu")
     seqs, auds, flags = [], [], []
     for o in outs:
         audio = o.speech_outputs[0] if o.speech_outputs else None
         seqs.append(o.sequences.reshape(-1).to(torch.int64))
         auds.append(torch.zeros(0) if audio is None else audio.reshape(-1))
         flags.append(torch.tensor([int(bool(o.reach_max_step_sample.reshape(-1)[0])), 0 if audio is None else 1], dtype=torch.int64))
+    if on_gpu:
+        torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    aud_dtype = torch.float32 if not on_gpu else model_dtype
     g_seq = _gather_rows(seqs, torch.int64, device, gather_to)
     g_flag = _gather_rows(flags, torch.int64, device, gather_to)
-    g_aud = _gather_rows(auds, torch.float32 if not on_gpu else model.dtype, device, gather_to)
+    g_aud = _gather_rows(auds, aud_dtype, device, gather_to)
+    if on_gpu:
+        torch.cuda.synchronize(device)
+    if stats is not None:
+        payload = sum(int(t.numel()) * 8 for t in seqs + flags) + sum(int(t.numel()) for t in auds) * torch.empty(0, dtype=aud_dtype).element_size()
+        stats.update(gather={"backend": dist.get_backend(), "ranks": world, "collective": "all_gather" if gather_to is None else "gather",
+                             "payload_bytes_this_rank": payload, "seconds": round(time.perf_counter() - t0, 6), "on_device": bool(on_gpu),
+                             "audio_dtype": str(aud_dtype).replace("torch.", "")})
     if g_seq is None:
         return None
-    res = [None] * len(requests)
+    res = [None] * n_requests
     for r in range(world):
         for j, i in enumerate(shards[r]):
             has_audio = bool(g_flag[r][j][1])
