@@ -98,6 +98,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eager-baseline", action="store_true", help="skip the PyTorch-ROCm eager (oracle loop on the GPU, bf16) leg")
     ap.add_argument("--no-parity", action="store_true", help="skip the full-depth parity leg (HIP engine vs the oracle legs, teacher-forced)")
+    ap.add_argument("--no-parity-long", action="store_true", help="skip the parity leg through the prompt pass at the timed prompt length")
     ap.add_argument("--no-roofline", action="store_true", help="skip the GEMV launch-duration passes (for rocprof --pmc runs)")
     ap.add_argument("--skip-extra", action="store_true", help="main workload only (no extra.configs lines)")
     ap.add_argument("--cpu-frames", type=int, default=3)
@@ -307,8 +308,11 @@ def main():
                     else:
                         a2.steps, a2.warmup = 60, 10
                         a2.no_parity = args.no_parity or args.no_cpu_baseline
+                        a2.no_parity_long = args.no_parity_long
                         r = bench_decode(a2, sp, ctx, with_cpu=False, with_roofline=not args.no_roofline, with_parity=True)
                     keep = {k: r[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup")}
+                    if r.get("parity_long"):
+                        keep["parity_long"] = r["parity_long"]
                     if r.get("parity"):
                         keep["parity"] = r["parity"]
                         keep["gpu_eager_baseline"] = r.get("gpu_eager_baseline")
@@ -664,6 +668,40 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline, with_parity=False):
             parity["error"] = repr(ex)[:300]
             parity["within_bounds"] = False
         model.set_ddpm_inference_steps(NS)
+    parity_long = None
+    if with_parity and not args.no_parity_long:
+        # ---- the same comparison THROUGH THE PROMPT PASS, at the timed length: the run's own request (voice prompts + the whole L0-token
+        # prompt) through the engine's prefill chain and through the oracle as fp32 eager ops on this GPU with the same weights; step 0 =
+        # the prompt's last position; then teacher-forced decode frames on the KV cache the prefill kernels wrote ----
+        from oracle import parity as oparity
+        try:
+            one = {k: (v[:1] if k in ("input_ids", "attention_mask", "speech_input_mask") else v[:spec["speakers"]]) for k, v in inputs.items()}
+            t_pl = time.perf_counter()
+            lf32 = oparity.oracle_leg(cfg, cpu_sd, synthetic.TOKENS, NS, args.cfg_scale, 4, device, torch.float32, 60.0, inputs=one, attn_rows=1024)
+            lbf16 = oparity.oracle_leg(cfg, cpu_sd, synthetic.TOKENS, NS, args.cfg_scale, 4, device, torch.bfloat16, 60.0, teacher=lf32, attn_rows=1024)
+            lfloor = oparity.compare_legs(lbf16, lf32)
+            lboth = oparity.compare_engine(model, lf32, synthetic.TOKENS, also={"bf16": lbf16})
+            l32 = oparity.verdict("vs_fp32", {k: v for k, v in lboth.items() if k != "also"})
+            l16 = oparity.verdict("vs_bf16_eager", lboth["also"]["bf16"], floor=lfloor, vs_fp32=l32)
+            closer = {k: bool(l32[k] <= 1.1 * lfloor[k] + 1e-3) for k in ("latent", "pos_hidden", "neg_hidden")}
+            parity_long = {"model": f"VibeVoice-{model_key}", "lm_layers": d["num_hidden_layers"], "prompt_tokens": L0, "speakers": spec["speakers"],
+                           "voice_frames_per_speaker": spec["voice_frames"], "solver_steps": NS, "frames": l32["frames"],
+                           "engine_mode": {"xsplit": args.xsplit, "hipgraph": not args.no_graph, "dtype": "bf16"},
+                           "definition": "the timed run's own request: voice prompts through the acoustic encoder + connector, the whole prompt through "
+                                         "vv_pack_rows -> vv_gemm4 (QKV + bias + RoPE + KV append) -> vv_attn_prefill4 -> vv_gemm4 at full depth, vs the oracle as "
+                                         "fp32 eager ops on this GPU (same weights, same sampling draws); step0 = the hidden state at the prompt's last "
+                                         "position / negative condition / first latent; then teacher-forced decode frames on the KV the prefill kernels wrote; "
+                                         "worst step; bounds = SURVEY 8(d)",
+                           "step0": oparity.compare_engine_first_step(lboth), "vs_fp32": l32, "vs_bf16_eager": l16,
+                           "reference_bf16_vs_fp32": lfloor, "engine_at_least_as_close_to_fp32_as_reference_bf16": closer,
+                           "oracle_prompt_phase_s": {"fp32_eager": round(lf32.prompt_s, 3), "bf16_eager": round(lbf16.prompt_s, 3)},
+                           "within_bounds": bool(l32["within_bounds"] and l16["within_bounds"] and all(closer.values())),
+                           "seconds": round(time.perf_counter() - t_pl, 1)}
+            del lf32, lbf16
+        except Exception as ex:
+            parity_long = {"error": repr(ex)[:300], "within_bounds": False}
+        model.set_ddpm_inference_steps(NS)
+        torch.cuda.empty_cache()
     legs.clear()
     cpu_sd.clear()
     res = {
@@ -680,7 +718,7 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline, with_parity=False):
                    "xsplit": args.xsplit, "hipgraph": not args.no_graph, "kv_len_timed": max(L0, kv_target) + W,
                    **({"host_delay_us": args.host_delay_us} if args.host_delay_us > 0 else {}),
                    "parallelism": f"utterance-dp{world}"},
-        "roofline": roof, "cpu_baseline": cpu, "gpu_eager_baseline": eager, "parity": parity,
+        "roofline": roof, "cpu_baseline": cpu, "gpu_eager_baseline": eager, "parity": parity, "parity_long": parity_long,
         "extra": {"frames_timed": frames, "weights_load_s": round(load_s, 2), "libvvhip_build_id": _build_id(),
                   "weights_broadcast": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in bc.items()},
                   "weights_source": (f"checkpoint {ckpt}" if ckpt else "synthetic (seeded N(0, 0.02^2) at the config's shapes)"),

@@ -65,6 +65,18 @@ class OracleModel:
     t_cast_dtype: Optional[torch.dtype] = None
 
 
+def cast_model(m: "OracleModel", dtype) -> "OracleModel":
+    """the same model with every weight in `dtype` (what from_pretrained(torch_dtype=...) gives the reference: bf16 on a GPU,
+    demo/inference_from_file.py:284-292); rotary frequencies stay fp32, as HF computes them"""
+    import copy
+    import dataclasses
+    c = lambda d: {k: v.to(dtype) for k, v in d.items()}
+    lm = copy.copy(m.lm)
+    lm.w = c(m.lm.w)
+    return dataclasses.replace(m, lm=lm, lm_head=m.lm_head.to(dtype), head_w=c(m.head_w), ac_w=c(m.ac_w), sem_w=c(m.sem_w),
+                               ac_conn=c(m.ac_conn), sem_conn=c(m.sem_conn))
+
+
 @dataclass
 class Trace:
     pos_hidden: list = field(default_factory=list)

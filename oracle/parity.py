@@ -185,7 +185,10 @@ def compare_traces(htr, wav, otr, n, seq_ok=True) -> dict:
         rh, ro = float(h.pow(2).mean().sqrt()), float(o.pow(2).mean().sqrt())
         db = max(db, abs(20.0 * math.log10(max(rh, 1e-30) / max(ro, 1e-30))))
         snr = min(snr, 20.0 * math.log10(max(float(o.norm()), 1e-30) / max(float((h - o).norm()), 1e-30)))
-    return {"frames": n, "latent": round(w["latent"], 6), "pos_hidden": round(w["pos_hidden"], 6), "neg_hidden": round(w["neg_hidden"], 6),
+    step0 = {"latent": round(_rel(htr.latents[0], otr.latents[0]), 6) if htr.latents and otr.latents else None,
+             "pos_hidden": round(_rel(htr.pos_hidden[0], otr.pos_hidden[0]), 6) if htr.pos_hidden and otr.pos_hidden else None,
+             "neg_hidden": round(_rel(htr.neg_hidden[0], otr.neg_hidden[0]), 6) if htr.neg_hidden and otr.neg_hidden else None}
+    return {"frames": n, "step0": step0, "latent": round(w["latent"], 6), "pos_hidden": round(w["pos_hidden"], 6), "neg_hidden": round(w["neg_hidden"], 6),
             "frame_rms_db": round(db, 4), "frame_snr_db": round(snr, 2), "tokens_equal": bool(seq_ok),
             "greedy_pick_equal": bool(pick_ok), "oracle_min_top2_margin": round(margin, 5),
             "mode": "teacher-forced per step (next LM input = the oracle's embedding of that step)"}
@@ -220,6 +223,15 @@ def compare_engine(model, leg: Leg, tokens, frames: Optional[int] = None, also: 
     if also:
         res["also"] = {k: compare_traces(htr, out.speech_outputs[0], o.trace, min(n, o.frames), seq_ok) for k, o in also.items()}
     return res
+
+
+def compare_engine_first_step(res: dict) -> dict:
+    """step 0 of a compare_engine result: the hidden state at the prompt's LAST position (what the prompt pass hands the first frame),
+    the negative condition and the first latent -- against the fp32 leg and, when present, against the bf16 eager leg"""
+    out = {"vs_fp32": res.get("step0")}
+    for k, v in (res.get("also") or {}).items():
+        out["vs_" + k] = v.get("step0")
+    return out
 
 
 def compare_legs(leg: Leg, teacher: Leg) -> dict:

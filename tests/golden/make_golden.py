@@ -336,10 +336,55 @@ def gen_generate(custom=None):
             # generate() stop at the first finished sample (:443-447); here the whole batch is recorded.
 
     def run(name, B, plans, seed, max_new_tokens=None, do_sample=False, wav_len=3 * 3200, streamer=False, sde=False, gen_cfg=None,
-            voices=None, **gen_kw):
+            voices=None, dtype=None, **gen_kw):
         """voices: per row, the frame counts (1..3) of its voice samples -- several speakers in one prompt, as the processor builds a
         multi-speaker script (speech_tensors / speech_masks hold ALL samples of the batch, row after row; each sample's placeholder
         positions follow one another in its row, separated by a text token).  None: one sample per row (2, 3, 1, 2 frames)."""
+        if dtype is not None:
+            # the reference's GPU dtype (demo/inference_from_file.py:284-292 loads bf16) on the CPU: a copy of the model cast as
+            # from_pretrained(torch_dtype=...) leaves it -- every parameter and buffer in `dtype`, the rotary inv_freq (a non-persistent
+            # buffer the rotary module computes in fp32 whatever the default dtype) kept in fp32.  Also records every frame's latents.
+            mm = Ref(cfg).eval()
+            mm.load_state_dict(m.state_dict(), strict=False)
+            mm.set_ddpm_inference_steps(5)
+            mm = mm.to(dtype)
+            ref_buf = dict(m.named_buffers())
+            for nm, buf in mm.named_buffers():
+                if "inv_freq" in nm:
+                    buf.data = ref_buf[nm].detach().clone()
+            lat_rec = []
+            o_sst = mm.sample_speech_tokens
+
+            def rec_sst(*a, **k):
+                out = o_sst(*a, **k)
+                lat_rec.append(out.detach().float().clone())
+                return out
+            mm.sample_speech_tokens = rec_sst
+            arrs = _run(mm, None, B, plans, seed, max_new_tokens, do_sample, wav_len, streamer, sde, gen_cfg, voices, lat_rec, gen_kw)
+            # ... and the fp32 model on the SAME draws (replayed in order): the distance between the two runs is the reference's own
+            # rounding noise in `dtype` on this model -- free-running, as the reference runs
+            lat32 = []
+            o32 = m.sample_speech_tokens
+
+            def rec32(*a, **k):
+                out = o32(*a, **k)
+                lat32.append(out.detach().float().clone())
+                return out
+            m.sample_speech_tokens = rec32
+            try:
+                replay = [arrs[f"draw_{i}"] for i in range(int(arrs["n_draws"]))]
+                a32 = _run(m, None, B, plans, seed, max_new_tokens, do_sample, wav_len, streamer, sde, gen_cfg, voices, lat32, gen_kw, replay=replay)
+            finally:
+                m.sample_speech_tokens = o32
+            assert torch.equal(a32["sequences"], arrs["sequences"])
+            for k, v in a32.items():
+                if k.startswith("latent_") or k.startswith("audio_"):
+                    arrs["fp32_" + k] = v
+            save(name, **arrs)
+            return arrs
+        return _run(m, name, B, plans, seed, max_new_tokens, do_sample, wav_len, streamer, sde, gen_cfg, voices, None, gen_kw)
+
+    def _run(m, name, B, plans, seed, max_new_tokens, do_sample, wav_len, streamer, sde, gen_cfg, voices, lat_rec, gen_kw, replay=None):
         g = synth.Gen(seed)
         lens = [21, 17, 19, 14][:B]
         L0 = max(lens)
@@ -386,13 +431,19 @@ def gen_generate(custom=None):
         draws = []
         o_randn, o_like = torch.randn, torch.randn_like
 
+        rp = iter(replay) if replay is not None else None
+
         def rec_randn(*a, **k):
             t = o_randn(*a, **k)
+            if rp is not None:
+                t = next(rp).reshape(t.shape).to(t.dtype)
             draws.append(t.detach().clone().reshape(-1))
             return t
 
         def rec_like(x, **k):
             t = o_like(x, **k)
+            if rp is not None:
+                t = next(rp).reshape(t.shape).to(t.dtype)
             draws.append(t.detach().clone().reshape(-1))
             return t
         Ref._get_logits_processor = glp
@@ -423,15 +474,25 @@ def gen_generate(custom=None):
                     forced=np.array([p + [X] * (64 - len(p)) for p in plans]) if plans is not None else np.zeros((0,)),
                     forced_len=np.array([len(p) for p in plans]) if plans is not None else np.zeros((0,)))
         for i, d in enumerate(draws):
-            arrs[f"draw_{i}"] = d
+            arrs[f"draw_{i}"] = d.float()
+        if lat_rec is not None:
+            arrs["n_latents"] = len(lat_rec)
+            for i, l in enumerate(lat_rec):
+                arrs[f"latent_{i}"] = l
         if rec is not None:
             w = max(len(r) for r in rec.log)
             arrs["streamer_log"] = np.array([r + [-1] * (w - len(r)) for r in rec.log])
         for b in range(B):
             a = out.speech_outputs[b]
-            arrs[f"audio_{b}"] = a.reshape(-1) if a is not None else torch.zeros(0)
-        save(name, **arrs)
+            arrs[f"audio_{b}"] = a.reshape(-1).float() if a is not None else torch.zeros(0)
+        if name is not None:
+            save(name, **arrs)
+        return arrs
 
+    if custom == "bf16":
+        run("generate_forced_b1_bf16.npz", 1, [[D, D, D, D, E, S, D, D, D, X]], seed=11, dtype=torch.bfloat16)
+        run("generate_forced_b2_bf16.npz", 2, [[D, D, D, E, S, D, D, X], [D, D, E, S, D, X]], seed=23, dtype=torch.bfloat16)
+        return
     if custom is not None:
         sym = {"D": D, "E": E, "S": S, "X": X}
         for name, B, plans, seed, kw in custom:
@@ -496,6 +557,11 @@ def gen_generate(custom=None):
     # 2.5-frame batch tensor): SConv1d right-pads per strided conv layer (get_extra_padding_for_conv1d), so past the end of the signal
     # every strided conv reads zeros -- the partial frame's latent, and through it the whole prompt of that row, depends on it
     run("generate_ragged_voice_full_b2.npz", 2, [[D, D, D, X], [D, D, E, X]], seed=611, wav_len=8000)
+    # the reference's own classes in bf16 (its GPU dtype) on the same model, plan and seed as generate_forced_b1 / _b2: what the oracle
+    # run in bf16 is held to (tests/test_oracle_golden.py), so that "reference bf16 vs fp32" in bench.py's parity blocks is the
+    # reference's rounding, not a restatement's
+    run("generate_forced_b1_bf16.npz", 1, [[D, D, D, D, E, S, D, D, D, X]], seed=11, dtype=torch.bfloat16)
+    run("generate_forced_b2_bf16.npz", 2, [[D, D, D, E, S, D, D, X], [D, D, E, S, D, X]], seed=23, dtype=torch.bfloat16)
 
 
 @torch.no_grad()
@@ -627,6 +693,9 @@ def gen_generate_streaming(custom=None):
 
 
 if __name__ == "__main__":
+    if "--bf16-only" in sys.argv:           # the two bf16 files alone (the full set takes ~4.5 minutes)
+        gen_generate(custom="bf16")
+        sys.exit(0)
     torch.manual_seed(0)
     gen_dpm_and_head()
     gen_codec()

@@ -61,3 +61,56 @@ def test_full_depth_bf16_engine_against_bf16_pytorch_rocm_eager(model_key, n_sol
             assert r16["greedy_pick_equal"] and r32["greedy_pick_equal"], (r16, r32)
     finally:
         model.engine.close()
+
+
+@pytest.mark.parametrize("text_tokens", [1857, 10731])
+def test_full_depth_through_the_prompt_pass_at_the_timed_length(text_tokens):
+    """What bench.py times, compared where it is timed: VibeVoice-7B shapes, 28 layers, the bench's own two-speaker request -- two
+    75-frame voice prompts through the non-streaming encoder + connector, then the whole prompt (2,048 tokens here; 10,922 = BASELINE
+    configs[2]'s, the driver line's) through vv_pack_rows -> vv_gemm4 (QKV + bias + RoPE + KV append) -> vv_attn_prefill4 -> vv_gemm4 in the
+    bf16 mode under hipGraph -- against the oracle as fp32 eager ops on the same GPU with the same weights
+    (modeling_vibevoice_inference.py:149-163, :467-482, then :432-675).  Compared: the hidden state at the prompt's last position (the
+    positive condition of the first frame), the negative condition, the first frame's latent and waveform, then 3 more decode frames
+    teacher-forced per step ON THE KV CACHE THE PREFILL KERNELS WROTE.  Bounds: SURVEY 8(d), bf16 HIP vs the fp32 oracle (latent <= 5e-2,
+    frame RMS within 0.5 dB); the reference's own bf16 path on identical inputs (bf16 eager, teacher-forced by the fp32 run) is printed
+    beside it and the engine must be at least as close to fp32 as that."""
+    from oracle import parity
+    from vibevoice_amd import synthetic
+    from vibevoice_amd.configs import CONFIGS
+    from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference
+    cfg = copy.deepcopy(CONFIGS["7b"])
+    dev = torch.device("cuda", torch.cuda.current_device())
+    sd = dict(synthetic.random_state_dict(cfg, dev, seed=0))
+    inputs = synthetic.synthetic_inputs(cfg, n_speakers=2, text_tokens=text_tokens, voice_frames=75, seed=100, batch=1)
+    L0 = inputs["input_ids"].shape[1]
+    assert L0 == text_tokens + 191
+    rows = (L0 + 255) // 256 * 256
+    model = VibeVoiceForConditionalGenerationInference.from_state_dict(cfg, sd, torch.bfloat16, None, n_slots=1, max_ctx=rows + 256, xsplit=1,
+                                                                       use_graph=True, enc_frames=75, max_rows=rows)
+    try:
+        assert model.engine.cfg.lm_layers == 28
+        model.set_speech_factors(0.2, -0.05)
+        T = synthetic.TOKENS
+        fp32 = parity.oracle_leg(cfg, sd, T, 20, 1.3, 4, dev, torch.float32, t_budget=120.0, inputs=inputs, attn_rows=1024)
+        bf16 = parity.oracle_leg(cfg, sd, T, 20, 1.3, 4, dev, torch.bfloat16, t_budget=120.0, teacher=fp32, attn_rows=1024)
+        assert fp32.frames >= 4 and bf16.frames >= 4, (fp32.frames, bf16.frames)
+        floor = parity.compare_legs(bf16, fp32)
+        both = parity.compare_engine(model, fp32, T, also={"bf16": bf16})
+        r32 = parity.verdict("vs_fp32", {k: v for k, v in both.items() if k != "also"})
+        r16 = parity.verdict("vs_bf16_eager", both["also"]["bf16"], floor=floor, vs_fp32=r32)
+        first = parity.compare_engine_first_step(both)
+        fmt = lambda r: (f"latent {r['latent']:.3e}, positive hidden {r['pos_hidden']:.3e}, negative hidden {r['neg_hidden']:.3e}, "
+                         f"frame RMS {r['frame_rms_db']:.3f} dB, SNR {r['frame_snr_db']:.1f} dB")
+        print(f"[full depth through the prompt pass, 7b, 28 layers, {L0}-token two-speaker prompt, N=20, xsplit=1 + hipGraph, 4 frames]")
+        print(f"   oracle fp32 prompt phase {fp32.prompt_s:.2f} s, bf16 eager {bf16.prompt_s:.2f} s; engine {getattr(model, 'last_prefill', None)}")
+        print(f"   step 0 (prompt's last position)  : {first}")
+        print(f"   HIP vs fp32 eager (worst step)   : {fmt(r32)}")
+        print(f"   reference bf16 eager vs fp32     : {fmt(floor)}")
+        print(f"   HIP vs bf16 eager                : {fmt(r16)}; bounds {r16['bounds']}")
+        assert r32["tokens_equal"]
+        assert r32["within_bounds"] and r32["latent"] <= 5e-2 and r32["frame_rms_db"] <= 0.5, r32
+        for k in ("latent", "pos_hidden", "neg_hidden"):
+            assert r32[k] <= 1.1 * floor[k] + 1e-3, (k, r32[k], floor[k])
+        assert r16["within_bounds"] and r16["frame_rms_db"] <= 0.5, r16
+    finally:
+        model.engine.close()

@@ -233,6 +233,52 @@ def test_generate_loop_matches_the_reference_generate(name):
         assert err <= 1e-4, err
 
 
+@pytest.mark.parametrize("name", ["generate_forced_b1_bf16", "generate_forced_b2_bf16"])
+def test_the_oracle_in_bf16_follows_the_reference_in_bf16(name):
+    """Pins what bench.py's parity blocks call `reference_bf16_vs_fp32` (the reference path's own rounding noise) to the REFERENCE:
+    golden = the reference's own classes cast to bf16 -- its GPU dtype (demo/inference_from_file.py:284-292), run here on the CPU -- through
+    its own generate() on the tiny seeded model with a forced plan, every draw and every frame's latents recorded; plus the fp32 reference
+    replaying THE SAME draws (tests/golden/make_golden.py: run(..., dtype=torch.bfloat16)).  Both runs are free-running, as the reference runs.
+    Held here: (1) the oracle in fp32 on those draws IS the fp32 reference (<= 1e-4); (2) the oracle with bf16 weights and activations picks
+    the same tokens and stays within 3e-2 (latents, per frame) / 3e-2 (waveform) of the reference in bf16 -- several times closer than
+    either is to fp32; (3) the two noise floors -- reference bf16 vs reference fp32, oracle bf16 vs oracle fp32 -- agree per frame to
+    within 10 % (+1e-2).  So a floor measured with the oracle is the reference's floor."""
+    from oracle import generate as ogen
+    z = np.load(os.path.join(G, name + ".npz"))
+    tok = ogen.TokenIds(speech_start_id=301, speech_end_id=302, speech_diffusion_id=303, eos_token_id=304, bos_token_id=None, pad_token_id=305)
+    ids = torch.from_numpy(z["input_ids"])
+    B = ids.shape[0]
+    draws = [torch.from_numpy(z[f"draw_{i}"]) for i in range(int(z["n_draws"]))]
+    forced = [z["forced"][b][:int(z["forced_len"][b])].tolist() for b in range(B)]
+    rel = lambda a, b: float((a.float() - b.float()).norm() / b.float().norm())
+    runs = {}
+    for dt in (torch.bfloat16, torch.float32):
+        it = iter(draws[2:])
+        tr = ogen.Trace()
+        seq, audio, reach = ogen.oracle_generate(
+            ogen.cast_model(_oracle_small(), dt), tok, ids, torch.from_numpy(z["attention_mask"]), torch.from_numpy(z["speech_tensors"]).to(dt),
+            torch.from_numpy(z["speech_masks"]), torch.from_numpy(z["speech_input_mask"]), cfg_scale=1.3, num_steps=5,
+            noise_fn=lambda step, n2: next(it).reshape(n2, 64).to(dt), prefill_noise=(draws[0].reshape(B).to(dt), draws[1].reshape(B, 3, 64).to(dt)),
+            forced_tokens=forced, trace=tr)
+        assert torch.equal(seq, torch.from_numpy(z["sequences"])) and next(it, None) is None
+        runs[dt] = (audio, tr.latents)
+    n = int(z["n_latents"])
+    assert len(runs[torch.bfloat16][1]) == n
+    for i in range(n):
+        r16, r32 = torch.from_numpy(z[f"latent_{i}"]), torch.from_numpy(z[f"fp32_latent_{i}"])
+        o16, o32 = runs[torch.bfloat16][1][i], runs[torch.float32][1][i]
+        assert rel(o32, r32) <= 1e-4, (i, rel(o32, r32))
+        assert rel(o16, r16) <= 3e-2, (i, rel(o16, r16))
+        f_ref, f_or = rel(r16, r32), rel(o16, o32)
+        assert abs(f_or - f_ref) <= 0.10 * f_ref + 1e-2, (i, f_ref, f_or)
+        assert rel(o16, r16) <= 0.5 * f_ref, (i, rel(o16, r16), f_ref)          # the two bf16 runs are closer to each other than to fp32
+    for b in range(B):
+        r16, r32 = torch.from_numpy(z[f"audio_{b}"]), torch.from_numpy(z[f"fp32_audio_{b}"])
+        o16, o32 = runs[torch.bfloat16][0][b].reshape(-1), runs[torch.float32][0][b].reshape(-1)
+        assert rel(o32, r32) <= 1e-4 and rel(o16, r16) <= 3e-2, (b, rel(o32, r32), rel(o16, r16))
+        assert abs(rel(o16, o32) - rel(r16, r32)) <= 0.10 * rel(r16, r32) + 1e-2
+
+
 @pytest.mark.parametrize("name", ["generate_sde_b1", "generate_sde_b2"])
 def test_generate_loop_under_the_gradio_scheduler_matches_the_reference(name):
     """Golden = the REFERENCE's own generate() after demo/gradio_demo.py:142-146's scheduler swap

@@ -6,6 +6,7 @@
 #   trace:<name>:<args>  rocprofv3 --kernel-trace of bench.py <args> + tools/rocprof_summary.py -> <name>_top.txt, _kernel_stats.csv, _gaps.txt
 #   pmc:<name>:<counters>:<args>  rocprofv3 --pmc <counters> --kernel-trace of bench.py <args> (its own pass, no other trace domain)
 #   py:<script>:<args>   python <script> <args>  (stdout -> <script basename>.log)
+#   sh:<name>:<command>  bash -c '<command, + for spaces>'  (stdout -> <name>.out), e.g. a torchrun launch of bench.py
 #   smoke              python __graft_entry__.py smoke
 R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=$1; shift
 O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R; export TMPDIR=/tmp
@@ -25,6 +26,8 @@ for step in "$@"; do
        python tools/rocprof_summary.py --pmc $O/c_$name/t_results.db $O/$name > $O/${name}_pmc_top.txt 2>&1; rm -rf $O/c_$name; head -25 $O/${name}_pmc_top.txt;;
     py) sc=${rest%%:*}; a=${rest#*:}; [ "$a" = "$rest" ] && a=""; a=${a//+/ }; n=$(basename $sc .py)
        timeout ${VV_STEP_TIMEOUT:-900} python $sc $a > $O/$n.log 2> $O/$n.err; echo "[py $sc] rc=$?"; tail -n ${VV_TAIL:-30} $O/$n.log; tail -c 600 $O/$n.err;;
+    sh) name=${rest%%:*}; a=${rest#*:}; a=${a//+/ }
+       timeout ${VV_STEP_TIMEOUT:-900} bash -c "$a" > $O/$name.out 2> $O/$name.err; echo "[sh $name] rc=$?"; tail -c ${VV_TAILC:-1500} $O/$name.out; echo; tail -c 400 $O/$name.err;;
     smoke) timeout 300 python __graft_entry__.py smoke > $O/smoke.log 2>&1; echo "[smoke] rc=$?"; tail -3 $O/smoke.log;;
     *) echo "unknown step $step";;
   esac
