@@ -21,7 +21,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
-
+/* libvvhip.so is built with -fvisibility=hidden: the functions declared in this header are its whole dynamic symbol table (the
+ * kernel-launch helpers the translation units share stay internal; __graft_entry__.build() fails on any other exported vv_*). */
 typedef struct vv_ctx vv_ctx;
 
 typedef struct vv_config {
@@ -51,6 +52,7 @@ typedef struct vv_config {
     int tts_layers;
 } vv_config;
 
+#pragma GCC visibility push(default)
 int vv_create(const vv_config* cfg, vv_ctx** out);
 void vv_destroy(vv_ctx* ctx);
 const char* vv_last_error(vv_ctx* ctx);
@@ -229,6 +231,7 @@ int vv_profile_replay_family(vv_ctx* ctx, void* stream, int family, int reps, in
 /* number of kernel launches issued by the last engine call (graph nodes when replayed) */
 int64_t vv_stat(vv_ctx* ctx, int what);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -107,7 +107,7 @@ def oracle_leg(cfg, sd, tokens, n_solver, cfg_scale, n_frames, device, dtype, t_
                     pre = teacher.prefill_noise
                 else:
                     gp = torch.Generator(device="cpu").manual_seed(seed + 1)
-                    pre = (torch.randn(n_spk, generator=gp), torch.randn(n_spk, n_fr, 64, generator=gp))
+                    pre = (torch.randn(n_spk, generator=gp, device="cpu"), torch.randn(n_spk, n_fr, 64, generator=gp, device="cpu"))
                 speech_kw = dict(speech_tensors=inputs["speech_tensors"].to(device=device, dtype=dtype),
                                  speech_masks=inputs["speech_masks"].to(device), speech_input_mask=inputs["speech_input_mask"].to(device),
                                  prefill_noise=tuple(t.to(device=device, dtype=dtype) for t in pre))

@@ -460,7 +460,8 @@ def test_acoustic_encode_ragged_tail(sm, samples):
         assert rel_err(out[f], ref[f]) <= 5e-4, (f, rel_err(out[f], ref[f]))
     if nfr > 1:
         assert rel_err(out_whole[:nfr - 1], ref[:nfr - 1]) <= 2e-4            # causal: the frames before the partial one agree either way
-    assert rel_err(out_whole[nfr - 1], ref[nfr - 1]) > 1e-3                    # ... and the partial frame is where the two paddings part
+    if nfr * 3200 - samples >= 64:                                             # (one missing sample moves the last latent by 4e-4)
+        assert rel_err(out_whole[nfr - 1], ref[nfr - 1]) > 1e-3                # ... and the partial frame is where the two paddings part
 
 
 def test_kv_move_keeps_the_rotation(sm):

@@ -21,7 +21,7 @@ def _hipcc():
     raise RuntimeError("hipcc not found: libvvhip.so cannot be built")
 
 
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-fvisibility-inlines-hidden",
          "-Wno-unused-value", "-Wno-unused-result", "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 
 

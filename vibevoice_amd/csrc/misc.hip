@@ -587,7 +587,7 @@ int vv_normdw_sliced_slots_launch(const float* xin, float* xout, float* nb, cons
     return okk();
 }
 // y[id[j] * stride + c] = x[j * L + c] * mul + add: the batch's latents into the per-utterance decoder input buffers
-__global__ void vv_affine_slots_kernel(const float* __restrict__ x, float* __restrict__ y, float mul, float add, int L,
+static __global__ void vv_affine_slots_kernel(const float* __restrict__ x, float* __restrict__ y, float mul, float add, int L,
                                        const VVSlotIds sl, int64_t stride) {
     const int j = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < L) y[(int64_t)vv_slot_id(sl.id, j) * stride + c] = x[(int64_t)j * L + c] * mul + add;

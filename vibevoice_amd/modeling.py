@@ -33,6 +33,7 @@ exactly as generate() would have produced it alone (the reference's batched loop
 no cross-sample arithmetic, :393-394,549,573,594).
 """
 import json
+import contextlib
 import os
 import time
 from dataclasses import dataclass
@@ -42,6 +43,24 @@ import numpy as np
 import torch
 
 from .engine import Engine, EngineConfig, map_param_name
+
+_WARNED_QUEUED_RNG = False
+
+
+@contextlib.contextmanager
+def _end_streamer_on_error(streamer):
+    """an exception out of the generate loops (an engine error, a failed request) must not leave an AudioStreamer consumer blocked in
+    get() forever: every stream is ended before the exception travels on"""
+    try:
+        yield
+    except BaseException:
+        if streamer is not None:
+            try:
+                streamer.end()
+            except Exception:
+                pass
+        raise
+
 
 MAX_BATCH = 8          # rows of one diffusion-head pass (2 per utterance, 16-row MFMA tile); vv_diffusion_sample's limit
 
@@ -418,8 +437,13 @@ class VibeVoiceForConditionalGenerationInference:
         if do_warm and hasattr(m.engine, "acoustic_encode") and getattr(m.engine, "lib", None) is not None:
             try:
                 m.warmup()
-            except Exception as ex:         # a failed warm-up costs the first request its latency, never the model load
-                import warnings
+            except Exception as ex:         # a failed warm-up costs the first request its latency, never the model load --
+                import warnings             # unless the device itself is gone: then the load fails here, with the cause
+                try:
+                    torch.cuda.synchronize(m.device)
+                    m.engine.sync()
+                except Exception as dead:
+                    raise RuntimeError(f"vibevoice_amd: warm-up failed ({ex!r}) and the device does not answer any more") from dead
                 warnings.warn(f"vibevoice_amd: warm-up failed ({ex!r}); the first generate() will pay the cold-start costs")
 
         def base_tensor(key):          # lazy access to the checkpoint's own tensors (LoRA merge: vibevoice_amd/lora.py)
@@ -781,6 +805,27 @@ class VibeVoiceForConditionalGenerationInference:
                     e.sync(); torch.cuda.synchronize(self.device)
                     self._t_kv_fill = getattr(self, "_t_kv_fill", 0.0) + (time.perf_counter() - t0)
             u.pos_len = kv_start
+
+    def _prefill_checked(self, jobs):
+        """_prefill for every (utterance, ids, speech rows, speech positions, kv_start, kv_fill_fn) of `jobs`; prompts long enough for the
+        prefill GEMM's K-split round (>= 1024 rows) are waited for and checked before the first frame is enqueued: a lost hand-off
+        (vv_check: the engine re-arms itself and says the pass in flight is invalid) is answered by ONE repeat of the prompt passes --
+        they only overwrite the same cache positions.  The wait costs nothing measurable: the first frame's launches would have
+        queued behind the prompt pass anyway."""
+        e = self.engine
+        for attempt in (0, 1):
+            for j in jobs:
+                self._prefill(*j)
+            if max(len(j[1]) for j in jobs) < 1024:
+                return
+            try:
+                e.sync()
+                return
+            except RuntimeError as ex:
+                if attempt or "K-split" not in str(ex):
+                    raise
+                import warnings
+                warnings.warn(f"vibevoice_amd: {ex}; repeating the prompt pass once", RuntimeWarning)
 
     def _block_rows(self, i: int):
         """row i of the frame store: [utterances in flight, hop] fp32, frame_block rows per block"""
@@ -1161,16 +1206,13 @@ class VibeVoiceForConditionalGenerationInference:
             attention_mask = torch.ones_like(input_ids)
         attention_mask = attention_mask.cpu()
         B, L0 = input_ids.shape
-        if B > MAX_BATCH:
-            # the reference's batch is unbounded (:393-394); one engine pass carries MAX_BATCH utterances, so a larger batch is
-            # decoded through the continuous-admission queue and handed back in the batch's own output form
+        if B > MAX_BATCH or B > e.cfg.n_slots or 2 * B > e.cfg.max_rows:
+            # the reference's batch is unbounded (:393-394); one engine pass carries MAX_BATCH utterances (and this engine was created with
+            # n_slots / max_rows), so a larger batch is decoded through the continuous-admission queue and handed back in the batch's own
+            # output form
             return self._generate_queued(input_ids, attention_mask, tokenizer, generation_config, cfg_scale, audio_streamer,
                                          speech_tensors, speech_masks, speech_input_mask, is_prefill, return_speech, stop_check_fn,
                                          max_length_times, prefill_noise, step_cb, kwargs)
-        if B > e.cfg.n_slots:
-            raise ValueError(f"batch {B} exceeds the engine's n_slots={e.cfg.n_slots}")
-        if 2 * B > e.cfg.max_rows:
-            raise ValueError(f"batch {B} needs {2*B} LM rows > max_rows={e.cfg.max_rows}")
         S = self._session(tokenizer, generation_config, cfg_scale, kwargs, audio_streamer, B)
         S["sample_rows"] = lambda order: list(range(B))
         self._frame_w = B                                 # frame-store rows are as wide as this call's batch
@@ -1190,7 +1232,7 @@ class VibeVoiceForConditionalGenerationInference:
         else:
             progress = range(max_steps)
         n_steps = 0
-        with torch.cuda.stream(e.stream):
+        with torch.cuda.stream(e.stream), _end_streamer_on_error(audio_streamer):
             for b in range(B):
                 e.codec_reset(b)
             e.embed([S["start_id"]], self._start_emb)
@@ -1233,13 +1275,15 @@ class VibeVoiceForConditionalGenerationInference:
                     if time_prefill:
                         e.sync(); torch.cuda.synchronize(self.device); t_pf.append(time.perf_counter())
                     sp_off = 0
+                    jobs = []
                     for u in utts:
                         rows = pos = None
                         if sp_embeds is not None and u.idx in sp_pos:
                             cnt, pos = sp_pos[u.idx]
                             rows = sp_embeds[sp_off:sp_off + cnt]
                             sp_off += cnt
-                        self._prefill(u, u.ids, rows, pos, kv_start, kv_fill_fn)
+                        jobs.append((u, u.ids, rows, pos, kv_start, kv_fill_fn))
+                    self._prefill_checked(jobs)
                     if time_prefill:
                         e.sync(); t_pf.append(time.perf_counter())
                         self.last_prefill = {"voice_encode_s": round(t_pf[1] - t_pf[0], 5),
@@ -1281,6 +1325,14 @@ class VibeVoiceForConditionalGenerationInference:
             raise NotImplementedError("_prefill_noise (test hook) is per call; not supported for batches above MAX_BATCH")
         forced = kwargs.pop("_forced_tokens", None)
         noise_fn = kwargs.pop("_noise_fn", None)
+        global _WARNED_QUEUED_RNG
+        if not _WARNED_QUEUED_RNG and (noise_fn is None or self._generation_options(generation_config)[0]):
+            _WARNED_QUEUED_RNG = True
+            import warnings
+            warnings.warn(f"generate(): a batch of {B} rows exceeds one engine pass ({min(MAX_BATCH, self.engine.cfg.n_slots, self.engine.cfg.max_rows // 2)} "
+                          "utterances) and is decoded through the continuous-admission queue: every row is what generate() gives it alone, but "
+                          "random draws (diffusion noise, do_sample) are consumed in queue order, not in the lock-step batch's order -- a seeded "
+                          "run does not reproduce the reference's batch bit for bit", UserWarning, stacklevel=3)
         # voice-prompt rows: speaker i of speech_tensors contributes speech_masks[i].sum() frames; the rows' speech positions
         # consume those frames in row-major order (_process_speech_inputs + the masked scatter, :149-163,470-474)
         spk_of_row = [[] for _ in range(B)]
@@ -1361,7 +1413,7 @@ class VibeVoiceForConditionalGenerationInference:
         active: List[_Utt] = []
         it = 0
         stats = {"iterations": 0, "admissions": [], "max_in_flight": 0}
-        with torch.cuda.stream(e.stream):
+        with torch.cuda.stream(e.stream), _end_streamer_on_error(audio_streamer):
             e.embed([S["start_id"]], self._start_emb)
             while queue or active:
                 S["step"] = it
@@ -1371,6 +1423,8 @@ class VibeVoiceForConditionalGenerationInference:
                     if audio_streamer is not None:
                         audio_streamer.end()
                     break
+                if audio_streamer is not None and hasattr(audio_streamer, "finished_flags") and any(audio_streamer.finished_flags):
+                    break                       # the batch loop's early exit (:443-447): a consumer closed its stream
                 # ---- retire by the loop-level conditions of a batch-1 generate(): range(max_steps) exhausted / max_length ----
                 keep, keep_rows = [], []
                 for i, u in enumerate(active):
@@ -1417,7 +1471,7 @@ class VibeVoiceForConditionalGenerationInference:
                             if idx.numel():
                                 pos = idx.to(self.device)
                                 rows = sp[:int(idx.numel())]
-                    self._prefill(u, u.ids, rows, pos)
+                    self._prefill_checked([(u, u.ids, rows, pos, 0, None)])
                     done[ri] = u
                     stats["admissions"].append((it, ri, slot))
                     if u.max_steps > 0 and u.seq_len0 < u.max_length:

@@ -202,6 +202,7 @@ class AudioStreamer:
                 break
             if item[0] == "slot":
                 item[3].synchronize()
+                self._free.put(item[2])                  # a producer still blocked in _free.get() wakes up, sees _closed, returns
         with self._lock:
             _pinned_give(self._ring)                     # every copy into them has completed (their events have been waited on)
             self._ring = [None] * len(self._ring)
