@@ -293,9 +293,16 @@ def test_streamer_contract_and_stop_check(sm):
     assert fs3.puts == []
     with pytest.raises(NotImplementedError):       # a rule over the rows of ONE lock-step batch: the request queue refuses it
         m.generate_continuous([dict(input_ids=ids[:1], attention_mask=mask[:1])], tokenizer=tok, refresh_negative=False)
-    with pytest.raises(ValueError):
-        big = torch.cat([ids, ids, ids], 0)
-        m.generate(input_ids=big, attention_mask=torch.ones_like(big), tokenizer=tok)
+    # a batch the engine cannot take in lock-step (6 rows, 2 slots) goes through the continuous-admission queue, as a batch above 8 does
+    big, bigm = torch.cat([ids, ids, ids], 0), torch.cat([mask, mask, mask], 0)
+    import vibevoice_amd.modeling as vmod
+    vmod._WARNED_QUEUED_RNG = False                # the notice is given once per process
+    with pytest.warns(UserWarning, match="continuous-admission queue"):
+        out6 = m.generate(input_ids=big, attention_mask=bigm, cfg_scale=1.3, tokenizer=tok, _forced_tokens=forced * 3, show_progress_bar=False)
+    assert out6.sequences.shape[0] == 6 and len(out6.speech_outputs) == 6
+    for b in range(6):
+        assert out6.speech_outputs[b].shape == out.speech_outputs[b % 2].shape
+        assert torch.equal(out6.sequences[b, :ids.shape[1] + len(forced[b % 2])].cpu(), out.sequences[b % 2, :ids.shape[1] + len(forced[b % 2])].cpu())
 
 
 def test_pinned_ring_streamer_delivers_the_generated_audio(sm):

@@ -15,7 +15,7 @@ for step in "$@"; do
   kind=${step%%:*}; rest=${step#*:}
   case $kind in
     pytest) a=${rest//+/ }; n=$(echo "$rest" | tr -c 'A-Za-z0-9_' '_' | cut -c1-60)
-       timeout ${VV_STEP_TIMEOUT:-1500} python -m pytest -m gpu -q -x $a > $O/pytest_$n.log 2>&1; echo "[pytest $a] rc=$?"; tail -n ${VV_TAIL:-15} $O/pytest_$n.log;;
+       timeout ${VV_STEP_TIMEOUT:-1500} python -m pytest -m gpu -q ${VV_PYTEST_X--x} $a > $O/pytest_$n.log 2>&1; echo "[pytest $a] rc=$?"; tail -n ${VV_TAIL:-15} $O/pytest_$n.log;;
     bench) name=${rest%%:*}; a=${rest#*:}; a=${a//+/ }
        timeout ${VV_STEP_TIMEOUT:-900} python bench.py $a > $O/$name.json 2> $O/$name.err; echo "[bench $name] rc=$?"; tail -c 300 $O/$name.err; head -c 1500 $O/$name.json; echo;;
     trace) name=${rest%%:*}; a=${rest#*:}; a=${a//+/ }

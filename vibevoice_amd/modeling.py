@@ -1063,7 +1063,10 @@ class VibeVoiceForConditionalGenerationInference:
                     e.codec_decode(u.slot, self._latent[j:j + 1], self._audio[j])
                     if e.cfg.sem_dim > 0:
                         e.semantic_encode(u.slot, self._audio[j], self._sem[j])
-            e.connect(n, self._latent, self._sem if e.cfg.sem_dim > 0 else None, self._emb_out)
+            # every live row diffuses, in order (the steady state of a speech segment): the connectors write the next step's LM input
+            # rows in place -- no staging through _emb_out / nxt_x, two device copies fewer on the step's dependency line
+            direct = diff == live and S["teacher"] is None
+            e.connect(n, self._latent, self._sem if e.cfg.sem_dim > 0 else None, self._x_in if direct else self._emb_out)
             chunk = self._block_rows(S["frame_rows"])
             S["frame_rows"] += 1
             chunk[:n].copy_(self._audio[:n])
@@ -1072,7 +1075,8 @@ class VibeVoiceForConditionalGenerationInference:
                 if fr is not None and not u.chunks:
                     fr[id(u)] = S["frame_rows"] - 1
                 u.chunks.append(chunk[j])
-                nxt_x[live.index(u)].copy_(self._emb_out[j])
+                if not direct:
+                    nxt_x[live.index(u)].copy_(self._emb_out[j])
             if audio_streamer is not None:
                 audio_streamer.put(chunk[:n, None, :].to(self.dtype), torch.tensor([u.idx for u in diff]))
             S["n_frames"] += n
@@ -1087,9 +1091,10 @@ class VibeVoiceForConditionalGenerationInference:
                 te = S["teacher"](S["step"], [u.idx for u in live])
                 if te is not None:
                     nxt_x[:len(live)].copy_(te.to(self.device, torch.float32))
-            self._x_in[:len(live)].copy_(nxt_x[:len(live)])
+            if not (diff and direct):
+                self._x_in[:len(live)].copy_(nxt_x[:len(live)])
             if trace is not None:
-                trace.next_embeds.append(nxt_x[:len(live)].cpu())
+                trace.next_embeds.append(self._x_in[:len(live)].cpu())
         for u in order:
             u.step += 1
         for u in live:
