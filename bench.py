@@ -106,6 +106,8 @@ def parse_args(argv=None):
                     "diffusion-head weight pass)")
     ap.add_argument("--continuous", type=int, default=0, help="queue this many utterances through generate_continuous() "
                     "(slots = --batch) instead of one synchronous batch")
+    ap.add_argument("--lanes", type=int, default=1, help="--continuous: split the queue over this many engine contexts sharing ONE weight upload "
+                                                         "(generate_interleaved: one host thread + stream per lane)")
     ap.add_argument("--host-delay-us", type=float, default=0.0, help="diagnostic: busy-wait this long on the HOST at the top of every step; the "
                     "largest delay that leaves ms_per_step unchanged is the host's slack per step (how far off the critical path it is)")
     ap.add_argument("--full-utterance", action="store_true", help="one whole utterance of the workload, KV really growing; the metric over the "
@@ -466,8 +468,20 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline, with_parity=False):
             r["speech_masks"] = inputs["speech_masks"][i * ns:(i + 1) * ns]
             r["_forced_tokens"] = forced[i][:W + K + 1 + 7 * (i % 3)] + [synthetic.TOKENS.eos_token_id]     # staggered ends
             reqs.append(r)
-        outs = model.generate_continuous(reqs, tokenizer=synthetic.TOKENS, cfg_scale=args.cfg_scale,
-                                         generation_config={"do_sample": False}, max_concurrent=B, _bench_hooks=BenchHooks(step_callback=step_cb))
+        if args.lanes > 1:
+            # the queue over `lanes` engine contexts sharing this model's weights (vv_create_shared), one host thread + stream per lane:
+            # the lanes exist before the clock starts (a serving process creates them once), one untimed queue warms their graphs
+            model.generate_interleaved(reqs[:args.lanes * 2], lanes=args.lanes, tokenizer=synthetic.TOKENS, cfg_scale=args.cfg_scale,
+                                       generation_config={"do_sample": False}, max_concurrent=B)
+            eng.sync(); torch.cuda.synchronize()
+            t_gen0 = time.perf_counter()
+            outs = model.generate_interleaved(reqs, lanes=args.lanes, tokenizer=synthetic.TOKENS, cfg_scale=args.cfg_scale,
+                                              generation_config={"do_sample": False}, max_concurrent=B)
+            torch.cuda.synchronize()
+            marks[W] = t_gen0
+        else:
+            outs = model.generate_continuous(reqs, tokenizer=synthetic.TOKENS, cfg_scale=args.cfg_scale,
+                                             generation_config={"do_sample": False}, max_concurrent=B, _bench_hooks=BenchHooks(step_callback=step_cb))
         out = outs[0]
     else:
         out = model.generate(tokenizer=synthetic.TOKENS, cfg_scale=args.cfg_scale, generation_config={"do_sample": False},
@@ -713,7 +727,8 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline, with_parity=False):
                                f"{NS} solver steps, cfg {args.cfg_scale}, decode timed at KV length {max(L0, kv_target) + W}..{max(L0, kv_target) + W + K}"
                                + (" (positions past the prompt: random bf16 K/V)" if kv_target > L0 else "")
                                + f", {B} utterance{'s' if B > 1 else ''} per GPU"
-                               + (f" ({n_utt} queued, continuous admission)" if args.continuous else "") + ", forced token schedule",
+                               + (f" ({n_utt} queued, continuous admission)" if args.continuous else "")
+                               + (f" over {args.lanes} engine contexts sharing one weight copy" if args.continuous and args.lanes > 1 else "") + ", forced token schedule",
                    "model": f"VibeVoice-{model_key}", "solver_steps": NS, "prompt_tokens": L0, "speakers": spec["speakers"],
                    "xsplit": args.xsplit, "hipgraph": not args.no_graph, "kv_len_timed": max(L0, kv_target) + W,
                    **({"host_delay_us": args.host_delay_us} if args.host_delay_us > 0 else {}),

@@ -53,6 +53,16 @@ class FakeEngine:
         self.calls = {"lm_rows": 0, "samples": 0, "spec_wasted": 0}
 
     # ---- plumbing ----
+    def fork(self, **runtime):
+        """the CPU image of Engine.fork: a second engine over the same (read-only) weights with its own state"""
+        f = FakeEngine(self.om, n_slots=runtime.get("n_slots", self.cfg.n_slots), max_rows=runtime.get("max_rows", self.cfg.max_rows),
+                       max_ctx=runtime.get("max_ctx", self.max_ctx))
+        f.shared_from = self
+        return f
+
+    def close(self):
+        self.closed = True
+
     def new(self, *shape):
         return torch.zeros(*shape, dtype=torch.float32)
 

@@ -240,6 +240,59 @@ def test_continuous_admission_equals_one_by_one(monkeypatch):
     assert st["iterations"] < sum(own) and st["iterations"] >= max(own)
 
 
+def test_interleaved_lanes_host_logic(monkeypatch):
+    """generate_interleaved(): the queue over two engine contexts sharing one weight copy, one host thread per lane (here: two
+    oracle-backed CPU engines over one oracle model).  Host logic under test: longest-prompt-first split, request order of the result,
+    the caller's streamer seeing every request under its own sample index with one end per request, the lanes kept for the next call,
+    an exception inside a lane surfacing in the caller after the streamer has been closed."""
+    from test_oracle_golden import _oracle_small
+    from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference
+    cfgd = {"decoder_config": {"max_position_embeddings": 4096}, "diffusion_head_config": {"ddpm_num_inference_steps": 5},
+            "acoustic_tokenizer_config": {"fix_std": 0.5, "std_dist_type": "gaussian"}}
+    reqs = _requests(5, 9)
+
+    class Rec:
+        def __init__(self, n):
+            self.finished_flags, self.puts, self.ends = [False] * n, [], []
+
+        def put(self, chunk, idx):
+            self.puts.append(idx.tolist())
+
+        def end(self, idx=None):
+            self.ends.append(None if idx is None else idx.tolist())
+    with fake_engine.cpu_cuda_shims(monkeypatch):
+        monkeypatch.setattr(torch.cuda, "set_device", lambda *a, **k: None)
+        m = VibeVoiceForConditionalGenerationInference(cfgd, fake_engine.FakeEngine(_oracle_small(), n_slots=2), model_dtype=torch.float32)
+        m.set_speech_factors(0.2, -0.05)
+        m.set_ddpm_inference_steps(5)
+        m.concurrent_codecs = False
+        kw = dict(tokenizer=TOK, generation_config={"do_sample": False}, cfg_scale=1.3)
+        solo = m.generate_continuous(reqs, **kw)
+        rec = Rec(5)
+        outs = m.generate_interleaved(reqs, lanes=2, audio_streamer=rec, **kw)
+        assert m.last_stats["lanes"] == 2 and sorted(i for sh in m.last_stats["shards"] for i in sh) == [0, 1, 2, 3, 4]
+        assert m.last_stats["frames"] == sum(o.speech_outputs[0].shape[-1] // 3200 for o in solo)
+        for a, b in zip(outs, solo):
+            assert torch.equal(a.sequences, b.sequences)
+            assert float((a.speech_outputs[0] - b.speech_outputs[0]).norm() / b.speech_outputs[0].norm()) <= 1e-5
+        n_put = [sum(p.count(i) for p in rec.puts) for i in range(5)]
+        assert [n * 3200 for n in n_put] == [o.speech_outputs[0].shape[-1] for o in solo]
+        assert sorted(i for e in rec.ends if e is not None for i in e) == [0, 1, 2, 3, 4] and rec.ends[-1] is None
+        lane = m._lanes[0]
+        assert lane.engine.shared_from is m.engine and lane._scaling == m._scaling and lane.ddpm_inference_steps == 5
+        m.generate_interleaved(reqs[:2], lanes=2, **kw)
+        assert m._lanes[0] is lane
+        # one lane fails: the exception reaches the caller, the streamer is closed first
+        bad = [dict(r) for r in reqs]
+        bad[3]["input_ids"] = torch.cat([reqs[3]["input_ids"], reqs[3]["input_ids"]], 0)       # two rows in one request: refused
+        rec2 = Rec(5)
+        with pytest.raises(ValueError, match="exactly one utterance"):
+            m.generate_interleaved(bad, lanes=2, audio_streamer=rec2, **kw)
+        assert rec2.ends and rec2.ends[-1] is None
+        m.close_lanes()
+        assert lane.engine.closed and m._lanes == []
+
+
 def test_continuous_frame_store_follows_the_audio_in_flight(monkeypatch):
     """the frame store used to grow by one row per diffusion iteration of the whole queue and was never released.
     Now a finished utterance's frames leave it at once and blocks no live utterance points into are dropped.  With 4-row blocks the

@@ -412,6 +412,78 @@ def test_continuous_admission_on_the_engine(sm):
         assert rel_err(o.speech_outputs[0][0], oaud[0][0]) <= 1e-2, rel_err(o.speech_outputs[0][0], oaud[0][0])
 
 
+def test_interleaved_lanes_over_one_weight_copy(sm):
+    """generate_interleaved: the request queue split over TWO engine contexts that share one weight upload (vv_create_shared), one host
+    thread and one stream per lane.  Every request must end exactly as generate_continuous() gives it on the single context (to 1e-5:
+    the lanes share nothing but read-only weights), in request order; the caller's streamer
+    sees every request's own sample index; a second call reuses the lanes; the child survives its owner being destroyed first."""
+    from vibevoice_amd.engine import EngineError
+    from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference
+    reqs = _mk_requests(sm, 6, 21)
+    cfgd = {"decoder_config": {"max_position_embeddings": sm.lmcfg.max_pos},
+            "diffusion_head_config": {"ddpm_num_inference_steps": 5},
+            "acoustic_tokenizer_config": {"fix_std": 0.5, "std_dist_type": "gaussian"}}
+    m = VibeVoiceForConditionalGenerationInference(cfgd, sm.eng, model_dtype=torch.float32)
+    m.set_speech_factors(sm.scaling, sm.bias)
+    m.set_ddpm_inference_steps(5)
+    tok = types.SimpleNamespace(speech_start_id=S, speech_end_id=E, speech_diffusion_id=D, eos_token_id=X,
+                                bos_token_id=None, pad_token_id=TOK.pad_token_id)
+    kw = dict(tokenizer=tok, generation_config={"do_sample": False}, cfg_scale=1.3)
+    solo = m.generate_continuous(reqs, **kw)
+    try:
+        fs = FakeStreamer(6)
+        two = m.generate_interleaved(reqs, lanes=2, audio_streamer=fs, **kw)
+        assert m.last_stats["lanes"] == 2 and sorted(i for sh in m.last_stats["shards"] for i in sh) == list(range(6))
+        assert all(len(sh) == 3 for sh in m.last_stats["shards"])
+        for a, b in zip(two, solo):
+            assert torch.equal(a.sequences.cpu(), b.sequences.cpu())
+            assert a.speech_outputs[0].shape == b.speech_outputs[0].shape
+            assert rel_err(a.speech_outputs[0], b.speech_outputs[0]) <= 1e-5          # (which rows share a weight pass differs)
+        # the streamer saw each request's frames under the request's own index, and one end per request (+ the closing end())
+        frames = {i: 0 for i in range(6)}
+        for shape, idx in fs.puts:
+            for i in idx:
+                frames[i] += 1
+        assert [frames[i] * 3200 for i in range(6)] == [o.speech_outputs[0].shape[-1] for o in solo]
+        assert sorted(i for e_ in fs.ends if e_ is not None for i in e_) == list(range(6)) and fs.ends[-1] is None
+        lane = m._lanes[0]
+        assert lane.engine.shared_from is sm.eng and lane.engine is not sm.eng
+        again = m.generate_interleaved(list(reversed(reqs)), lanes=2, **kw)             # the lanes are reused
+        assert m._lanes[0] is lane
+        for a, b in zip(again, reversed(solo)):
+            assert torch.equal(a.sequences.cpu(), b.sequences.cpu()) and rel_err(a.speech_outputs[0], b.speech_outputs[0]) <= 1e-5
+        with pytest.raises(EngineError, match="upload through the parent"):
+            lane.engine.upload("lm.norm.weight", torch.ones(sm.lmcfg.hidden))
+        with pytest.raises(EngineError, match="itself a shared context|model fields"):
+            import dataclasses
+            from vibevoice_amd.engine import Engine
+            Engine(dataclasses.replace(sm.eng.cfg, lm_layers=sm.eng.cfg.lm_layers + 1), sm.eng.device, share_from=sm.eng)
+    finally:
+        m.close_lanes()
+
+
+def test_shared_context_outlives_its_owner():
+    """vv_destroy on the owner of shared weights while a child still uses them: the storage lives until the last child goes"""
+    from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference
+    s = build_small(synth.LMCfg(), xsplit=3, n_slots=1, max_ctx=256, use_graph=True)
+    forced = [[D, D, E, S, D, X]]
+    o, h = run_both(s, 1, forced, with_speech=True, seed=5)
+    child = s.eng.fork()
+    s.eng.close()                                   # owner first
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
+    junk = torch.randn(64 << 20, device=child.device)          # would land in freed weight storage if it had been released
+    s.eng = child
+    try:
+        o2, h2 = run_both(s, 1, forced, with_speech=True, seed=5)
+        check(o2, h2)
+        assert rel_err(h2[0].speech_outputs[0], h[0].speech_outputs[0]) <= 1e-6
+    finally:
+        child.close()
+        del junk
+
+
 def test_generate_batch8_desynchronised():
     """Eight utterances in one batch (BASELINE config 4's per-GPU batch), every row on its own token plan: 16-row LM passes,
     16-row diffusion-head GEMV forms, per-utterance codec chains on side streams -- against the oracle loop."""

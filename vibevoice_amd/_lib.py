@@ -27,6 +27,7 @@ class VVRow(C.Structure):
 _P = C.c_void_p
 _SIGS = {
     "vv_create": (C.c_int, [C.POINTER(VVConfig), C.POINTER(_P)]),
+    "vv_create_shared": (C.c_int, [C.POINTER(VVConfig), _P, C.POINTER(_P)]),
     "vv_destroy": (None, [_P]),
     "vv_last_error": (C.c_char_p, [_P]),
     "vv_num_weights": (C.c_int, [_P]),

@@ -231,6 +231,11 @@ struct vv_ctx {
     uint64_t graph_tick = 0; size_t graph_cap = 512;
     std::set<std::string> seen;
     std::set<void*> allocs;                // every dalloc() of this engine: released by vv_destroy
+    // weight sharing (vv_create_shared): a child context's weight storage IS its parent's -- the k-th weight allocation of
+    // vv_create returns the parent's k-th one (same model configuration -> same sequence); everything else (KV caches, activations,
+    // tokenizer state, graphs, staging) is the child's own, so two contexts decode concurrently on two streams over one weight copy
+    vv_ctx* parent = nullptr; int n_children = 0; bool zombie = false, creating = false;
+    std::vector<std::pair<void*, size_t>> wallocs; size_t wshare_i = 0;
     int64_t launches = 0;
     // optional per-GEMM-launch hipEvent timing (vv_profile_begin/end)
     bool prof_on = false;
@@ -303,10 +308,27 @@ static void add_mat(vv_ctx* ctx, const std::string& name, int N, int K, void* ba
     const int k_tiles = (K + 31) / 32;
     w.dev = (char*)base + (int64_t)ntile_off * k_tiles * 1024;
 }
-static void* alloc_packed(vv_ctx* ctx, int N, int K) { return dalloc(ctx, (size_t)vv_packed_elems(N, K) * 2); }
+// weight storage: during vv_create the allocation sequence is recorded (parent) or replayed from the parent (shared child)
+static void* walloc(vv_ctx* ctx, size_t bytes, bool zero = true) {
+    if (!ctx->creating) return dalloc(ctx, bytes, zero);
+    if (ctx->parent) {
+        vv_ctx* p = ctx->parent;
+        if (ctx->wshare_i >= p->wallocs.size() || p->wallocs[ctx->wshare_i].second != bytes) {
+            fail(ctx, "vv_create_shared: weight allocation %zu (%zu bytes) does not match the parent's -- different model configuration", ctx->wshare_i, bytes);
+            return nullptr;
+        }
+        void* q = p->wallocs[ctx->wshare_i++].first;
+        ctx->wallocs.push_back({q, bytes});
+        return q;
+    }
+    void* q = dalloc(ctx, bytes, zero);
+    ctx->wallocs.push_back({q, bytes});
+    return q;
+}
+static void* alloc_packed(vv_ctx* ctx, int N, int K) { return walloc(ctx, (size_t)vv_packed_elems(N, K) * 2); }
 static float* add_vec(vv_ctx* ctx, const std::string& name, int64_t n, float* dst = nullptr, int kind = W_VEC, int rep = 1) {
     int i = add_w(ctx, name, kind, n);
-    if (!dst) dst = (float*)dalloc(ctx, (size_t)n * rep * 4);
+    if (!dst) dst = (float*)walloc(ctx, (size_t)n * rep * 4);
     ctx->w[i].dev = dst; ctx->w[i].rep = rep;
     return dst;
 }
@@ -824,9 +846,10 @@ extern "C" const char* vv_last_error(vv_ctx* ctx) { return ctx ? ctx->err : g_er
 #endif
 extern "C" const char* vv_build_id() { return "VVHIP_BUILD_ID=" VV_BUILD_ID; }
 
-extern "C" int vv_create(const vv_config* cfg, vv_ctx** out) {
+static int create_impl(const vv_config* cfg, vv_ctx* parent, vv_ctx** out) {
     vv_ctx* ctx = new vv_ctx();
     ctx->c = *cfg; ctx->err[0] = 0;
+    ctx->parent = parent; ctx->creating = true;
     { const char* e = getenv("VVHIP_FOLD_NORMDW"); if (e && e[0] == '0') ctx->fold_normdw = false; }
     vv_config& c = ctx->c;
     if (c.max_rows < 1 || c.max_rows > 16384) { delete ctx; return fail(nullptr, "max_rows must be in [1,16384]"); }
@@ -847,7 +870,7 @@ extern "C" int vv_create(const vv_config* cfg, vv_ctx** out) {
     const int QKV = ctx->QKV = (Hq + 2 * Hkv) * D;
     const int R = c.max_rows;
     // ---- LM ----
-    ctx->embed = dalloc(ctx, (size_t)c.lm_vocab * H * 2);
+    ctx->embed = walloc(ctx, (size_t)c.lm_vocab * H * 2);
     { int i = add_w(ctx, "lm.embed_tokens.weight", W_TABLE, (int64_t)c.lm_vocab * H); ctx->w[i].dev = ctx->embed; }
     { int i = add_w(ctx, "lm_head.weight", W_TABLE, (int64_t)c.lm_vocab * H, true); ctx->w[i].dev = nullptr; }
     ctx->inv_freq = add_vec(ctx, "lm.rope.inv_freq", D / 2);
@@ -868,7 +891,7 @@ extern "C" int vv_create(const vv_config* cfg, vv_ctx** out) {
         L.ln1 = add_vec(ctx, p + "input_layernorm.weight", H);
         L.ln2 = add_vec(ctx, p + "post_attention_layernorm.weight", H);
         L.wqkv = alloc_packed(ctx, QKV, H);
-        L.bqkv = (float*)dalloc(ctx, (size_t)QKV * 4);
+        L.bqkv = (float*)walloc(ctx, (size_t)QKV * 4);
         add_mat(ctx, p + "self_attn.q_proj.weight", Hq * D, H, L.wqkv, 0);
         add_mat(ctx, p + "self_attn.k_proj.weight", Hkv * D, H, L.wqkv, Hq * D / 16);
         add_mat(ctx, p + "self_attn.v_proj.weight", Hkv * D, H, L.wqkv, (Hq + Hkv) * D / 16);
@@ -976,13 +999,52 @@ extern "C" int vv_create(const vv_config* cfg, vv_ctx** out) {
     if (c.sem_dim > 0 && build_codec(ctx, ctx->senc, "senc.", false, c.sem_dim, 1, c.n_slots)) { *out = ctx; return -1; }
     if (c.has_acoustic_encoder && build_codec(ctx, ctx->aenc, "aenc.", false, L, c.enc_frames, 1)) { *out = ctx; return -1; }
     if (hipDeviceSynchronize() != hipSuccess || ctx->err[0]) { *out = ctx; return fail(ctx, "vv_create: allocation failed: %s", ctx->err); }
+    ctx->creating = false;
+    if (parent) {
+        if (ctx->wshare_i != parent->wallocs.size() || ctx->w.size() != parent->w.size()) {
+            *out = ctx;
+            return fail(ctx, "vv_create_shared: the child registered %zu weight buffers / %zu parameters, the parent %zu / %zu -- different model configuration",
+                        ctx->wshare_i, ctx->w.size(), parent->wallocs.size(), parent->w.size());
+        }
+        for (size_t i = 0; i < ctx->w.size(); ++i) {
+            if (ctx->w[i].name != parent->w[i].name || ctx->w[i].nelem != parent->w[i].nelem) { *out = ctx; return fail(ctx, "vv_create_shared: parameter table differs at '%s'", ctx->w[i].name.c_str()); }
+            ctx->w[i].loaded = parent->w[i].loaded;
+            if (ctx->w[i].name == "lm_head.weight") ctx->w[i].dev = parent->w[i].dev;
+        }
+        ctx->lm_head = parent->lm_head; ctx->lm_head_loaded = parent->lm_head_loaded;
+        ctx->scaling = parent->scaling; ctx->bias = parent->bias;
+        parent->n_children++;
+    }
     *out = ctx;
     return 0;
+}
+
+extern "C" int vv_create(const vv_config* cfg, vv_ctx** out) { return create_impl(cfg, nullptr, out); }
+
+// A second context over the SAME weight storage as `parent` (which must be fully uploaded and is not a shared child itself): own KV
+// caches, activations, tokenizer state, graphs and staging, sized by cfg's runtime fields (n_slots, max_ctx, max_rows, attn_splits,
+// use_graph); the model fields must equal the parent's.  Two such contexts, each driven on its own stream, interleave two independent
+// decode chains on one GPU over one copy of the weights: one chain's launch boundaries are filled by the other's kernels.
+extern "C" int vv_create_shared(const vv_config* cfg, vv_ctx* parent, vv_ctx** out) {
+    if (!parent) return fail(nullptr, "vv_create_shared: no parent context");
+    if (parent->parent) return fail(nullptr, "vv_create_shared: the parent is itself a shared context; share from the owner of the weights");
+    for (auto& w : parent->w)
+        if (!w.loaded && !w.optional) return fail(nullptr, "vv_create_shared: parent parameter '%s' is not uploaded yet", w.name.c_str());
+    vv_config a = *cfg, b = parent->c;
+    a.n_slots = b.n_slots; a.max_ctx = b.max_ctx; a.max_rows = b.max_rows; a.attn_splits = b.attn_splits; a.use_graph = b.use_graph;
+    if (a.xsplit < 1 || a.xsplit > 3) a.xsplit = 2;
+    if (a.enc_frames < 1) a.enc_frames = 1;
+    if (memcmp(&a, &b, sizeof(vv_config)) != 0) return fail(nullptr, "vv_create_shared: the model fields of the configuration differ from the parent's");
+    int r = create_impl(cfg, parent, out);
+    if (r != 0 && *out) { vv_ctx* c = *out; c->parent = nullptr; }      // a failed child holds no reference
+    return r;
 }
 
 extern "C" void vv_destroy(vv_ctx* ctx) {
     if (!ctx) return;
     hipDeviceSynchronize();
+    if (ctx->n_children > 0) { ctx->zombie = true; return; }          // shared children still read these weights: the last of them frees
+    vv_ctx* par = ctx->parent;
     for (auto& g : ctx->graphs) hipGraphExecDestroy(g.second.exec);
     if (ctx->side_ready) {
         for (int j = 0; j < 8; ++j) { hipStreamDestroy(ctx->side[j]); hipEventDestroy(ctx->ev_join[j]); }
@@ -995,6 +1057,7 @@ extern "C" void vv_destroy(vv_ctx* ctx) {
     if (ctx->gws.err) hipHostFree(ctx->gws.err);
     for (int i = 0; i < vv_ctx::RING; ++i) if (ctx->ring_ev[i]) hipEventDestroy(ctx->ring_ev[i]);
     delete ctx;
+    if (par && --par->n_children == 0 && par->zombie) vv_destroy(par);
 }
 
 extern "C" int vv_num_weights(vv_ctx* ctx) { return (int)ctx->w.size(); }
@@ -1011,6 +1074,7 @@ extern "C" int vv_upload(vv_ctx* ctx, const char* name, const void* src, int src
     auto it = ctx->widx.find(name);
     if (it == ctx->widx.end()) return fail(ctx, "unknown parameter '%s'", name);
     Weight& w = ctx->w[it->second];
+    if (ctx->parent) return fail(ctx, "parameter '%s': this context shares its parent's weights -- upload through the parent", name);
     if (nelem != w.nelem) return fail(ctx, "parameter '%s': expected %lld elements, got %lld", name, (long long)w.nelem, (long long)nelem);
     const size_t esz = src_dtype ? 2 : 4;
     hipPointerAttribute_t attr;

@@ -545,11 +545,6 @@ static bool gemv_parts_ok(int pro, int epi, bool xside) {
     return false;
 }
 
-static bool gu_wpb2() {             // VVHIP_GU_WPB2=0: the 4-wave form for every wide launch (A/B switch)
-    static const int on = [] { const char* e = getenv("VVHIP_GU_WPB2"); return (e && e[0] == '0') ? 0 : 1; }();
-    return on != 0;
-}
-
 extern "C" int vv_gemv_launch(VVGemm a, int xs, hipStream_t s) {
     const int n_tiles = (a.N + 15) / 16, k_tiles = (a.K + 31) / 32;
     if (a.epi == VV_EPI_SWIGLU && !a.W2) return -1;
@@ -610,12 +605,6 @@ extern "C" int vv_gemv_launch(VVGemm a, int xs, hipStream_t s) {
     }
     if (a.kgrid > 1) grid.y = a.kgrid;
     if (xs == 1 && a.kgrid <= 1) {
-        if (n_tiles > 768 && a.T <= 2 && a.pro == VV_PRO_RMS && a.epi == VV_EPI_SWIGLU && gu_wpb2()) {
-            // more tiles than the chip holds 4-wave workgroups at once (the 7B LM gate/up: 1184 tiles against 3 x 256 slots): the first
-            // 768 finish together and the other 416 run as a thin second round.  Two waves per workgroup (each wave twice the K range)
-            // keeps every workgroup of the launch resident from the start: 4 or 5 per CU, all streaming to the end
-            VV_GO(1, VV_PRO_RMS, VV_EPI_SWIGLU, 2, 2);
-        }
         if (n_tiles > 256) {
             // one utterance = two rows (cond + uncond): the 2-row form halves the activation registers and the staging tile, so
             // one more workgroup fits per SIMD (RMS_MOD + SwiGLU: 160 -> <= 128 VGPRs) and a 672-tile launch is resident at once

@@ -89,7 +89,10 @@ class EngineError(RuntimeError):
 
 
 class Engine:
-    def __init__(self, cfg: EngineConfig, device: Optional[torch.device] = None):
+    def __init__(self, cfg: EngineConfig, device: Optional[torch.device] = None, share_from: Optional["Engine"] = None):
+        """share_from: another Engine of the same model on the same device whose weights are fully uploaded -- this engine then reads
+        THOSE weights (vv_create_shared) and owns only its runtime state (KV caches, activations, tokenizer state, graphs) and its
+        stream; uploads / LoRA merges go through the owner.  See Engine.fork()."""
         if not torch.cuda.is_available():
             raise EngineError("vibevoice_amd.Engine needs an AMD GPU (torch.cuda.is_available() is False); "
                               "there is no CPU fallback")
@@ -117,6 +120,21 @@ class Engine:
         self._ctx = C.c_void_p()
         # a dedicated non-default stream: hipGraph capture is illegal on the null stream
         self.stream = torch.cuda.Stream(device=self.device)
+        self.shared_from = share_from
+        if share_from is not None:
+            if share_from.device != self.device:
+                raise EngineError("a shared engine lives on its owner's device")
+            rc = self.lib.vv_create_shared(C.byref(c), share_from._ctx, C.byref(self._ctx))
+            if rc != 0:
+                msg = self._err()
+                if self._ctx:
+                    self.lib.vv_destroy(self._ctx)
+                    self._ctx = C.c_void_p()
+                raise EngineError("vv_create_shared failed: " + msg)
+            self.max_ctx = (cfg.max_ctx + 127) // 128 * 128
+            self._n_steps = None
+            self._loaded = set(share_from._loaded)
+            return
         rc = self.lib.vv_create(C.byref(c), C.byref(self._ctx))
         if rc != 0:
             raise EngineError("vv_create failed: " + self._err())
@@ -127,6 +145,14 @@ class Engine:
         d = cfg.lm_head_dim
         inv_freq = 1.0 / (cfg.rope_theta ** (torch.arange(0, d, 2, dtype=torch.int64).float() / d))
         self.upload("lm.rope.inv_freq", inv_freq)
+
+    def fork(self, **runtime) -> "Engine":
+        """A second engine over this engine's weights (one copy in HBM) with its own runtime state and stream; runtime: n_slots, max_ctx,
+        max_rows, attn_splits, use_graph overrides.  Two engines driven from two host threads interleave two independent utterance
+        batches on the GPU: each chain's launch boundaries are filled by the other's kernels."""
+        import dataclasses
+        owner = self.shared_from or self
+        return Engine(dataclasses.replace(self.cfg, **runtime), self.device, share_from=owner)
 
     # ------------------------------------------------------------------ plumbing
     def _err(self):

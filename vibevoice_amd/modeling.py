@@ -294,6 +294,30 @@ class _ModelNamespace:
         self._owner._sched_cfg = dict(view.config)
 
 
+class _LaneStreamer:
+    """one lane's view of the caller's AudioStreamer in generate_interleaved: the lane's request j is the caller's sample idx[j]; the
+    lane's closing end() ends only the lane's own samples (the caller's streamer is closed once, after every lane has finished)"""
+
+    def __init__(self, inner, idx):
+        self.inner, self.idx = inner, [int(i) for i in idx]
+        self._ended = set()
+
+    @property
+    def finished_flags(self):
+        ff = getattr(self.inner, "finished_flags", None)
+        return [bool(ff[i]) for i in self.idx] if ff is not None else [False] * len(self.idx)
+
+    def put(self, chunks, sample_indices):
+        self.inner.put(chunks, torch.tensor([self.idx[int(i)] for i in sample_indices.tolist()]))
+
+    def end(self, sample_indices=None):
+        ids = self.idx if sample_indices is None else [self.idx[int(i)] for i in sample_indices.tolist()]
+        ids = [i for i in ids if i not in self._ended]          # one end per sample, as one generate() call gives
+        self._ended.update(ids)
+        if ids:
+            self.inner.end(torch.tensor(ids))
+
+
 class _Utt:
     """One utterance in flight: its engine slot (KV caches 2*slot / 2*slot+1, codec states), lengths and outputs."""
     __slots__ = ("idx", "slot", "ids", "seq_len0", "init_len", "max_length", "max_steps", "max_step_sample", "step", "pos_len",
@@ -1372,7 +1396,7 @@ class VibeVoiceForConditionalGenerationInference:
         outs = self.generate_continuous(reqs, tokenizer=tokenizer, generation_config=generation_config, cfg_scale=cfg_scale,
                                         audio_streamer=audio_streamer, is_prefill=is_prefill, return_speech=return_speech,
                                         max_new_tokens=kwargs.get("max_new_tokens"), max_length_times=max_length_times,
-                                        stop_check_fn=stop_check_fn, _bench_hooks=BenchHooks(step_callback=step_cb), **kw)
+                                        stop_check_fn=stop_check_fn, _bench_hooks=BenchHooks(step_callback=step_cb), _batch_exit=True, **kw)
         eos = tokenizer.eos_token_id
         width = max(int(o.sequences.shape[1]) for o in outs)
         seq = torch.full((B, width), eos, dtype=torch.long, device=self.device)
@@ -1381,6 +1405,70 @@ class VibeVoiceForConditionalGenerationInference:
         speech = [o.speech_outputs[0] if o.speech_outputs else None for o in outs] if return_speech else None
         return VibeVoiceGenerationOutput(sequences=seq, speech_outputs=speech,
                                          reach_max_step_sample=torch.cat([o.reach_max_step_sample.reshape(1) for o in outs]).to(self.device))
+
+    # ------------------------------------------------------------------ two decode chains over one weight copy
+    def fork(self, **runtime):
+        """A second model object over THIS model's weights (Engine.fork -> vv_create_shared: one copy in HBM) with its own engine
+        context -- KV caches, tokenizer state, graphs, stream -- and its own host-side buffers.  runtime: n_slots / max_ctx / max_rows
+        overrides.  generate() on the fork and on the original may run at the same time from two host threads."""
+        m = type(self)(self.config_dict, self.engine.fork(**runtime), self.dtype, self.requested_attn_implementation)
+        m.set_speech_factors(self._scaling, self._bias)
+        m.set_ddpm_inference_steps(self.ddpm_inference_steps)
+        m._sched_cfg = dict(self._sched_cfg)
+        m.concurrent_codecs, m.batched_codecs, m.speculate_sampling = self.concurrent_codecs, self.batched_codecs, self.speculate_sampling
+        return m
+
+    def generate_interleaved(self, requests: List[dict], lanes: int = 2, audio_streamer=None, **kwargs) -> List[VibeVoiceGenerationOutput]:
+        """generate_continuous() over `lanes` engine contexts that share this model's weights, one host thread and one stream per lane.
+        A decode step is a chain of ~300-450 DEPENDENT launches, each paying a fixed boundary cost the chip idles through; a second,
+        independent chain fills those boundaries (measured with two processes on one GPU in round 4: 1.63 x the aggregate at 1.5B).
+        The queue is split longest-prompt-first over the lanes (parallel.shard_utterances); every request still ends exactly as
+        generate() on it alone (the lanes share nothing but read-only weights).  Returns the outputs in request order.  The lanes are
+        created on first use (each owns KV caches for its n_slots) and kept: `model.close_lanes()` releases them."""
+        import threading
+        from .parallel import shard_utterances
+        lanes = max(1, min(int(lanes), len(requests)))
+        if lanes == 1:
+            return self.generate_continuous(requests, audio_streamer=audio_streamer, **kwargs)
+        pool = getattr(self, "_lanes", None) or []
+        while len(pool) < lanes - 1:
+            pool.append(self.fork())
+        self._lanes = pool
+        models = [self] + pool[:lanes - 1]
+        shards = shard_utterances([int(r["input_ids"].shape[-1]) for r in requests], lanes)
+        outs: List[Optional[VibeVoiceGenerationOutput]] = [None] * len(requests)
+        errs: List[Optional[BaseException]] = [None] * lanes
+
+        def run(k):
+            try:
+                torch.cuda.set_device(self.device)
+                st = _LaneStreamer(audio_streamer, shards[k]) if audio_streamer is not None else None
+                res = models[k].generate_continuous([requests[i] for i in shards[k]], audio_streamer=st, **kwargs)
+                for i, o in zip(shards[k], res):
+                    outs[i] = o
+            except BaseException as ex:                 # noqa: BLE001 -- handed to the caller's thread below
+                errs[k] = ex
+        threads = [threading.Thread(target=run, args=(k,), name=f"vv-lane-{k}") for k in range(1, lanes)]
+        for t in threads:
+            t.start()
+        run(0)
+        for t in threads:
+            t.join()
+        for ex in errs:
+            if ex is not None:
+                if audio_streamer is not None:
+                    audio_streamer.end()
+                raise ex
+        if audio_streamer is not None:
+            audio_streamer.end()
+        self.last_stats = {"lanes": lanes, "frames": sum(m.last_stats.get("frames", 0) for m in models),
+                           "per_lane": [dict(m.last_stats) for m in models], "shards": shards}
+        return outs
+
+    def close_lanes(self):
+        for m in getattr(self, "_lanes", None) or []:
+            m.engine.close()
+        self._lanes = []
 
     # ------------------------------------------------------------------ continuous batching (SURVEY 8f rank 2)
     @torch.no_grad()
@@ -1402,6 +1490,7 @@ class VibeVoiceForConditionalGenerationInference:
             raise ValueError("no engine slot available")
         kwargs = dict(kwargs)
         step_cb = (kwargs.pop("_bench_hooks", None) or BenchHooks()).step_callback
+        batch_exit = bool(kwargs.pop("_batch_exit", False))      # _generate_queued: the reference's batch-level early exit applies
         if not kwargs.get("refresh_negative", True):
             # with refresh_negative=False a row's negative cache depends on whether ANOTHER row of the same batch diffuses at that
             # step (the correction of :590-624): defined for the lock-step batch of generate(), not for a queue of requests
@@ -1428,8 +1517,8 @@ class VibeVoiceForConditionalGenerationInference:
                     if audio_streamer is not None:
                         audio_streamer.end()
                     break
-                if audio_streamer is not None and hasattr(audio_streamer, "finished_flags") and any(audio_streamer.finished_flags):
-                    break                       # the batch loop's early exit (:443-447): a consumer closed its stream
+                if batch_exit and audio_streamer is not None and hasattr(audio_streamer, "finished_flags") and any(audio_streamer.finished_flags):
+                    break                       # standing in for ONE batched generate(): its loop ends with the first finished stream (:443-447)
                 # ---- retire by the loop-level conditions of a batch-1 generate(): range(max_steps) exhausted / max_length ----
                 keep, keep_rows = [], []
                 for i, u in enumerate(active):
