@@ -959,6 +959,38 @@ def bench_streaming(args, spec, ctx):
     wall = time.perf_counter() - t0
     audio_s = out.speech_outputs[0].shape[-1] / 24000.0
     n_frames = audio_s / FRAME_SEC
+    # two concurrent sessions over ONE weight copy (model.fork(): vv_create_shared), one host thread + stream each: the same steady-state
+    # request in both at once; aggregate = both sessions' audio / the wall clock around both
+    two = None
+    if not os.environ.get("VVHIP_NO_TWO_SESSIONS"):
+        try:
+            import threading
+            m2 = model.fork()
+            sess = [model, m2]
+            texts = [text, torch.randint(0, 151000, (1, n_text), generator=g)]
+            res2 = [None, None]
+
+            def run_session(k):
+                torch.cuda.set_device(device)
+                res2[k] = sess[k].generate(tts_text_ids=texts[k], all_prefilled_outputs=preset, cfg_scale=1.5, tokenizer=tok,
+                                           max_new_tokens=n_text + (n_text // 5) * 6)
+            m2.generate(tts_text_ids=text[:, :5], all_prefilled_outputs=preset, cfg_scale=1.5, tokenizer=tok, max_new_tokens=5 + 6)   # its graphs
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            th = threading.Thread(target=run_session, args=(1,))
+            th.start()
+            run_session(0)
+            th.join()
+            torch.cuda.synchronize()
+            wall2 = time.perf_counter() - t2
+            a2 = sum(r.speech_outputs[0].shape[-1] for r in res2) / 24000.0
+            two = {"sessions": 2, "aggregate_audio_s_per_wall_s": round(a2 / wall2, 3), "single_session": round(audio_s / wall, 3),
+                   "ratio": round((a2 / wall2) / (audio_s / wall), 3), "ms_per_frame_per_session": round(wall2 / (a2 / 2 / FRAME_SEC) * 1e3, 4),
+                   "weights": "one copy (vv_create_shared)"}
+            m2.engine.close()
+            del m2
+        except Exception as ex:
+            two = {"error": repr(ex)[:200]}
     # SURVEY 8d's first-audio latency: generate() entry -> first chunk handed to an AudioStreamer consumer on the host
     text5 = torch.randint(0, 151000, (1, 5), generator=g)
     lat_host = first_audio_trials(lambda st: model.generate(tts_text_ids=text5, all_prefilled_outputs=preset, cfg_scale=1.5, tokenizer=tok,
@@ -999,7 +1031,7 @@ def bench_streaming(args, spec, ctx):
                      "consumer thread on the host (preset KV import + first text window + first frame + D2H + queue hand-off); SURVEY 8d",
                      "p50_first_chunk_on_device_ms": round(statistics.median(lat), 3),
                      "weights_source": (f"checkpoint {ckpt}" if ckpt else "synthetic"), "libvvhip_build_id": _build_id(),
-                     "finished_by_eos_or_cap": True}}
+                     "two_sessions": two, "finished_by_eos_or_cap": True}}
     model.engine.close()
     del model
     torch.cuda.empty_cache()

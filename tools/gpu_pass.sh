@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU pass under gpurun:  gpurun --timeout T -- 'bash tools/gpu_pass.sh <tag> <step> [<step> ...]'
 # Steps (each writes under gpurun_out/<tag>/ and prints a short digest to stdout, which is what gpurun hands back):
-#   pytest:<expr>      python -m pytest -m gpu -q <expr words, '+' for spaces>     e.g.  pytest:tests/test_gpu_kernels.py+-k+ragged
+#   pytest:<expr>      python -m pytest -m gpu -q <expr words, '+' for spaces>     e.g.  pytest:tests/test_gpu_kernels.py+-k+ragged%or%kv_move
 #   bench:<name>:<args>  python bench.py <args, '+' for spaces>  -> <name>.json     e.g.  bench:default:   bench:1p5b:--workload+1p5b
 #   trace:<name>:<args>  rocprofv3 --kernel-trace of bench.py <args> + tools/rocprof_summary.py -> <name>_top.txt, _kernel_stats.csv, _gaps.txt
 #   pmc:<name>:<counters>:<args>  rocprofv3 --pmc <counters> --kernel-trace of bench.py <args> (its own pass, no other trace domain)
@@ -14,8 +14,9 @@ Q="--no-cpu-baseline --no-eager-baseline --skip-extra"
 for step in "$@"; do
   kind=${step%%:*}; rest=${step#*:}
   case $kind in
-    pytest) a=${rest//+/ }; n=$(echo "$rest" | tr -c 'A-Za-z0-9_' '_' | cut -c1-60)
-       timeout ${VV_STEP_TIMEOUT:-1500} python -m pytest -m gpu -q ${VV_PYTEST_X--x} $a > $O/pytest_$n.log 2>&1; echo "[pytest $a] rc=$?"; tail -n ${VV_TAIL:-15} $O/pytest_$n.log;;
+    pytest) IFS='+' read -ra ARGS <<< "$rest"; for i in "${!ARGS[@]}"; do ARGS[$i]=${ARGS[$i]//%/ }; done      # '%' = a space INSIDE one argument (-k+a%or%b)
+       n=$(echo "$rest" | tr -c 'A-Za-z0-9_' '_' | cut -c1-60)
+       timeout ${VV_STEP_TIMEOUT:-1500} python -m pytest -m gpu -q ${VV_PYTEST_X--x} "${ARGS[@]}" > $O/pytest_$n.log 2>&1; echo "[pytest ${ARGS[*]}] rc=$?"; tail -n ${VV_TAIL:-15} $O/pytest_$n.log;;
     bench) name=${rest%%:*}; a=${rest#*:}; a=${a//+/ }
        timeout ${VV_STEP_TIMEOUT:-900} python bench.py $a > $O/$name.json 2> $O/$name.err; echo "[bench $name] rc=$?"; tail -c 300 $O/$name.err; head -c 1500 $O/$name.json; echo;;
     trace) name=${rest%%:*}; a=${rest#*:}; a=${a//+/ }

@@ -573,7 +573,7 @@ extern "C" int vv_rope_append_launch(int D, const float* qkv, const VVRow* rows,
         hipLaunchKernelGGL((vv_rope_append_kernel<64>), grid, dim3(64), 0, s, qkv, rows, inv_freq, q_out,
                            (__bf16*)kc, (__bf16*)vc, Hq, Hkv, cache_stride, head_stride, scale);
     else return -1;
-    return hipGetLastError() == hipSuccess ? 0 : -2;
+    return vv_launch_rc(0);
 }
 
 template <int D, int XS>
@@ -587,7 +587,7 @@ static void attn_go(const float* q, const VVRow* rows, const void* kc, const voi
 extern "C" int vv_rope_table_launch(const float* inv_freq, void* tab, int n_pos, int half, hipStream_t s) {
     const int64_t n = (int64_t)n_pos * half;
     hipLaunchKernelGGL(vv_rope_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, inv_freq, (float2*)tab, n_pos, half);
-    return hipGetLastError() == hipSuccess ? 0 : -2;
+    return vv_launch_rc(0);
 }
 
 // Decode-step attention in one launch; requires every row to own a different cache (the new token of row r must not
@@ -626,7 +626,7 @@ extern "C" int vv_attn_fused_launch(int D, int xs, const float* qkv, const VVRow
         if (D == 128) hipLaunchKernelGGL((vv_attn_merge2_kernel<128>), dim3(R, Hq), dim3(512), 0, s, pm, pl, po, rows, out, Hq, Hkv, S);
         else hipLaunchKernelGGL((vv_attn_merge2_kernel<64>), dim3(R, Hq), dim3(512), 0, s, pm, pl, po, rows, out, Hq, Hkv, S);
     }
-    return hipGetLastError() == hipSuccess ? 0 : -2;
+    return vv_launch_rc(0);
 }
 
 extern "C" int vv_attn_launch(int D, int xs, const float* q, const VVRow* rows, const void* kc, const void* vc,
@@ -643,5 +643,5 @@ extern "C" int vv_attn_launch(int D, int xs, const float* q, const VVRow* rows, 
     else if (D == 64) VV_A(64);
     else return -1;
 #undef VV_A
-    return hipGetLastError() == hipSuccess ? 0 : -2;
+    return vv_launch_rc(0);
 }

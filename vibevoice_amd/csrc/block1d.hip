@@ -297,5 +297,5 @@ extern "C" int vv_block1d_slots_launch(int C, int xs, const float* xin, float* x
     else if (C == 128) VV_B(128);
     else return -1;
 #undef VV_B
-    return hipGetLastError() == hipSuccess ? 0 : -2;
+    return vv_launch_rc(0);
 }

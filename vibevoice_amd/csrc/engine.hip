@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 
+#include <mutex>
 #include "../../include/vvhip.h"
 #include "vv_common.h"
 
@@ -100,6 +101,7 @@ int vv_block1d_launch(int C, int xs, const float* xin, float* xout, float* nst, 
 struct VVShiftH { float* buf; int T, hist, C; };
 
 static thread_local char g_err[512] = "";
+static std::mutex g_capture_mu;
 
 namespace {
 
@@ -269,7 +271,7 @@ static int fail(vv_ctx* ctx, const char* fmt, ...) {
     return -1;
 }
 #define HIPCHK(ctx, e) do { hipError_t _e = (e); if (_e != hipSuccess) return fail(ctx, "%s:%d hip error %s", __FILE__, __LINE__, hipGetErrorString(_e)); } while (0)
-#define VVCHK(e) do { int _r = (e); if (_r != 0) return _r < 0 ? fail(ctx, "%s:%d launch failed (%d): %s", __FILE__, __LINE__, _r, hipGetErrorString(hipGetLastError())) : _r; } while (0)
+#define VVCHK(e) do { int _r = (e); if (_r != 0) return _r < 0 ? fail(ctx, "%s:%d launch failed (%d): hip error %d (%s)", __FILE__, __LINE__, _r, g_vv_launch_err, hipGetErrorString((hipError_t)g_vv_launch_err)) : _r; } while (0)
 
 static int ring_acquire(vv_ctx* ctx) {
     const int slot = ctx->ring_i;
@@ -807,14 +809,17 @@ static int graphed(vv_ctx* ctx, const std::string& key, hipStream_t st, F&& body
         if (ctx->seen.size() > 8192) ctx->seen.clear();
         if (ctx->seen.insert(key).second) return body();
         hipGraph_t graph;
-        HIPCHK(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
-        int r = body();
-        hipError_t e = hipStreamEndCapture(st, &graph);
-        if (r) return r;
-        HIPCHK(ctx, e);
         GraphEntry ge; ge.last_use = 0;
-        HIPCHK(ctx, hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0));
-        hipGraphDestroy(graph);
+        {   // one capture at a time in the process: contexts sharing weights are driven from several host threads (Engine.fork)
+            std::lock_guard<std::mutex> lk(g_capture_mu);
+            HIPCHK(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+            int r = body();
+            hipError_t e = hipStreamEndCapture(st, &graph);
+            if (r) return r;
+            HIPCHK(ctx, e);
+            HIPCHK(ctx, hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0));
+            hipGraphDestroy(graph);
+        }
         if (ctx->graphs.size() >= ctx->graph_cap) {
             // a long-running process with varied launch shapes (prefill remainders over temporary buffers) must not
             // accumulate executables: drop the least-recently-used quarter.  Rare (a cache miss at the cap), so it may wait
@@ -1371,6 +1376,7 @@ extern "C" int vv_lm_forward_range(vv_ctx* ctx, void* stream, int n_rows, const 
     if (l0 < 0 || l1 > ctx->c.lm_layers || l0 >= l1) return fail(ctx, "layer range [%d,%d) invalid", l0, l1);
     if (n_rows < 1 || n_rows > ctx->c.max_rows) return fail(ctx, "n_rows %d out of range [1,%d]", n_rows, ctx->c.max_rows);
     if (ksplit_check(ctx, st)) return -1;
+    (void)hipGetLastError();            // a stale error of this host thread (another library's query) is not a launch failure of ours
     for (int i = 0; i < n_rows; ++i) {
         if (rows[i].cache < 0 || rows[i].cache >= 2 * ctx->c.n_slots) return fail(ctx, "row %d: cache id %d out of range", i, rows[i].cache);
         if (rows[i].pos < 0 || rows[i].pos >= ctx->c.max_ctx) return fail(ctx, "row %d: position %d exceeds max_ctx %d", i, rows[i].pos, ctx->c.max_ctx);

@@ -557,7 +557,7 @@ extern "C" int vv_gemm_launch(VVGemm a, int xs, hipStream_t s) {
         else VV_XS(1, false, 4, 16, true);
     }
 #undef VV_XS
-    return hipGetLastError() == hipSuccess ? 0 : -2;
+    return vv_launch_rc(0);
 }
 
 extern "C" int vv_pack_launch(const void* src, int src_is_bf16, void* dst, int N, int K, int kind,
@@ -571,5 +571,5 @@ extern "C" int vv_pack_launch(const void* src, int src_is_bf16, void* dst, int N
     else
         hipLaunchKernelGGL((vv_pack_kernel<float>), dim3(blocks), dim3(256), 0, s, (const float*)src,
                            (__bf16*)dst, N, K, kind, Cin, Cout, ksz, stride);
-    return hipGetLastError() == hipSuccess ? 0 : -2;
+    return vv_launch_rc(0);
 }

@@ -551,7 +551,7 @@ extern "C" int vv_gemv_launch(VVGemm a, int xs, hipStream_t s) {
     dim3 grid(n_tiles);
 #define VV_GO(XS_, P, E, MR_, WP_)                                                                      \
     do { hipLaunchKernelGGL((vv_gemv_kernel<XS_, P, E, MR_, WP_>), grid, dim3(WP_ * 64), 0, s, a.W, a.W2, a.X, a.Y, a.nw, a.T, a.N, a.K, a.ldx, a.ldy, a);       \
-         return hipGetLastError() == hipSuccess ? 0 : -2; } while (0)
+         return vv_launch_rc(0); } while (0)
     if (a.T > 4 || a.sl_n > 0) {
         if (xs > 2) return -3;       // 16-row staging tiles of the exact mode exceed the LDS: general kernel
         grid.y = (a.T + 15) / 16;
@@ -562,7 +562,7 @@ extern "C" int vv_gemv_launch(VVGemm a, int xs, hipStream_t s) {
         if (a.sl_n > 0) {
 #define VV_GOSL(XS_, P, E, WP_)                                                                         \
     do { hipLaunchKernelGGL((vv_gemv_kernel<XS_, P, E, 16, WP_, 0, 1>), grid, dim3(WP_ * 64), 0, s, a.W, a.W2, a.X, a.Y, a.nw, a.T, a.N, a.K, a.ldx, a.ldy, a);   \
-         return hipGetLastError() == hipSuccess ? 0 : -2; } while (0)
+         return vv_launch_rc(0); } while (0)
 #define X(P, E) if (a.pro == P && a.epi == E) { if (xs == 2) VV_GOSL(2, P, E, 8); else if ((int64_t)n_tiles * grid.y > wide4_wgs) VV_GOSL(1, P, E, 4); else VV_GOSL(1, P, E, 8); }
             VV_GEMV_SL(X)
 #undef X
@@ -586,7 +586,7 @@ extern "C" int vv_gemv_launch(VVGemm a, int xs, hipStream_t s) {
         if (a.kgrid > 1) grid.y = a.kgrid;
 #define VV_GOP(XS_, P, E, WP_, S_)                                                                      \
     do { hipLaunchKernelGGL((vv_gemv_kernel<XS_, P, E, 4, WP_, S_>), grid, dim3(WP_ * 64), 0, s, a.W, a.W2, a.X, a.Y, a.nw, a.T, a.N, a.K, a.ldx, a.ldy, a);     \
-         return hipGetLastError() == hipSuccess ? 0 : -2; } while (0)
+         return vv_launch_rc(0); } while (0)
 #define X(P, E)                                                                                         \
     if (a.pro == P && a.epi == E) {                                                                     \
         if (xs == 1 && n_tiles > 256 && E == VV_EPI_SWIGLU) VV_GOP(1, P, E, 4, 1);                       \

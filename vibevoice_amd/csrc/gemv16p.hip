@@ -215,7 +215,7 @@ int vv_pack16_launch(const float* x, int ldx, int mode, const float* nw, float e
     if (mode == 2) hipLaunchKernelGGL((vv_pack16_kernel<2>), dim3(16), dim3(256), 0, s, x, ldx, nw, eps, sc, sh, ld_mod, (unsigned char*)xp, T, K);
     else if (mode == 1) hipLaunchKernelGGL((vv_pack16_kernel<1>), dim3(16), dim3(256), 0, s, x, ldx, nw, eps, sc, sh, ld_mod, (unsigned char*)xp, T, K);
     else hipLaunchKernelGGL((vv_pack16_kernel<0>), dim3(16), dim3(256), 0, s, x, ldx, nw, eps, sc, sh, ld_mod, (unsigned char*)xp, T, K);
-    return hipGetLastError() == hipSuccess ? 0 : -2;
+    return vv_launch_rc(0);
 }
 
 // Y / Yp (op)= W . Xp for one packed 16-row activation tile.  Returns -3 when the shape has no instantiation.
@@ -237,7 +237,7 @@ int vv_gemv16p_launch(const void* W, const void* W2, const void* Xp, float* Y, v
     else if (epi == VV_EPI_GATED_RESID) { if (!Y || !gate || (ldy & 3) || (ld_gate & 3)) return -3; VV_P(VV_EPI_GATED_RESID); }
     else return -3;
 #undef VV_P
-    return hipGetLastError() == hipSuccess ? 0 : -2;
+    return vv_launch_rc(0);
 }
 
 }  // extern "C"

@@ -534,7 +534,7 @@ __global__ __launch_bounds__(256) void vv_logits_full_kernel(const __bf16* __res
 
 }  // namespace
 
-static inline int okk() { return hipGetLastError() == hipSuccess ? 0 : -2; }
+static inline int okk() { return vv_launch_rc(0); }
 
 extern "C" {
 
@@ -700,7 +700,7 @@ int vv_ada_in_launch(const float* cproj, const float* temb, float* out, int rows
     if (H & 3) return -1;
     const int n4 = rows * n_steps * (H >> 2);
     hipLaunchKernelGGL(vv_ada_in_kernel, dim3((n4 + 255) / 256), dim3(256), 0, s, cproj, temb, out, rows, n_steps, H);
-    return hipGetLastError() == hipSuccess ? 0 : -2;
+    return vv_launch_rc(0);
 }
 int vv_silu_launch(float* x, int n, hipStream_t s) {
     hipLaunchKernelGGL(vv_silu_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, n);

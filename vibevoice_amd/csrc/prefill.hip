@@ -1070,13 +1070,13 @@ extern "C" {
 int vv_pack_rows_launch(const float* x, int ldx, const float* nw, float eps, void* xp, int T, int K, hipStream_t s) {
     if ((K & 7) || (ldx & 3) || (((uintptr_t)x) & 15) || (((uintptr_t)xp) & 15) || (nw && (((uintptr_t)nw) & 15))) return -1;
     hipLaunchKernelGGL(vv_pack_rows_kernel, dim3((T + 15) / 16), dim3(256), 0, s, x, ldx, nw, eps, (u32x4*)xp, T, K);
-    return hipGetLastError() == hipSuccess ? 0 : -2;
+    return vv_launch_rc(0);
 }
 
 int vv_unpack_rows_launch(const void* xp, float* x, int T, int K, hipStream_t s) {
     const int64_t n = (int64_t)T * K;
     hipLaunchKernelGGL(vv_unpack_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const __bf16*)xp, x, T, K);
-    return hipGetLastError() == hipSuccess ? 0 : -2;
+    return vv_launch_rc(0);
 }
 
 // Y (op)= Xp . W^T.  epi: VV_EPI_STORE / BIAS / RESID -> fp32 Y[T][ldy];  VV_EPI_SWIGLU -> packed bf16 Yp [T][N] (W = gate, W2 = up)
@@ -1084,7 +1084,7 @@ int vv_ada_pack_launch(const float* cproj, const float* temb, void* xp, int rows
     if ((H & 7) || rows < 1 || n_steps < 1) return -1;
     const int T = rows * n_steps, KT = (H + 31) >> 5;
     hipLaunchKernelGGL(vv_ada_pack_kernel, dim3((T + 15) / 16, (KT + 3) / 4), dim3(256), 0, s, cproj, temb, (u32x4*)xp, rows, n_steps, H);
-    return hipGetLastError() == hipSuccess ? 0 : -2;
+    return vv_launch_rc(0);
 }
 
 int vv_gemm3_launch(const void* W, const void* W2, const void* Xp, float* Y, void* Yp, const float* bias, int T, int N, int K,
@@ -1128,7 +1128,7 @@ int vv_gemm3_launch(const void* W, const void* W2, const void* Xp, float* Y, voi
         if (epi == VV_EPI_SWIGLU) hipLaunchKernelGGL((vv_gemm4_kernel<VV_EPI_SWIGLU>), grid4, dim3(512), smem4, s, a);
         else if (epi == VV_EPI_RESID) hipLaunchKernelGGL((vv_gemm4_kernel<VV_EPI_RESID>), grid4, dim3(512), smem4, s, a);
         else hipLaunchKernelGGL((vv_gemm4_kernel<VV_EPI_BIAS>), grid4, dim3(512), smem4, s, a);
-        return hipGetLastError() == hipSuccess ? 0 : -2;
+        return vv_launch_rc(0);
     }
     const int ft = (epi == VV_EPI_SWIGLU) ? 4 : 8;
     a.n_blocks = (n_tiles + ft - 1) / ft;
@@ -1175,7 +1175,7 @@ int vv_gemm3_launch(const void* W, const void* W2, const void* Xp, float* Y, voi
         const int64_t n4 = ((int64_t)T * N + 3) / 4;
         hipLaunchKernelGGL(vv_g3_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, ws->g3_partials, ks, T, N, bias_r, Y, ldy, resid_r);
     }
-    return hipGetLastError() == hipSuccess ? 0 : -2;
+    return vv_launch_rc(0);
 }
 
 // causal prefill attention of R consecutive rows of one cache (64 query rows x the GQA group of one kv head per workgroup)
@@ -1204,7 +1204,7 @@ int vv_gemm_qkv_rope_launch(const void* W, const void* Xp, const float* bias, in
         attr = true;
     }
     hipLaunchKernelGGL((vv_gemm4_kernel<VV_EPI_QKV_ROPE>), dim3(n_wgs), dim3(512), (size_t)4 * 32 * 1024, s, a);
-    return hipGetLastError() == hipSuccess ? 1 : -2;
+    return vv_launch_rc(1);
 }
 
 // out_packed != null: the result goes out as packed bf16 B fragments [R][Hq * D] (the o-projection GEMM's operand) instead of fp32 rows
@@ -1223,7 +1223,7 @@ int vv_attn_prefill4_launch(int D, const float* q, const VVRow* rows, const void
     const int sm = 4 * 2 * (2 * (D / 32) + D / 16) * 1024;          // 4 stages of K + V fragments
     if (D == 128) hipLaunchKernelGGL((vv_attn_prefill4_kernel<128>), grid, dim3(512), sm, s, q, rows, (const __bf16*)kc, (const __bf16*)vc, R, Hq, Hkv, cache_stride, head_stride, out, (u32x4*)out_packed);
     else hipLaunchKernelGGL((vv_attn_prefill4_kernel<64>), grid, dim3(512), sm, s, q, rows, (const __bf16*)kc, (const __bf16*)vc, R, Hq, Hkv, cache_stride, head_stride, out, (u32x4*)out_packed);
-    return hipGetLastError() == hipSuccess ? 0 : -2;
+    return vv_launch_rc(0);
 }
 
 }  // extern "C"

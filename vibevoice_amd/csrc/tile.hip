@@ -282,7 +282,7 @@ static int tile_go(const VVGemm& a, hipStream_t s) {
         attr = true;
     }
     hipLaunchKernelGGL((vv_gemm_tile_kernel<XS, PRO, EPI>), grid, dim3(256), smem, s, a.W, a.W2, a.X, a.Y, a.nw, a.T, a.N, a.K, a.ldx, a.ldy, a);
-    return hipGetLastError() == hipSuccess ? 0 : -2;
+    return vv_launch_rc(0);
 }
 
 extern "C" int vv_tile_launch(VVGemm a, int xs, hipStream_t s) {

@@ -114,3 +114,13 @@ __device__ __forceinline__ int vv_slot_id(const int (&id)[8], int j) {     // se
     return r;
 }
 
+// Launch status of the calling host thread: hipGetLastError() after a launch (it clears the thread's error state, so the code is
+// kept here for the message the API layer prints).  rc_ok is what the launcher returns on success.
+inline thread_local int g_vv_launch_err = 0;
+static inline int vv_launch_rc(int rc_ok) {
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return rc_ok;
+    g_vv_launch_err = (int)e;
+    return -2;
+}
+

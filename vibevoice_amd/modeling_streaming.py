@@ -214,6 +214,15 @@ class VibeVoiceStreamingForConditionalGenerationInference:
             m.set_speech_factors(scaling, bias)
         return m
 
+    def fork(self, **runtime):
+        """A second session over THIS model's weights (Engine.fork -> vv_create_shared: one copy in HBM), with its own engine context
+        (KV caches, decoder state, graphs, stream): generate() on the fork and on the original may run at the same time from two host
+        threads -- the reference class is one session at a time (B = 1 only, modeling_vibevoice_streaming_inference.py:511)."""
+        m = type(self)(self.config_dict, self.engine.fork(**runtime), self.dtype, self.requested_attn_implementation)
+        m.set_speech_factors(self.speech_scaling_factor, self.speech_bias_factor)
+        m.set_ddpm_inference_steps(self.ddpm_inference_steps)
+        return m
+
     def set_speech_factors(self, scaling, bias):
         self.speech_scaling_factor, self.speech_bias_factor = float(scaling), float(bias)
         self.engine.set_speech_factors(scaling, bias)
