@@ -102,6 +102,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-roofline", action="store_true", help="skip the GEMV launch-duration passes (for rocprof --pmc runs)")
     ap.add_argument("--skip-extra", action="store_true", help="main workload only (no extra.configs lines)")
     ap.add_argument("--cpu-frames", type=int, default=3)
+    ap.add_argument("--cpu-windows", action="store_true", help="SURVEY 8(d)'s CPU baseline as specified, nothing else: --cpu-frames decode frames "
+                                                               "of the oracle loop at three KV lengths (minutes of host time)")
     ap.add_argument("--batch", type=int, default=1, help="utterances decoded together on each GPU (up to 8 share every LM / "
                     "diffusion-head weight pass)")
     ap.add_argument("--continuous", type=int, default=0, help="queue this many utterances through generate_continuous() "
@@ -287,6 +289,9 @@ def main():
         if a is not None:
             spec[k] = a
     ctx = dict(rank=rank, world=world, device=device, use_dist=use_dist)
+    if args.cpu_windows:
+        print(json.dumps(cpu_baseline_windows(args, spec, device)), flush=True)
+        return
     if "streaming" in spec["model"]:
         res = bench_streaming(args, spec, ctx)
     elif args.full_utterance:
@@ -1067,6 +1072,77 @@ def cpu_baseline(cfg, cpu_sd, n_solver, cfg_scale, n_frames, model_key):
                       f"NOT reproduced on the CPU (attention is <5% of a CPU frame); oracle loop = CPU restatement of the reference's "
                       f"generate(), torch intra-op threads capped at {ncpu} of {host_cpus} logical CPUs",
             "ms_per_step": round(per_frame * 1e3, 2)}
+
+
+def cpu_baseline_windows(args, spec, device):
+    """SURVEY 8(d)'s CPU baseline as specified, run once per round (minutes of host time: not part of the default line): the oracle loop
+    (CPU restatement of the reference's generate(), fp32 = the reference's CPU dtype) on the workload's model shapes and weights, a
+    fixed window of `--cpu-frames` decode frames at three KV lengths -- the prompt length L0, the middle and the end of the utterance --
+    with the positive cache pre-filled with noise up to that length right after a short prompt pass (the 10,922-token prompt pass itself
+    would be ~150 s of CPU time per window and is not what the window measures).  The cache grows by torch.cat per step, as the
+    reference's DynamicCache does.  Prints / returns one JSON object; profiles/r05_cpu_baseline.json is this output."""
+    from oracle import generate as ogen
+    from oracle import parity as oparity
+    from vibevoice_amd import synthetic
+    from vibevoice_amd.configs import CONFIGS
+    model_key = spec["model"]
+    cfg = CONFIGS[model_key]
+    NS = spec["solver_steps"]
+    d = cfg["decoder_config"]
+    kvh, hd = d["num_key_value_heads"], d["hidden_size"] // d["num_attention_heads"]
+    inputs = synthetic.synthetic_inputs(cfg, n_speakers=spec["speakers"], text_tokens=spec["text_tokens"], voice_frames=spec["voice_frames"], seed=100)
+    L0 = inputs["input_ids"].shape[1]
+    L_end = min(3 * L0, d.get("max_position_embeddings", 32768)) - args.cpu_frames - 2
+    lengths = [L0, (L0 + L_end) // 2, L_end]
+    host_cpus = os.cpu_count() or 1
+    ncpu = min(int(os.environ.get("VVHIP_CPU_THREADS", "16")), host_cpus)
+    torch.set_num_threads(ncpu)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(0)
+    sd = {k: synthetic.random_tensor(k, shp, gen, device, torch.bfloat16).to("cpu") for k, shp in synthetic.param_shapes(cfg).items()}
+    m = oparity.oracle_model(cfg, sd, "cpu", torch.float32)
+    sd.clear()
+    m.t_cast_dtype = torch.bfloat16
+    T = synthetic.TOKENS
+    tok = ogen.TokenIds(T.speech_start_id, T.speech_end_id, T.speech_diffusion_id, T.eos_token_id, None, T.pad_token_id)
+    target = {"L": 0}
+    plain_forward = m.lm.forward
+
+    def forward(embeds, cache, final_norm=True):
+        out = plain_forward(embeds, cache, final_norm)
+        if embeds.shape[0] > 1 and cache.length < target["L"]:        # the prompt pass of the positive branch: pad its cache with noise
+            pad = target["L"] - cache.length
+            g = torch.Generator().manual_seed(4321)
+            for i in range(len(cache.k)):
+                cache.k[i] = torch.cat([cache.k[i], torch.randn(kvh, pad, hd, generator=g) * 0.5], dim=1)
+                cache.v[i] = torch.cat([cache.v[i], torch.randn(kvh, pad, hd, generator=g) * 0.5], dim=1)
+            cache.length = target["L"]
+        return out
+    m.lm.forward = forward
+    g = torch.Generator().manual_seed(7)
+    ids = torch.randint(0, 151000, (1, 48), generator=g)
+    ids[0, -1] = T.speech_start_id
+    windows = []
+    for L in lengths:
+        target["L"] = L
+        stamps = []
+
+        def noise_fn(step, n2):
+            stamps.append(time.perf_counter())
+            return torch.randn(n2, 64, generator=g)
+        n = args.cpu_frames
+        with torch.no_grad():
+            ogen.oracle_generate(m, tok, ids, torch.ones_like(ids), cfg_scale=args.cfg_scale, num_steps=NS, max_new_tokens=n + 1,
+                                 noise_fn=noise_fn, forced_tokens=[[T.speech_diffusion_id] * (n + 1)])
+        per = (stamps[-1] - stamps[0]) / (len(stamps) - 1)
+        windows.append({"kv_length": L, "frames": len(stamps) - 1, "s_per_frame": round(per, 3), "audio_s_per_wall_s": round(FRAME_SEC / per, 5)})
+        print(f"[cpu window] KV {L}: {per:.3f} s/frame over {len(stamps) - 1} frames", file=sys.stderr, flush=True)
+    return {"metric": "audio-sec/wall-sec", "kind": "port", "cores": ncpu, "host_logical_cpus": host_cpus, "dtype": "f32",
+            "model": f"VibeVoice-{model_key}", "solver_steps": NS, "cfg_scale": args.cfg_scale, "windows": windows,
+            "mean_audio_s_per_wall_s": round(sum(w["audio_s_per_wall_s"] for w in windows) / len(windows), 5),
+            "sample": f"oracle loop (CPU restatement of the reference's generate()), synthetic weights at the model's shapes, {args.cpu_frames}-frame "
+                      f"windows at KV lengths {lengths} (positive cache pre-filled with noise after a 48-token prompt pass), CFG pos + neg passes, "
+                      f"torch intra-op threads {ncpu} of {host_cpus}"}
 
 
 def gpu_eager_baseline(cfg, dev_sd, n_solver, cfg_scale, n_frames, model_key, device):

@@ -155,9 +155,22 @@ def oracle_leg(cfg, sd, tokens, n_solver, cfg_scale, n_frames, device, dtype, t_
 
 
 def _rel(a, b):
+    """relative L2 distance; a non-finite value on either side is an infinite distance (never a silently dropped step)"""
     a = a.detach().float().cpu().reshape(-1)
     b = b.detach().float().cpu().reshape(-1)
+    if not (bool(torch.isfinite(a).all()) and bool(torch.isfinite(b).all())):
+        return float("inf")
     return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _nonfinite_steps(tr, n):
+    """per traced quantity: the steps at which it holds a NaN / Inf (empty lists on a healthy run)"""
+    out = {}
+    for name in ("pos_hidden", "neg_hidden", "latents", "next_embeds"):
+        bad = [i for i, t in enumerate(getattr(tr, name)[:n]) if not bool(torch.isfinite(t.detach().float()).all())]
+        if bad:
+            out[name] = bad
+    return out
 
 
 def compare_traces(htr, wav, otr, n, seq_ok=True) -> dict:
@@ -182,13 +195,19 @@ def compare_traces(htr, wav, otr, n, seq_ok=True) -> dict:
     for i in range(min(n, wav.numel() // 3200, len(otr.audio))):
         h = wav[i * 3200:(i + 1) * 3200]
         o = otr.audio[i].float().cpu().reshape(-1)
+        if not (bool(torch.isfinite(h).all()) and bool(torch.isfinite(o).all())):
+            db, snr = float("inf"), float("-inf")
+            continue
         rh, ro = float(h.pow(2).mean().sqrt()), float(o.pow(2).mean().sqrt())
         db = max(db, abs(20.0 * math.log10(max(rh, 1e-30) / max(ro, 1e-30))))
         snr = min(snr, 20.0 * math.log10(max(float(o.norm()), 1e-30) / max(float((h - o).norm()), 1e-30)))
     step0 = {"latent": round(_rel(htr.latents[0], otr.latents[0]), 6) if htr.latents and otr.latents else None,
              "pos_hidden": round(_rel(htr.pos_hidden[0], otr.pos_hidden[0]), 6) if htr.pos_hidden and otr.pos_hidden else None,
              "neg_hidden": round(_rel(htr.neg_hidden[0], otr.neg_hidden[0]), 6) if htr.neg_hidden and otr.neg_hidden else None}
-    return {"frames": n, "step0": step0, "latent": round(w["latent"], 6), "pos_hidden": round(w["pos_hidden"], 6), "neg_hidden": round(w["neg_hidden"], 6),
+    bad = {"run": _nonfinite_steps(htr, n), "oracle": _nonfinite_steps(otr, n)}
+    if len(htr.latents) < n or len(htr.pos_hidden) < n or len(htr.neg_hidden) < n:
+        w = {k: float("inf") for k in w}                   # a run that traced fewer steps than it is compared on did not finish them
+    return {"frames": n, "nonfinite_steps": {k: v for k, v in bad.items() if v}, "step0": step0, "latent": round(w["latent"], 6), "pos_hidden": round(w["pos_hidden"], 6), "neg_hidden": round(w["neg_hidden"], 6),
             "frame_rms_db": round(db, 4), "frame_snr_db": round(snr, 2), "tokens_equal": bool(seq_ok),
             "greedy_pick_equal": bool(pick_ok), "oracle_min_top2_margin": round(margin, 5),
             "mode": "teacher-forced per step (next LM input = the oracle's embedding of that step)"}

@@ -499,6 +499,43 @@ def test_kv_move_keeps_the_rotation(sm):
         eng.close()
 
 
+@pytest.mark.parametrize("case", ["d64", "gqa"])
+def test_decode_attention_ignores_cache_slots_past_the_sequence(case):
+    """Cache positions >= the row's length carry a softmax weight of exactly 0 -- but the kernel multiplies whole 32-position blocks,
+    and 0 x NaN is NaN.  A slot re-used by the next utterance, imported K/V, or a profiling replay (bench.py's roofline chains append
+    whatever their stale inputs give) leaves arbitrary bits there: poison every position past the sequence with NaN / Inf in every
+    layer and decode on -- the result must be the clean run's, bit for bit."""
+    s = build_small(LM_CASES[case], xsplit=3, max_ctx=256)
+    eng = s.eng
+    try:
+        cfg = s.lmcfg
+        H, kvh, hd = cfg.hidden, cfg.kv_heads, cfg.hidden // cfg.heads
+        g = synth.Gen(707)
+        x = g.normal((40, H), 1.0, mat=False)
+        xd = dev(x, eng)
+
+        def run(poison):
+            hid = eng.new(1, H)
+            outs = []
+            with torch.cuda.stream(eng.stream):
+                for t in range(40):
+                    if poison and t in (1, 5, 31, 33):
+                        bad = torch.full((kvh, 96, hd), float("nan"), device=eng.device)
+                        bad[:, ::3] = float("inf")
+                        for layer in range(cfg.layers):
+                            eng.kv_import_at(0, layer, t, bad, bad)          # positions t .. t+95: everything past the sequence
+                    eng.lm_forward([(0, t)], xd[t:t + 1], hid)
+                    outs.append(hid.clone())
+            eng.sync()
+            return torch.cat(outs)
+        clean = run(False)
+        dirty = run(True)
+        assert bool(torch.isfinite(dirty).all())
+        assert torch.equal(clean, dirty)
+    finally:
+        eng.close()
+
+
 LM_CASES = {"d64": synth.LMCfg(), "d128": synth.LMCfg(hidden=256, heads=2, kv_heads=1, inter=384),
             "gqa": synth.LMCfg(hidden=256, heads=4, kv_heads=2, inter=320, layers=3)}
 

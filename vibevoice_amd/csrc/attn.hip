@@ -44,6 +44,21 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8 (&out)[XS]) {
     }
 }
 
+// The V^T fragments of a sequence's ragged last 32-position block: slots of positions >= end hold whatever the cache held (an
+// earlier utterance's values, imported data, a profiling replay's output).  Their softmax weight is exactly 0, but 0 x NaN is NaN:
+// zero them.  Slot j of lane group qg is position p0 + 4 qg + (j & 3) + 16 (j >> 2) (the layout at the top of this file).
+template <int DT>
+__device__ __forceinline__ void vv_zero_v_past_end(u32x4 (&vt)[DT], int p0, int qg, int end) {
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        bf16x8 t = __builtin_bit_cast(bf16x8, vt[dt]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (p0 + qg * 4 + (j & 3) + ((j >> 2) << 4) >= end) t[j] = (__bf16)0.0f;
+        vt[dt] = __builtin_bit_cast(u32x4, t);
+    }
+}
+
 // qkv: [R][(Hq + 2 Hkv) * D] fp32 (bias already added).  One wave per (row, head).
 template <int D>
 __global__ __launch_bounds__(64) void vv_rope_append_kernel(
@@ -146,6 +161,7 @@ __global__ __launch_bounds__(256) void vv_attn_split_kernel(
         const int64_t vt0 = (int64_t)(p0 >> 5) * DT;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) vt[dt] = vt_base[(vt0 + dt) * 64 + lane];
+        if (p0 + 32 > end) vv_zero_v_past_end<DT>(vt, p0, qg, end);
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll
@@ -389,6 +405,7 @@ __global__ __launch_bounds__(WAVES * 64) void vv_attn_fused_kernel(
                 }
             }
         }
+        if (p0 + 32 > end) vv_zero_v_past_end<DT>(vt, p0, qg, end);     // cache slots past the sequence hold anything: never 0 x NaN
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include <mutex>
+#include <shared_mutex>
 #include "../../include/vvhip.h"
 #include "vv_common.h"
 
@@ -101,7 +102,11 @@ int vv_block1d_launch(int C, int xs, const float* xin, float* xout, float* nst, 
 struct VVShiftH { float* buf; int T, hist, C; };
 
 static thread_local char g_err[512] = "";
-static std::mutex g_capture_mu;
+// Contexts that share weights are driven from several host threads (Engine.fork): a stream capture in one thread must not overlap
+// device calls of this library in another (hipErrorStreamCaptureInvalidated was seen with three lanes: one capturing, one running
+// first-sight eager launches).  Every API call that enqueues work holds this lock shared; a capture holds it exclusively.
+static std::shared_mutex g_dev_mu;
+#define VV_SHARED std::shared_lock<std::shared_mutex> _vv_dev_lk(g_dev_mu)
 
 namespace {
 
@@ -801,17 +806,17 @@ static int zero_codec(vv_ctx* ctx, CodecNet& net, int sl, hipStream_t st) {
 // ------------------------------------------------------------------ graphs
 template <class F>
 static int graphed(vv_ctx* ctx, const std::string& key, hipStream_t st, F&& body) {
-    if (!ctx->c.use_graph || ctx->prof_on) return body();
+    if (!ctx->c.use_graph || ctx->prof_on) { VV_SHARED; return body(); }
     auto it = ctx->graphs.find(key);
     if (it == ctx->graphs.end()) {
         // first sight of a key: run eagerly (lazy allocations, shift tables) and remember it; a key that comes back is
         // captured then.  One-off launch shapes (prompt prefill chunks: unique pointers) never pay for a capture.
         if (ctx->seen.size() > 8192) ctx->seen.clear();
-        if (ctx->seen.insert(key).second) return body();
+        if (ctx->seen.insert(key).second) { VV_SHARED; return body(); }
         hipGraph_t graph;
         GraphEntry ge; ge.last_use = 0;
         {   // one capture at a time in the process: contexts sharing weights are driven from several host threads (Engine.fork)
-            std::lock_guard<std::mutex> lk(g_capture_mu);
+            std::unique_lock<std::shared_mutex> lk(g_dev_mu);
             HIPCHK(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
             int r = body();
             hipError_t e = hipStreamEndCapture(st, &graph);
@@ -837,6 +842,7 @@ static int graphed(vv_ctx* ctx, const std::string& key, hipStream_t st, F&& body
         it = ctx->graphs.emplace(key, ge).first;
     }
     it->second.last_use = ++ctx->graph_tick;
+    VV_SHARED;
     HIPCHK(ctx, hipGraphLaunch(it->second.exec, st));
     return 0;
 }
@@ -1427,6 +1433,7 @@ extern "C" int vv_lm_forward_range(vv_ctx* ctx, void* stream, int n_rows, const 
 }
 
 extern "C" int vv_kv_import_at(vv_ctx* ctx, void* stream, int cache, int layer, int pos0, int n_pos, const void* k_dev, const void* v_dev, int src_dtype) {
+    VV_SHARED;
     hipStream_t st = (hipStream_t)stream;
     if (cache < 0 || cache >= 2 * ctx->c.n_slots) return fail(ctx, "cache id %d out of range", cache);
     if (layer < 0 || layer >= ctx->c.lm_layers) return fail(ctx, "layer %d out of range", layer);
@@ -1437,6 +1444,7 @@ extern "C" int vv_kv_import_at(vv_ctx* ctx, void* stream, int cache, int layer, 
     return 0;
 }
 extern "C" int vv_kv_move(vv_ctx* ctx, void* stream, int cache, int src_pos, int dst_pos) {
+    VV_SHARED;
     hipStream_t st = (hipStream_t)stream;
     if (cache < 0 || cache >= 2 * ctx->c.n_slots) return fail(ctx, "cache id %d out of range", cache);
     if (src_pos < 0 || dst_pos < 0 || src_pos >= ctx->c.max_ctx || dst_pos >= ctx->c.max_ctx)
@@ -1453,6 +1461,7 @@ extern "C" int vv_kv_import(vv_ctx* ctx, void* stream, int cache, int layer, int
 }
 
 extern "C" int vv_audio_to_pcm16(vv_ctx* ctx, void* stream, int n, int samples, const float* audio_dev, int16_t* pcm_out_dev) {
+    VV_SHARED;
     hipStream_t st = (hipStream_t)stream;
     if (n < 1 || samples < 1) return fail(ctx, "vv_audio_to_pcm16: n and samples must be positive");
     VVCHK(vv_pcm16_launch(audio_dev, (short*)pcm_out_dev, n, samples, st));
@@ -1460,6 +1469,7 @@ extern "C" int vv_audio_to_pcm16(vv_ctx* ctx, void* stream, int n, int samples, 
 }
 
 extern "C" int vv_add_type_embedding(vv_ctx* ctx, void* stream, int n, const float* x_dev, int type, float* out_dev) {
+    VV_SHARED;
     hipStream_t st = (hipStream_t)stream;
     if (!ctx->tts_types) return fail(ctx, "engine was not configured with tts_layers");
     if (type < 0 || type > 1) return fail(ctx, "type must be 0 (speech) or 1 (text)");
@@ -1468,6 +1478,7 @@ extern "C" int vv_add_type_embedding(vv_ctx* ctx, void* stream, int n, const flo
 }
 
 extern "C" int vv_eos_logit(vv_ctx* ctx, void* stream, int n, const float* hidden_dev, float* out_dev) {
+    VV_SHARED;
     hipStream_t st = (hipStream_t)stream;
     if (!ctx->eos_w1) return fail(ctx, "engine was not configured with tts_layers");
     if (n < 1 || n > 16) return fail(ctx, "vv_eos_logit: n must be in [1,16]");
@@ -1481,6 +1492,7 @@ extern "C" int vv_eos_logit(vv_ctx* ctx, void* stream, int n, const float* hidde
 }
 
 extern "C" int vv_embed(vv_ctx* ctx, void* stream, int n, const int* ids, float* out_dev) {
+    VV_SHARED;
     hipStream_t st = (hipStream_t)stream;
     if (n < 1 || n > ctx->ids_cap) return fail(ctx, "vv_embed: n must be in [1,%d] (max(64, max_rows))", ctx->ids_cap);
     for (int i = 0; i < n; ++i) if (ids[i] < 0 || ids[i] >= ctx->c.lm_vocab) return fail(ctx, "token id %d out of range", ids[i]);
@@ -1494,6 +1506,7 @@ extern "C" int vv_embed(vv_ctx* ctx, void* stream, int n, const int* ids, float*
 }
 
 extern "C" int vv_lm_logits_full(vv_ctx* ctx, void* stream, int n, const float* hidden_dev, float* logits_out_dev) {
+    VV_SHARED;
     const void* table = ctx->lm_head_loaded ? ctx->lm_head : ctx->embed;
     if (!table) return fail(ctx, "vv_lm_logits_full: no lm_head / embedding table has been uploaded");
     if (n < 1 || n > 16) return fail(ctx, "vv_lm_logits_full: n must be in [1,16]");
@@ -1502,6 +1515,7 @@ extern "C" int vv_lm_logits_full(vv_ctx* ctx, void* stream, int n, const float* 
     return 0;
 }
 extern "C" int vv_lm_logits(vv_ctx* ctx, void* stream, int n, const float* hidden_dev, float* logits_out_dev) {
+    VV_SHARED;
     hipStream_t st = (hipStream_t)stream;
     if (!ctx->valid_w) return fail(ctx, "vv_set_valid_tokens has not been called");
     if (n < 1 || n > 16) return fail(ctx, "vv_lm_logits: n must be in [1,16]");
@@ -1632,6 +1646,7 @@ extern "C" int vv_diffusion_sample_sde(vv_ctx* ctx, void* stream, int n, const f
 }
 
 extern "C" int vv_head_forward(vv_ctx* ctx, void* stream, int n, const float* noisy_dev, const float* t_host, const float* cond_dev, float* out_dev) {
+    VV_SHARED;
     hipStream_t st = (hipStream_t)stream;
     if (n < 1 || n > 16) return fail(ctx, "vv_head_forward: n must be in [1,16]");
     const int H = ctx->H;
@@ -1768,6 +1783,7 @@ extern "C" int vv_codec_chain_batch(vv_ctx* ctx, void* stream, int n, const int*
 
 // valid_samples: samples of real signal in wav_dev [frames * hop] (the rest must be zeros); frames = ceil(valid_samples / hop).
 extern "C" int vv_acoustic_encode_ragged(vv_ctx* ctx, void* stream, int frames, long long valid_samples, const float* wav_dev, float* mean_out_dev) {
+    VV_SHARED;
     hipStream_t st = (hipStream_t)stream;
     if (!ctx->c.has_acoustic_encoder) return fail(ctx, "no acoustic encoder configured");
     if (valid_samples <= (int64_t)(frames - 1) * ctx->hop || valid_samples > (int64_t)frames * ctx->hop)
@@ -1798,6 +1814,7 @@ extern "C" int vv_set_enc_pass_frames(vv_ctx* ctx, int frames_per_pass) {
 }
 
 extern "C" int vv_codec_reset(vv_ctx* ctx, void* stream, int slot) {
+    VV_SHARED;
     hipStream_t st = (hipStream_t)stream;
     if (slot < 0 || slot >= ctx->c.n_slots) return fail(ctx, "slot %d out of range", slot);
     if (zero_codec(ctx, ctx->dec, slot, st)) return -1;
@@ -1806,6 +1823,7 @@ extern "C" int vv_codec_reset(vv_ctx* ctx, void* stream, int slot) {
 }
 
 extern "C" int vv_connect(vv_ctx* ctx, void* stream, int n, const float* latent_dev, const float* sem_dev, float* out_dev) {
+    VV_SHARED;
     hipStream_t st = (hipStream_t)stream;
     const int H = ctx->H, L = ctx->c.latent_dim;
     for (int i0 = 0; i0 < n; i0 += 16) {
