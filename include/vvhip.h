@@ -235,7 +235,9 @@ int vv_profile_replay(vv_ctx* ctx, void* stream, int reps, int64_t* launches, do
  * V once.  launches = 0 when the window recorded none of that family.  bench.py's roofline for batch decode and for the
  * attention kernels. */
 int vv_profile_replay_family(vv_ctx* ctx, void* stream, int family, int reps, int64_t* launches, double* total_ms, double* bytes);
-/* number of kernel launches issued by the last engine call (graph nodes when replayed) */
+/* what = 0: kernel launches issued by the last engine call (graph nodes when replayed); 1: hipGraph executables cached; 2 / 3: raw
+ * timings of the last profile window; 4: stream captures that did not close cleanly and were run eagerly instead (seen when
+ * several host threads drive several contexts: another thread's activity can invalidate a capture; the result is unaffected) */
 int64_t vv_stat(vv_ctx* ctx, int what);
 
 #pragma GCC visibility pop

@@ -242,6 +242,7 @@ struct vv_ctx {
     // vv_create returns the parent's k-th one (same model configuration -> same sequence); everything else (KV caches, activations,
     // tokenizer state, graphs, staging) is the child's own, so two contexts decode concurrently on two streams over one weight copy
     vv_ctx* parent = nullptr; int n_children = 0; bool zombie = false, creating = false;
+    int64_t capture_fallbacks = 0; char last_capture_issue[256] = "";     // stream captures that fell back to an eager run (graphed())
     std::vector<std::pair<void*, size_t>> wallocs; size_t wshare_i = 0;
     int64_t launches = 0;
     // optional per-GEMM-launch hipEvent timing (vv_profile_begin/end)
@@ -813,18 +814,29 @@ static int graphed(vv_ctx* ctx, const std::string& key, hipStream_t st, F&& body
         // captured then.  One-off launch shapes (prompt prefill chunks: unique pointers) never pay for a capture.
         if (ctx->seen.size() > 8192) ctx->seen.clear();
         if (ctx->seen.insert(key).second) { VV_SHARED; return body(); }
-        hipGraph_t graph;
+        hipGraph_t graph = nullptr;
         GraphEntry ge; ge.last_use = 0;
+        bool captured = false;
         {   // one capture at a time in the process: contexts sharing weights are driven from several host threads (Engine.fork)
             std::unique_lock<std::shared_mutex> lk(g_dev_mu);
             HIPCHK(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
-            int r = body();
-            hipError_t e = hipStreamEndCapture(st, &graph);
-            if (r) return r;
-            HIPCHK(ctx, e);
-            HIPCHK(ctx, hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0));
-            hipGraphDestroy(graph);
+            const int r = body();
+            const hipError_t e = hipStreamEndCapture(st, &graph);
+            if (r == 0 && e == hipSuccess) {
+                HIPCHK(ctx, hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0));
+                hipGraphDestroy(graph);
+                captured = true;
+            } else {
+                // A capture that did not close cleanly executed nothing.  Seen with three host threads on three contexts: another
+                // thread's activity invalidates this thread's capture (hipErrorStreamCaptureInvalidated) although the mode is Relaxed.
+                // The work itself is fine: run it as the first sight of a key runs (eagerly), keep no graph, try again next time.
+                (void)hipGetLastError();
+                if (graph) hipGraphDestroy(graph);
+                ctx->capture_fallbacks++;
+                snprintf(ctx->last_capture_issue, sizeof(ctx->last_capture_issue), "capture of '%s': body rc %d, hipStreamEndCapture: %s", key.c_str(), r, hipGetErrorString(e));
+            }
         }
+        if (!captured) { VV_SHARED; return body(); }
         if (ctx->graphs.size() >= ctx->graph_cap) {
             // a long-running process with varied launch shapes (prefill remainders over temporary buffers) must not
             // accumulate executables: drop the least-recently-used quarter.  Rare (a cache miss at the cap), so it may wait
@@ -858,6 +870,7 @@ extern "C" const char* vv_last_error(vv_ctx* ctx) { return ctx ? ctx->err : g_er
 extern "C" const char* vv_build_id() { return "VVHIP_BUILD_ID=" VV_BUILD_ID; }
 
 static int create_impl(const vv_config* cfg, vv_ctx* parent, vv_ctx** out) {
+    VV_SHARED;
     vv_ctx* ctx = new vv_ctx();
     ctx->c = *cfg; ctx->err[0] = 0;
     ctx->parent = parent; ctx->creating = true;
@@ -1051,7 +1064,7 @@ extern "C" int vv_create_shared(const vv_config* cfg, vv_ctx* parent, vv_ctx** o
     return r;
 }
 
-extern "C" void vv_destroy(vv_ctx* ctx) {
+static void destroy_impl(vv_ctx* ctx) {
     if (!ctx) return;
     hipDeviceSynchronize();
     if (ctx->n_children > 0) { ctx->zombie = true; return; }          // shared children still read these weights: the last of them frees
@@ -1068,7 +1081,11 @@ extern "C" void vv_destroy(vv_ctx* ctx) {
     if (ctx->gws.err) hipHostFree(ctx->gws.err);
     for (int i = 0; i < vv_ctx::RING; ++i) if (ctx->ring_ev[i]) hipEventDestroy(ctx->ring_ev[i]);
     delete ctx;
-    if (par && --par->n_children == 0 && par->zombie) vv_destroy(par);
+    if (par && --par->n_children == 0 && par->zombie) destroy_impl(par);
+}
+extern "C" void vv_destroy(vv_ctx* ctx) {
+    VV_SHARED;                   // device-wide synchronisation + frees: never while another context's capture is open
+    destroy_impl(ctx);
 }
 
 extern "C" int vv_num_weights(vv_ctx* ctx) { return (int)ctx->w.size(); }
@@ -1082,6 +1099,7 @@ extern "C" int vv_weight_info(vv_ctx* ctx, int idx, char* name, int cap, int64_t
 }
 
 extern "C" int vv_upload(vv_ctx* ctx, const char* name, const void* src, int src_dtype, int64_t nelem) {
+    VV_SHARED;
     auto it = ctx->widx.find(name);
     if (it == ctx->widx.end()) return fail(ctx, "unknown parameter '%s'", name);
     Weight& w = ctx->w[it->second];
@@ -1142,6 +1160,7 @@ extern "C" int vv_upload(vv_ctx* ctx, const char* name, const void* src, int src
 }
 
 extern "C" int vv_set_speech_factors(vv_ctx* ctx, float scaling, float bias) {
+    VV_SHARED;
     ctx->scaling = scaling; ctx->bias = bias;
     for (auto it = ctx->graphs.begin(); it != ctx->graphs.end();) {
         if (it->first.rfind("dec", 0) == 0) { hipGraphExecDestroy(it->second.exec); it = ctx->graphs.erase(it); } else ++it;
@@ -1150,6 +1169,7 @@ extern "C" int vv_set_speech_factors(vv_ctx* ctx, float scaling, float bias) {
 }
 
 extern "C" int vv_set_valid_tokens(vv_ctx* ctx, const int* ids, int n) {
+    VV_SHARED;
     if (n < 1 || n > 16) return fail(ctx, "n_valid must be in [1,16]");
     const int H = ctx->H;
     const void* table = ctx->lm_head_loaded ? ctx->lm_head : ctx->embed;
@@ -1178,6 +1198,7 @@ extern "C" int vv_set_schedule_sde(vv_ctx* ctx, int n_steps, const float* t, con
     return set_schedule(ctx, n_steps, t, coef6, 6, stream);
 }
 static int set_schedule(vv_ctx* ctx, int n_steps, const float* t, const float* coef, int width, void* stream) {
+    VV_SHARED;
     hipStream_t st = (hipStream_t)stream;
     if (n_steps < 1 || n_steps > 64) return fail(ctx, "n_steps must be in [1,64]");
     const int H = ctx->H;
@@ -1973,6 +1994,7 @@ extern "C" int64_t vv_stat(vv_ctx* ctx, int what) {
         case 0: return ctx->launches;
         case 2: return ctx->prof_raw_ns;          // last profile: sum of raw event-pair times over the decode-GEMV launches
         case 3: return ctx->prof_ev_over_ns;      // last profile: time of an empty event pair
+        case 4: return ctx->capture_fallbacks;    // stream captures that did not close and ran eagerly instead (multi-threaded lanes)
         default: return (int64_t)ctx->graphs.size();
     }
 }

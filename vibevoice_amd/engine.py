@@ -218,7 +218,9 @@ class Engine:
         if t.dtype not in (torch.float32, torch.bfloat16):
             t = t.to(torch.float32)
         t = t.contiguous()
-        torch.cuda.synchronize(self.device)
+        # the tensor must exist before the library reads it (vv_upload works on the null stream).  The producing stream only: a
+        # device-wide synchronize from one host thread invalidates a stream capture another thread's context has open (lanes)
+        torch.cuda.current_stream(self.device).synchronize()
         rc = self.lib.vv_upload(self._ctx, name.encode(), C.c_void_p(t.data_ptr()),
                                 1 if t.dtype == torch.bfloat16 else 0, t.numel())
         self._chk(rc, f"vv_upload({name})")

@@ -807,7 +807,7 @@ class VibeVoiceForConditionalGenerationInference:
                 emb.index_copy_(0, speech_pos, speech_rows)     # int64 positions, uploaded by the caller ahead of the encoder
         timed = os.environ.get("VVHIP_TIME_PREFILL") is not None
         if timed:                    # split the reported prefill time: embedding + voice-row scatter | LM passes
-            e.sync(); torch.cuda.synchronize(self.device); t_emb = time.perf_counter()
+            e.sync(); torch.cuda.current_stream(self.device).synchronize(); t_emb = time.perf_counter()
         for i0 in range(0, n, CH):
             k = min(CH, n - i0)
             if hasattr(e, "lm_forward_span"):
@@ -816,7 +816,7 @@ class VibeVoiceForConditionalGenerationInference:
                 e.lm_forward([(2 * u.slot, i0 + j) for j in range(k)], emb[i0:i0 + k], hid)
         self._hid_fresh[u.slot].copy_(hid[(n - 1) % CH])
         if timed:
-            e.sync(); torch.cuda.synchronize(self.device)
+            e.sync(); torch.cuda.current_stream(self.device).synchronize()
             self._t_lm_pass = getattr(self, "_t_lm_pass", 0.0) + (time.perf_counter() - t_emb)
         u.pos_len = n
         if kv_start > n:             # bench hook: decode measured at a long context (kv_fill_fn supplies the cache contents)
@@ -826,7 +826,7 @@ class VibeVoiceForConditionalGenerationInference:
                     e.sync(); t0 = time.perf_counter()
                 kv_fill_fn(e, 2 * u.slot, n, kv_start)
                 if timed:
-                    e.sync(); torch.cuda.synchronize(self.device)
+                    e.sync(); torch.cuda.current_stream(self.device).synchronize()
                     self._t_kv_fill = getattr(self, "_t_kv_fill", 0.0) + (time.perf_counter() - t0)
             u.pos_len = kv_start
 
@@ -1302,7 +1302,7 @@ class VibeVoiceForConditionalGenerationInference:
                     if with_voice:
                         _, sp_embeds = self._process_speech_inputs(speech_tensors, speech_masks, prefill_noise)
                     if time_prefill:
-                        e.sync(); torch.cuda.synchronize(self.device); t_pf.append(time.perf_counter())
+                        e.sync(); torch.cuda.current_stream(self.device).synchronize(); t_pf.append(time.perf_counter())
                     sp_off = 0
                     jobs = []
                     for u in utts:
@@ -1462,6 +1462,7 @@ class VibeVoiceForConditionalGenerationInference:
         if audio_streamer is not None:
             audio_streamer.end()
         self.last_stats = {"lanes": lanes, "frames": sum(m.last_stats.get("frames", 0) for m in models),
+                           "capture_fallbacks": [m.engine.stat(4) if hasattr(m.engine, "stat") else 0 for m in models],
                            "per_lane": [dict(m.last_stats) for m in models], "shards": shards}
         return outs
 
