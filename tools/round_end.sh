@@ -1,6 +1,6 @@
 #!/bin/bash
 # The round-end measurement suite on one MI355X box (run through gpurun; ~25 GPU-minutes):   bash tools/round_end.sh <tag> [part ...]
-# parts (default: all): tests bench configs traces pmc dist lanes cpuwin
+# parts (default: all but utterance): tests bench configs traces pmc dist lanes cpuwin utterance
 # Everything lands under gpurun_out/<tag>_final/ with the file names profiles/ uses (<tag>_*); copy what is to be judged into profiles/.
 R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=${1:-r05}; shift; PARTS=${*:-tests bench configs traces pmc dist lanes cpuwin}
 O=$R/gpurun_out/${TAG}_final; mkdir -p $O; cd $R; export TMPDIR=/tmp
@@ -72,4 +72,7 @@ PY
 fi
 if has cpuwin; then
   say "CPU baseline windows (SURVEY 8d): 16 frames at three KV lengths"; timeout 1200 python bench.py --cpu-windows --cpu-frames 16 > $O/${TAG}_cpu_baseline.json 2> $O/cpuwin.err; tail -4 $O/cpuwin.err; head -c 600 $O/${TAG}_cpu_baseline.json; echo
+fi
+if has utterance; then
+  say "one whole utterance (configs[2] to the reference's length cap: ~3 minutes)"; timeout 900 python bench.py --full-utterance > $O/${TAG}_full_utterance.json 2> $O/utt.err; head -c 500 $O/${TAG}_full_utterance.json; echo
 fi
