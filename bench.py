@@ -1069,7 +1069,8 @@ def cpu_baseline(cfg, cpu_sd, n_solver, cfg_scale, n_frames, model_key):
             "host_logical_cpus": host_cpus,
             "sample": f"{n} decode frames of the same model shapes and weights (VibeVoice-{model_key}, fp32 = the reference's CPU "
                       f"dtype, {n_solver} solver steps, CFG pos+neg passes) after a 48-token text-only prompt -- the GPU leg's 32K-token context is "
-                      f"NOT reproduced on the CPU (attention is <5% of a CPU frame); oracle loop = CPU restatement of the reference's "
+                      f"NOT reproduced here, which flatters the CPU: 16-frame windows of the same loop at KV 10.9K / 21.8K / 32.7K measure 4.7 / 6.0 / 8.1 s per "
+                      f"7B frame (bench.py --cpu-windows, profiles/r05_cpu_baseline.json); oracle loop = CPU restatement of the reference's "
                       f"generate(), torch intra-op threads capped at {ncpu} of {host_cpus} logical CPUs",
             "ms_per_step": round(per_frame * 1e3, 2)}
 
