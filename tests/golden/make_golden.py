@@ -690,9 +690,15 @@ def gen_generate_streaming(custom=None):
     run("streaming_text12_cap40.npz", 12, 40, seed=5)
     run("streaming_text3_cap20.npz", 3, 20, seed=6)
     run("streaming_eos.npz", 12, 60, seed=7, eos_bias=0.35)
+    # the length cap falls ON a text window (found by the fuzz tool, round 5): the reference concatenates the window's ids before it
+    # checks the cap (:573-582), so `sequences` ends with those ids although the window is never fed to the model
+    run("streaming_cap_on_text.npz", 23, 35, seed=191019, eos_bias=0.0)
 
 
 if __name__ == "__main__":
+    if "--streaming-cap-only" in sys.argv:
+        gen_generate_streaming(custom=[("streaming_cap_on_text.npz", 23, 35, 191019, 0.0)])
+        sys.exit(0)
     if "--bf16-only" in sys.argv:           # the two bf16 files alone (the full set takes ~4.5 minutes)
         gen_generate(custom="bf16")
         sys.exit(0)

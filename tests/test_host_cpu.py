@@ -372,7 +372,7 @@ def test_host_generate_loop_matches_reference_goldens(monkeypatch, name, specula
         assert err <= 1e-4, err
 
 
-@pytest.mark.parametrize("name", ["streaming_text12_cap40", "streaming_text3_cap20", "streaming_eos"])
+@pytest.mark.parametrize("name", ["streaming_text12_cap40", "streaming_text3_cap20", "streaming_eos", "streaming_cap_on_text"])
 def test_host_streaming_loop_matches_reference_goldens(monkeypatch, name):
     """vibevoice_amd/modeling_streaming.py::generate on CPU through FakeStreamingEngine (oracle arithmetic), started from
     the prefilled branches the reference produced, against the goldens recorded from the reference's streaming
@@ -393,7 +393,7 @@ def test_host_streaming_loop_matches_reference_goldens(monkeypatch, name):
         return _types.SimpleNamespace(past_key_values=kv, last_hidden_state=hid)
     pre = {"lm": branch("lm"), "tts_lm": branch("tts"), "neg_lm": None, "neg_tts_lm": branch("neg_tts")}
     with fake_engine.cpu_cuda_shims(monkeypatch):
-        eng = fake_engine.FakeStreamingEngine(_oracle_streaming_small(eos_bias=float(z["eos_bias"]) if name == "streaming_eos" else None), 1, 2)
+        eng = fake_engine.FakeStreamingEngine(_oracle_streaming_small(eos_bias=float(z["eos_bias"]) if name in ("streaming_eos", "streaming_cap_on_text") else None), 1, 2)
         cfgd = {"decoder_config": {"max_position_embeddings": 512}, "diffusion_head_config": {"ddpm_num_inference_steps": 5},
                 "tts_backbone_num_hidden_layers": 2}
         m = VibeVoiceStreamingForConditionalGenerationInference(cfgd, eng, model_dtype=torch.float32)

@@ -339,7 +339,7 @@ def _oracle_streaming_small(n_lm=1, n_tts=2, eos_bias=None):
 
 
 # ---------------------------------------------------------------- row Z: the Streaming-0.5B loop
-@pytest.mark.parametrize("name", ["streaming_text12_cap40", "streaming_text3_cap20", "streaming_eos"])
+@pytest.mark.parametrize("name", ["streaming_text12_cap40", "streaming_text3_cap20", "streaming_eos", "streaming_cap_on_text"])
 def test_streaming_loop_matches_the_reference_generate(name):
     """Golden = the reference's VibeVoiceStreamingForConditionalGenerationInference.generate()
     (modeling_vibevoice_streaming_inference.py:412-751) on the tiny seeded split model, started from prefilled branches
@@ -348,7 +348,7 @@ def test_streaming_loop_matches_the_reference_generate(name):
     from oracle import generate_streaming as ogs
     from oracle import lm as olm
     z = np.load(os.path.join(G, name + ".npz"))
-    om = _oracle_streaming_small(eos_bias=float(z["eos_bias"]) if name == "streaming_eos" else None)
+    om = _oracle_streaming_small(eos_bias=float(z["eos_bias"]) if name in ("streaming_eos", "streaming_cap_on_text") else None)
 
     def cache(tag, oracle_lm):
         c = oracle_lm.new_cache()

@@ -76,6 +76,9 @@ def streaming_main(n, seed):
     rnd = random.Random(seed)
     runs = [(f"fuzz_z{k}.npz", rnd.randint(1, 23), rnd.randint(4, 70), 500 + seed * 100 + k, rnd.choice([-1.5, -1.0, -0.5, -0.2, 0.0, 0.1, 0.35]))
             for k in range(n)]
+    only = [a for a in sys.argv if a.startswith("--only=")]
+    if only:                                             # --only=K: the K-th configuration of this (n, seed) alone (to reproduce a failure)
+        runs = [runs[int(only[0].split("=")[1])]]
     out = tempfile.mkdtemp(prefix="vv_fuzz_z_")
     make_golden.OUT_DIR = out
     make_golden.gen_generate_streaming(custom=runs)
@@ -140,6 +143,9 @@ def streaming_main(n, seed):
                                max_new_tokens=int(z["max_new"]), cfg_scale=1.5, tokenizer=TOK, generation_config={"do_sample": False}, verbose=False,
                                all_prefilled_outputs=copy.deepcopy(pre_out), _noise_fn=lambda frame, n2: pdraws[frame])
         pgot = o.speech_outputs[0].reshape(-1) if (o.speech_outputs and o.speech_outputs[0] is not None) else torch.zeros(0)
+        if os.environ.get("VV_FUZZ_VERBOSE"):
+            print(f"   product: {int(o.sequences.shape[1])} tokens (reference {int(z['n_tokens'])}), reach_max {bool(o.reach_max_step_sample[0])} "
+                  f"({bool(z['reach_max'][0])}), {pgot.numel()} samples ({ref.numel()})")
         pok = int(o.sequences.shape[1]) == int(z["n_tokens"]) and bool(o.reach_max_step_sample[0]) == bool(z["reach_max"][0]) and pgot.shape == ref.shape
         perr = float((pgot - ref).norm() / ref.norm()) if pok and ref.numel() else (0.0 if pok else float("inf"))
         good = ok and err <= 1e-4 and pok and perr <= 1e-4

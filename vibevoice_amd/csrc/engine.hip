@@ -827,16 +827,28 @@ static int graphed(vv_ctx* ctx, const std::string& key, hipStream_t st, F&& body
                 hipGraphDestroy(graph);
                 captured = true;
             } else {
-                // A capture that did not close cleanly executed nothing.  Seen with three host threads on three contexts: another
-                // thread's activity invalidates this thread's capture (hipErrorStreamCaptureInvalidated) although the mode is Relaxed.
-                // The work itself is fine: run it as the first sight of a key runs (eagerly), keep no graph, try again next time.
+                // A capture that did not close cleanly executed nothing.  Known cause: ANOTHER host thread called a device-wide
+                // synchronize (hipDeviceSynchronize / torch.cuda.synchronize()) while this capture was open -- ROCm 7.0.2 refuses
+                // that call in its thread and marks this capture invalid although its mode is Relaxed.  The work is run the way the
+                // first sight of a key runs (eagerly).  On that ROCm the stream itself does not recover from an invalidated capture
+                // (every later call on it answers hipErrorStreamCaptureInvalidated; ending the capture a second time or destroying
+                // the returned graph handle crashes inside the runtime -- both tried): then the eager run fails too and the message
+                // below says why.  Callers keep device-wide synchronizes out of processes that generate.
                 (void)hipGetLastError();
-                if (graph) hipGraphDestroy(graph);
                 ctx->capture_fallbacks++;
                 snprintf(ctx->last_capture_issue, sizeof(ctx->last_capture_issue), "capture of '%s': body rc %d, hipStreamEndCapture: %s", key.c_str(), r, hipGetErrorString(e));
             }
         }
-        if (!captured) { VV_SHARED; return body(); }
+        if (!captured) {
+            VV_SHARED;
+            const int r2 = body();
+            if (r2 != 0) {
+                char prev[200]; snprintf(prev, sizeof(prev), "%s", ctx->err);
+                return fail(ctx, "%s; the eager re-run failed as well (%s).  If another host thread called a device-wide synchronize "
+                                 "(torch.cuda.synchronize()) during the capture, the stream is lost: synchronize streams or events instead", ctx->last_capture_issue, prev);
+            }
+            return 0;
+        }
         if (ctx->graphs.size() >= ctx->graph_cap) {
             // a long-running process with varied launch shapes (prefill remainders over temporary buffers) must not
             // accumulate executables: drop the least-recently-used quarter.  Rare (a cache miss at the cap), so it may wait
@@ -844,6 +856,7 @@ static int graphed(vv_ctx* ctx, const std::string& key, hipStream_t st, F&& body
             std::vector<std::pair<uint64_t, std::string>> order;
             for (auto& g : ctx->graphs) order.push_back({g.second.last_use, g.first});
             std::sort(order.begin(), order.end());
+            std::unique_lock<std::shared_mutex> lk(g_dev_mu);      // a device-wide synchronize: never while another context's capture is open
             HIPCHK(ctx, hipDeviceSynchronize());
             for (size_t i = 0; i < order.size() / 4 + 1; ++i) {
                 auto v = ctx->graphs.find(order[i].second);

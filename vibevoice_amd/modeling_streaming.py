@@ -288,11 +288,11 @@ class VibeVoiceStreamingForConditionalGenerationInference:
                 w += 1
                 if cur:
                     n_tok += len(cur)
-                    if n_tok > max_length:
+                    seq_tail.extend(cur)        # the reference concatenates the window's ids BEFORE it checks the length cap (:573-582):
+                    if n_tok > max_length:      # a cap that falls on a text window leaves that window's ids in `sequences`
                         reach_max = True
                         break
                     k = len(cur)
-                    seq_tail.extend(cur)
                     e.embed(cur, self._x)
                     e.lm_forward_range([(LM_CACHE, lm_len + j) for j in range(k)], self._x, self._h, 0, self.n_lm, False)
                     lm_len += k
