@@ -289,6 +289,14 @@ def test_interleaved_lanes_host_logic(monkeypatch):
         with pytest.raises(ValueError, match="exactly one utterance"):
             m.generate_interleaved(bad, lanes=2, audio_streamer=rec2, **kw)
         assert rec2.ends and rec2.ends[-1] is None
+        # the multi-GPU entry point with lanes on each rank (no process group here: one rank, its shard = the whole queue)
+        from vibevoice_amd import parallel
+        st = {}
+        sharded = parallel.generate_sharded(m, reqs, stats=st, lanes=2, **kw)
+        assert st["utterances_per_rank"] == [5] and m.last_stats["lanes"] == 2
+        for a, b in zip(sharded, solo):
+            assert torch.equal(a.sequences, b.sequences.cpu())
+            assert float((a.speech_outputs[0] - b.speech_outputs[0].float().cpu()).norm() / b.speech_outputs[0].norm()) <= 1e-5
         m.close_lanes()
         assert lane.engine.closed and m._lanes == []
 

@@ -173,7 +173,7 @@ def _gather_rows(rows: List[torch.Tensor], dtype, device, gather_to):
     return out
 
 
-def generate_sharded(model, requests: Sequence[dict], gather_to: int = 0, stats: dict = None, **gen_kwargs):
+def generate_sharded(model, requests: Sequence[dict], gather_to: int = 0, stats: dict = None, lanes: int = 1, **gen_kwargs):
     """Utterance-parallel generation over the ranks of the current process group (BASELINE config 4): the
     requests (single-utterance processor outputs, as for model.generate_continuous) are assigned to ranks by
     longest-prompt-first (max_steps ~ prompt length, modeling_vibevoice_inference.py:421), every rank decodes its own shard
@@ -181,7 +181,9 @@ def generate_sharded(model, requests: Sequence[dict], gather_to: int = 0, stats:
     the end as tensor collectives: one padded int64 buffer of token sequences and one padded buffer of waveforms per rank (a
     45-minute utterance is 65 M samples: gathered as a tensor it never passes through pickle or a CPU staging copy; on RCCL it
     goes GPU to GPU over xGMI).  Returns, on rank `gather_to` (every rank if gather_to is None), the list of
-    VibeVoiceGenerationOutput in request order; None elsewhere.  `stats` receives the sharding report (shard_report)."""
+    VibeVoiceGenerationOutput in request order; None elsewhere.  `stats` receives the sharding report (shard_report).
+    lanes > 1: every rank decodes its shard through model.generate_interleaved (that many engine contexts over the rank's ONE
+    weight copy, a host thread and stream each): 1.6 x per GPU at the small models' shapes, no gain at 7B long-form."""
     from .modeling import VibeVoiceGenerationOutput
     rank, world = world_info()
     costs = [int(r["input_ids"].shape[-1]) for r in requests]
@@ -189,7 +191,10 @@ def generate_sharded(model, requests: Sequence[dict], gather_to: int = 0, stats:
     if stats is not None:
         stats.update(shard_report(costs, shards))
     mine = shards[rank]
-    outs = model.generate_continuous([requests[i] for i in mine], **gen_kwargs) if mine else []
+    if mine and lanes > 1:
+        outs = model.generate_interleaved([requests[i] for i in mine], lanes=lanes, **gen_kwargs)
+    else:
+        outs = model.generate_continuous([requests[i] for i in mine], **gen_kwargs) if mine else []
     if not (dist.is_available() and dist.is_initialized()):
         # no process group at all: a plain single-process call.  With a group -- a ONE-rank group included -- the results always go
         # through the collectives below: the path an 8-GPU job takes is the path every test and every 1-GPU run takes
