@@ -333,6 +333,23 @@ def main():
                     extra[sp["baseline_config"]] = keep
                 except Exception as ex:          # an extra line must never take the main line down
                     extra[sp["baseline_config"]] = {"error": repr(ex)[:200]}
+            # the small model with MORE THAN ONE decode chain on the GPU: the same 16-utterance queue through one engine context (8 slots,
+            # continuous admission) and through two contexts sharing one weight copy (generate_interleaved: a host thread + stream each)
+            try:
+                lanes_res = {}
+                for n_l in (1, 2):
+                    a3 = parse_args([])
+                    a3.xsplit, a3.no_graph, a3.cfg_scale = args.xsplit, args.no_graph, args.cfg_scale
+                    a3.steps, a3.warmup, a3.batch, a3.continuous, a3.lanes = 100, 5, 8, 16, n_l
+                    r3 = bench_decode(a3, dict(WORKLOADS["1p5b"]), ctx, with_cpu=False, with_roofline=False, with_parity=False)
+                    lanes_res[f"{n_l}_context{'s' if n_l > 1 else ''}"] = {"audio_s_per_wall_s": r3["value"], "queue_wall_s": r3["extra"]["utterance_wall_s"],
+                                                                            "capture_fallbacks": (r3["extra"]["continuous"] or {}).get("capture_fallbacks")}
+                lanes_res["ratio"] = round(lanes_res["2_contexts"]["audio_s_per_wall_s"] / lanes_res["1_context"]["audio_s_per_wall_s"], 3)
+                lanes_res["workload"] = ("BASELINE configs[1] shapes, 16 queued utterances of ~107 frames, 8 slots per engine context; whole queue incl. every prefill; "
+                                         "2 contexts = vv_create_shared over ONE weight copy, one host thread + stream each")
+                extra["configs[1] queue over engine contexts"] = lanes_res
+            except Exception as ex:
+                extra["configs[1] queue over engine contexts"] = {"error": repr(ex)[:200]}
             res["extra"]["configs"] = extra
     if rank == 0:
         if shared_gpu:
