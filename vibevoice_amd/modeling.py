@@ -340,7 +340,7 @@ class _Utt:
         self.forced = self.noise_fn = self.req = None
         self.t_admit = self.t_done = None
         # the reference's bookkeeping of this row's negative cache, without the tensors: [attention mask incl. the next token's slot,
-        # entries ever appended, corrections so far (correct_cnt)] -- only to RECOGNISE the one correction the engine cannot follow
+        # entries ever appended, corrections so far (correct_cnt)] -- to recognise the one correction that keeps THIS step's entry (vv_kv_move)
         self.neg_book = [[1], 0, 0]
 
 
