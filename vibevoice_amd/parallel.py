@@ -183,7 +183,7 @@ def generate_sharded(model, requests: Sequence[dict], gather_to: int = 0, stats:
     goes GPU to GPU over xGMI).  Returns, on rank `gather_to` (every rank if gather_to is None), the list of
     VibeVoiceGenerationOutput in request order; None elsewhere.  `stats` receives the sharding report (shard_report).
     lanes > 1: every rank decodes its shard through model.generate_interleaved (that many engine contexts over the rank's ONE
-    weight copy, a host thread and stream each): 1.6 x per GPU at the small models' shapes, no gain at 7B long-form."""
+    weight copy, a host thread and stream each): 1.6 x per GPU at the small models' shapes; at 7B only once a context's 8 slots are full (+13 %)."""
     from .modeling import VibeVoiceGenerationOutput
     rank, world = world_info()
     costs = [int(r["input_ids"].shape[-1]) for r in requests]
