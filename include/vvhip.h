@@ -58,8 +58,10 @@ int vv_create(const vv_config* cfg, vv_ctx** out);
  * tokenizer state, graphs and staging, sized by cfg's runtime fields (n_slots, max_ctx, max_rows, attn_splits, use_graph); the model
  * fields must equal the parent's.  Two contexts driven on two streams interleave two independent utterance batches on one GPU over
  * one copy of the weights (new surface: the reference shares weights between concurrent generate() calls by being one nn.Module,
- * and forbids the concurrency -- it is not re-entrant).  vv_upload / LoRA merges go through the parent and are seen by
- * every child; destroying the parent first is allowed (the storage lives until the last child is destroyed). */
+ * and forbids the concurrency -- it is not re-entrant).  vv_upload / LoRA merges go through the parent, BEFORE any child
+ * exists: a child snapshots what it derives from the parameters (lm_head / tied table, valid-token rows, RoPE table, speech factors), so
+ * vv_upload on a parent with live children is refused -- destroy the children, upload, create them again.  Destroying the parent
+ * first is allowed (the storage lives until the last child is destroyed). */
 int vv_create_shared(const vv_config* cfg, vv_ctx* parent, vv_ctx** out);
 void vv_destroy(vv_ctx* ctx);
 const char* vv_last_error(vv_ctx* ctx);

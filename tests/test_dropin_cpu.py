@@ -240,6 +240,50 @@ def test_continuous_admission_equals_one_by_one(monkeypatch):
     assert st["iterations"] < sum(own) and st["iterations"] >= max(own)
 
 
+def test_interleaved_lanes_draw_from_their_own_generators(monkeypatch):
+    """Random draws under generate_interleaved(): every lane owns a CPU / device generator seeded from the global CPU generator on the
+    caller's thread.  A seeded call is reproducible although the lanes run on racing host threads, a wrong speculative guess in one lane
+    (plans with <speech_end> right after a frame: the speculative noise draw is undone) rewinds that lane's generator only, and the
+    process-global generator moves by exactly the seed draw -- nothing a lane does reaches it."""
+    from test_oracle_golden import _oracle_small
+    from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference
+    cfgd = {"decoder_config": {"max_position_embeddings": 4096}, "diffusion_head_config": {"ddpm_num_inference_steps": 5},
+            "acoustic_tokenizer_config": {"fix_std": 0.5, "std_dist_type": "gaussian"}}
+    reqs = [{k: v for k, v in r.items() if k != "_noise_fn"} for r in _requests(6, 11)]     # no injected noise: torch.randn draws
+    reqs[1]["input_ids"] = reqs[0]["input_ids"].clone()                 # two identical requests (they land in different lanes)
+    reqs[1]["attention_mask"] = reqs[0]["attention_mask"].clone()
+    reqs[1]["_forced_tokens"] = list(reqs[0]["_forced_tokens"])
+    with fake_engine.cpu_cuda_shims(monkeypatch):
+        monkeypatch.setattr(torch.cuda, "set_device", lambda *a, **k: None)
+        m = VibeVoiceForConditionalGenerationInference(cfgd, fake_engine.FakeEngine(_oracle_small(), n_slots=2), model_dtype=torch.float32)
+        m.set_speech_factors(0.2, -0.05)
+        m.set_ddpm_inference_steps(5)
+        m.concurrent_codecs = False
+        m.speculate_sampling = True
+        kw = dict(tokenizer=TOK, generation_config={"do_sample": False}, cfg_scale=1.3)
+        runs, states = [], []
+        for _ in range(3):
+            torch.manual_seed(77)
+            runs.append(m.generate_interleaved(reqs, lanes=2, **kw))
+            states.append(torch.get_rng_state())
+        torch.manual_seed(77)
+        torch.randint(0, 2 ** 62, (2, 2), dtype=torch.int64)
+        only_the_seed_draw = torch.get_rng_state()
+        shards = m.last_stats["shards"]
+        m.close_lanes()
+    for other in runs[1:]:
+        for a, b in zip(runs[0], other):
+            assert torch.equal(a.sequences, b.sequences)
+            # same draws -> the same waveform up to the CPU BLAS's thread-dependent summation order (another stream would be O(1) away)
+            assert float((a.speech_outputs[0] - b.speech_outputs[0]).norm() / b.speech_outputs[0].norm()) <= 1e-5
+    assert all(torch.equal(s, only_the_seed_draw) for s in states)
+    # identical requests in different lanes hear different noise (each lane has its own stream)
+    lane_of = {i: k for k, sh in enumerate(shards) for i in sh}
+    if lane_of[0] != lane_of[1]:
+        a, b = runs[0][0].speech_outputs[0], runs[0][1].speech_outputs[0]
+        assert float((a - b).norm() / b.norm()) > 1e-2
+
+
 def test_interleaved_lanes_host_logic(monkeypatch):
     """generate_interleaved(): the queue over two engine contexts sharing one weight copy, one host thread per lane (here: two
     oracle-backed CPU engines over one oracle model).  Host logic under test: longest-prompt-first split, request order of the result,

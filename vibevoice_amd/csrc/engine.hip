@@ -107,6 +107,9 @@ static thread_local char g_err[512] = "";
 // first-sight eager launches).  Every API call that enqueues work holds this lock shared; a capture holds it exclusively.
 static std::shared_mutex g_dev_mu;
 #define VV_SHARED std::shared_lock<std::shared_mutex> _vv_dev_lk(g_dev_mu)
+// parent / child bookkeeping of shared contexts (n_children, zombie): forks are created and closed from lane threads that hold
+// g_dev_mu only SHARED, so the counters have their own mutex
+static std::mutex g_family_mu;
 
 namespace {
 
@@ -597,6 +600,7 @@ static int gemm_tl(vv_ctx* ctx, VVGemm g, hipStream_t st) {
     return vv_gemm_launch(g, ctx->c.xsplit, st);
 }
 extern "C" int vv_timeline_dump(vv_ctx* ctx, unsigned long long* out_host, int* meta_host, int max_launches) {
+    VV_SHARED;                   // a device-wide synchronize: never while another context's capture is open
     hipDeviceSynchronize();
     const int n = std::min(max_launches, ctx->tl_idx);
     if (n > 0) hipMemcpy(out_host, ctx->tl_base, (size_t)n * TL_STRIDE * 8, hipMemcpyDeviceToHost);
@@ -1050,7 +1054,7 @@ static int create_impl(const vv_config* cfg, vv_ctx* parent, vv_ctx** out) {
         }
         ctx->lm_head = parent->lm_head; ctx->lm_head_loaded = parent->lm_head_loaded;
         ctx->scaling = parent->scaling; ctx->bias = parent->bias;
-        parent->n_children++;
+        { std::lock_guard<std::mutex> fl(g_family_mu); parent->n_children++; }
     }
     *out = ctx;
     return 0;
@@ -1080,7 +1084,10 @@ extern "C" int vv_create_shared(const vv_config* cfg, vv_ctx* parent, vv_ctx** o
 static void destroy_impl(vv_ctx* ctx) {
     if (!ctx) return;
     hipDeviceSynchronize();
-    if (ctx->n_children > 0) { ctx->zombie = true; return; }          // shared children still read these weights: the last of them frees
+    {   // shared children still read these weights: the last of them frees
+        std::lock_guard<std::mutex> fl(g_family_mu);
+        if (ctx->n_children > 0) { ctx->zombie = true; return; }
+    }
     vv_ctx* par = ctx->parent;
     for (auto& g : ctx->graphs) hipGraphExecDestroy(g.second.exec);
     if (ctx->side_ready) {
@@ -1094,7 +1101,9 @@ static void destroy_impl(vv_ctx* ctx) {
     if (ctx->gws.err) hipHostFree(ctx->gws.err);
     for (int i = 0; i < vv_ctx::RING; ++i) if (ctx->ring_ev[i]) hipEventDestroy(ctx->ring_ev[i]);
     delete ctx;
-    if (par && --par->n_children == 0 && par->zombie) destroy_impl(par);
+    bool last_child = false;
+    if (par) { std::lock_guard<std::mutex> fl(g_family_mu); last_child = (--par->n_children == 0 && par->zombie); }
+    if (last_child) destroy_impl(par);
 }
 extern "C" void vv_destroy(vv_ctx* ctx) {
     VV_SHARED;                   // device-wide synchronisation + frees: never while another context's capture is open
@@ -1117,6 +1126,13 @@ extern "C" int vv_upload(vv_ctx* ctx, const char* name, const void* src, int src
     if (it == ctx->widx.end()) return fail(ctx, "unknown parameter '%s'", name);
     Weight& w = ctx->w[it->second];
     if (ctx->parent) return fail(ctx, "parameter '%s': this context shares its parent's weights -- upload through the parent", name);
+    {   // a child snapshots what it derives from the parameters when it is created (lm_head / tied embedding table, the valid-token
+        // rows, the RoPE table from inv_freq, the speech factors): an upload behind its back would leave those stale
+        std::lock_guard<std::mutex> fl(g_family_mu);
+        if (ctx->n_children > 0)
+            return fail(ctx, "parameter '%s': %d shared context(s) were created from this one and hold snapshots derived from its parameters -- "
+                             "destroy them (model.close_lanes()), upload / merge, then fork again", name, ctx->n_children);
+    }
     if (nelem != w.nelem) return fail(ctx, "parameter '%s': expected %lld elements, got %lld", name, (long long)w.nelem, (long long)nelem);
     const size_t esz = src_dtype ? 2 : 4;
     hipPointerAttribute_t attr;
@@ -1396,9 +1412,14 @@ extern "C" int vv_lm_forward_range(vv_ctx* ctx, void* stream, int n_rows, const 
 // stays usable.
 static int ksplit_check(vv_ctx* ctx, hipStream_t st) {
     if (!(ctx->gws.err && *ctx->gws.err)) return 0;
-    hipStreamSynchronize(st);
-    hipDeviceSynchronize();
-    if (ctx->gws.flags) { hipMemset(ctx->gws.flags, 0, 256 * sizeof(unsigned)); hipDeviceSynchronize(); }
+    {   // stream-level waits only, under the lock captures take exclusively: a device-wide synchronize (or a null-stream memset) here
+        // would invalidate a capture ANOTHER context of the process has open (lanes: vv_create_shared) -- exactly when one lane
+        // recovers from a timed-out hand-off while the other keeps decoding.  The arrival words belong to this context; the launches
+        // that touch them run on st (the only stream a prompt pass is enqueued on).
+        VV_SHARED;
+        hipStreamSynchronize(st);
+        if (ctx->gws.flags) { hipMemsetAsync(ctx->gws.flags, 0, 256 * sizeof(unsigned), st); hipStreamSynchronize(st); }
+    }
     *ctx->gws.err = 0u;
     return fail(ctx, "prefill GEMM: a K-split hand-off timed out (lost producer workgroup); the prompt pass that was in flight is invalid -- "
                      "the arrival words were re-armed, retry the pass (VVHIP_NO_KSPLIT=1 disables the split)");
@@ -1907,13 +1928,13 @@ extern "C" int vv_gemm3_raw(vv_ctx* ctx, void* stream, const void* w, const void
     return r;
 }
 extern "C" int vv_profile_begin(vv_ctx* ctx) {
-    HIPCHK(ctx, hipDeviceSynchronize());
+    { VV_SHARED; HIPCHK(ctx, hipDeviceSynchronize()); }     // device-wide: excluded from other contexts' open captures by the lock
     ctx->prof_on = true; ctx->prof_n = 0; ctx->prof_bytes = 0.0; ctx->prof_rec.clear();
     ctx->prof_gemv.clear(); ctx->prof_gemv_bytes = 0.0; ctx->prof_other.clear();
     return 0;
 }
 extern "C" int vv_profile_end(vv_ctx* ctx, int64_t* launches, double* total_ms, double* bytes) {
-    HIPCHK(ctx, hipDeviceSynchronize());
+    { VV_SHARED; HIPCHK(ctx, hipDeviceSynchronize()); }
     double ms = 0.0, raw_ms = 0.0;
     int64_t n_other = 0; double ms_other = 0.0, by_other = 0.0;
     // The fixed cost of an event pair with nothing in between, measured in the regime the samples were taken in: pairs

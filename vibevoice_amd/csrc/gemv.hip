@@ -71,6 +71,14 @@ __device__ __forceinline__ void split4(const float (&v)[4], uint2 (&out)[XS]) {
 
 constexpr int U = 8;       // k-steps per batch (256 k = one float4 per lane per row)
 
+// adaLN-modulated norm, decode rows (MR <= 4): the shift rows ride in the SAME B tile as the modulated activation rows, as columns
+// MR..2MR-1 of the MFMA's 16 (a decode launch uses 2..4 of them) -- one operand, one accumulator set, half the ds_reads and MFMAs
+// per k-step; the epilogue adds column r + MR to column r with one DPP row shift.  -DVV_MOD_FOLD=0 restores the two-operand form
+// (A/B: profiles/r06_mod_fold_ab.json); the 16-row batch form has no spare columns and keeps two operands.
+#ifndef VV_MOD_FOLD
+#define VV_MOD_FOLD 1
+#endif
+
 // PRO / EPI are compile-time: a launch executes only the code of its own prologue/epilogue (the runtime-
 // switched version spent a third of a small launch fetching and skipping code it never needed).
 // MR = activation rows a launch can carry: 4 for decode steps, 16 for prefill chunks / batched adaLN / the T = 8 codec
@@ -95,10 +103,12 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const u32x4* __restri
     // LDS: [wave][XS][U][4][MR] x 16 B staging tiles, then [wave][NM][64] f32x4 partials, then [wave][MR] ssq
     // adaLN-modulated norm: y = rs * W.(x*nw*(1+scale)) + W.shift -- two B operands and two accumulator sets, so the
     // 1/rms of the row is only needed in the epilogue (as for plain RMSNorm) and no pre-pass over x exists
-    constexpr int NOP = (PRO == VV_PRO_RMS_MOD) ? 2 : 1;
+    constexpr bool FOLD = VV_MOD_FOLD && (PRO == VV_PRO_RMS_MOD) && MR <= 4;
+    constexpr int NOP = (PRO == VV_PRO_RMS_MOD && !FOLD) ? 2 : 1;
+    constexpr int MRS = FOLD ? 2 * MR : MR;         // staged B columns: activation rows, then (folded form) their shift rows
     // one (k-step, k-group) plane of the staging tile = MR rows x 16 B; the 16-row form pads it by 16 B so that the planes
     // one staging store touches fall into different bank groups (unpadded: 256-B stride = the same 4 banks, 16-way conflict)
-    constexpr int GSB = MR * 16 + (MR == 16 ? 16 : 0);
+    constexpr int GSB = MRS * 16 + (MR == 16 ? 16 : 0);
     __shared__ __attribute__((aligned(16))) unsigned char stg_all[WPB * NOP * XS * U * 4 * GSB];
     __shared__ f32x4 red[WPB][NM * NOP][64];
     __shared__ float ssq_sh[WPB][MR];
@@ -302,8 +312,10 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const u32x4* __restri
                     uint2 sparts[XS];
                     split4<XS>(sh4, sparts);
 #pragma unroll
-                    for (int p = 0; p < XS; ++p)
-                        *reinterpret_cast<uint2*>(stg + (XS + p) * (U * 4 * GSB) + st_off + r * 16) = sparts[p];
+                    for (int p = 0; p < XS; ++p) {
+                        if constexpr (FOLD) *reinterpret_cast<uint2*>(stg + p * (U * 4 * GSB) + st_off + (MR + r) * 16) = sparts[p];
+                        else *reinterpret_cast<uint2*>(stg + (XS + p) * (U * 4 * GSB) + st_off + r * 16) = sparts[p];
+                    }
                 } else if constexpr (PRO == VV_PRO_ADD_SILU) {
                     v[0] = silu_acc(v[0] + R.addv[r].x) * msk; v[1] = silu_acc(v[1] + R.addv[r].y) * msk;
                     v[2] = silu_acc(v[2] + R.addv[r].z) * msk; v[3] = silu_acc(v[3] + R.addv[r].w) * msk;
@@ -323,7 +335,7 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const u32x4* __restri
 #pragma unroll
                 for (int p = 0; p < XS; ++p) {
                     u32x4 f = u32x4{0u, 0u, 0u, 0u};
-                    if (frow < MR) f = *reinterpret_cast<const u32x4*>(stg + (size_t)((p * U + u) * 4 + fq) * GSB + frow * 16);
+                    if (frow < MRS) f = *reinterpret_cast<const u32x4*>(stg + (size_t)((p * U + u) * 4 + fq) * GSB + frow * 16);
                     const bf16x8 xb = __builtin_bit_cast(bf16x8, f);
 #pragma unroll
                     for (int i = 0; i < NM; ++i)
@@ -389,6 +401,17 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const u32x4* __restri
     for (int w = 1; w < WPB; ++w)
 #pragma unroll
         for (int i = 0; i < NM * NOP; ++i) acc[i] += red[w][i][lane];
+    f32x4 shf[FOLD ? NM : 1];                      // folded form: W.shift of row r sits in column r + MR -> row_shl:MR brings it to lane r
+    if constexpr (FOLD) {
+#pragma unroll
+        for (int i = 0; i < NM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float av = acc[i][r];        // through a scalar temporary: bit_cast applied to a vector ELEMENT reads element 0 under this clang
+                const int sv = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, av), 0x100 + MR, 0xF, 0xF, true);
+                shf[i][r] = __builtin_bit_cast(float, sv);
+            }
+    }
     if (!epi_lane) return;
     float rs = 1.0f;
     if constexpr (PRO == VV_PRO_RMS || PRO == VV_PRO_RMS_MOD || PRO == VV_PRO_NORMDW) {
@@ -403,6 +426,10 @@ __global__ __launch_bounds__(WPB * 64) void vv_gemv_kernel(const u32x4* __restri
     if constexpr (NOP == 2) {                      // + W.shift
 #pragma unroll
         for (int r = 0; r < 4; ++r) { o[r] += acc[NM][r]; if constexpr (DUAL) up[r] += acc[NM + 1][r]; }
+    }
+    if constexpr (FOLD) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { o[r] += shf[0][r]; if constexpr (DUAL) up[r] += shf[1][r]; }
     }
     const float pb[4] = {pre_b.x, pre_b.y, pre_b.z, pre_b.w};
     const float py[4] = {(pre_y.x + pre_y0.x) + pre_y1.x, (pre_y.y + pre_y0.y) + pre_y1.y, (pre_y.z + pre_y0.z) + pre_y1.z, (pre_y.w + pre_y0.w) + pre_y1.w};

@@ -623,8 +623,9 @@ class VibeVoiceForConditionalGenerationInference:
         pin[:n].copy_(nz[:n])
         self._noise[:n].copy_(pin[:n], non_blocking=True)
 
-    def _process_speech_inputs(self, speech_tensors, speech_masks, prefill_noise=None):
+    def _process_speech_inputs(self, speech_tensors, speech_masks, prefill_noise=None, dev_gen=None):
         """_process_speech_inputs (:149-163): encode voice prompts, sample, scale, connect.
+        dev_gen: a lane's own device generator (generate_interleaved); None = the device's global generator, as the reference.
         Every host -> device copy of the call (waveform, frame selection, explicit noise) goes out BEFORE the encoder is enqueued:
         a pageable copy blocks the host until the stream has drained, and a boolean-mask gather synchronises to count its rows --
         behind the encoder either one keeps the prompt pass from being enqueued while the encoder runs."""
@@ -660,14 +661,22 @@ class VibeVoiceForConditionalGenerationInference:
                 # two draws from the device generator.  The reference's `mean` is latents.permute(0, 2, 1) (:1085) and its noise is
                 # randn_like(mean): the same call on a tensor with the same strides is what stays on the reference's RNG stream
                 # (a contiguous draw takes a different generator path).  Pinned by tests/golden/generate_sampled_b1.npz.
-                r1 = torch.randn(n_spk, device=self.device, dtype=torch.float32)
-                r2 = torch.randn_like(torch.empty(n_spk, mean.shape[2], mean.shape[1], device=self.device, dtype=torch.float32).permute(0, 2, 1))
+                if dev_gen is not None:
+                    r1 = torch.randn(n_spk, device=self.device, dtype=torch.float32, generator=dev_gen)
+                    r2 = torch.randn(tuple(mean.shape), device=self.device, dtype=torch.float32, generator=dev_gen)
+                else:
+                    r1 = torch.randn(n_spk, device=self.device, dtype=torch.float32)
+                    r2 = torch.randn_like(torch.empty(n_spk, mean.shape[2], mean.shape[1], device=self.device, dtype=torch.float32).permute(0, 2, 1))
             else:
                 r1, r2 = prefill_noise
             lat = mean + (r1 * (self.fix_std / 0.8))[:, None, None] * r2
         elif self.std_dist_type == "fix":
-            r2 = (torch.randn_like(torch.empty(n_spk, mean.shape[2], mean.shape[1], device=self.device).permute(0, 2, 1))
-                  if prefill_noise is None else prefill_noise[1])
+            if prefill_noise is not None:
+                r2 = prefill_noise[1]
+            elif dev_gen is not None:
+                r2 = torch.randn(tuple(mean.shape), device=self.device, dtype=torch.float32, generator=dev_gen)
+            else:
+                r2 = torch.randn_like(torch.empty(n_spk, mean.shape[2], mean.shape[1], device=self.device).permute(0, 2, 1))
             lat = mean + self.fix_std * r2
         else:
             lat = mean
@@ -917,8 +926,12 @@ class VibeVoiceForConditionalGenerationInference:
                 and all(u.last in (diff_id, start_id) for u in run)):
             nz = self._draw_noise(S, run)
             if nz is None:
-                rng_state = torch.get_rng_state()
-                nz = torch.randn(2 * nR, e.cfg.latent_dim)
+                # the draw is undone if the guess is wrong: on the session's OWN generator when it has one (a lane of
+                # generate_interleaved) -- rewinding the process-global generator from one lane would hand another lane draws it has
+                # already consumed
+                cg = S.get("cpu_gen")
+                rng_state = cg.get_state() if cg is not None else torch.get_rng_state()
+                nz = torch.randn(2 * nR, e.cfg.latent_dim, generator=cg)
             self._stage_noise(nz, nR)
             # all active rows diffusing, in order: cond rows == [hidden[:nR]; hidden[nR:2nR]]
             e.diffusion_sample(nR, self._hidden, self._noise, cfg_scale, self._latent)
@@ -957,7 +970,7 @@ class VibeVoiceForConditionalGenerationInference:
             for i, u in enumerate(order):
                 full[rows_of.index(u.idx), vt] = lg[i]
             if do_sample:
-                pick_ids = torch.multinomial(torch.softmax(full, dim=-1), num_samples=1).squeeze(1).cpu()
+                pick_ids = torch.multinomial(torch.softmax(full, dim=-1), num_samples=1, generator=S.get("dev_gen")).squeeze(1).cpu()
             else:
                 pick_ids = torch.argmax(full, dim=-1).cpu()
             for u in order:
@@ -1014,7 +1027,10 @@ class VibeVoiceForConditionalGenerationInference:
         if spec_sample and diff != order:
             spec_sample = False                                  # wrong guess: drop the latent, undo the draw
             if rng_state is not None:
-                torch.set_rng_state(rng_state)
+                if S.get("cpu_gen") is not None:
+                    S["cpu_gen"].set_state(rng_state)
+                else:
+                    torch.set_rng_state(rng_state)
         cond_used = self._hidden if spec_sample else self._cond
         n = len(diff)
         if S.get("lockstep", True) and len(order) > 1:
@@ -1045,7 +1061,7 @@ class VibeVoiceForConditionalGenerationInference:
             # ---- diffusion sampling (:697-710) ----
             nz = self._draw_noise(S, diff)
             if nz is None:
-                nz = torch.randn(2 * n, e.cfg.latent_dim)      # CPU global RNG, as the reference (:701)
+                nz = torch.randn(2 * n, e.cfg.latent_dim, generator=S.get("cpu_gen"))      # CPU global RNG, as the reference (:701), unless the session has its own
             self._stage_noise(nz, n)
             if S["sde"]:
                 e.diffusion_sample(n, self._cond, self._noise, cfg_scale, self._latent, step_noise=self._sde_draws(S, n))
@@ -1175,7 +1191,7 @@ class VibeVoiceForConditionalGenerationInference:
             buf.copy_(S["sde_noise_fn"](S["step"], N, 2 * n)[:, :n].to(buf.device, torch.float32))
             return buf
         for i in range(N):
-            buf[i].copy_(torch.randn(2 * n, L, device=self.device, dtype=torch.float32)[:n])
+            buf[i].copy_(torch.randn(2 * n, L, device=self.device, dtype=torch.float32, generator=S.get("dev_gen"))[:n])
         return buf
 
     @staticmethod
@@ -1209,7 +1225,10 @@ class VibeVoiceForConditionalGenerationInference:
                     trace=kwargs.pop("_trace", None), audio_streamer=audio_streamer, verbose=kwargs.get("verbose", False),
                     forced=kwargs.pop("_forced_tokens", None), noise_fn=kwargs.pop("_noise_fn", None), n_rows=n_rows,
                     teacher=kwargs.pop("_teacher_embeds", None), refresh_negative=bool(kwargs.get("refresh_negative", True)),
-                    frame_rows=0, n_frames=0, step=0, sample_rows=None)
+                    frame_rows=0, n_frames=0, step=0, sample_rows=None,
+                    # a session's own generators (generate_interleaved gives every lane a pair): None = the process-global CPU / device
+                    # generators, i.e. the reference's RNG streams
+                    cpu_gen=(kwargs.get("_generators") or (None, None))[0], dev_gen=(kwargs.pop("_generators", None) or (None, None))[1])
 
     # ------------------------------------------------------------------ generate
     @torch.no_grad()
@@ -1422,8 +1441,11 @@ class VibeVoiceForConditionalGenerationInference:
         """generate_continuous() over `lanes` engine contexts that share this model's weights, one host thread and one stream per lane.
         A decode step is a chain of ~300-450 DEPENDENT launches, each paying a fixed boundary cost the chip idles through; a second,
         independent chain fills those boundaries (measured with two processes on one GPU in round 4: 1.63 x the aggregate at 1.5B).
-        The queue is split longest-prompt-first over the lanes (parallel.shard_utterances); every request still ends exactly as
-        generate() on it alone (the lanes share nothing but read-only weights).  Returns the outputs in request order.  The lanes are
+        The queue is split longest-prompt-first over the lanes (parallel.shard_utterances); with greedy / forced decoding and explicit
+        noise every request ends exactly as generate() on it alone (the lanes share nothing but read-only weights).  Random draws:
+        every lane owns a CPU and a device torch.Generator seeded from the process-global CPU generator when the call starts, so a
+        seeded call is reproducible and no lane consumes (or, undoing a speculative draw, rewinds) another lane's stream -- but the
+        noise a request sees is its lane's, not what the same request would draw on the global generators through generate().  Returns the outputs in request order.  The lanes are
         created on first use (each owns KV caches for its n_slots) and kept: `model.close_lanes()` releases them."""
         import threading
         from .parallel import shard_utterances
@@ -1438,12 +1460,24 @@ class VibeVoiceForConditionalGenerationInference:
         shards = shard_utterances([int(r["input_ids"].shape[-1]) for r in requests], lanes)
         outs: List[Optional[VibeVoiceGenerationOutput]] = [None] * len(requests)
         errs: List[Optional[BaseException]] = [None] * lanes
+        # every lane draws from its OWN generators (diffusion noise and the speculative draw's rewind on the CPU one; voice-prompt
+        # sampling, multinomial and the sde variance noise on the device one), seeded here, on the caller's thread, from the
+        # process-global CPU generator: a seeded call (torch.manual_seed) is reproducible, no lane can rewind or consume another
+        # lane's draws, and the global device generator is not touched from the lane threads
+        seeds = torch.randint(0, 2 ** 62, (lanes, 2), dtype=torch.int64).tolist()
+        gens = []
+        for k in range(lanes):
+            cg = torch.Generator()
+            cg.manual_seed(seeds[k][0])
+            dg = torch.Generator(device=self.device)
+            dg.manual_seed(seeds[k][1])
+            gens.append((cg, dg))
 
         def run(k):
             try:
                 torch.cuda.set_device(self.device)
                 st = _LaneStreamer(audio_streamer, shards[k]) if audio_streamer is not None else None
-                res = models[k].generate_continuous([requests[i] for i in shards[k]], audio_streamer=st, **kwargs)
+                res = models[k].generate_continuous([requests[i] for i in shards[k]], audio_streamer=st, _generators=gens[k], **kwargs)
                 for i, o in zip(shards[k], res):
                     outs[i] = o
             except BaseException as ex:                 # noqa: BLE001 -- handed to the caller's thread below
@@ -1559,7 +1593,7 @@ class VibeVoiceForConditionalGenerationInference:
                     e.codec_reset(slot)
                     rows = pos = None
                     if is_prefill and r.get("speech_tensors") is not None and r.get("speech_masks") is not None:
-                        _, sp = self._process_speech_inputs(r["speech_tensors"], r["speech_masks"], r.get("_prefill_noise"))
+                        _, sp = self._process_speech_inputs(r["speech_tensors"], r["speech_masks"], r.get("_prefill_noise"), dev_gen=S.get("dev_gen"))
                         sim = r.get("speech_input_mask")
                         if sim is not None:
                             idx = sim[0].cpu()[am[0].bool().cpu()].to(torch.bool).nonzero().squeeze(1)      # host data: no device count
