@@ -101,6 +101,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-parity-long", action="store_true", help="skip the parity leg through the prompt pass at the timed prompt length")
     ap.add_argument("--no-roofline", action="store_true", help="skip the GEMV launch-duration passes (for rocprof --pmc runs)")
     ap.add_argument("--skip-extra", action="store_true", help="main workload only (no extra.configs lines)")
+    ap.add_argument("--no-config3", action="store_true", help="skip the configs[3] per-GPU leg (7B, 4 speakers, 8 utterances at 32K on each GPU)")
     ap.add_argument("--cpu-frames", type=int, default=3)
     ap.add_argument("--cpu-windows", action="store_true", help="SURVEY 8(d)'s CPU baseline as specified, nothing else: --cpu-frames decode frames "
                                                                "of the oracle loop at three KV lengths (minutes of host time)")
@@ -351,6 +352,29 @@ def main():
             except Exception as ex:
                 extra["configs[1] queue over engine contexts"] = {"error": repr(ex)[:200]}
             res["extra"]["configs"] = extra
+        if not args.skip_extra and args.workload == "north-star" and args.batch == 1 and not args.continuous and not args.no_config3:
+            # BASELINE configs[3]'s per-GPU unit, the configuration north_star's ">= 5x real-time" sentence names: 7B, 4 speakers, EIGHT utterances in
+            # lock-step on each GPU, every one at a 32K context, N = 20 -- on EVERY rank (weak scaling: 8 utterances per GPU, the value is the
+            # whole job's), with the batch kernels' own roofline (vv_gemv16p_kernel + the attention unit) and a batch-8 parity block on rank 0
+            try:
+                a4 = parse_args([])
+                a4.xsplit, a4.no_graph, a4.cfg_scale, a4.gpus = args.xsplit, args.no_graph, args.cfg_scale, args.gpus
+                a4.batch, a4.steps, a4.warmup = 8, 20, 5
+                a4.no_eager_baseline, a4.no_parity_long, a4.no_cpu_baseline = True, True, True
+                a4.no_parity = args.no_parity or args.no_cpu_baseline
+                sp4 = dict(WORKLOADS["north-star"], speakers=4, text_tokens=10569, baseline_config="configs[3] per-GPU unit")
+                r4 = bench_decode(a4, sp4, ctx, with_cpu=False, with_roofline=not args.no_roofline, with_parity=True)
+                if rank == 0:
+                    keep4 = {k: r4[k] for k in ("value", "unit", "n_gpus", "ms_per_step", "steps", "warmup", "scaling", "roofline", "parity")}
+                    keep4["workload"] = r4["config"]["workload"]
+                    keep4["utterances_per_gpu"] = 8
+                    keep4["audio_s_per_wall_s_per_utterance"] = round(r4["value"] / (8 * world), 3)
+                    keep4["per_rank_ms_per_step"] = r4["extra"]["per_rank_ms_per_step"]
+                    keep4["prefill_phases"] = r4["extra"].get("prefill_phases")
+                    res["extra"].setdefault("configs", {})["configs[3] per GPU"] = keep4
+            except Exception as ex:          # an extra line must never take the main line down
+                if rank == 0:
+                    res["extra"].setdefault("configs", {})["configs[3] per GPU"] = {"error": repr(ex)[:300]}
     if rank == 0:
         if shared_gpu:
             res["harness"] = ("VVHIP_BENCH_SHARED_GPU=1: every rank time-shares cuda:0 over a gloo group -- a control-flow check of the "
@@ -397,7 +421,7 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline, with_parity=False):
     t_load0 = time.time()
     eng = Engine(ecfg, device)
     exp = eng.expected_weights()
-    with_parity = with_parity and rank == 0 and world == 1 and not args.no_parity
+    with_parity = with_parity and rank == 0 and not args.no_parity
     keep_cpu = rank == 0 and (with_cpu or with_parity)
     cpu_sd = {}
     # rank 0 draws the weights; ONE packed-blob broadcast over RCCL/xGMI at start-up, no collective later
@@ -659,18 +683,48 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline, with_parity=False):
     legs = {}
     if keep_cpu and with_cpu:
         try:
-            legs["vs_fp32"], cpu = cpu_baseline(cfg, cpu_sd, NS, args.cfg_scale, args.cpu_frames, model_key)
+            # on the configuration the GPU number is quoted on: the window runs at the timed KV length (kv_target > 0); its leg is then
+            # not a parity leg (the parity block below runs its own fp32 oracle on the GPU)
+            leg_cpu, cpu = cpu_baseline(cfg, cpu_sd, NS, args.cfg_scale, args.cpu_frames, model_key, kv_len=(max(L0, kv_target) + W if kv_target else 0))
+            if leg_cpu is not None:
+                legs["vs_fp32"] = leg_cpu
         except Exception as ex:   # the baseline is a reported number, never the product path
             cpu = {"value": None, "error": repr(ex)[:200]}
     if keep_cpu and not args.no_eager_baseline:
         try:
-            _free_run_leg, eager = gpu_eager_baseline(cfg, cpu_sd, NS, args.cfg_scale, 8, model_key, device)     # timing only
+            _free_run_leg, eager = gpu_eager_baseline(cfg, cpu_sd, NS, args.cfg_scale, 8, model_key, device,
+                                                      kv_len=(max(L0, kv_target) + W if kv_target else 0))     # timing only
             del _free_run_leg
             eager["speedup_of_this_path"] = round(value / world / eager["value"], 2) if eager["value"] else None
         except Exception as ex:   # a reported number, never the product path
             eager = {"value": None, "error": repr(ex)[:200]}
         torch.cuda.empty_cache()
-    if with_parity:
+    if with_parity and B > 1:
+        # ---- the batch that was just timed, full depth, against the oracle: B rows in lock-step (16-row LM / head projections over
+        # pre-packed activations, batch attention, slot-batched tokenizer chains), two DIFFERENT requests alternating over the rows,
+        # every row teacher-forced per step by its own fp32 oracle leg (oracle/parity.py::compare_engine_batch) ----
+        from oracle import parity as oparity
+        parity = {"model": f"VibeVoice-{model_key}", "lm_layers": d["num_hidden_layers"], "head_layers": cfg["diffusion_head_config"].get("head_layers", 4),
+                  "solver_steps": NS, "rows": B, "engine_mode": {"xsplit": args.xsplit, "hipgraph": not args.no_graph, "dtype": "bf16"}, "prompt_tokens": 48,
+                  "definition": "the timed engine (same weights, batch kernels) decoding B rows in lock-step: rows alternate over two requests (different "
+                                "prompt ids and noise), each row teacher-forced per step by the fp32 oracle run of ITS request (oracle/generate.py as fp32 "
+                                "eager ops on this GPU); worst row and step; rel-L2 unless marked dB; bounds = the stated tolerance vs fp32 (SURVEY 8d)"}
+        try:
+            t_pb = time.perf_counter()
+            blegs = [oparity.oracle_leg(cfg, cpu_sd, synthetic.TOKENS, NS, args.cfg_scale, 3, device, torch.float32, 20.0, seed=sd_) for sd_ in (7, 11)]
+            rb = oparity.compare_engine_batch(model, blegs, synthetic.TOKENS, B)
+            vb = oparity.verdict("vs_fp32", rb)
+            vb["oracle"] = "float32 eager ops on this GPU, one run per distinct request"
+            parity["vs_fp32"] = vb
+            parity["within_bounds"] = bool(vb["within_bounds"] and vb["greedy_pick_equal"] and not vb["nonfinite_steps"])
+            parity["seconds"] = round(time.perf_counter() - t_pb, 1)
+            del blegs
+        except Exception as ex:
+            parity["error"] = repr(ex)[:300]
+            parity["within_bounds"] = False
+        model.set_ddpm_inference_steps(NS)
+        torch.cuda.empty_cache()
+    elif with_parity:
         # ---- full-depth parity of the engine that was just timed (same weights, same execution mode) against the oracle legs ----
         from oracle import parity as oparity
         parity = {"model": f"VibeVoice-{model_key}", "lm_layers": d["num_hidden_layers"], "head_layers": cfg["diffusion_head_config"].get("head_layers", 4),
@@ -705,7 +759,7 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline, with_parity=False):
             parity["within_bounds"] = False
         model.set_ddpm_inference_steps(NS)
     parity_long = None
-    if with_parity and not args.no_parity_long:
+    if with_parity and B == 1 and not args.no_parity_long:
         # ---- the same comparison THROUGH THE PROMPT PASS, at the timed length: the run's own request (voice prompts + the whole L0-token
         # prompt) through the engine's prefill chain and through the oracle as fp32 eager ops on this GPU with the same weights; step 0 =
         # the prompt's last position; then teacher-forced decode frames on the KV cache the prefill kernels wrote ----
@@ -1070,9 +1124,72 @@ def _oracle_leg(cfg, sd, n_solver, cfg_scale, n_frames, device, dtype, t_budget)
     return parity.oracle_leg(cfg, sd, synthetic.TOKENS, n_solver, cfg_scale, n_frames, device, dtype, t_budget)
 
 
-def cpu_baseline(cfg, cpu_sd, n_solver, cfg_scale, n_frames, model_key):
+def _oracle_window(cfg, sd, n_solver, cfg_scale, n_frames, device, dtype, t_budget, kv_len):
+    """Timing only: `n_frames` decode frames of the oracle loop on `device` in `dtype` AT A KV LENGTH OF `kv_len` -- a 48-token text-only
+    prompt pass, then the positive branch's cache is padded with noise (N(0, 0.5^2), the scale bench_decode's kv_fill uses) up to kv_len, so
+    every frame's attention, its softmax over kv_len positions and the DynamicCache-style torch.cat run at the length the GPU leg is timed at
+    (the 10,922-token prompt pass itself would cost ~150 s of CPU time and is not what the window measures; the negative branch's cache is
+    short in the real run too: it restarts at every <speech_start>).  Stops after t_budget seconds once two whole frames are in.
+    Returns (seconds per frame, frames timed, first-interval seconds)."""
+    from oracle import generate as ogen
+    from oracle import parity as oparity
+    from vibevoice_amd import synthetic
+    d = cfg["decoder_config"]
+    kvh, hd = d["num_key_value_heads"], d["hidden_size"] // d["num_attention_heads"]
+    on_gpu = torch.device(device).type == "cuda"
+    T = synthetic.TOKENS
+    with torch.device(device):
+        m = oparity.oracle_model(cfg, sd, device, dtype)
+        m.t_cast_dtype = torch.bfloat16
+        tok = ogen.TokenIds(T.speech_start_id, T.speech_end_id, T.speech_diffusion_id, T.eos_token_id, None, T.pad_token_id)
+        plain_forward = m.lm.forward
+
+        def forward(embeds, cache, final_norm=True):
+            out = plain_forward(embeds, cache, final_norm)
+            if embeds.shape[0] > 1 and cache.length < kv_len:        # the prompt pass of the positive branch: pad its cache with noise
+                pad = kv_len - cache.length
+                gk = torch.Generator(device="cpu").manual_seed(4321)
+                for i in range(len(cache.k)):
+                    cache.k[i] = torch.cat([cache.k[i], (torch.randn(kvh, pad, hd, generator=gk, device="cpu") * 0.5).to(device=device, dtype=dtype)], dim=1)
+                    cache.v[i] = torch.cat([cache.v[i], (torch.randn(kvh, pad, hd, generator=gk, device="cpu") * 0.5).to(device=device, dtype=dtype)], dim=1)
+                cache.length = kv_len
+            return out
+        m.lm.forward = forward
+        g = torch.Generator(device="cpu").manual_seed(7)
+        ids = torch.randint(0, min(151000, d["vocab_size"] - 64), (1, 48), generator=g, device="cpu")
+        ids[0, -1] = T.speech_start_id
+        stamps = []
+
+        class _Budget(Exception):
+            pass
+
+        def noise_fn(step, n2):
+            if on_gpu:
+                torch.cuda.synchronize()
+            stamps.append(time.perf_counter())
+            if len(stamps) >= 3 and stamps[-1] - stamps[0] > t_budget:
+                raise _Budget()
+            return torch.randn(n2, 64, generator=g, device="cpu").to(device=device, dtype=dtype)
+        ids_d = ids.to(device)
+        try:
+            with torch.no_grad():
+                ogen.oracle_generate(m, tok, ids_d, torch.ones_like(ids_d), cfg_scale=cfg_scale, num_steps=n_solver, max_new_tokens=n_frames + 1,
+                                     noise_fn=noise_fn, forced_tokens=[[T.speech_diffusion_id] * (n_frames + 1)])
+        except _Budget:
+            pass
+        if on_gpu:
+            torch.cuda.synchronize()
+    first = 1 if (on_gpu and len(stamps) >= 4) else 0        # a GPU's first interval carries one-off costs (kernel selection, allocator growth)
+    n = len(stamps) - 1 - first
+    per = (stamps[-1] - stamps[first]) / max(1, n)
+    del m
+    return per, n, (stamps[1] - stamps[0]) if len(stamps) > 1 else 0.0
+
+
+def cpu_baseline(cfg, cpu_sd, n_solver, cfg_scale, n_frames, model_key, kv_len=0):
     """Times oracle/ (the CPU restatement of the reference loop) on this host: `n_frames` decode
-    frames after a short prompt, fp32, a bounded number of host threads.  kind = "port"."""
+    frames, fp32, a bounded number of host threads.  kind = "port".  kv_len > 0: the window runs AT THAT KV LENGTH (the timed GPU
+    leg's: _oracle_window) and the returned leg is None -- the parity block then takes its fp32 oracle run on the GPU."""
     # the GPU box advertises hundreds of logical CPUs but the job may be cgroup-limited; a modest
     # thread count keeps torch's intra-op pool from thrashing.  Measured on the box, ms per 7B frame: 16 threads 3150-3635,
     # 32 threads 3657, 64 threads 5958, 256 threads ~200,000: 16 is at the optimum, more cores do not make this baseline faster
@@ -1080,6 +1197,16 @@ def cpu_baseline(cfg, cpu_sd, n_solver, cfg_scale, n_frames, model_key):
     ncpu = min(int(os.environ.get("VVHIP_CPU_THREADS", "16")), host_cpus)
     torch.set_num_threads(ncpu)
     t_budget = float(os.environ.get("VVHIP_CPU_BUDGET_S", "30"))
+    if kv_len > 48:
+        per_frame, n, _ = _oracle_window(cfg, cpu_sd, n_solver, cfg_scale, n_frames, "cpu", torch.float32, t_budget, kv_len)
+        return None, {"value": round(FRAME_SEC / per_frame, 5), "unit": "audio-s/wall-s", "cores": ncpu, "kind": "port", "host_logical_cpus": host_cpus,
+                      "kv_length": kv_len,
+                      "sample": f"{n} decode frames AT A KV LENGTH OF {kv_len} (the GPU leg's timed context: the positive cache holds {kv_len} positions -- a 48-token "
+                                f"prompt pass + noise K/V, as the GPU leg's window past its prompt does; cache growth by torch.cat as the reference's DynamicCache) of the "
+                                f"same model shapes and weights (VibeVoice-{model_key}, fp32 = the reference's CPU dtype, {n_solver} solver steps, CFG pos+neg passes); "
+                                f"oracle loop = CPU restatement of the reference's generate(), torch intra-op threads capped at {ncpu} of {host_cpus} logical CPUs "
+                                f"(16 is the measured optimum on the box); the 16-frame windows at three KV lengths: bench.py --cpu-windows, profiles/r05_cpu_baseline.json",
+                      "ms_per_step": round(per_frame * 1e3, 2)}
     leg = _oracle_leg(cfg, cpu_sd, n_solver, cfg_scale, n_frames, "cpu", torch.float32, t_budget)
     per_frame, n = leg.per_frame_s, leg.frames_timed
     return leg, {"value": round(FRAME_SEC / per_frame, 4), "unit": "audio-s/wall-s", "cores": ncpu, "kind": "port",
@@ -1163,7 +1290,7 @@ def cpu_baseline_windows(args, spec, device):
                       f"torch intra-op threads {ncpu} of {host_cpus}"}
 
 
-def gpu_eager_baseline(cfg, dev_sd, n_solver, cfg_scale, n_frames, model_key, device):
+def gpu_eager_baseline(cfg, dev_sd, n_solver, cfg_scale, n_frames, model_key, device, kv_len=0):
     """SURVEY 8(d)'s "GPU before": the same oracle loop as plain PyTorch-ROCm eager ops in bf16 on the SAME GPU (what the
     reference's generate() issues per frame: ~2-3 k library kernels, a second weight pass for the CFG-negative row, the
     full-vocabulary lm_head, DynamicCache-style torch.cat of the KV cache).  A reported baseline like cpu_baseline: it is the
@@ -1173,6 +1300,17 @@ def gpu_eager_baseline(cfg, dev_sd, n_solver, cfg_scale, n_frames, model_key, de
     # shapes to the BLAS libraries, and in the first process of a fresh box each of them pulls code objects from a cold disk:
     # measured 212 ms/frame for the first pass against 104 for the same pass repeated (a second process in the same box also
     # runs at 104).  The warm figure is the honest "GPU before".
+    if kv_len > 48:
+        # at the timed KV length: the eager loop's attention over kv_len positions and its torch.cat of the whole cache per layer and step
+        # are part of the frame, as they are in the reference on a GPU
+        cold, _, _ = _oracle_window(cfg, dev_sd, n_solver, cfg_scale, n_frames, device, torch.bfloat16, t_budget, kv_len)
+        per_frame, n, _ = _oracle_window(cfg, dev_sd, n_solver, cfg_scale, n_frames, device, torch.bfloat16, t_budget, kv_len)
+        return None, {"value": round(FRAME_SEC / per_frame, 4), "unit": "audio-s/wall-s", "kind": "port, PyTorch-ROCm eager bf16, same GPU", "kv_length": kv_len,
+                      "sample": f"{n} decode frames (after one untimed frame) AT A KV LENGTH OF {kv_len} (48-token prompt pass + noise K/V in the positive cache, "
+                                f"grown by torch.cat per step) of the same model shapes and weights (VibeVoice-{model_key}, bf16, {n_solver} solver steps, CFG "
+                                f"pos+neg passes), the second of two identical passes (the first one, which also loads the libraries' code objects: "
+                                f"{cold * 1e3:.0f} ms/frame)",
+                      "ms_per_step": round(per_frame * 1e3, 3), "first_pass_ms_per_step": round(cold * 1e3, 3)}
     cold = _oracle_leg(cfg, dev_sd, n_solver, cfg_scale, n_frames, device, torch.bfloat16, t_budget).per_frame_s
     leg = _oracle_leg(cfg, dev_sd, n_solver, cfg_scale, n_frames, device, torch.bfloat16, t_budget)
     per_frame, n = leg.per_frame_s, leg.frames_timed

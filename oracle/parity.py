@@ -244,6 +244,65 @@ def compare_engine(model, leg: Leg, tokens, frames: Optional[int] = None, also: 
     return res
 
 
+def compare_engine_batch(model, legs: List[Leg], tokens, batch: int, frames: Optional[int] = None, also: Optional[dict] = None) -> dict:
+    """compare_engine for a LOCK-STEP BATCH of `batch` rows (BASELINE configs[3]'s per-GPU unit: 8 utterances share every LM / diffusion-head
+    weight pass; modeling_vibevoice_inference.py:393-394, :549, :573, :594 -- the reference's rows are independent).  Row b decodes the request
+    of legs[b % len(legs)] (the legs differ in prompt ids and noise, same prompt length), teacher-forced per step with that leg's own
+    embeddings: a row that picked up another row's state, noise or cache cannot land on its own leg's trajectory.  Every row is compared
+    with its leg like compare_engine does; returned: the worst row per figure, the per-row latent distances, and the largest distance
+    between two rows that decoded the SAME leg (their inputs are identical: they may differ by the batch kernels' row position only).
+    also: {name: [one leg per entry of `legs`]} -- further oracle runs on the same inputs, as in compare_engine."""
+    k = len(legs)
+    n = min(l.frames for l in legs) if frames is None else min([frames] + [l.frames for l in legs])
+    if n < 1:
+        return {"frames": 0, "error": "an oracle leg completed no frame"}
+    L0 = legs[0].ids.shape[1]
+    assert all(l.ids.shape[1] == L0 and l.inputs is None for l in legs), "text-only legs of one prompt length"
+    D, X = tokens.speech_diffusion_id, tokens.eos_token_id
+    htr = ogen.Trace()
+    model.set_ddpm_inference_steps(legs[0].n_solver)
+    ids = torch.cat([legs[b % k].ids for b in range(batch)], 0)
+
+    def noise_fn(step, n2):
+        rows = [legs[b % k].noise[step][:1] for b in range(n2 // 2)]
+        return torch.cat(rows + rows, 0)
+
+    def teacher(step, rows):
+        return torch.cat([legs[b % k].trace.next_embeds[step][:1].float() for b in rows], 0)
+    out = model.generate(tokenizer=tokens, cfg_scale=legs[0].cfg_scale, generation_config={"do_sample": False}, max_new_tokens=n,
+                         show_progress_bar=False, _forced_tokens=[[D] * n + [X] for _ in range(batch)], _noise_fn=noise_fn, _trace=htr,
+                         _teacher_embeds=teacher, input_ids=ids, attention_mask=torch.ones_like(ids))
+    seq_ok = out.sequences.shape[1] == L0 + n and bool((out.sequences[:, L0:].cpu() == D).all())
+
+    def row_trace(b):
+        t = ogen.Trace()
+        for name in ("pos_hidden", "neg_hidden", "latents", "logits"):
+            setattr(t, name, [x[b:b + 1] for x in getattr(htr, name)])
+        return t
+    per_row = [compare_traces(row_trace(b), out.speech_outputs[b], legs[b % k].trace, n, seq_ok) for b in range(batch)]
+    worst = {}
+    for key in ("latent", "pos_hidden", "neg_hidden", "frame_rms_db"):
+        worst[key] = max(r[key] for r in per_row)
+    worst["frame_snr_db"] = min(r["frame_snr_db"] for r in per_row)
+    same = 0.0
+    for b in range(k, batch):
+        for a, c in zip(htr.latents[:n], htr.latents[:n]):
+            same = max(same, _rel(a[b:b + 1], c[b % k:b % k + 1]))
+    res = {"frames": n, "rows": batch, "distinct_requests": k, "nonfinite_steps": {f"row{b}": r["nonfinite_steps"] for b, r in enumerate(per_row) if r["nonfinite_steps"]},
+           **worst, "per_row_latent": [r["latent"] for r in per_row], "rows_of_one_request_latent_spread": round(same, 6),
+           "tokens_equal": bool(seq_ok), "greedy_pick_equal": all(r["greedy_pick_equal"] for r in per_row),
+           "oracle_min_top2_margin": min(r["oracle_min_top2_margin"] for r in per_row),
+           "mode": "lock-step batch, every row teacher-forced per step by its own oracle leg; worst row per figure"}
+    if also:
+        res["also"] = {}
+        for name, olegs in also.items():
+            pr = [compare_traces(row_trace(b), out.speech_outputs[b], olegs[b % k].trace, min(n, olegs[b % k].frames), seq_ok) for b in range(batch)]
+            res["also"][name] = {**{key: max(r[key] for r in pr) for key in ("latent", "pos_hidden", "neg_hidden", "frame_rms_db")},
+                                 "frame_snr_db": min(r["frame_snr_db"] for r in pr), "frames": min(r["frames"] for r in pr), "tokens_equal": bool(seq_ok),
+                                 "greedy_pick_equal": all(r["greedy_pick_equal"] for r in pr)}
+    return res
+
+
 def compare_engine_first_step(res: dict) -> dict:
     """step 0 of a compare_engine result: the hidden state at the prompt's LAST position (what the prompt pass hands the first frame),
     the negative condition and the first latent -- against the fp32 leg and, when present, against the bf16 eager leg"""

@@ -123,6 +123,48 @@ def timeline(db, out):
             f.write(f"  {c:28s} {k:8d} dispatches {ns / 1e6:10.2f} ms  {100.0 * ns / span:5.1f} % of the bursts\n")
 
 
+def decode_step_table(db, out, layers_hint=None):
+    """Per-kernel time of ONE decode step: the dispatches of the decode bursts (same burst rule as timeline()), grouped by kernel name
+    and launch grid, divided by the number of steps in those bursts (= decode-attention dispatches / LM layers; the layer count is
+    taken from the most common number of attention launches between two token-embedding / logits launches when not given).
+    Writes <out>_decode_step.csv: us per step, launches per step, mean us, kernel, grid."""
+    cur = db.cursor()
+    rows = cur.execute("select name, start, end, grid_x, grid_y, workgroup_x from kernels order by start").fetchall()
+    PREFILL = ("vv_gemm4", "vv_gemm3", "vv_attn_prefill", "vv_pack_rows", "vv_rope_append", "vv_pack_kernel", "vv_kv_import",
+               "distribution_elementwise", "vv_cvt_kernel")
+    kept, burst, last_end = [], [], None
+
+    def close(b):
+        if len(b) >= 50 and sum(1 for r in b if "vv_gemv" in r[0] or "vv_attn_fused" in r[0]) >= 0.3 * len(b):
+            kept.extend(b)
+    for rec in rows:
+        if any(p in rec[0] for p in PREFILL):
+            close(burst); burst = []; last_end = None
+            continue
+        if last_end is not None and rec[1] - last_end > 300000:
+            close(burst); burst = []
+        burst.append(rec)
+        last_end = max(last_end or 0, rec[2])
+    close(burst)
+    if not kept:
+        return
+    n_attn = sum(1 for r in kept if "vv_attn_fused" in r[0])
+    layers = layers_hint or 28
+    steps = max(1.0, n_attn / layers)
+    agg = {}
+    for n, s_, e, gx, gy, wx in kept:
+        k = (short(n)[:90], gx // max(1, wx), gy, wx)
+        a = agg.setdefault(k, [0, 0])
+        a[0] += e - s_; a[1] += 1
+    tot = sum(a[0] for a in agg.values())
+    with open(out + "_decode_step.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow([f"# decode bursts only: {len(kept)} dispatches, {steps:.1f} steps (attention launches / {layers} layers), sum of kernel intervals {tot / steps / 1e3:.1f} us per step"])
+        w.writerow(["UsPerStep", "LaunchesPerStep", "MeanUs", "Kernel", "Workgroups", "GridY", "Threads"])
+        for k, (ns, c) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+            w.writerow([round(ns / steps / 1e3, 2), round(c / steps, 2), round(ns / c / 1e3, 2), k[0], k[1], k[2], k[3]])
+
+
 def gap_report(db, out, min_burst=50):
     """Where the idle time inside the decode bursts sits: every pause between the end of the latest-ending kernel so far and the
     start of the next one, keyed by (kernel before -> kernel after), summed.  Kernel boundaries inside one hipGraph show as
@@ -212,6 +254,7 @@ if __name__ == "__main__":
         rows, tot = kernel_stats(db, sys.argv[2])
         timeline(db, sys.argv[2])
         gap_report(db, sys.argv[2])
+        decode_step_table(db, sys.argv[2], int(sys.argv[sys.argv.index("--layers") + 1]) if "--layers" in sys.argv else None)
         if "--around" in sys.argv:
             k = sys.argv.index("--around")
             dump_around(db, sys.argv[2], sys.argv[k + 1], int(sys.argv[k + 2]))

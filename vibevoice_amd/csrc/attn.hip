@@ -263,7 +263,9 @@ __global__ __launch_bounds__(WAVES * 64) void vv_attn_fused_kernel(
     const float* __restrict__ qkv, const VVRow* __restrict__ rows, const float2* __restrict__ rope_tab,
     __bf16* __restrict__ kc, __bf16* __restrict__ vc, int Hq, int Hkv, int64_t cache_stride, int64_t head_stride,
     float q_scale, float* __restrict__ part_m, float* __restrict__ part_l, float* __restrict__ part_o,
-    float* __restrict__ out) {
+    float* __restrict__ out, unsigned char* __restrict__ out_packed) {
+    // out_packed (batch decode, <= 16 rows): the finished rows also go out as ONE packed bf16 tile [Hq D / 32][64 lanes][8] -- the
+    // o-projection's MFMA B operand (gemv16p.hip), element (row r, k) at lane (r & 15) + 16 ((k & 31) >> 3), slot k & 7 of k-tile k >> 5
     constexpr int KT = D / 32, DT = D / 16, HALF = D / 2;
     const int S = gridDim.x;
     const int split = blockIdx.x, kvh = blockIdx.y, r = blockIdx.z;
@@ -479,9 +481,17 @@ __global__ __launch_bounds__(WAVES * 64) void vv_attn_fused_kernel(
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) O += so[w][dt][lane] * fw[w];
         if (g < G) {
-            if (used == 1)                        // short sequence: this workgroup saw everything
+            if (used == 1) {                      // short sequence: this workgroup saw everything
                 *reinterpret_cast<float4*>(orow + dt * 16) = float4{O[0] * inv, O[1] * inv, O[2] * inv, O[3] * inv};
-            else                                  // several splits: vv_attn_merge2_kernel (a separate wide launch that follows in
+                if (out_packed) {
+                    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+                    bf16x4 pk;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pk[e] = (__bf16)(O[e] * inv);
+                    const int k = (kvh * G + g) * D + dt * 16 + qg * 4;
+                    *reinterpret_cast<uint2*>(out_packed + ((((int64_t)(k >> 5) * 64 + (r & 15) + 16 * ((k & 31) >> 3)) * 8 + (k & 7)) * 2)) = __builtin_bit_cast(uint2, pk);
+                }
+            } else                                  // several splits: vv_attn_merge2_kernel (a separate wide launch that follows in
                                                   // the stream: no fence, no ticket) combines the partials in a fixed order
                 *reinterpret_cast<float4*>(part_o + (pidx * 16 + g) * D + dt * 16 + qg * 4) = float4{O[0], O[1], O[2], O[3]};
         }
@@ -522,7 +532,7 @@ __global__ void vv_attn_merge_kernel(const float* __restrict__ part_m, const flo
 template <int D>
 __global__ __launch_bounds__(512) void vv_attn_merge2_kernel(const float* __restrict__ part_m, const float* __restrict__ part_l,
                                                              const float* __restrict__ part_o, const VVRow* __restrict__ rows,
-                                                             float* __restrict__ out, int Hq, int Hkv, int S) {
+                                                             float* __restrict__ out, int Hq, int Hkv, int S, unsigned char* __restrict__ out_packed) {
     constexpr int NG = 512 / D, MB = 8;
     __shared__ float sm[NG][D], sl[NG][D], sa[NG][D];
     const int r = blockIdx.x, h = blockIdx.y;
@@ -574,6 +584,10 @@ __global__ __launch_bounds__(512) void vv_attn_merge2_kernel(const float* __rest
         A += sa[j][d] * f;
     }
     out[((int64_t)r * Hq + h) * D + d] = A / L;
+    if (out_packed) {                                // batch decode: the o-projection's packed bf16 operand (see vv_attn_fused_kernel)
+        const int k = h * D + d;
+        *reinterpret_cast<__bf16*>(out_packed + ((((int64_t)(k >> 5) * 64 + (r & 15) + 16 * ((k & 31) >> 3)) * 8 + (k & 7)) * 2)) = (__bf16)(A / L);
+    }
 }
 
 }  // namespace
@@ -613,7 +627,7 @@ extern "C" int vv_rope_table_launch(const float* inv_freq, void* tab, int n_pos,
 // K/V requests in flight at once, half the dependent load -> consume iterations per wave)
 template <int D, int XS, int W>
 static void attn_fused_go(dim3 grid, hipStream_t s, const float* qkv, const VVRow* rows, const void* rope_tab, void* kc, void* vc,
-                          int Hq, int Hkv, int64_t cache_stride, int64_t head_stride, float scale, float* pm, float* pl, float* po, float* out) {
+                          int Hq, int Hkv, int64_t cache_stride, int64_t head_stride, float scale, float* pm, float* pl, float* po, float* out, void* out_packed) {
     constexpr size_t smem = (size_t)W * (D / 16) * 64 * 16 + (size_t)2 * W * 16 * 4 + (size_t)2 * D * 2;
     static bool attr = false;
     if (!attr) {
@@ -622,26 +636,27 @@ static void attn_fused_go(dim3 grid, hipStream_t s, const float* qkv, const VVRo
         attr = true;
     }
     hipLaunchKernelGGL((vv_attn_fused_kernel<D, XS, W>), grid, dim3(W * 64), smem, s, qkv, rows, (const float2*)rope_tab, (__bf16*)kc, (__bf16*)vc,
-                       Hq, Hkv, cache_stride, head_stride, scale, pm, pl, po, out);
+                       Hq, Hkv, cache_stride, head_stride, scale, pm, pl, po, out, (unsigned char*)out_packed);
 }
 extern "C" int vv_attn_fused_launch(int D, int xs, const float* qkv, const VVRow* rows, const void* rope_tab, void* kc, void* vc,
                                     int R, int Hq, int Hkv, int64_t cache_stride, int64_t head_stride, int S, int waves,
-                                    float* pm, float* pl, float* po, float* out, hipStream_t s) {
+                                    float* pm, float* pl, float* po, float* out, void* out_packed, hipStream_t s) {
     if (Hq % Hkv != 0 || Hq / Hkv > 16 || (waves != 4 && waves != 8)) return -1;
+    if (out_packed && (R > 16 || ((Hq * D) & 31))) return -1;
     const float scale = 1.0f / sqrtf((float)D);
     const dim3 grid(S, Hkv, R);
 #define VV_F(D_, XS_)                                                                                                                   \
     do {                                                                                                                                \
-        if (waves == 8) attn_fused_go<D_, XS_, 8>(grid, s, qkv, rows, rope_tab, kc, vc, Hq, Hkv, cache_stride, head_stride, scale, pm, pl, po, out); \
-        else attn_fused_go<D_, XS_, 4>(grid, s, qkv, rows, rope_tab, kc, vc, Hq, Hkv, cache_stride, head_stride, scale, pm, pl, po, out);            \
+        if (waves == 8) attn_fused_go<D_, XS_, 8>(grid, s, qkv, rows, rope_tab, kc, vc, Hq, Hkv, cache_stride, head_stride, scale, pm, pl, po, out, out_packed); \
+        else attn_fused_go<D_, XS_, 4>(grid, s, qkv, rows, rope_tab, kc, vc, Hq, Hkv, cache_stride, head_stride, scale, pm, pl, po, out, out_packed);            \
     } while (0)
     if (D == 128) { if (xs == 1) VV_F(128, 1); else if (xs == 2) VV_F(128, 2); else VV_F(128, 3); }
     else if (D == 64) { if (xs == 1) VV_F(64, 1); else if (xs == 2) VV_F(64, 2); else VV_F(64, 3); }
     else return -1;
 #undef VV_F
     if (S > 1) {      // rows that needed one split were finished by the attention kernel; the merge kernel skips them
-        if (D == 128) hipLaunchKernelGGL((vv_attn_merge2_kernel<128>), dim3(R, Hq), dim3(512), 0, s, pm, pl, po, rows, out, Hq, Hkv, S);
-        else hipLaunchKernelGGL((vv_attn_merge2_kernel<64>), dim3(R, Hq), dim3(512), 0, s, pm, pl, po, rows, out, Hq, Hkv, S);
+        if (D == 128) hipLaunchKernelGGL((vv_attn_merge2_kernel<128>), dim3(R, Hq), dim3(512), 0, s, pm, pl, po, rows, out, Hq, Hkv, S, (unsigned char*)out_packed);
+        else hipLaunchKernelGGL((vv_attn_merge2_kernel<64>), dim3(R, Hq), dim3(512), 0, s, pm, pl, po, rows, out, Hq, Hkv, S, (unsigned char*)out_packed);
     }
     return vv_launch_rc(0);
 }

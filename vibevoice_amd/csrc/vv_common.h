@@ -105,6 +105,30 @@ struct VVGemm {
     float* dw_hnew;        // [K]
 };
 
+// ---- batch decode over pre-packed activations (gemv16p.hip) ----
+struct VVGemv16p {
+    const u32x4* W;        // packed [N][K]
+    const u32x4* W2;       // SwiGLU "up" matrix, same shape
+    const u32x4* Xp;       // packed activations, ONE 16-row tile: [K/32][64][8]
+    float* Y;              // fp32 [T][ldy]  (bias / residual / gated residual)
+    unsigned char* Yp;     // packed bf16 [16][N]  (SwiGLU; PK: the new residual rows x pk_nw (x (1 + pk_sc)))
+    const float* bias;     // [N] or null
+    const float* gate;     // gated residual: per-row [T][ld_gate]
+    int T, N, K, ldy, ld_gate;
+    // RS: the operand is UN-normalised (x * norm weight): the accumulator rows are scaled by rsqrt(sum_tiles ssq_in[tile][row] / K + eps)
+    const float* ssq_in;   // [ssq_tiles][16]
+    int ssq_tiles;
+    float eps;
+    const u32x4* Xs;       // SH: second packed operand (adaLN shift rows), added unscaled: y = rs * W.Xp + W.Xs
+    // PK (residual epilogues): besides Y, write bf16(y_new * pk_nw[n] * (1 + pk_sc[row][n])) packed to Yp and sum_n y_new^2 to ssq_out
+    const float* pk_nw;    // [N] or null (= 1)
+    const float* pk_sc;    // per-row [T][ld_pk] or null
+    int ld_pk;
+    float* ssq_out;        // [N / 16][16]
+    // VV_EPI_CFG_DPM (the sampler's final layer): rows [0, n) cond, [n, 2n) uncond -> CFG + DPM-Solver++ update of z in place (gemv.hip)
+    float* z; float* x0p; const float* coef; float cfg; int n_cfg; const float* sde_noise;
+};
+
 // up to 8 utterance slots of one launch (per-utterance kernels take the slot from blockIdx.y / .z)
 struct VVSlotIds { int n; int id[8]; };
 __device__ __forceinline__ int vv_slot_id(const int (&id)[8], int j) {     // select chain: no dynamic indexing of a by-value kernel argument
