@@ -300,8 +300,8 @@ def main():
             raise SystemExit("--full-utterance is a one-GPU measurement")
         res = bench_full_utterance(args, spec, ctx)
     else:
-        res = bench_decode(args, spec, ctx, with_cpu=(world == 1 and not args.no_cpu_baseline), with_roofline=not args.no_roofline,
-                           with_parity=(world == 1 and not args.no_cpu_baseline and args.batch == 1 and not args.continuous))
+        res = bench_decode(args, spec, ctx, with_cpu=(world == 1 and not args.no_cpu_baseline and args.batch == 1), with_roofline=not args.no_roofline,
+                           with_parity=(world == 1 and not args.no_cpu_baseline and not args.continuous))
         if rank == 0 and world == 1 and not args.skip_extra and args.workload == "north-star" and args.batch == 1 and not args.continuous:
             # the other single-GPU BASELINE configs, same run, same code
             extra = {}

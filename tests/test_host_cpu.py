@@ -276,6 +276,33 @@ def test_lora_merge_math_and_key_mapping(tmp_path):
         lora.merge_lora(torch.zeros(3, 3), torch.zeros(2, 4), torch.zeros(3, 2), 1.0)
 
 
+def test_lora_merge_rounding_equals_the_peft_operations_on_a_bf16_model():
+    """peft is not installed here; its merge is three tensor operations (peft/tuners/lora/layer.py: Linear.get_delta_weight, then
+    `base_layer.weight.data += delta_weight`), replayed literally on a bf16 weight: with fp32 adapter matrices (peft's loader upcasts
+    them, the reference's trainer saves fp32) the in-place add computes in fp32 and rounds once = merge_dtype "float32" bit for bit;
+    with bf16 adapter matrices on the CPU get_delta_weight upcasts, multiplies, scales and rounds the DELTA to bf16 first = "bfloat16"."""
+    from vibevoice_amd import lora
+    g = torch.Generator().manual_seed(11)
+    W = (torch.randn(96, 64, generator=g) * 0.02).to(torch.bfloat16)
+    A, B = torch.randn(8, 64, generator=g) * 0.05, torch.randn(96, 8, generator=g) * 0.05
+    scale = 32 / 8
+    # (1) fp32 adapters: delta fp32, `+=` on the bf16 parameter
+    w1 = W.clone()
+    w1 += (B @ A) * scale
+    assert w1.dtype == torch.bfloat16
+    assert torch.equal(lora.merge_lora(W, A, B, scale, merge_dtype="float32"), w1)
+    # (2) bf16 adapters on the CPU: cast_to_fp32 branch of get_delta_weight
+    Ab, Bb = A.to(torch.bfloat16), B.to(torch.bfloat16)
+    delta = ((Bb.float() @ Ab.float()) * scale).to(torch.bfloat16)
+    w2 = W.clone()
+    w2 += delta
+    assert torch.equal(lora.merge_lora(W, Ab, Bb, scale, merge_dtype="bfloat16"), w2)
+    assert not torch.equal(w1, w2)                                   # the two roundings do differ somewhere
+    assert float((w1.float() - w2.float()).abs().max()) <= 2.0 ** -8 * float(w1.float().abs().max())       # by about one ulp
+    with pytest.raises(ValueError):
+        lora.merge_lora(W, A, B, scale, merge_dtype="fp16")
+
+
 def test_streamer_surface_and_ordering_cpu():
     from vibevoice_amd.streamer import AudioStreamer
     s = AudioStreamer(batch_size=2, stop_signal=None, timeout=5.0)

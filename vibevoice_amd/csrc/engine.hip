@@ -27,7 +27,7 @@ int vv_rope_append_launch(int D, const float* qkv, const VVRow* rows, const floa
 int vv_rope_table_launch(const float* inv_freq, void* tab, int n_pos, int half, hipStream_t s);
 int vv_attn_fused_launch(int D, int xs, const float* qkv, const VVRow* rows, const void* rope_tab, void* kc, void* vc,
                          int R, int Hq, int Hkv, int64_t cache_stride, int64_t head_stride, int S, int waves,
-                         float* pm, float* pl, float* po, float* out, hipStream_t s);
+                         float* pm, float* pl, float* po, float* out, void* out_packed, hipStream_t s);
 int vv_attn_launch(int D, int xs, const float* q, const VVRow* rows, const void* kc, const void* vc, int R, int Hq,
                    int Hkv, int64_t cache_stride, int64_t head_stride, int S, float* pm, float* pl, float* po,
                    float* out, hipStream_t s);
@@ -82,6 +82,9 @@ int vv_pack16_launch(const float* x, int ldx, int mode, const float* nw, float e
                      void* xp, int T, int K, hipStream_t s);
 int vv_gemv16p_launch(const void* W, const void* W2, const void* Xp, float* Y, void* Yp, const float* bias, const float* gate,
                       int T, int N, int K, int ldy, int ld_gate, int epi, hipStream_t s);
+int vv_gemv16p_launch2(const VVGemv16p* a, int epi, int flags, hipStream_t s);
+int vv_pack16_tiles_launch(const float* x, int ldx, int64_t stride_outer, int n_inner, int64_t stride_inner, void* xp, int64_t tile_bytes,
+                           int T, int K, int n_tiles, hipStream_t s);
 int vv_ada_pack_launch(const float* cproj, const float* temb, void* xp, int rows, int n_steps, int H, hipStream_t s);
 int vv_gemm3_launch(const void* W, const void* W2, const void* Xp, float* Y, void* Yp, const float* bias, int T, int N, int K,
                     int ldy, int epi, const VVGemmWs* ws, hipStream_t s);
@@ -211,6 +214,12 @@ struct vv_ctx {
     bool fold_normdw = true;      // one-row tokenizer stages: norm + depthwise conv inside FFN1's prologue (VVHIP_FOLD_NORMDW=0: separate launch)
     // batch decode (5..16 rows, bf16 mode): activations packed once per op into one 16-row fragment tile (gemv16p.hip)
     void *p16_x = nullptr, *p16_act = nullptr; bool p16_ok = false;
+    // round 6: the producer's residual epilogue packs the next projection's operand (x * norm weight, un-normalised) and leaves per-tile
+    // partial sums of squares; the consumer applies 1/rms to its accumulator rows (gemv16p.hip RS / PK / SH).  VVHIP_P16_FUSE=0: the
+    // separate vv_pack16 launches of round 3.
+    void *p16_y = nullptr, *p16_shift = nullptr; float *ssq_a = nullptr, *ssq_b = nullptr; bool p16_fuse = false;
+    bool p16_head_sh = false;       // the head's layers 1.. take the two-operand (x, shift) form; off: they keep their vv_pack16 launch
+    size_t p16_shift_tile = 0;      // bytes of one packed [16][H] tile of the head's shift rows
     float *pm = nullptr, *pl = nullptr, *po = nullptr;
     // head
     int HF = 0, MODW = 0;
@@ -987,6 +996,15 @@ static int create_impl(const vv_config* cfg, vv_ctx* parent, vv_ctx** out) {
         ctx->p16_x = dalloc(ctx, (size_t)vv_packed_elems(16, kx) * 2);
         ctx->p16_act = dalloc(ctx, (size_t)vv_packed_elems(16, ka + 32) * 2);
         ctx->p16_ok = ctx->p16_x && ctx->p16_act;
+        const char* fz = getenv("VVHIP_P16_FUSE");
+        if (ctx->p16_ok && !(fz && fz[0] == '0') && (H % 16) == 0) {
+            ctx->p16_y = dalloc(ctx, (size_t)vv_packed_elems(16, kx) * 2);
+            ctx->ssq_a = (float*)dalloc(ctx, (size_t)(H / 16) * 16 * 4);
+            ctx->ssq_b = (float*)dalloc(ctx, (size_t)(H / 16) * 16 * 4);
+            ctx->p16_fuse = ctx->p16_y && ctx->ssq_a && ctx->ssq_b;
+            const char* hs = getenv("VVHIP_P16_HEAD_SH");
+            ctx->p16_head_sh = hs && hs[0] == '1';
+        }
     }
     ctx->rope_tab = dalloc(ctx, (size_t)c.max_ctx * (D / 2) * 8, false);
     // split-attention partials exist for decode rows and short ragged launches only (prompt chunks use the prefill kernel)
@@ -1270,6 +1288,11 @@ static int set_schedule(vv_ctx* ctx, int n_steps, const float* t, const float* c
             dfree(ctx, ctx->ada_p);
             ctx->ada_p = (ctx->c.xsplit == 1 && (ctx->H & 7) == 0) ? dalloc(ctx, (size_t)vv_packed_elems(n_steps * 16, ctx->H) * 2, false) : nullptr;
             ctx->mod_all_bytes = (ctx->mod_all && ctx->ada_in) ? need : 0;
+            dfree(ctx, ctx->p16_shift); ctx->p16_shift = nullptr;
+            if (ctx->p16_fuse) {          // the adaLN shift rows of every (solver step, layer) as packed bf16 operand tiles
+                ctx->p16_shift_tile = (size_t)vv_packed_elems(16, ctx->H) * 2;
+                ctx->p16_shift = dalloc(ctx, (size_t)n_steps * (ctx->c.head_layers + 1) * ctx->p16_shift_tile);
+            }
         }
     }
     for (auto it = ctx->graphs.begin(); it != ctx->graphs.end();) {
@@ -1287,6 +1310,24 @@ static int p16_gemv(vv_ctx* ctx, hipStream_t st, const void* W, const void* W2, 
         ctx->prof_other.push_back({1, by, [=](hipStream_t s) { return vv_gemv16p_launch(W, W2, Xp, Y, Yp, bias, gate, T, N, K, ldy, ld_gate, epi, s); }});
     }
     return vv_gemv16p_launch(W, W2, Xp, Y, Yp, bias, gate, T, N, K, ldy, ld_gate, epi, st);
+}
+
+// the struct form (round 6: RS / SH / PK operands); recorded for the family replay like p16_gemv
+static int p16_go(vv_ctx* ctx, hipStream_t st, const VVGemv16p& a, int epi, int flags) {
+    if (ctx->prof_on) {
+        const double by = (double)vv_packed_elems(a.N, a.K) * 2.0 * (a.W2 ? 2.0 : 1.0) + (double)vv_packed_elems(16, a.K) * 2.0 * ((flags & 2) ? 2.0 : 1.0) +
+                          ((epi == VV_EPI_SWIGLU) ? (double)a.T * a.N * 2.0 : (double)a.T * a.N * 4.0 * (epi == VV_EPI_RESID || epi == VV_EPI_GATED_RESID ? 2.0 : 1.0)) +
+                          ((flags & 4) ? (double)a.T * a.N * 2.0 : 0.0);
+        const VVGemv16p ac = a;
+        ctx->prof_other.push_back({1, by, [=](hipStream_t s) { return vv_gemv16p_launch2(&ac, epi, flags, s); }});
+    }
+    return vv_gemv16p_launch2(&a, epi, flags, st);
+}
+static VVGemv16p p16_args(const void* W, const void* W2, const void* Xp, float* Y, void* Yp, int T, int N, int K, int ldy) {
+    VVGemv16p a{};
+    a.W = (const u32x4*)W; a.W2 = (const u32x4*)W2; a.Xp = (const u32x4*)Xp; a.Y = Y; a.Yp = (unsigned char*)Yp;
+    a.T = T; a.N = N; a.K = K; a.ldy = ldy;
+    return a;
 }
 
 static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float* hidden_out, int l0, int l1, int final_norm, bool fused_attn, bool contiguous,
@@ -1331,7 +1372,13 @@ static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float*
     const bool p16 = R > 4 && R <= 16 && ctx->p16_ok && fused_attn;      // batch decode rows: packed-activation projections
     for (int l = l0; l < l1; ++l) {
         auto& L = ctx->layers[l];
-        if (p16) {
+        if (p16 && ctx->p16_fuse && l > l0) {
+            // the previous layer's down projection left x * ln1 packed in p16_x and the rows' partial sums of squares in ssq_b
+            ctx->launches += 1;
+            VVGemv16p a = p16_args(L.wqkv, nullptr, ctx->p16_x, ctx->qkv, nullptr, R, QKV, H, QKV);
+            a.bias = L.bqkv; a.ssq_in = ctx->ssq_b; a.ssq_tiles = H / 16; a.eps = c.lm_eps;
+            VVCHK(p16_go(ctx, st, a, VV_EPI_BIAS, 1));
+        } else if (p16) {
             ctx->launches += 2;
             VVCHK(vv_pack16_launch(ctx->h, H, 1, L.ln1, c.lm_eps, nullptr, nullptr, 0, ctx->p16_x, R, H, st));
             VVCHK(p16_gemv(ctx, st, L.wqkv, nullptr, ctx->p16_x, ctx->qkv, nullptr, L.bqkv, nullptr, R, QKV, H, QKV, 0, VV_EPI_BIAS));
@@ -1350,12 +1397,14 @@ static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float*
                 // algorithmic bytes: every cached position of every row once, K and V (bf16) + the row's q / new k, v / output
                 const double by = (double)kv_positions * Hkv * D * 2.0 * 2.0 + (double)R * (QKV + Hq * D) * 4.0;
                 const int xs = c.xsplit; vv_ctx* cx = ctx;
+                void* opk = (p16 && ctx->p16_fuse) ? ctx->p16_y : nullptr;
                 ctx->prof_other.push_back({2, by, [=](hipStream_t s) {
                     return vv_attn_fused_launch(D, xs, cx->qkv, cx->rows_dev, cx->rope_tab, kl, vl, R, Hq, Hkv, cx->cache_stride,
-                                                cx->head_stride, attn_S, attn_W, cx->pm, cx->pl, cx->po, cx->attn, s); }});
+                                                cx->head_stride, attn_S, attn_W, cx->pm, cx->pl, cx->po, cx->attn, opk, s); }});
             }
+            // batch decode: the attention (or its merge) writes the o-projection's packed bf16 operand itself
             VVCHK(vv_attn_fused_launch(D, c.xsplit, ctx->qkv, ctx->rows_dev, ctx->rope_tab, kl, vl, R, Hq, Hkv, ctx->cache_stride,
-                                       ctx->head_stride, attn_S, attn_W, ctx->pm, ctx->pl, ctx->po, ctx->attn, st));
+                                       ctx->head_stride, attn_S, attn_W, ctx->pm, ctx->pl, ctx->po, ctx->attn, (p16 && ctx->p16_fuse) ? ctx->p16_y : nullptr, st));
         } else {
             // rows of one launch share caches (prefill chunks): every append must land before any row attends
             ctx->launches += 3;
@@ -1373,6 +1422,23 @@ static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float*
                                          ctx->head_stride, attn_S, ctx->pm, ctx->pl, ctx->po, ctx->attn + (size_t)g0 * Hq * D, st));
                 }
             }
+        }
+        if (p16 && ctx->p16_fuse) {
+            ctx->launches += 3;
+            // o-projection: h += Wo . attn; its epilogue packs h * ln2 (-> p16_x) and the rows' partial sums of squares (-> ssq_a)
+            VVGemv16p ao = p16_args(L.wo, nullptr, ctx->p16_y, ctx->h, ctx->p16_x, R, H, Hq * D, H);
+            ao.pk_nw = L.ln2; ao.ssq_out = ctx->ssq_a;
+            VVCHK(p16_go(ctx, st, ao, VV_EPI_RESID, 4));
+            VVGemv16p ag = p16_args(L.wg, L.wu, ctx->p16_x, nullptr, ctx->p16_act, R, I, H, 0);
+            ag.ssq_in = ctx->ssq_a; ag.ssq_tiles = H / 16; ag.eps = c.lm_eps;
+            VVCHK(p16_go(ctx, st, ag, VV_EPI_SWIGLU, 1));
+            // down projection: h += Wd . act; the next layer's QKV operand (h * its ln1 -> p16_x, ssq_b) unless this is the last layer
+            VVGemv16p ad = p16_args(L.wd, nullptr, ctx->p16_act, ctx->h, nullptr, R, H, I, H);
+            if (l + 1 < l1) {
+                ad.Yp = (unsigned char*)ctx->p16_x; ad.pk_nw = ctx->layers[l + 1].ln1; ad.ssq_out = ctx->ssq_b;
+                VVCHK(p16_go(ctx, st, ad, VV_EPI_RESID, 4));
+            } else VVCHK(p16_go(ctx, st, ad, VV_EPI_RESID, 0));
+            continue;
         }
         if (p16) {
             ctx->launches += 2;
@@ -1581,7 +1647,8 @@ extern "C" int vv_lm_logits(vv_ctx* ctx, void* stream, int n, const float* hidde
 
 // one head evaluation on 2n rows; mod/xh/hact/eps are ctx scratch. temb = t-embedding row for this step.
 static int head_eval(vv_ctx* ctx, hipStream_t st, int rows, const float* zrows, const float* temb_row, float* eps_out,
-                     const float* coef = nullptr, float cfg = 0.f, const float* mod_ready = nullptr, const float* sde_noise = nullptr) {
+                     const float* coef = nullptr, float cfg = 0.f, const float* mod_ready = nullptr, const float* sde_noise = nullptr,
+                     const unsigned char* sh_tiles = nullptr) {
     const vv_config& c = ctx->c;
     const int H = ctx->H, L = c.latent_dim, HL = c.head_layers, HF = ctx->HF, MODW = ctx->MODW;
     const float* mod = mod_ready ? mod_ready : ctx->mod;
@@ -1596,11 +1663,40 @@ static int head_eval(vv_ctx* ctx, hipStream_t st, int rows, const float* zrows, 
     const int xps = 16 * H;
     for (int l = 0; l < HL; ++l) {
         const float* base = mod + (size_t)l * 3 * H;
+        if (rows > 4 && rows <= 16 && ctx->p16_ok && (HF % 32) == 0 && ctx->p16_fuse && sh_tiles && coef && ctx->p16_head_sh) {
+            // batch rows, round 6: layer 0 packs its operand (the in-projection is not a packed-activation launch); every later layer
+            // finds x * w * (1 + scale) packed by the previous down projection's epilogue, the rows' sums of squares beside it, and the
+            // shift rows of this (step, layer) packed once per frame: y = rs * W.xm + W.shift
+            if (l == 0) {
+                ctx->launches += 1;
+                VVCHK(vv_pack16_launch(ctx->xh, H, 2, ctx->hl[l].norm, c.head_eps, base + H, base, MODW, ctx->p16_x, rows, H, st));
+                VVCHK(p16_gemv(ctx, st, ctx->hl[l].wg, ctx->hl[l].wu, ctx->p16_x, nullptr, ctx->p16_act, nullptr, nullptr, rows, HF, H, 0, 0, VV_EPI_SWIGLU));
+            } else {
+                VVGemv16p ag = p16_args(ctx->hl[l].wg, ctx->hl[l].wu, ctx->p16_x, nullptr, ctx->p16_act, rows, HF, H, 0);
+                ag.ssq_in = ctx->ssq_a; ag.ssq_tiles = H / 16; ag.eps = c.head_eps;
+                ag.Xs = (const u32x4*)(sh_tiles + (size_t)l * ctx->p16_shift_tile);
+                VVCHK(p16_go(ctx, st, ag, VV_EPI_SWIGLU, 3));
+            }
+            ctx->launches += 2;
+            VVGemv16p ad = p16_args(ctx->hl[l].wd, nullptr, ctx->p16_act, ctx->xh, ctx->p16_x, rows, H, HF, H);
+            ad.gate = base + 2 * H; ad.ld_gate = MODW; ad.ssq_out = ctx->ssq_a;
+            ad.pk_nw = (l + 1 < HL) ? ctx->hl[l + 1].norm : nullptr;
+            ad.pk_sc = mod + (size_t)(l + 1) * 3 * H + H; ad.ld_pk = MODW;          // layer l + 1's scale rows (l + 1 == HL: the final layer's)
+            VVCHK(p16_go(ctx, st, ad, VV_EPI_GATED_RESID, 4));
+            continue;
+        }
         if (rows > 4 && rows <= 16 && ctx->p16_ok && (HF % 32) == 0) {
             // batch rows: normalise + modulate + pack ONCE, then both projections stream weights against packed fragments
             ctx->launches += 3;
             VVCHK(vv_pack16_launch(ctx->xh, H, 2, ctx->hl[l].norm, c.head_eps, base + H, base, MODW, ctx->p16_x, rows, H, st));
             VVCHK(p16_gemv(ctx, st, ctx->hl[l].wg, ctx->hl[l].wu, ctx->p16_x, nullptr, ctx->p16_act, nullptr, nullptr, rows, HF, H, 0, 0, VV_EPI_SWIGLU));
+            if (l + 1 == HL && ctx->p16_fuse && sh_tiles && coef) {
+                // the last layer's down projection leaves the FINAL layer's operand (x * (1 + scale), un-normalised) packed and the rows' sums of squares
+                VVGemv16p ad = p16_args(ctx->hl[l].wd, nullptr, ctx->p16_act, ctx->xh, ctx->p16_x, rows, H, HF, H);
+                ad.gate = base + 2 * H; ad.ld_gate = MODW; ad.ssq_out = ctx->ssq_a;
+                ad.pk_nw = nullptr; ad.pk_sc = mod + (size_t)HL * 3 * H + H; ad.ld_pk = MODW;
+                VVCHK(p16_go(ctx, st, ad, VV_EPI_GATED_RESID, 4));
+            } else
             VVCHK(p16_gemv(ctx, st, ctx->hl[l].wd, nullptr, ctx->p16_act, ctx->xh, nullptr, nullptr, base + 2 * H, rows, H, HF, H, MODW, VV_EPI_GATED_RESID));
             continue;
         }
@@ -1618,6 +1714,17 @@ static int head_eval(vv_ctx* ctx, hipStream_t st, int rows, const float* zrows, 
         GEMM(g2);
     }
     const float* fb = mod + (size_t)HL * 3 * H;
+    if (rows > 4 && rows <= 16 && ctx->p16_ok && (HF % 32) == 0 && ctx->p16_fuse && sh_tiles && coef && HL > 0) {
+        // the sampler's final layer over the packed operand the last down projection left (4 workgroups that only stream: the 16-row
+        // vv_gemv form staged 16 x H modulated rows in each of its 4 workgroups, 21 us), CFG + DPM-Solver++ update in the epilogue
+        ctx->launches += 1;
+        VVGemv16p af = p16_args(ctx->h_out, nullptr, ctx->p16_x, nullptr, nullptr, rows, L, H, L);
+        af.ssq_in = ctx->ssq_a; af.ssq_tiles = H / 16; af.eps = c.head_eps;
+        af.Xs = (const u32x4*)(sh_tiles + (size_t)HL * ctx->p16_shift_tile);
+        af.z = ctx->zz; af.x0p = ctx->x0p; af.coef = coef; af.cfg = cfg; af.n_cfg = rows / 2; af.sde_noise = sde_noise;
+        VVCHK(p16_go(ctx, st, af, VV_EPI_CFG_DPM, 3));
+        return 0;
+    }
     VVGemm gf = mk_gemm(ctx->h_out, ctx->xh, eps_out, rows, L, H, H, L);
     gf.pro = VV_PRO_RMS_MOD; gf.nw = nullptr; gf.eps = c.head_eps; gf.mod_shift = fb; gf.mod_scale = fb + H; gf.ld_mod = MODW;
     gf.xa = ctx->xh_parts + (size_t)(HL & 1) * 2 * xps; gf.n_xa = xp; gf.part_stride = xps;
@@ -1666,10 +1773,19 @@ static int sample_body(vv_ctx* ctx, hipStream_t st, int n, const float* cond, co
         }
         }
     }
+    const bool sh_ok = batch_ada && rows > 4 && rows <= 16 && ctx->p16_fuse && ctx->p16_shift;
+    if (sh_ok) {
+        // the shift rows of every (solver step, layer) -- and the final layer's -- as packed bf16 tiles, one launch per frame:
+        // tile (i, l) = rows [i * rows, (i + 1) * rows) of mod_all, columns [l * 3H, l * 3H + H)
+        ctx->launches++;
+        VVCHK(vv_pack16_tiles_launch(ctx->mod_all, MODW, (int64_t)rows * MODW, ctx->c.head_layers + 1, (int64_t)3 * H, ctx->p16_shift,
+                                     (int64_t)ctx->p16_shift_tile, rows, H, ctx->n_steps * (ctx->c.head_layers + 1), st));
+    }
     for (int i = 0; i < ctx->n_steps; ++i) {
         const float* mod_i = batch_ada ? ctx->mod_all + (size_t)i * rows * MODW : nullptr;
         const float* sn = step_noise ? step_noise + (size_t)i * n * L : nullptr;
-        if (head_eval(ctx, st, rows, ctx->zz, ctx->temb + (size_t)i * H, ctx->eps, ctx->coef + i * 6, cfg, mod_i, sn)) return -1;
+        const unsigned char* sht = sh_ok ? (const unsigned char*)ctx->p16_shift + (size_t)i * (ctx->c.head_layers + 1) * ctx->p16_shift_tile : nullptr;
+        if (head_eval(ctx, st, rows, ctx->zz, ctx->temb + (size_t)i * H, ctx->eps, ctx->coef + i * 6, cfg, mod_i, sn, sht)) return -1;
     }
     HIPCHK(ctx, hipMemcpyAsync(latent_out, ctx->zz, (size_t)n * L * 4, hipMemcpyDeviceToDevice, st));
     return 0;

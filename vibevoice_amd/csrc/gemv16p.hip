@@ -85,6 +85,28 @@ __global__ __launch_bounds__(256) void vv_pack16_kernel(const float* __restrict_
 }
 
 
+// Plain conversion of MANY [T][K] fp32 row blocks to packed 16-row tiles in one launch: tile j reads rows at
+// x + (j / n_inner) * stride_outer + (j % n_inner) * stride_inner (row stride ldx) and writes xp + j * tile_bytes.  grid (16, n_tiles):
+// blockIdx.x = row, blockIdx.y = tile.  Used once per frame for the diffusion head's adaLN shift rows of every (solver step, layer).
+__global__ __launch_bounds__(256) void vv_pack16_tiles_kernel(const float* __restrict__ x, int ldx, int64_t stride_outer, int n_inner,
+                                                              int64_t stride_inner, unsigned char* __restrict__ xp, int64_t tile_bytes, int T, int K) {
+    const int t = blockIdx.x, j = blockIdx.y;
+    const float* xr = x + (int64_t)(j / n_inner) * stride_outer + (int64_t)(j % n_inner) * stride_inner + (int64_t)t * ldx;
+    unsigned char* out = xp + (int64_t)j * tile_bytes;
+    const int KT = K >> 5;
+    for (int q = threadIdx.x; q < (K >> 2); q += 256) {
+        const int k = q * 4;
+        const float4 v = (t < T) ? *reinterpret_cast<const float4*>(xr + k) : float4{0.f, 0.f, 0.f, 0.f};
+        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+        bf16x4 b;
+        b[0] = (__bf16)v.x; b[1] = (__bf16)v.y; b[2] = (__bf16)v.z; b[3] = (__bf16)v.w;
+        const int64_t tile = (k >> 5);
+        const int ol = (t & 15) + 16 * ((k & 31) >> 3);
+        *reinterpret_cast<uint2*>(out + ((tile * 64 + ol) * 16 + (k & 7) * 2)) = __builtin_bit_cast(uint2, b);
+    }
+    (void)KT;
+}
+
 constexpr int PU = 8;      // k-steps per batch
 
 // EPI: VV_EPI_BIAS (bias may be null = store), VV_EPI_RESID (Y += acc (+ bias)), VV_EPI_GATED_RESID (Y += gate * acc),
@@ -314,6 +336,14 @@ int vv_pack16_launch(const float* x, int ldx, int mode, const float* nw, float e
     if (mode == 2) hipLaunchKernelGGL((vv_pack16_kernel<2>), dim3(16), dim3(256), 0, s, x, ldx, nw, eps, sc, sh, ld_mod, (unsigned char*)xp, T, K);
     else if (mode == 1) hipLaunchKernelGGL((vv_pack16_kernel<1>), dim3(16), dim3(256), 0, s, x, ldx, nw, eps, sc, sh, ld_mod, (unsigned char*)xp, T, K);
     else hipLaunchKernelGGL((vv_pack16_kernel<0>), dim3(16), dim3(256), 0, s, x, ldx, nw, eps, sc, sh, ld_mod, (unsigned char*)xp, T, K);
+    return vv_launch_rc(0);
+}
+
+int vv_pack16_tiles_launch(const float* x, int ldx, int64_t stride_outer, int n_inner, int64_t stride_inner, void* xp, int64_t tile_bytes,
+                           int T, int K, int n_tiles, hipStream_t s) {
+    if (T < 1 || T > 16 || (K & 31) || (ldx & 3) || (stride_outer & 3) || (stride_inner & 3) || (((uintptr_t)x) & 15) || n_inner < 1 || n_tiles < 1 ||
+        n_tiles > 65535 || (tile_bytes & 15)) return -1;
+    hipLaunchKernelGGL(vv_pack16_tiles_kernel, dim3(16, n_tiles), dim3(256), 0, s, x, ldx, stride_outer, n_inner, stride_inner, (unsigned char*)xp, tile_bytes, T, K);
     return vv_launch_rc(0);
 }
 
