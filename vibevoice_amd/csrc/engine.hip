@@ -561,7 +561,12 @@ static VVGemm mk_gemm(const void* W, const float* X, float* Y, int T, int N, int
 // streams; the partial tensors are added back by the consumers (VVGemm::xa / ya).  Returns the number of EXTRA parts.
 static int ksplit_parts(const vv_ctx* ctx, VVGemm& g, float* parts, int part_stride) {
     const int n_tiles = (g.N + 15) / 16, k_tiles = (g.K + 31) / 32;
-    if (g.T > 4 || n_tiles > 128 || k_tiles < 96) return 0;
+    // few tiles x long K only: at 7B widths (224 tiles for 256 CUs) three K columns put 672 workgroups on the chip, i.e. the SAME 87.5 %
+    // balance (2.625 per CU against 3) as 224 workgroups on 256 CUs, and the consumer reads two more part tensors -- measured, not shipped
+    // (profiles/r06_down_ksplit_7b_ab.json; VVHIP_KSPLIT_MAX_TILES raises the limit for that A/B)
+    static int max_tiles = -1;
+    if (max_tiles < 0) { const char* e = getenv("VVHIP_KSPLIT_MAX_TILES"); max_tiles = e ? atoi(e) : 128; }
+    if (g.T > 4 || n_tiles > max_tiles || k_tiles < 96) return 0;
     const int ks = 3;
     g.kgrid = ks; g.yparts = parts; g.part_stride = part_stride;
     if (!vv_gemv_ok(&g)) { g.kgrid = 0; g.yparts = nullptr; g.part_stride = 0; return 0; }

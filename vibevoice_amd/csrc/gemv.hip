@@ -614,8 +614,12 @@ extern "C" int vv_gemv_launch(VVGemm a, int xs, hipStream_t s) {
 #define VV_GOP(XS_, P, E, WP_, S_)                                                                      \
     do { hipLaunchKernelGGL((vv_gemv_kernel<XS_, P, E, 4, WP_, S_>), grid, dim3(WP_ * 64), 0, s, a.W, a.W2, a.X, a.Y, a.nw, a.T, a.N, a.K, a.ldx, a.ldy, a);     \
          return vv_launch_rc(0); } while (0)
+#define VV_GOP2(P, E)   /* two rows, wide output: the 2-row form of the K-split consumer (7B-width A/B of the column split, round 6) */ \
+    do { hipLaunchKernelGGL((vv_gemv_kernel<1, P, E, 2, 4, 1>), grid, dim3(256), 0, s, a.W, a.W2, a.X, a.Y, a.nw, a.T, a.N, a.K, a.ldx, a.ldy, a);     \
+         return vv_launch_rc(0); } while (0)
 #define X(P, E)                                                                                         \
     if (a.pro == P && a.epi == E) {                                                                     \
+        if (xs == 1 && n_tiles > 256 && E == VV_EPI_SWIGLU && a.T <= 2) VV_GOP2(P, E);                   \
         if (xs == 1 && n_tiles > 256 && E == VV_EPI_SWIGLU) VV_GOP(1, P, E, 4, 1);                       \
         if (xs == 1) VV_GOP(1, P, E, 8, 1); else if (xs == 2) VV_GOP(2, P, E, 8, 1); else VV_GOP(3, P, E, 8, 1); \
     }
@@ -628,6 +632,7 @@ extern "C" int vv_gemv_launch(VVGemm a, int xs, hipStream_t s) {
         if (a.n_ya > 0) { VV_GEMV_PARTS_Y(X) }
 #undef X
 #undef VV_GOP
+#undef VV_GOP2
         return -3;
     }
     if (a.kgrid > 1) grid.y = a.kgrid;
