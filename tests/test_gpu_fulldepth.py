@@ -114,3 +114,104 @@ def test_full_depth_through_the_prompt_pass_at_the_timed_length(text_tokens):
         assert r16["within_bounds"] and r16["frame_rms_db"] <= 0.5, r16
     finally:
         model.engine.close()
+
+
+def _plant_outlier_structure(cfg, sd, first_token_id):
+    """What released Qwen2.5 checkpoints carry and N(0, 0.02^2) weights do not (no checkpoint is reachable offline):
+      * MASSIVE ACTIVATIONS: four residual channels 300 - 3000 x the typical magnitude (synthetic embeddings are N(0, 1)) in EVERY token's input -- the matching columns of
+        embed_tokens and the matching output rows of both connectors' fc2 (the decode rows' inputs) scaled up, the matching entries of every
+        RMSNorm weight scaled down (trained norms do tame their massive channels); the rows' 1/rms is then set by four channels and every
+        other channel reaches the projections two to three orders of magnitude smaller;
+      * a HEAVY-TAILED down projection in every layer (Student-t, 3 degrees of freedom, same variance as the Gaussian it replaces);
+      * an ATTENTION SINK: the first prompt token's embedding carries one more large channel, every layer's k projection maps it onto a
+        low-frequency head dimension (RoPE leaves it alone over this context) and every query head has a bias on that dimension: all
+        queries see a logit of ~50 on position 0 (> 40), next to O(1) logits elsewhere.
+    In place; returns a description for the printout."""
+    d = cfg["decoder_config"]
+    H, nl = d["hidden_size"], d["num_hidden_layers"]
+    nh, nkv = d["num_attention_heads"], d["num_key_value_heads"]
+    hd = H // nh
+    chans, facs = [7, 1033, 2050, 3333], [3000.0, 1000.0, 300.0, 300.0]
+    dev = sd["model.language_model.embed_tokens.weight"].device
+    g = torch.Generator(device=dev).manual_seed(99)
+    for c, f in zip(chans, facs):
+        sd["model.language_model.embed_tokens.weight"][:, c] *= f
+        for conn in ("acoustic_connector", "semantic_connector"):
+            sd[f"model.{conn}.fc2.weight"][c, :] *= f
+            sd[f"model.{conn}.fc2.bias"][c] *= f
+        for l in range(nl):
+            sd[f"model.language_model.layers.{l}.input_layernorm.weight"][c] /= f
+            sd[f"model.language_model.layers.{l}.post_attention_layernorm.weight"][c] /= f
+        sd["model.language_model.norm.weight"][c] /= f
+    for l in range(nl):
+        w = sd[f"model.language_model.layers.{l}.mlp.down_proj.weight"]
+        # Student-t(3) = normal / sqrt(chi2_3 / 3), scaled to the variance of the N(0, 1 / fan_in) it replaces (Var t_3 = 3)
+        z = torch.randn(w.shape, generator=g, device=dev)
+        chi = (torch.randn((3,) + tuple(w.shape), generator=g, device=dev) ** 2).sum(0) / 3.0
+        w.copy_((w.shape[1] ** -0.5 * z / chi.sqrt() / 3.0 ** 0.5).to(w.dtype))
+        del z, chi
+    cs, j, qb, sink = 123, hd // 2 - 4, 5.0, 20000.0  # sink channel, low-frequency rotary dimension (pairs with j + hd/2), query bias, its size
+    # the first token's own massive activation (what makes position 0 a sink in released models): it sets that row's 1/rms, so the
+    # normalised channel is ~sqrt(H) = 60 in every layer, k[j] = 2 x 60, logit = qb x 120 / sqrt(hd) ~ 53 against O(1) elsewhere
+    sd["model.language_model.embed_tokens.weight"][first_token_id, cs] = sink
+    for l in range(nl):
+        kw = sd[f"model.language_model.layers.{l}.self_attn.k_proj.weight"]
+        qbias = sd[f"model.language_model.layers.{l}.self_attn.q_proj.bias"]
+        for kv in range(nkv):
+            kw[kv * hd + j, cs] = 2.0
+        for h in range(nh):
+            qbias[h * hd + j] = qb
+    return (f"residual channels {chans} x {facs} (embedding columns + connector output rows up, norm weights down), Student-t(3) down_proj in "
+            f"{nl} layers, attention sink on position 0 (token {first_token_id}: channel {cs} = {sink:.0f} -> k[{j}] of every kv head, q bias {qb} on every head)")
+
+
+def test_full_depth_parity_survives_massive_activations_heavy_tails_and_an_attention_sink():
+    """every parity figure of this tree is on benign N(0, 0.02^2) weights; released checkpoints have outlier channels
+    10^2 - 10^3 x the typical magnitude, heavy-tailed projections and attention sinks.  The structure is planted into the synthetic 7B
+    (28 layers, real widths) and the SAME three-run comparison as above is held to the SAME bounds: bf16 engine (xsplit = 1 + hipGraph:
+    fp32 residual stream and norms, bf16 only at the matrix-unit inputs, fp32 softmax) vs the fp32 oracle <= 5e-2 / 0.5 dB, and at least
+    as close to fp32 as the reference's own bf16 path on identical inputs (HF Qwen2: RMSNorm upcast to fp32, softmax in fp32, everything
+    else bf16 -- SURVEY 8a row L)."""
+    from oracle import parity
+    from vibevoice_amd import synthetic
+    from vibevoice_amd.configs import CONFIGS
+    from vibevoice_amd.modeling import VibeVoiceForConditionalGenerationInference
+    cfg = copy.deepcopy(CONFIGS["7b"])
+    dev = torch.device("cuda", torch.cuda.current_device())
+    sd = dict(synthetic.random_state_dict(cfg, dev, seed=0))
+    gi = torch.Generator(device="cpu").manual_seed(7)                                       # oracle_leg's own prompt draw (seed 7)
+    vocab = cfg["decoder_config"]["vocab_size"]
+    ids = torch.randint(0, 151000 if vocab > 151000 else vocab - 64, (1, 48), generator=gi, device="cpu")
+    assert int((ids[0] == ids[0, 0]).sum()) == 1
+    what = _plant_outlier_structure(cfg, sd, int(ids[0, 0]))
+    model = VibeVoiceForConditionalGenerationInference.from_state_dict(cfg, sd, torch.bfloat16, None, n_slots=1, max_ctx=512, xsplit=1,
+                                                                       use_graph=True, enc_frames=2, max_rows=64)
+    try:
+        model.set_speech_factors(0.2, -0.05)
+        T = synthetic.TOKENS
+        fp32 = parity.oracle_leg(cfg, sd, T, 20, 1.3, 4, dev, torch.float32, t_budget=60.0)
+        assert torch.equal(fp32.ids.cpu(), torch.cat([ids[:, :-1], torch.tensor([[T.speech_start_id]])], 1))
+        bf16 = parity.oracle_leg(cfg, sd, T, 20, 1.3, 4, dev, torch.bfloat16, t_budget=60.0, teacher=fp32)
+        assert fp32.frames >= 3 and bf16.frames >= 3
+        # the planted structure is really there: the decode rows' inputs carry the massive channels
+        emb = fp32.trace.next_embeds[0].float().reshape(-1)
+        ratio = float(emb.abs().max() / emb.abs().median())
+        floor = parity.compare_legs(bf16, fp32)
+        both = parity.compare_engine(model, fp32, T, also={"bf16": bf16})
+        r32 = parity.verdict("vs_fp32", {k: v for k, v in both.items() if k != "also"})
+        r16 = parity.verdict("vs_bf16_eager", both["also"]["bf16"], floor=floor, vs_fp32=r32)
+        fmt = lambda r: (f"latent {r['latent']:.3e}, positive hidden {r['pos_hidden']:.3e}, negative hidden {r['neg_hidden']:.3e}, "
+                         f"frame RMS {r['frame_rms_db']:.3f} dB, SNR {r['frame_snr_db']:.1f} dB")
+        print(f"[full depth 7B with planted outlier structure: {what}]")
+        print(f"   LM input rows: max |x| / median |x| = {ratio:.0f}")
+        print(f"   HIP vs fp32 eager             : {fmt(r32)}")
+        print(f"   reference bf16 eager vs fp32  : {fmt(floor)}")
+        print(f"   HIP vs bf16 eager             : {fmt(r16)}")
+        assert ratio > 300.0, ratio
+        assert not r32["nonfinite_steps"] and r32["tokens_equal"], r32
+        assert r32["within_bounds"] and r32["latent"] <= 5e-2 and r32["frame_rms_db"] <= 0.5, r32
+        for k in ("latent", "pos_hidden", "neg_hidden"):
+            assert r32[k] <= 1.1 * floor[k] + 1e-3, (k, r32[k], floor[k])
+        assert r16["within_bounds"], r16
+    finally:
+        model.engine.close()

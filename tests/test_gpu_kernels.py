@@ -536,6 +536,39 @@ def test_decode_attention_ignores_cache_slots_past_the_sequence(case):
         eng.close()
 
 
+def test_prefill_attention_ignores_cache_slots_past_the_prompt():
+    """The same for the prompt pass of the bf16 mode (vv_attn_prefill4 multiplies whole 64-position stages): NaN / Inf in the cache
+    slots past the prompt's end, in every layer -- a re-used slot, imported K/V -- must not reach the prompt's hidden states.  The pass
+    zeroes the V tail of its last stage first (vv_kv_zero_v_tail_kernel); prompt lengths off and on the 64-position grid."""
+    s = build_small(LM_CASES["gqa"], xsplit=1, max_ctx=512, max_rows=256)
+    eng = s.eng
+    try:
+        cfg = s.lmcfg
+        H, kvh, hd = cfg.hidden, cfg.kv_heads, cfg.hidden // cfg.heads
+        g = synth.Gen(708)
+        for L0 in (70, 100, 128, 191):
+            x = dev(g.normal((L0, H), 1.0, mat=False), eng)
+
+            def run(poison):
+                hid = eng.new(L0, H)
+                with torch.cuda.stream(eng.stream):
+                    if poison:
+                        bad = torch.full((kvh, 512 - L0, hd), float("nan"), device=eng.device)
+                        bad[:, ::3] = float("inf")
+                    else:
+                        bad = torch.zeros((kvh, 512 - L0, hd), device=eng.device)
+                    for layer in range(cfg.layers):
+                        eng.kv_import_at(0, layer, L0, bad, bad)              # everything past the prompt
+                    eng.lm_forward_span(0, 0, L0, x, hid)
+                eng.sync()
+                return hid.clone()
+            clean, dirty = run(False), run(True)
+            assert bool(torch.isfinite(dirty).all()), L0
+            assert torch.equal(clean, dirty), L0
+    finally:
+        eng.close()
+
+
 LM_CASES = {"d64": synth.LMCfg(), "d128": synth.LMCfg(hidden=256, heads=2, kv_heads=1, inter=384),
             "gqa": synth.LMCfg(hidden=256, heads=4, kv_heads=2, inter=320, layers=3)}
 

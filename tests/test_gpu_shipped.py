@@ -624,6 +624,74 @@ def test_from_pretrained_checkpoint_directory_on_the_gpu_engine(tmp_path, monkey
     assert sorted(k for k, _ in bench.checkpoint_tensors(str(d))) == keys
 
 
+def test_long_prompt_prefill_in_one_lane_while_another_lane_decodes_a_batch():
+    """The one inter-workgroup hand-off of the path (the K split of vv_gemm4's partial round, prefill.hip) relies on dispatch order for
+    forward progress and on a timeout + one repeat for recovery; with lanes (vv_create_shared) a second context's grids share the chip
+    with it.  Lane A runs the 10,922-row 7B-width prompt pass 20 times while lane B, a forked context on its own stream and host thread,
+    keeps decoding a batch of 8 rows (the 16-row packed-activation projections + batch attention): vv_check must never fire on either
+    context, no stream capture may fall back, every repetition of the prompt pass must equal -- bit for bit -- the pass lane A ran
+    alone, and lane B's rows must equal its own solo run."""
+    import threading
+    L0 = 10922
+    c = GEOM["7b"]
+    s = build_fast(c, xsplit=1, max_ctx=L0 + 128, max_rows=L0, head_layers=1)
+    eng = s.eng
+    lane = None
+    try:
+        H = c.hidden
+        g = _FastGen(4242)
+        x = dev(g.normal((L0, H), 1.0, mat=False), eng)
+        xb = dev(g.normal((40, 16, H), 1.0, mat=False), eng)
+        lane = eng.fork(n_slots=8, max_rows=16, max_ctx=512)
+
+        def prompt_pass():
+            hid = eng.new(L0, H)
+            with torch.cuda.stream(eng.stream):
+                eng.lm_forward_span(0, 0, L0, x, hid)
+            eng.sync()                                   # stream wait + vv_check
+            return hid
+
+        def decode_batch(n_steps):
+            outs = []
+            with torch.cuda.stream(lane.stream):
+                for t in range(n_steps):
+                    out = lane.new(16, H)
+                    lane.lm_forward([(r, t) for r in range(16)], xb[t % 40], out)
+                    outs.append(out)
+            lane.sync()
+            return torch.stack(outs).float().cpu()
+        alone = prompt_pass().clone()
+        solo_b = decode_batch(40)
+        errs, got_b, stop = [], [], threading.Event()
+
+        def lane_b():
+            try:
+                torch.cuda.set_device(eng.device)
+                while not stop.is_set():
+                    got_b.append(decode_batch(40))
+            except BaseException as ex:       # noqa: BLE001
+                errs.append(ex)
+        th = threading.Thread(target=lane_b, name="vv-lane-b")
+        th.start()
+        try:
+            for rep in range(20):
+                hid = prompt_pass()
+                assert torch.equal(hid, alone), f"repetition {rep}: the prompt pass beside a decoding lane differs from the pass alone"
+        finally:
+            stop.set()
+            th.join()
+        assert not errs, errs
+        assert len(got_b) >= 1
+        for gb in got_b:
+            assert torch.equal(gb, solo_b)
+        assert eng.stat(4) == 0 and lane.stat(4) == 0          # no capture fell back to an eager run
+        print(f"[lanes] 20 prompt passes of {L0} rows beside {len(got_b)} x 40 decode steps of a 16-row batch: bit-identical, no hand-off timeout")
+    finally:
+        if lane is not None:
+            lane.close()
+        eng.close()
+
+
 # ---------------------------------------------------------------------------------------------- utterance sharding over RCCL
 def test_generate_sharded_over_an_rccl_process_group():
     """parallel.generate_sharded on the real engine with torch.distributed's "nccl" backend (= RCCL; a one-rank group is what a

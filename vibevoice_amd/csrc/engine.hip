@@ -73,6 +73,8 @@ int vv_add_rows_launch(const float* x, const float* v, float* y, int n, int C, h
 int vv_relu_launch(float* x, int n, hipStream_t s);
 int vv_kv_import_launch(const void* k, const void* v, int src_bf16, void* kc, void* vc, int L, int Hkv, int D, int64_t head_stride, int pos0, hipStream_t s);
 int vv_kv_move_launch(void* kc, void* vc, int layers, int Hkv, int D, int64_t layer_stride, int64_t head_stride, int src, int dst, hipStream_t s);
+int vv_kv_zero_v_tail_launch(void* vc, const VVRow* rows, int R, int layers, int Hkv, int D, int64_t cache_stride, int64_t layer_stride,
+                             int64_t head_stride, int max_ctx, hipStream_t s);
 int vv_pcm16_launch(const float* x, short* out, int n, int samples, hipStream_t s);
 int vv_cvt_launch(const void* src, void* dst, int64_t n, int to_bf16, hipStream_t s);
 int vv_dw_transpose_launch(const float* src, float* dst, int C, hipStream_t s);
@@ -1344,6 +1346,10 @@ static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float*
     const int hps = ctx->c.max_rows * H;
     if (contiguous && ctx->tile3_ok && R >= 64) {
         // ---- prompt prefill, bf16-activation mode: packed activations + LDS-staged MFMA GEMMs + 64-row prefill attention ----
+        // cache slots past the chunk inside its last 64-position stage: V zeroed once for every layer of this pass (0 x NaN, see misc.hip)
+        ctx->launches++;
+        VVCHK(vv_kv_zero_v_tail_launch((char*)ctx->vc + (size_t)l0 * ctx->layer_stride * 2, ctx->rows_dev, R, l1 - l0, Hkv, D, ctx->cache_stride,
+                                       ctx->layer_stride, ctx->head_stride, ctx->c.max_ctx, st));
         for (int l = l0; l < l1; ++l) {
             auto& L = ctx->layers[l];
             char* kl = (char*)ctx->kc + (size_t)l * ctx->layer_stride * 2;

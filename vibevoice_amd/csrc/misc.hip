@@ -435,6 +435,25 @@ __global__ void vv_kv_move_kernel(__bf16* __restrict__ kc, __bf16* __restrict__ 
     vb[vidx(dst)] = vb[vidx(src)];
 }
 
+// Prompt pass: the V slots between the end of the chunk and the end of its last 64-position attention stage are zeroed in every layer and
+// kv head of the chunk's cache.  vv_attn_prefill4 multiplies whole 64-position stages; the positions past the chunk get a softmax weight
+// of exactly 0 (their scores are selected to -inf), but 0 x NaN = NaN and a re-used / imported / replay-polluted slot may hold anything
+// (the decode kernels zero the fragments in registers instead: vv_zero_v_past_end).  The chunk's last row is read from the DEVICE row
+// table (the launch sits in a hipGraph keyed by shapes, not by positions).  grid (layers, kvh), block D threads.
+__global__ void vv_kv_zero_v_tail_kernel(__bf16* __restrict__ vc, const VVRow* __restrict__ rows, int R, int D, int64_t cache_stride,
+                                         int64_t layer_stride, int64_t head_stride, int max_ctx) {
+    const int d = threadIdx.x;
+    const VVRow last = rows[R - 1];
+    const int p0 = last.pos + 1;
+    const int p1 = min(max_ctx, (p0 + 63) & ~63);
+    __bf16* vb = vc + (int64_t)last.cache * cache_stride + (int64_t)blockIdx.x * layer_stride + (int64_t)blockIdx.y * head_stride;
+    for (int pos = p0; pos < p1; ++pos) {
+        const int p = pos & 31, half = p >> 4, pp = p & 15, q4 = pp >> 2, rr = pp & 3;
+        const int64_t tile = (int64_t)(pos >> 5) * (D / 16) + (d >> 4);
+        vb[(tile * 64 + (d & 15) + 16 * q4) * 8 + half * 4 + rr] = (__bf16)0.0f;
+    }
+}
+
 // 16-bit PCM of one chunk per workgroup, the arithmetic of the reference's convert_to_16_bit_wav (demo/gradio_demo.py:1058-1073):
 // peak = max|x|; if peak > 1: x /= peak (fp32, IEEE division); (x * 32767) truncated toward zero to int16.
 __global__ __launch_bounds__(256) void vv_pcm16_kernel(const float* __restrict__ x, short* __restrict__ out, int samples) {
@@ -690,6 +709,11 @@ int vv_kv_import_launch(const void* k, const void* v, int src_bf16, void* kc, vo
 }
 int vv_kv_move_launch(void* kc, void* vc, int layers, int Hkv, int D, int64_t layer_stride, int64_t head_stride, int src, int dst, hipStream_t s) {
     hipLaunchKernelGGL(vv_kv_move_kernel, dim3(layers, Hkv), dim3(D), 0, s, (__bf16*)kc, (__bf16*)vc, D, layer_stride, head_stride, src, dst);
+    return okk();
+}
+int vv_kv_zero_v_tail_launch(void* vc, const VVRow* rows, int R, int layers, int Hkv, int D, int64_t cache_stride, int64_t layer_stride,
+                             int64_t head_stride, int max_ctx, hipStream_t s) {
+    hipLaunchKernelGGL(vv_kv_zero_v_tail_kernel, dim3(layers, Hkv), dim3(D), 0, s, (__bf16*)vc, rows, R, D, cache_stride, layer_stride, head_stride, max_ctx);
     return okk();
 }
 int vv_pcm16_launch(const float* x, short* out, int n, int samples, hipStream_t s) {

@@ -184,6 +184,23 @@ class Engine:
         self.stream.synchronize()
         if self._ctx:
             self._chk(self.lib.vv_check(self._ctx, self._s), "vv_check")
+            self._warn_capture_fallbacks()
+
+    def _warn_capture_fallbacks(self):
+        """One warning per engine the first time a stream capture did not close and its work ran eagerly instead (vv_stat(ctx, 4) > 0):
+        the step is still correct, but that launch sequence will be enqueued kernel by kernel from now on -- a serving process that
+        lost its graphs should hear about it.  The known cause is a device-wide synchronize (torch.cuda.synchronize(),
+        hipDeviceSynchronize) in ANOTHER host thread while this engine was capturing: synchronize streams or events instead."""
+        if getattr(self, "_fallback_warned", False) or not self._ctx:
+            return
+        n = int(self.lib.vv_stat(self._ctx, 4))
+        if n > 0:
+            self._fallback_warned = True
+            import warnings
+            warnings.warn(f"vibevoice_amd: {n} hipGraph capture(s) of this engine did not close and ran eagerly instead -- those launch sequences "
+                          "stay un-graphed (slower steps, same results).  Usual cause: another host thread called a device-wide synchronize "
+                          "(torch.cuda.synchronize()) during the capture; synchronize streams or events in a process that generates.",
+                          RuntimeWarning, stacklevel=3)
 
     def new(self, *shape, dtype=torch.float32):
         """zero tensor whose fill is ordered on the engine stream"""

@@ -1365,7 +1365,10 @@ class VibeVoiceForConditionalGenerationInference:
         independent in the reference's loop (no cross-sample arithmetic, :393-394,549,573,594) with ONE exception this path does not
         reproduce: a row whose first frame comes later than another's costs the rows decoded with it their tokenizer conv history
         for that frame (the cache quirk described in _iterate; impossible on processor-built prompts, where every row takes its first
-        frame at step 0).  So under greedy / forced decoding each row is exactly what the batched call gives it; RNG-dependent draws (diffusion noise, do_sample) are consumed in queue
+        frame at step 0) -- and one consequence of the queue itself: the batch-level early exit with an audio_streamer (the loop ends when
+        ANY stream has finished, :443-447) can fire while rows are still waiting for a slot; those rows return as their prompt without
+        audio (the lock-step batch would have advanced them to that step) and a RuntimeWarning says so.
+        So under greedy / forced decoding each row is exactly what the batched call gives it; RNG-dependent draws (diffusion noise, do_sample) are consumed in queue
         order instead of the batch's lock-step order.  Loop lengths follow the batch: every row's cap uses the batch's padded
         width L0 (:421-422)."""
         B, L0 = input_ids.shape
@@ -1553,7 +1556,16 @@ class VibeVoiceForConditionalGenerationInference:
                         audio_streamer.end()
                     break
                 if batch_exit and audio_streamer is not None and hasattr(audio_streamer, "finished_flags") and any(audio_streamer.finished_flags):
-                    break                       # standing in for ONE batched generate(): its loop ends with the first finished stream (:443-447)
+                    # standing in for ONE batched generate(): its loop ends with the first finished stream (:443-447).  The reference's
+                    # lock-step batch has advanced EVERY row to this step by then; a queue has not -- rows still waiting for a slot come
+                    # back as their prompt with no audio.  Said once, loudly: a caller that streams a batch this large wants to know.
+                    if queue:
+                        import warnings
+                        warnings.warn(f"generate(): the batch-level early exit (a finished audio stream, modeling_vibevoice_inference.py:443-447) fired "
+                                      f"while {len(queue)} of {n_req} rows were still queued for an engine slot: the reference's lock-step batch would "
+                                      "have decoded them up to this step, here they return as their prompt without audio.  Use batches of at most "
+                                      f"{cap} rows with an audio_streamer, or generate_continuous() (no batch-level exit).", RuntimeWarning, stacklevel=3)
+                    break
                 # ---- retire by the loop-level conditions of a batch-1 generate(): range(max_steps) exhausted / max_length ----
                 keep, keep_rows = [], []
                 for i, u in enumerate(active):
