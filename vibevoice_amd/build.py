@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvvhip.so")
-SOURCES = ["gemm.hip", "gemv.hip", "gemv16p.hip", "tile.hip", "prefill.hip", "attn.hip", "misc.hip", "block1d.hip", "engine.hip"]
+SOURCES = ["gemm.hip", "gemv.hip", "gemv16p.hip", "headtail.hip", "tile.hip", "prefill.hip", "attn.hip", "misc.hip", "block1d.hip", "engine.hip"]
 HEADERS = [os.path.join(CSRC, "vv_common.h"), os.path.join(os.path.dirname(HERE), "include", "vvhip.h")]
 
 

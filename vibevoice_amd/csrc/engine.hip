@@ -85,6 +85,8 @@ int vv_pack16_launch(const float* x, int ldx, int mode, const float* nw, float e
 int vv_gemv16p_launch(const void* W, const void* W2, const void* Xp, float* Y, void* Yp, const float* bias, const float* gate,
                       int T, int N, int K, int ldy, int ld_gate, int epi, hipStream_t s);
 int vv_gemv16p_launch2(const VVGemv16p* a, int epi, int flags, hipStream_t s);
+int vv_head_tail_ok(const VVTail* a);
+int vv_head_tail_launch(const VVTail* a, int tiles_per_wg, hipStream_t s);
 int vv_pack16_tiles_launch(const float* x, int ldx, int64_t stride_outer, int n_inner, int64_t stride_inner, void* xp, int64_t tile_bytes,
                            int T, int K, int n_tiles, hipStream_t s);
 int vv_ada_pack_launch(const float* cproj, const float* temb, void* xp, int rows, int n_steps, int H, hipStream_t s);
@@ -235,6 +237,9 @@ struct vv_ctx {
     float* ada_in = nullptr;
     void* ada_p = nullptr;                 // the same rows as packed bf16 MFMA fragments (bf16 mode: one tile GEMM for all steps)
     float *cproj = nullptr, *mod = nullptr, *zz = nullptr, *x0p = nullptr, *xh = nullptr, *hact = nullptr, *eps = nullptr;
+    // second generation of the sampler's state (headtail.hip: a solver step reads one generation and writes the other)
+    float *zz2 = nullptr, *x0p2 = nullptr, *xh2 = nullptr;
+    int head_tail_tpw = 0;          // in-projection tiles per workgroup of the fused seam; 0 = off (VVHIP_HEAD_TAIL=0 / exact modes)
     float *tmp1 = nullptr, *tmp2 = nullptr;
     // connectors
     struct Conn { void *fc1, *fc2; float *b1, *b2, *norm; } ac_conn, sem_conn;
@@ -1044,6 +1049,14 @@ static int create_impl(const vv_config* cfg, vv_ctx* parent, vv_ctx** out) {
     ctx->zz = (float*)dalloc(ctx, (size_t)R2 * L * 4);
     ctx->x0p = (float*)dalloc(ctx, (size_t)R2 * L * 4);
     ctx->xh = (float*)dalloc(ctx, (size_t)R2 * H * 4);
+    ctx->zz2 = (float*)dalloc(ctx, (size_t)R2 * L * 4);
+    ctx->x0p2 = (float*)dalloc(ctx, (size_t)R2 * L * 4);
+    ctx->xh2 = (float*)dalloc(ctx, (size_t)R2 * H * 4);
+    {   // decode rows of the bf16 mode: final layer + solver update + next in-projection as one launch (headtail.hip)
+        const char* e = getenv("VVHIP_HEAD_TAIL");
+        const int tpw = e ? atoi(e) : 4;
+        ctx->head_tail_tpw = (c.xsplit == 1 && L == 64 && (H % 32) == 0 && (tpw == 1 || tpw == 2 || tpw == 4 || tpw == 8)) ? tpw : 0;
+    }
     ctx->xh_parts = (float*)dalloc(ctx, (size_t)4 * R2 * H * 4);      // two generations: a layer reads one while writing the other
     ctx->hact = (float*)dalloc(ctx, (size_t)R2 * HF * 4);
     ctx->eps = (float*)dalloc(ctx, (size_t)R2 * L * 4);
@@ -1659,17 +1672,25 @@ extern "C" int vv_lm_logits(vv_ctx* ctx, void* stream, int n, const float* hidde
 // one head evaluation on 2n rows; mod/xh/hact/eps are ctx scratch. temb = t-embedding row for this step.
 static int head_eval(vv_ctx* ctx, hipStream_t st, int rows, const float* zrows, const float* temb_row, float* eps_out,
                      const float* coef = nullptr, float cfg = 0.f, const float* mod_ready = nullptr, const float* sde_noise = nullptr,
-                     const unsigned char* sh_tiles = nullptr) {
+                     const unsigned char* sh_tiles = nullptr, int gen = 0, bool have_x = false, bool seam = false) {
+    // gen / have_x / seam (sampler, decode rows, bf16 mode): the step's state is generation `gen` (xh / zz / x0p or their second copies);
+    // have_x: the previous step's seam launch already produced this step's in-projection; seam: end this step with the fused launch
+    // (final layer + CFG + solver update + the NEXT step's in-projection, written to the other generation) instead of the final layer
     const vv_config& c = ctx->c;
     const int H = ctx->H, L = c.latent_dim, HL = c.head_layers, HF = ctx->HF, MODW = ctx->MODW;
     const float* mod = mod_ready ? mod_ready : ctx->mod;
+    float* const xh = gen ? ctx->xh2 : ctx->xh;
+    float* const zcur = gen ? ctx->zz2 : ctx->zz;
+    float* const x0cur = gen ? ctx->x0p2 : ctx->x0p;
     if (!mod_ready) {
         VVGemm ga = mk_gemm(ctx->h_ada, ctx->cproj, ctx->mod, rows, MODW, H, H, MODW);
         ga.pro = VV_PRO_ADD_SILU; ga.addvec = temb_row; ga.nt = 1;
         GEMM(ga);
     }
-    VVGemm gi = mk_gemm(ctx->h_in, zrows, ctx->xh, rows, H, L, L, H);
-    GEMM(gi);
+    if (!have_x) {
+        VVGemm gi = mk_gemm(ctx->h_in, zrows, xh, rows, H, L, L, H);
+        GEMM(gi);
+    }
     int xp = 0;                                    // extra parts xh currently consists of
     const int xps = 16 * H;
     for (int l = 0; l < HL; ++l) {
@@ -1680,7 +1701,7 @@ static int head_eval(vv_ctx* ctx, hipStream_t st, int rows, const float* zrows, 
             // shift rows of this (step, layer) packed once per frame: y = rs * W.xm + W.shift
             if (l == 0) {
                 ctx->launches += 1;
-                VVCHK(vv_pack16_launch(ctx->xh, H, 2, ctx->hl[l].norm, c.head_eps, base + H, base, MODW, ctx->p16_x, rows, H, st));
+                VVCHK(vv_pack16_launch(xh, H, 2, ctx->hl[l].norm, c.head_eps, base + H, base, MODW, ctx->p16_x, rows, H, st));
                 VVCHK(p16_gemv(ctx, st, ctx->hl[l].wg, ctx->hl[l].wu, ctx->p16_x, nullptr, ctx->p16_act, nullptr, nullptr, rows, HF, H, 0, 0, VV_EPI_SWIGLU));
             } else {
                 VVGemv16p ag = p16_args(ctx->hl[l].wg, ctx->hl[l].wu, ctx->p16_x, nullptr, ctx->p16_act, rows, HF, H, 0);
@@ -1689,7 +1710,7 @@ static int head_eval(vv_ctx* ctx, hipStream_t st, int rows, const float* zrows, 
                 VVCHK(p16_go(ctx, st, ag, VV_EPI_SWIGLU, 3));
             }
             ctx->launches += 2;
-            VVGemv16p ad = p16_args(ctx->hl[l].wd, nullptr, ctx->p16_act, ctx->xh, ctx->p16_x, rows, H, HF, H);
+            VVGemv16p ad = p16_args(ctx->hl[l].wd, nullptr, ctx->p16_act, xh, ctx->p16_x, rows, H, HF, H);
             ad.gate = base + 2 * H; ad.ld_gate = MODW; ad.ssq_out = ctx->ssq_a;
             ad.pk_nw = (l + 1 < HL) ? ctx->hl[l + 1].norm : nullptr;
             ad.pk_sc = mod + (size_t)(l + 1) * 3 * H + H; ad.ld_pk = MODW;          // layer l + 1's scale rows (l + 1 == HL: the final layer's)
@@ -1699,26 +1720,26 @@ static int head_eval(vv_ctx* ctx, hipStream_t st, int rows, const float* zrows, 
         if (rows > 4 && rows <= 16 && ctx->p16_ok && (HF % 32) == 0) {
             // batch rows: normalise + modulate + pack ONCE, then both projections stream weights against packed fragments
             ctx->launches += 3;
-            VVCHK(vv_pack16_launch(ctx->xh, H, 2, ctx->hl[l].norm, c.head_eps, base + H, base, MODW, ctx->p16_x, rows, H, st));
+            VVCHK(vv_pack16_launch(xh, H, 2, ctx->hl[l].norm, c.head_eps, base + H, base, MODW, ctx->p16_x, rows, H, st));
             VVCHK(p16_gemv(ctx, st, ctx->hl[l].wg, ctx->hl[l].wu, ctx->p16_x, nullptr, ctx->p16_act, nullptr, nullptr, rows, HF, H, 0, 0, VV_EPI_SWIGLU));
             if (l + 1 == HL && ctx->p16_fuse && sh_tiles && coef) {
                 // the last layer's down projection leaves the FINAL layer's operand (x * (1 + scale), un-normalised) packed and the rows' sums of squares
-                VVGemv16p ad = p16_args(ctx->hl[l].wd, nullptr, ctx->p16_act, ctx->xh, ctx->p16_x, rows, H, HF, H);
+                VVGemv16p ad = p16_args(ctx->hl[l].wd, nullptr, ctx->p16_act, xh, ctx->p16_x, rows, H, HF, H);
                 ad.gate = base + 2 * H; ad.ld_gate = MODW; ad.ssq_out = ctx->ssq_a;
                 ad.pk_nw = nullptr; ad.pk_sc = mod + (size_t)HL * 3 * H + H; ad.ld_pk = MODW;
                 VVCHK(p16_go(ctx, st, ad, VV_EPI_GATED_RESID, 4));
             } else
-            VVCHK(p16_gemv(ctx, st, ctx->hl[l].wd, nullptr, ctx->p16_act, ctx->xh, nullptr, nullptr, base + 2 * H, rows, H, HF, H, MODW, VV_EPI_GATED_RESID));
+            VVCHK(p16_gemv(ctx, st, ctx->hl[l].wd, nullptr, ctx->p16_act, xh, nullptr, nullptr, base + 2 * H, rows, H, HF, H, MODW, VV_EPI_GATED_RESID));
             continue;
         }
-        VVGemm g1 = mk_gemm(ctx->hl[l].wg, ctx->xh, ctx->hact, rows, HF, H, H, HF);
+        VVGemm g1 = mk_gemm(ctx->hl[l].wg, xh, ctx->hact, rows, HF, H, H, HF);
         g1.W2 = (const u32x4*)ctx->hl[l].wu; g1.pro = VV_PRO_RMS_MOD; g1.nw = ctx->hl[l].norm; g1.eps = c.head_eps;
         g1.mod_shift = base; g1.mod_scale = base + H; g1.ld_mod = MODW; g1.epi = VV_EPI_SWIGLU; g1.nt = 1;
         float* cur = ctx->xh_parts + (size_t)(l & 1) * 2 * xps;          // parts written by layer l-1
         float* nxt = ctx->xh_parts + (size_t)((l + 1) & 1) * 2 * xps;    // parts layer l writes
         g1.xa = cur; g1.n_xa = xp; g1.part_stride = xps;
         GEMM(g1);
-        VVGemm g2 = mk_gemm(ctx->hl[l].wd, ctx->hact, ctx->xh, rows, H, HF, HF, H);
+        VVGemm g2 = mk_gemm(ctx->hl[l].wd, ctx->hact, xh, rows, H, HF, HF, H);
         g2.epi = VV_EPI_GATED_RESID; g2.gate = base + 2 * H; g2.ld_gate = MODW; g2.nt = 1;
         g2.ya = cur; g2.n_ya = xp; g2.part_stride = xps;
         xp = ksplit_parts(ctx, g2, nxt, xps);
@@ -1732,15 +1753,35 @@ static int head_eval(vv_ctx* ctx, hipStream_t st, int rows, const float* zrows, 
         VVGemv16p af = p16_args(ctx->h_out, nullptr, ctx->p16_x, nullptr, nullptr, rows, L, H, L);
         af.ssq_in = ctx->ssq_a; af.ssq_tiles = H / 16; af.eps = c.head_eps;
         af.Xs = (const u32x4*)(sh_tiles + (size_t)HL * ctx->p16_shift_tile);
-        af.z = ctx->zz; af.x0p = ctx->x0p; af.coef = coef; af.cfg = cfg; af.n_cfg = rows / 2; af.sde_noise = sde_noise;
+        af.z = zcur; af.x0p = x0cur; af.coef = coef; af.cfg = cfg; af.n_cfg = rows / 2; af.sde_noise = sde_noise;
         VVCHK(p16_go(ctx, st, af, VV_EPI_CFG_DPM, 3));
         return 0;
     }
-    VVGemm gf = mk_gemm(ctx->h_out, ctx->xh, eps_out, rows, L, H, H, L);
+    if (seam && coef && rows == 2 && ctx->head_tail_tpw > 0) {
+        VVTail t{};
+        t.Wout = (const u32x4*)ctx->h_out; t.Win = (const u32x4*)ctx->h_in; t.bin = nullptr;
+        t.X = xh; t.xa = ctx->xh_parts + (size_t)(HL & 1) * 2 * xps; t.n_xa = xp; t.part_stride = xps;
+        t.sc = fb + H; t.sh = fb; t.ld_mod = MODW;
+        t.Xout = gen ? ctx->xh : ctx->xh2;
+        t.z_in = zcur; t.x0p_in = x0cur; t.z_out = gen ? ctx->zz : ctx->zz2; t.x0p_out = gen ? ctx->x0p : ctx->x0p2;
+        t.coef = coef; t.cfg = cfg; t.n_cfg = rows / 2; t.sde_noise = sde_noise;
+        t.T = rows; t.H = H; t.L = L; t.eps = c.head_eps;
+        if (vv_head_tail_ok(&t)) {
+            ctx->launches++;
+            if (ctx->prof_on) {
+                const VVTail tc = t; const int tpw = ctx->head_tail_tpw;
+                ctx->prof_other.push_back({3, (double)vv_packed_elems(L, H) * 2.0 + (double)vv_packed_elems(H, L) * 2.0 + (double)rows * H * 8.0,
+                                           [=](hipStream_t s2) { return vv_head_tail_launch(&tc, tpw, s2); }});
+            }
+            VVCHK(vv_head_tail_launch(&t, ctx->head_tail_tpw, st));
+            return 1;          // the next step's in-projection is done (generation gen ^ 1)
+        }
+    }
+    VVGemm gf = mk_gemm(ctx->h_out, xh, eps_out, rows, L, H, H, L);
     gf.pro = VV_PRO_RMS_MOD; gf.nw = nullptr; gf.eps = c.head_eps; gf.mod_shift = fb; gf.mod_scale = fb + H; gf.ld_mod = MODW;
     gf.xa = ctx->xh_parts + (size_t)(HL & 1) * 2 * xps; gf.n_xa = xp; gf.part_stride = xps;
     if (coef) {   // CFG + DPM-Solver++ update fused into the epilogue: the noisy latent is rewritten in place
-        gf.epi = VV_EPI_CFG_DPM; gf.z = ctx->zz; gf.x0p = ctx->x0p; gf.coef = coef; gf.cfg = cfg; gf.n_cfg = rows / 2;
+        gf.epi = VV_EPI_CFG_DPM; gf.z = zcur; gf.x0p = x0cur; gf.coef = coef; gf.cfg = cfg; gf.n_cfg = rows / 2;
         gf.sde_noise = sde_noise;
     }
     GEMM(gf);
@@ -1792,13 +1833,21 @@ static int sample_body(vv_ctx* ctx, hipStream_t st, int n, const float* cond, co
         VVCHK(vv_pack16_tiles_launch(ctx->mod_all, MODW, (int64_t)rows * MODW, ctx->c.head_layers + 1, (int64_t)3 * H, ctx->p16_shift,
                                      (int64_t)ctx->p16_shift_tile, rows, H, ctx->n_steps * (ctx->c.head_layers + 1), st));
     }
+    int gen = 0; bool have_x = false;
     for (int i = 0; i < ctx->n_steps; ++i) {
         const float* mod_i = batch_ada ? ctx->mod_all + (size_t)i * rows * MODW : nullptr;
         const float* sn = step_noise ? step_noise + (size_t)i * n * L : nullptr;
         const unsigned char* sht = sh_ok ? (const unsigned char*)ctx->p16_shift + (size_t)i * (ctx->c.head_layers + 1) * ctx->p16_shift_tile : nullptr;
-        if (head_eval(ctx, st, rows, ctx->zz, ctx->temb + (size_t)i * H, ctx->eps, ctx->coef + i * 6, cfg, mod_i, sn, sht)) return -1;
+        // decode rows, bf16 mode: every step but the last ends with the fused seam (final layer + CFG + solver update + the next step's
+        // in-projection, headtail.hip), which leaves the next step's state in the other generation of (xh, zz, x0p)
+        const bool seam = (i + 1 < ctx->n_steps) && rows == 2 && ctx->head_tail_tpw > 0;
+        const int hr = head_eval(ctx, st, rows, gen ? ctx->zz2 : ctx->zz, ctx->temb + (size_t)i * H, ctx->eps, ctx->coef + i * 6, cfg, mod_i, sn, sht,
+                                 gen, have_x, seam);
+        if (hr < 0) return -1;
+        have_x = (hr == 1);
+        if (have_x) gen ^= 1;
     }
-    HIPCHK(ctx, hipMemcpyAsync(latent_out, ctx->zz, (size_t)n * L * 4, hipMemcpyDeviceToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(latent_out, gen ? ctx->zz2 : ctx->zz, (size_t)n * L * 4, hipMemcpyDeviceToDevice, st));
     return 0;
 }
 

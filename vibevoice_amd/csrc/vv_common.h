@@ -129,6 +129,21 @@ struct VVGemv16p {
     float* z; float* x0p; const float* coef; float cfg; int n_cfg; const float* sde_noise;
 };
 
+// ---- the seam between two solver steps of the diffusion head (headtail.hip): final layer + CFG + DPM-Solver++ update + in-projection ----
+struct VVTail {
+    const u32x4* Wout;     // packed [L][H]   final layer (adaLN-modulated norm without affine, then linear)
+    const u32x4* Win;      // packed [H][L]   noisy_images_proj of the NEXT step
+    const float* bin;      // [H] or null
+    const float* X;        // residual rows [T][H] after the last head layer (+ n_xa part tensors: xa, part_stride)
+    const float* xa; int n_xa, part_stride;
+    const float* sc; const float* sh; int ld_mod;      // the final layer's scale / shift rows [T][ld_mod]
+    float* Xout;           // the next step's residual rows [T][H] (a DIFFERENT buffer than X)
+    const float* z_in; const float* x0p_in;            // [2n][L], [n][L]: this step's state
+    float* z_out; float* x0p_out;                      // the next step's state (different buffers)
+    const float* coef; float cfg; int n_cfg; const float* sde_noise;
+    int T, H, L; float eps;
+};
+
 // up to 8 utterance slots of one launch (per-utterance kernels take the slot from blockIdx.y / .z)
 struct VVSlotIds { int n; int id[8]; };
 __device__ __forceinline__ int vv_slot_id(const int (&id)[8], int j) {     // select chain: no dynamic indexing of a by-value kernel argument
