@@ -2,7 +2,7 @@
 # The round-end measurement suite on one MI355X box (run through gpurun; ~25 GPU-minutes):   bash tools/round_end.sh <tag> [part ...]
 # parts (default: all but utterance): tests bench configs traces pmc dist lanes cpuwin utterance
 # Everything lands under gpurun_out/<tag>_final/ with the file names profiles/ uses (<tag>_*); copy what is to be judged into profiles/.
-R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=${1:-r05}; shift; PARTS=${*:-tests bench configs traces pmc dist lanes cpuwin}
+R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=${1:-r06}; shift; PARTS=${*:-tests bench configs traces pmc dist lanes cpuwin}
 O=$R/gpurun_out/${TAG}_final; mkdir -p $O; cd $R; export TMPDIR=/tmp
 Q="--no-cpu-baseline --no-eager-baseline --skip-extra --no-parity"
 has() { [[ " $PARTS " == *" $1 "* ]]; }
