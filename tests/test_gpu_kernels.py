@@ -668,10 +668,12 @@ def test_bf16_activation_mode_tolerance():
         eng.close()
 
 
-@pytest.mark.parametrize("n", [3, 8])
+@pytest.mark.parametrize("n", [1, 3, 8])
 def test_bf16_mode_batched_sampler_rows(n):
     """8 utterances diffusing together = 16 head rows: the 16-row adaLN / gated-residual / CFG+DPM GEMV forms (bench mode
-    only) against the oracle sampler, SURVEY 8d tolerance for bf16 activations."""
+    only) against the oracle sampler, SURVEY 8d tolerance for bf16 activations.  n = 1 (two rows): the decode forms of the bf16 mode,
+    i.e. the folded shift operand and the solver-step seam launch (headtail.hip) over its double-buffered state, deterministic and
+    stochastic solver."""
     s = build_small(synth.LMCfg(), xsplit=1, n_slots=8)
     eng = s.eng
     try:

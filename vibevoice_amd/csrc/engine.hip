@@ -1558,7 +1558,9 @@ extern "C" int vv_lm_forward_range(vv_ctx* ctx, void* stream, int n_rows, const 
     // ... and no more splits than it takes to put ~256 workgroups on the chip: with eight 32K-context utterances in flight the
     // rows themselves are the parallelism (8 splits of 4096 positions: 122 us per layer against 162 us with 32 splits).
     // Measured and left alone: 512 / 256 positions per split (no gain once the merge is its own launch), 8-wave workgroups.
-    constexpr int split_pos = 1024, target_wgs = 256;
+    constexpr int split_pos = 1024;
+    static int target_wgs = -1;            // workgroups a launch of long rows aims for (VVHIP_ATTN_TARGET_WGS: A/B of round 6)
+    if (target_wgs < 0) { const char* e = getenv("VVHIP_ATTN_TARGET_WGS"); target_wgs = e ? std::max(64, atoi(e)) : 256; }
     int n_long = 0;
     for (int i = 0; i < n_rows; ++i) if (rows[i].pos + 1 > split_pos) ++n_long;
     const int by_wgs = std::max(1, (target_wgs + std::max(1, n_long) * ctx->Hkv - 1) / (std::max(1, n_long) * ctx->Hkv));
