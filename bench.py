@@ -632,7 +632,8 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline, with_parity=False):
         ach = by_rep / 1e9 / (ms_rep / 1e3) if ms_rep > 0 else 0.0                      # GB/s
         # (2) secondary: hipEvent pair around each EAGER launch minus an in-stream empty pair (a lower bound on the duration)
         ach_pair = by / 1e9 / (ms_cal / 1e3) if ms_cal > 0 else 0.0
-        traffic, traffic_src = pmc_traffic(model_key, "vv_gemv_kernel", by_rep / max(1, n_rep))
+        pmc_key = model_key if B == 1 else f"{model_key}-batch{B}"       # the batch leg has its own FETCH_SIZE pass (other launch geometry)
+        traffic, traffic_src = pmc_traffic(pmc_key, "vv_gemv_kernel", by_rep / max(1, n_rep))
         roof = {"bound": "hbm", "kernel": "vv_gemv_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "traffic_source": traffic_src,
@@ -656,7 +657,7 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline, with_parity=False):
             if not n_f or ms_f <= 0:
                 return None
             a_f = by_f / 1e9 / (ms_f / 1e3)
-            tr, tsrc = pmc_traffic(model_key, name.split(" ")[0], by_f / n_f)
+            tr, tsrc = pmc_traffic(pmc_key, name.split(" ")[0], by_f / n_f)
             return {"kernel": name, "achieved": round(a_f, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a_f / HBM_PEAK_GBS, 4),
                     "launches_per_step": round(n_f / 3 / kprof, 1), "avg_launch_us": round(ms_f * 1e3 / n_f, 3),
                     "bytes_per_launch": round(by_f / n_f, 1), "traffic": tr, "traffic_source": tsrc}

@@ -13,4 +13,6 @@ run() {   # key, bench args, bench json
 run 7b "--steps 40 --warmup 2" 7b $B/${TAG}_bench_default.json
 run 1p5b "--workload 1p5b --steps 100 --warmup 2" 1.5b $B/${TAG}_1p5b.json
 run streaming "--workload streaming --steps 60" 0.5b-streaming $B/${TAG}_streaming.json
+# the configs[3] per-GPU unit (8 utterances in lock-step: vv_gemv16p_kernel + batch attention) under its own key
+run 7b_batch8 "--batch 8 --speakers 4 --text-tokens 10569 --steps 20 --warmup 2" 7b-batch8 $B/${TAG}_7b_4spk_batch8_32k.json
 cp profiles/pmc_traffic.json $O/pmc_traffic.json

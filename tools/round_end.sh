@@ -39,7 +39,7 @@ if has traces; then
     timeout 600 rocprofv3 --kernel-trace -d $O/p_$name -o t -- python bench.py $a $Q --no-roofline > $O/${TAG}_${name}_under_rocprof.json 2> $O/rp_$name.err
     python tools/rocprof_summary.py $O/p_$name/t_results.db $O/${TAG}_$name > $O/${TAG}_${name}_top.txt 2>&1; rm -rf $O/p_$name; head -12 $O/${TAG}_${name}_top.txt
   done
-  timeout 600 rocprofv3 --kernel-trace --stats -d $O/p_stats -o s -- python bench.py --steps 20 --warmup 5 $Q --no-roofline > /dev/null 2> $O/rp_stats.err
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_stats -o s -- python bench.py --steps 20 --warmup 5 $Q --no-roofline > /dev/null 2> $O/rp_stats.err
   cp $O/p_stats/*/s_kernel_stats.csv $O/${TAG}_bench_default_rocprofv3_stats.csv 2>/dev/null || find $O/p_stats -name "*kernel_stats*" -exec cp {} $O/${TAG}_bench_default_rocprofv3_stats.csv \; ; rm -rf $O/p_stats
 fi
 if has pmc; then
