@@ -239,7 +239,9 @@ int vv_profile_replay(vv_ctx* ctx, void* stream, int reps, int64_t* launches, do
 int vv_profile_replay_family(vv_ctx* ctx, void* stream, int family, int reps, int64_t* launches, double* total_ms, double* bytes);
 /* what = 0: kernel launches issued by the last engine call (graph nodes when replayed); 1: hipGraph executables cached; 2 / 3: raw
  * timings of the last profile window; 4: stream captures that did not close cleanly and were run eagerly instead (seen when
- * several host threads drive several contexts: another thread's activity can invalidate a capture; the result is unaffected) */
+ * several host threads drive several contexts: another thread's activity can invalidate a capture; the result is unaffected);
+ * 5: nodes of the captured graphs that are not kernel launches -- 0 by construction: copies and fills inside captured sequences are
+ * kernels of the library, because a memset node of a replayed graph was seen to fill with stale words */
 int64_t vv_stat(vv_ctx* ctx, int what);
 
 #pragma GCC visibility pop

@@ -36,6 +36,8 @@ def test_full_depth_bf16_engine_against_bf16_pytorch_rocm_eager(model_key, n_sol
         assert fp32.frames >= 3 and bf16.frames >= 3, (fp32.frames, bf16.frames)
         floor = parity.compare_legs(bf16, fp32)                   # the reference bf16 path's own rounding noise at this depth
         both = parity.compare_engine(model, fp32, T, also={"bf16": bf16})
+        # captured sequences hold kernel nodes only: no memset / memcpy nodes (tests/test_gpu_generate.py::assert_kernel_nodes_only)
+        assert model.engine.stat(1) > 0 and model.engine.stat(5) == 0, (model.engine.stat(1), model.engine.stat(5))
         r32 = parity.verdict("vs_fp32", {k: v for k, v in both.items() if k != "also"})
         r16 = parity.verdict("vs_bf16_eager", both["also"]["bf16"], floor=floor, vs_fp32=r32)
         fmt = lambda r: (f"latent {r['latent']:.3e}, positive hidden {r['pos_hidden']:.3e}, negative hidden {r['neg_hidden']:.3e}, "

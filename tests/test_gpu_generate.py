@@ -213,8 +213,18 @@ def test_generate_with_graphs():
         forced = [[D, D, D, D, E, S, D, D, D, X]]
         o, h = run_both(s, 1, forced, with_speech=True)
         check(o, h)
+        assert_kernel_nodes_only(s.eng)
     finally:
         s.eng.close()
+
+
+def assert_kernel_nodes_only(eng):
+    """Round 6: a MEMSET node of a replayed hipGraph was seen to fill its range with stale words (host stack addresses among them) instead of the
+    captured zero once other graph executables had come and gone in the process -- the sampler's previous-x0 buffer then held a NaN bit
+    pattern on some GPUs of the pool and not on others (profiles/r06_memset_node_ab.txt).  Copies and fills inside captured sequences are
+    kernels of the library now; vv_stat(ctx, 5) counts the nodes of every captured graph that are not kernel launches."""
+    assert eng.stat(1) > 0, "the run captured no graph at all"
+    assert eng.stat(5) == 0, f"{eng.stat(5)} memset / memcpy nodes inside the engine's captured graphs"
 
 
 def test_speculative_sampler_is_invisible(sm):
@@ -524,6 +534,7 @@ def test_generate_batch8_desynchronised():
                          _forced_tokens=forced, _noise_fn=noise_fn, _trace=htr, show_progress_bar=False)
         # xsplit=2 (the two-term activation mode the 16-row GEMV forms exist in): ~fp24-class arithmetic
         check((oseq, oaud, omax, otr), (out, htr), lat_tol=2e-2, wav_tol=3e-2)
+        assert_kernel_nodes_only(s.eng)
     finally:
         s.eng.close()
 

@@ -65,6 +65,9 @@ int vv_shift_rows_launch(const void* tab, int n_entries, int maxC, hipStream_t s
 int vv_zero_hist_launch(const void* tab, int n_entries, hipStream_t s);
 int vv_cfg_dpm_launch(const float* eps, float* x, float* x0_prev, const float* coef, float cfg, int n, int L, const float* sde_noise, hipStream_t s);
 int vv_affine_launch(const float* x, float* y, float mul, float add, int n, hipStream_t s);
+int vv_copy_launch(void* dst, const void* src, size_t bytes, hipStream_t s);
+int vv_zero_launch(void* dst, size_t bytes, hipStream_t s);
+int vv_sampler_init_launch(const float* noise, float* z, float* x0p, int nL, hipStream_t s);
 int vv_add_launch(const float* a, const float* b, float* y, int n, hipStream_t s);
 int vv_tfreq_launch(const float* t, float* out, int n, hipStream_t s);
 int vv_silu_launch(float* x, int n, hipStream_t s);
@@ -261,6 +264,10 @@ struct vv_ctx {
     // vv_create returns the parent's k-th one (same model configuration -> same sequence); everything else (KV caches, activations,
     // tokenizer state, graphs, staging) is the child's own, so two contexts decode concurrently on two streams over one weight copy
     vv_ctx* parent = nullptr; int n_children = 0; bool zombie = false, creating = false;
+    // VVHIP_NAN_PROBE=1 (debugging): scan kernels behind the sampler's launches, inside the captured graph as well; the first stage whose
+    // output holds a non-finite value is printed after the call (nan_probe())
+    unsigned* probe_rec = nullptr; std::vector<std::string> probe_names; int probe_on = -1; int probe_calls = 0;
+    int64_t foreign_nodes = 0;        // nodes of captured graphs that are not kernel launches (memset / memcpy nodes: none must exist, see misc.hip's copy kernels)
     int64_t capture_fallbacks = 0; char last_capture_issue[256] = "";     // stream captures that fell back to an eager run (graphed())
     std::vector<std::pair<void*, size_t>> wallocs; size_t wshare_i = 0;
     int64_t launches = 0;
@@ -298,6 +305,56 @@ static int fail(vv_ctx* ctx, const char* fmt, ...) {
 #define HIPCHK(ctx, e) do { hipError_t _e = (e); if (_e != hipSuccess) return fail(ctx, "%s:%d hip error %s", __FILE__, __LINE__, hipGetErrorString(_e)); } while (0)
 #define VVCHK(e) do { int _r = (e); if (_r != 0) return _r < 0 ? fail(ctx, "%s:%d launch failed (%d): hip error %d (%s)", __FILE__, __LINE__, _r, g_vv_launch_err, hipGetErrorString((hipError_t)g_vv_launch_err)) : _r; } while (0)
 
+static __global__ void vv_nan_probe_kernel(const float* __restrict__ p, int n, unsigned* __restrict__ rec) {
+    unsigned cnt = 0, first = 0xffffffffu, mx = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float v = p[i];
+        if (!(fabsf(v) <= 3.0e38f)) { cnt++; first = min(first, (unsigned)i); }
+        else mx = max(mx, __float_as_uint(fabsf(v)));
+    }
+    if (cnt) { atomicAdd(rec, cnt); atomicMax(rec + 1, 0xffffffffu - first); }
+    atomicMax(rec + 2, mx);
+}
+constexpr int PROBE_MAX = 1024;
+static void nan_probe(vv_ctx* ctx, hipStream_t st, const char* name, const void* p, size_t n) {
+    if (ctx->probe_on < 0) { const char* e = getenv("VVHIP_NAN_PROBE"); ctx->probe_on = (e && (e[0] == '1' || e[0] == '2')) ? 1 : 0; }
+    if (!ctx->probe_on || !p || n == 0) return;
+    if (!ctx->probe_rec) { if (hipMalloc(&ctx->probe_rec, PROBE_MAX * 16) != hipSuccess) { ctx->probe_on = 0; return; } hipMemset(ctx->probe_rec, 0, PROBE_MAX * 16); }
+    const int id = (int)ctx->probe_names.size();
+    if (id >= PROBE_MAX) return;
+    ctx->probe_names.push_back(name);
+    if (id == 0) {       // VVHIP_NAN_PROBE=2: reset the records with a MEMSET NODE (the form that showed the stale-pattern fills); 1: with a kernel
+        const char* e = getenv("VVHIP_NAN_PROBE");
+        if (e && e[0] == '2') (void)hipMemsetAsync(ctx->probe_rec, 0, PROBE_MAX * 16, st); else (void)vv_zero_launch(ctx->probe_rec, PROBE_MAX * 16, st);
+    }
+    hipLaunchKernelGGL(vv_nan_probe_kernel, dim3(64), dim3(256), 0, st, (const float*)p, (int)n, ctx->probe_rec + 4 * id);
+}
+static void nan_probe_report(vv_ctx* ctx, hipStream_t st, const char* what) {
+    if (ctx->probe_on != 1 || !ctx->probe_rec) return;
+    std::vector<unsigned> h(PROBE_MAX * 4);
+    const hipError_t e1 = hipStreamSynchronize(st);
+    const hipError_t e2 = hipMemcpy(h.data(), ctx->probe_rec, PROBE_MAX * 16, hipMemcpyDeviceToHost);
+    const int call = ctx->probe_calls++;
+    if (e1 != hipSuccess || e2 != hipSuccess) { fprintf(stderr, "[nan_probe] %s call %d: sync %d copy %d\n", what, call, (int)e1, (int)e2); (void)hipGetLastError(); return; }
+    { const size_t ns = ctx->probe_names.size(); bool tail_dirty = false;      // the words past the last stage must still be the memset's zeros
+      for (size_t i = 4 * ns; i < (size_t)PROBE_MAX * 4; ++i) if (h[i]) { tail_dirty = true; break; }
+      if (tail_dirty) fprintf(stderr, "[nan_probe] %s call %d (prof %d): record buffer %p holds words nobody wrote: %08x %08x %08x %08x | %08x %08x %08x %08x (last 4 words)\n",
+                              what, call, (int)ctx->prof_on, (void*)ctx->probe_rec, h[0], h[1], h[2], h[3], h[4092], h[4093], h[4094], h[4095]); }
+    int bad = 0;
+    for (size_t i = 0; i < ctx->probe_names.size(); ++i) if (h[4 * i]) bad++;
+    if (!bad) { if (call < 6) fprintf(stderr, "[nan_probe] %s call %d: %zu stages clean\n", what, call, ctx->probe_names.size()); return; }
+    fprintf(stderr, "[nan_probe] %s call %d: %d of %zu stages hold non-finite values\n", what, call, bad, ctx->probe_names.size());
+    int shown = 0;
+    for (size_t i = 0; i < ctx->probe_names.size() && shown < 12; ++i) {
+        float mx; memcpy(&mx, &h[4 * i + 2], 4);
+        if (h[4 * i] || (i + 1 < ctx->probe_names.size() && h[4 * (i + 1)] && !shown)) {
+            fprintf(stderr, "[nan_probe]   stage %3zu %-28s non-finite %u (first at %u), finite absmax %.4e\n", i, ctx->probe_names[i].c_str(), h[4 * i],
+                    h[4 * i] ? 0xffffffffu - h[4 * i + 1] : 0u, mx);
+            if (h[4 * i]) shown++;
+        }
+    }
+}
+
 static int ring_acquire(vv_ctx* ctx) {
     const int slot = ctx->ring_i;
     ctx->ring_i = (ctx->ring_i + 1) % vv_ctx::RING;
@@ -311,6 +368,8 @@ static void* dalloc(vv_ctx* ctx, size_t bytes, bool zero = true) {
     if (bytes == 0) bytes = 16;
     if (hipMalloc(&p, bytes) != hipSuccess) { fail(ctx, "hipMalloc(%zu) failed", bytes); return nullptr; }
     if (zero) hipMemset(p, 0, bytes);
+    else { static const int poison = [] { const char* e = getenv("VVHIP_POISON"); return (e && e[0] == '1') ? 1 : 0; }();      // debugging: NaN words in
+           if (poison) hipMemset(p, 0xFF, bytes); }                                                                              // every buffer handed out un-zeroed
     if (ctx) ctx->allocs.insert(p);
     return p;
 }
@@ -657,7 +716,7 @@ static int run_codec(vv_ctx* ctx, CodecNet& net, int sl, int F, float* out, hipS
             Stage& pv = stages[i - 1];
             const int Tp = pv.Tpf * F;
             if (tail_valid < Tp)
-                HIPCHK(ctx, hipMemsetAsync(pv.xfinal + ((size_t)pv.hist + tail_valid) * pv.C, 0, (size_t)(Tp - tail_valid) * pv.C * 4, st));
+                VVCHK(vv_zero_launch(pv.xfinal + ((size_t)pv.hist + tail_valid) * pv.C, (size_t)(Tp - tail_valid) * pv.C * 4, st));
             const int r = pv.Tpf / s.Tpf;                       // this stage's incoming stride
             tail_valid = (tail_valid + r - 1) / r;
         }
@@ -848,6 +907,12 @@ static int graphed(vv_ctx* ctx, const std::string& key, hipStream_t st, F&& body
             const int r = body();
             const hipError_t e = hipStreamEndCapture(st, &graph);
             if (r == 0 && e == hipSuccess) {
+                size_t nn = 0;
+                if (hipGraphGetNodes(graph, nullptr, &nn) == hipSuccess && nn) {
+                    std::vector<hipGraphNode_t> nodes(nn);
+                    if (hipGraphGetNodes(graph, nodes.data(), &nn) == hipSuccess)
+                        for (size_t i = 0; i < nn; ++i) { hipGraphNodeType t; if (hipGraphNodeGetType(nodes[i], &t) == hipSuccess && t != hipGraphNodeTypeKernel) ctx->foreign_nodes++; }
+                }
                 HIPCHK(ctx, hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0));
                 hipGraphDestroy(graph);
                 captured = true;
@@ -1354,7 +1419,7 @@ static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float*
                    int attn_S, int64_t kv_positions = 0, int attn_W = 4) {
     const vv_config& c = ctx->c;
     const int H = ctx->H, D = ctx->D, Hq = ctx->Hq, Hkv = ctx->Hkv, I = ctx->I, QKV = ctx->QKV;
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h, x_in, (size_t)R * H * 4, hipMemcpyDeviceToDevice, st));
+    VVCHK(vv_copy_launch(ctx->h, x_in, (size_t)R * H * 4, st));        // copies / fills inside captured sequences are kernels, never memcpy / memset nodes (misc.hip)
     int hp = 0;                                    // extra parts the residual stream h currently consists of
     const int hps = ctx->c.max_rows * H;
     if (contiguous && ctx->tile3_ok && R >= 64) {
@@ -1390,7 +1455,7 @@ static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float*
         }
         ctx->launches++;
         if (final_norm) VVCHK(vv_rmsnorm_rows_launch(ctx->h, H, hidden_out, H, ctx->lm_norm, R, H, c.lm_eps, st));
-        else HIPCHK(ctx, hipMemcpyAsync(hidden_out, ctx->h, (size_t)R * H * 4, hipMemcpyDeviceToDevice, st));
+        else VVCHK(vv_copy_launch(hidden_out, ctx->h, (size_t)R * H * 4, st));
         return 0;
     }
     const bool p16 = R > 4 && R <= 16 && ctx->p16_ok && fused_attn;      // batch decode rows: packed-activation projections
@@ -1489,7 +1554,7 @@ static int lm_body(vv_ctx* ctx, hipStream_t st, int R, const float* x_in, float*
     }
     ctx->launches++;
     if (final_norm) VVCHK(vv_rmsnorm_rows_launch(ctx->h, H, hidden_out, H, ctx->lm_norm, R, H, c.lm_eps, st));
-    else HIPCHK(ctx, hipMemcpyAsync(hidden_out, ctx->h, (size_t)R * H * 4, hipMemcpyDeviceToDevice, st));
+    else VVCHK(vv_copy_launch(hidden_out, ctx->h, (size_t)R * H * 4, st));
     return 0;
 }
 
@@ -1692,6 +1757,7 @@ static int head_eval(vv_ctx* ctx, hipStream_t st, int rows, const float* zrows, 
     if (!have_x) {
         VVGemm gi = mk_gemm(ctx->h_in, zrows, xh, rows, H, L, L, H);
         GEMM(gi);
+        nan_probe(ctx, st, "in-proj xh", xh, (size_t)rows * H);
     }
     int xp = 0;                                    // extra parts xh currently consists of
     const int xps = 16 * H;
@@ -1745,7 +1811,12 @@ static int head_eval(vv_ctx* ctx, hipStream_t st, int rows, const float* zrows, 
         g2.epi = VV_EPI_GATED_RESID; g2.gate = base + 2 * H; g2.ld_gate = MODW; g2.nt = 1;
         g2.ya = cur; g2.n_ya = xp; g2.part_stride = xps;
         xp = ksplit_parts(ctx, g2, nxt, xps);
+        if (ctx->probe_on == 1) { char nm[64]; snprintf(nm, 64, "layer %d hact (parts in %d)", l, g1.n_xa); nan_probe(ctx, st, nm, ctx->hact, (size_t)rows * HF); }
         GEMM(g2);
+        if (ctx->probe_on == 1) {
+            char nm[64]; snprintf(nm, 64, "layer %d xh", l); nan_probe(ctx, st, nm, xh, (size_t)rows * H);
+            for (int q = 0; q < xp; ++q) { snprintf(nm, 64, "layer %d part %d", l, q); nan_probe(ctx, st, nm, nxt + (size_t)q * xps, (size_t)rows * H); }
+        }
     }
     const float* fb = mod + (size_t)HL * 3 * H;
     if (rows > 4 && rows <= 16 && ctx->p16_ok && (HF % 32) == 0 && ctx->p16_fuse && sh_tiles && coef && HL > 0) {
@@ -1795,10 +1866,11 @@ static int sample_body(vv_ctx* ctx, hipStream_t st, int n, const float* cond, co
     const vv_config& c = ctx->c;
     const int H = ctx->H, L = c.latent_dim;
     const int rows = 2 * n;
+    ctx->probe_names.clear();
+    nan_probe(ctx, st, "cond (input)", cond, (size_t)rows * H);
+    nan_probe(ctx, st, "noise (input)", noise, (size_t)n * L);
     // both CFG halves see the same noisy latent (modeling_vibevoice_inference.py:703-704)
-    HIPCHK(ctx, hipMemcpyAsync(ctx->zz, noise, (size_t)n * L * 4, hipMemcpyDeviceToDevice, st));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->zz + (size_t)n * L, noise, (size_t)n * L * 4, hipMemcpyDeviceToDevice, st));
-    HIPCHK(ctx, hipMemsetAsync(ctx->x0p, 0, (size_t)n * L * 4, st));
+    VVCHK(vv_sampler_init_launch(noise, ctx->zz, ctx->x0p, n * L, st));
     VVGemm gc = mk_gemm(ctx->h_cond, cond, ctx->cproj, rows, H, H, H, H);
     gc.nt = 1;
     GEMM(gc);
@@ -1827,6 +1899,8 @@ static int sample_body(vv_ctx* ctx, hipStream_t st, int n, const float* cond, co
         }
         }
     }
+    nan_probe(ctx, st, "cproj", ctx->cproj, (size_t)rows * H);
+    if (batch_ada) nan_probe(ctx, st, "mod_all", ctx->mod_all, (size_t)rows * ctx->n_steps * MODW);
     const bool sh_ok = batch_ada && rows > 4 && rows <= 16 && ctx->p16_fuse && ctx->p16_shift;
     if (sh_ok) {
         // the shift rows of every (solver step, layer) -- and the final layer's -- as packed bf16 tiles, one launch per frame:
@@ -1846,10 +1920,16 @@ static int sample_body(vv_ctx* ctx, hipStream_t st, int n, const float* cond, co
         const int hr = head_eval(ctx, st, rows, gen ? ctx->zz2 : ctx->zz, ctx->temb + (size_t)i * H, ctx->eps, ctx->coef + i * 6, cfg, mod_i, sn, sht,
                                  gen, have_x, seam);
         if (hr < 0) return -1;
+        if (ctx->probe_on == 1) {
+            char nm[64];
+            snprintf(nm, 64, "step %d z%s", i, hr == 1 ? " (seam, next gen)" : ""); nan_probe(ctx, st, nm, (gen ^ (hr == 1)) ? ctx->zz2 : ctx->zz, (size_t)rows * L);
+            snprintf(nm, 64, "step %d x0p", i); nan_probe(ctx, st, nm, (gen ^ (hr == 1)) ? ctx->x0p2 : ctx->x0p, (size_t)n * L);
+            if (hr == 1) { snprintf(nm, 64, "step %d next xh", i); nan_probe(ctx, st, nm, (gen ^ 1) ? ctx->xh2 : ctx->xh, (size_t)rows * H); }
+        }
         have_x = (hr == 1);
         if (have_x) gen ^= 1;
     }
-    HIPCHK(ctx, hipMemcpyAsync(latent_out, gen ? ctx->zz2 : ctx->zz, (size_t)n * L * 4, hipMemcpyDeviceToDevice, st));
+    VVCHK(vv_copy_launch(latent_out, gen ? ctx->zz2 : ctx->zz, (size_t)n * L * 4, st));
     return 0;
 }
 
@@ -1860,7 +1940,9 @@ extern "C" int vv_diffusion_sample(vv_ctx* ctx, void* stream, int n, const float
     if (ctx->sde_on) return fail(ctx, "the schedule is stochastic (vv_set_schedule_sde): sample with vv_diffusion_sample_sde and its per-step noise");
     ctx->launches = 0;
     char key[128]; snprintf(key, 128, "samp:%d:%p:%p:%p:%a", n, (const void*)cond_dev, (const void*)noise_dev, (void*)latent_out_dev, cfg_scale);
-    return graphed(ctx, key, st, [&]() { return sample_body(ctx, st, n, cond_dev, noise_dev, cfg_scale, latent_out_dev); });
+    const int rc = graphed(ctx, key, st, [&]() { return sample_body(ctx, st, n, cond_dev, noise_dev, cfg_scale, latent_out_dev); });
+    nan_probe_report(ctx, st, key);
+    return rc;
 }
 
 // The stochastic solver: step_noise_dev = [n_steps][n][latent_dim] fp32, the variance noise scheduler.step() draws per solver step
@@ -1922,7 +2004,7 @@ extern "C" int vv_semantic_encode(vv_ctx* ctx, void* stream, int slot, int frame
     ctx->launches = 0;
     char key[128]; snprintf(key, 128, "senc:%d:%d:%p:%p", slot, frames, (const void*)audio_dev, (void*)sem_out_dev);
     return graphed(ctx, key, st, [&]() {
-        HIPCHK(ctx, hipMemcpyAsync(net.in_buf[slot] + 6, audio_dev, (size_t)frames * ctx->hop * 4, hipMemcpyDeviceToDevice, st));
+        VVCHK(vv_copy_launch(net.in_buf[slot] + 6, audio_dev, (size_t)frames * ctx->hop * 4, st));
         return run_codec(ctx, net, slot, frames, sem_out_dev, st);
     });
 }
@@ -1993,7 +2075,7 @@ extern "C" int vv_codec_chain_batch(vv_ctx* ctx, void* stream, int n, const int*
                     if (run_codec(ctx, dec, sl, 1, audio, ss, bd ? dec.kd : 0, ns_d, true, true)) return -1;
                 }
                 if (sem) {
-                    HIPCHK(ctx, hipMemcpyAsync(senc.in_buf[sl] + 6, audio, (size_t)hop * 4, hipMemcpyDeviceToDevice, ss));
+                    VVCHK(vv_copy_launch(senc.in_buf[sl] + 6, audio, (size_t)hop * 4, ss));
                     if (run_codec(ctx, senc, sl, 1, sem_out_dev + (size_t)j * S, ss, 0, be ? senc.ke : ns_e, !be, !be)) return -1;
                 }
                 if (fork) HIPCHK(ctx, hipEventRecord(ctx->ev_join[j], ss));
@@ -2027,7 +2109,7 @@ extern "C" int vv_acoustic_encode_ragged(vv_ctx* ctx, void* stream, int frames, 
     const int pass = ctx->enc_pass > 0 ? std::min(ctx->enc_pass, net.Fmax) : net.Fmax;
     for (int f0 = 0; f0 < frames; f0 += pass) {
         const int F = std::min(pass, frames - f0);
-        HIPCHK(ctx, hipMemcpyAsync(net.in_buf[0] + 6, wav_dev + (size_t)f0 * ctx->hop, (size_t)F * ctx->hop * 4, hipMemcpyDeviceToDevice, st));
+        VVCHK(vv_copy_launch(net.in_buf[0] + 6, wav_dev + (size_t)f0 * ctx->hop, (size_t)F * ctx->hop * 4, st));
         const int64_t v = valid_samples - (int64_t)f0 * ctx->hop;            // real samples inside this pass
         const int tail = (f0 + F == frames && v < (int64_t)F * ctx->hop) ? (int)v : -1;
         if (run_codec(ctx, net, 0, F, mean_out_dev + (size_t)f0 * L, st, 0, -1, true, true, tail)) return -1;
@@ -2206,6 +2288,7 @@ extern "C" int64_t vv_stat(vv_ctx* ctx, int what) {
         case 0: return ctx->launches;
         case 2: return ctx->prof_raw_ns;          // last profile: sum of raw event-pair times over the decode-GEMV launches
         case 3: return ctx->prof_ev_over_ns;      // last profile: time of an empty event pair
+        case 5: return ctx->foreign_nodes;        // nodes of the captured graphs that are not kernel launches (expected: 0)
         case 4: return ctx->capture_fallbacks;    // stream captures that did not close and ran eagerly instead (multi-threaded lanes)
         default: return (int64_t)ctx->graphs.size();
     }

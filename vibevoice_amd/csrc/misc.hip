@@ -370,6 +370,27 @@ __global__ void vv_affine_kernel(const float* __restrict__ x, float* __restrict_
     if (i < n) y[i] = x[i] * mul + add;
 }
 
+// Plain copies and zero fills as kernels of our own.  The launch sequences of a decode step are captured into hipGraphs, and a MEMSET NODE of a
+// replayed graph was observed (round 6, ROCm 7.0.2 + 7.2 user space, every GPU of the pool) to fill its range with stale 16-byte patterns
+// instead of zeros once other graph executables had been created and destroyed in the process (profiles/r06_memset_node_*):
+// the sampler's "previous x0" buffer then held whatever words the pattern was, harmless as denormals (x 0 = 0), a NaN in the processes
+// where a word of the pattern had all exponent bits set.  Nothing the engine captures uses hipMemsetAsync / hipMemcpyAsync device-to-device any more.
+__global__ void vv_copy_words_kernel(const unsigned* __restrict__ src, unsigned* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+__global__ void vv_copy_quads_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+__global__ void vv_zero_words_kernel(unsigned* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = 0u;
+}
+// the sampler's start of a frame: both CFG halves of the noisy latent = the noise rows, previous x0 prediction = 0 (one launch for
+// what used to be two copy nodes and a memset node)
+__global__ void vv_sampler_init_kernel(const float* __restrict__ noise, float* __restrict__ z, float* __restrict__ x0p, int nL) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nL) { const float v = noise[i]; z[i] = v; z[nL + i] = v; x0p[i] = 0.f; }
+}
+
 // y[i] = a[i] + b[i]
 __global__ void vv_add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -683,6 +704,29 @@ int vv_cfg_dpm_launch(const float* eps, float* x, float* x0_prev, const float* c
 }
 int vv_affine_launch(const float* x, float* y, float mul, float add, int n, hipStream_t s) {
     hipLaunchKernelGGL(vv_affine_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, y, mul, add, n);
+    return okk();
+}
+int vv_copy_launch(void* dst, const void* src, size_t bytes, hipStream_t s) {      // bytes: a multiple of 4
+    if (bytes == 0) return 0;
+    if ((bytes & 3) || ((uintptr_t)dst & 3) || ((uintptr_t)src & 3)) { g_vv_launch_err = (int)hipErrorInvalidValue; return -1; }
+    if (!(bytes & 15) && !((uintptr_t)dst & 15) && !((uintptr_t)src & 15)) {
+        const size_t n = bytes >> 4;
+        hipLaunchKernelGGL(vv_copy_quads_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, s, (const uint4*)src, (uint4*)dst, n);
+    } else {
+        const size_t n = bytes >> 2;
+        hipLaunchKernelGGL(vv_copy_words_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, s, (const unsigned*)src, (unsigned*)dst, n);
+    }
+    return okk();
+}
+int vv_zero_launch(void* dst, size_t bytes, hipStream_t s) {                        // bytes: a multiple of 4
+    if (bytes == 0) return 0;
+    if ((bytes & 3) || ((uintptr_t)dst & 3)) { g_vv_launch_err = (int)hipErrorInvalidValue; return -1; }
+    const size_t n = bytes >> 2;
+    hipLaunchKernelGGL(vv_zero_words_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, s, (unsigned*)dst, n);
+    return okk();
+}
+int vv_sampler_init_launch(const float* noise, float* z, float* x0p, int nL, hipStream_t s) {
+    hipLaunchKernelGGL(vv_sampler_init_kernel, dim3((nL + 255) / 256), dim3(256), 0, s, noise, z, x0p, nL);
     return okk();
 }
 int vv_add_launch(const float* a, const float* b, float* y, int n, hipStream_t s) {
