@@ -185,6 +185,13 @@ class Engine:
         if self._ctx:
             self._chk(self.lib.vv_check(self._ctx, self._s), "vv_check")
             self._warn_capture_fallbacks()
+            n = int(self.lib.vv_stat(self._ctx, 5))
+            if n:
+                # an invariant of the library, checked where every generate() ends: a memset node of a replayed hipGraph was seen to
+                # fill with stale words on this runtime, so captured sequences hold kernel launches only
+                raise RuntimeError(f"vibevoice_amd: {n} memset / memcpy node(s) inside this engine's captured hipGraphs -- a copy or fill "
+                                   "was enqueued with hipMemsetAsync / hipMemcpyAsync inside a captured sequence; use the library's copy "
+                                   "and fill kernels (csrc/misc.hip: vv_copy_launch, vv_zero_launch)")
 
     def _warn_capture_fallbacks(self):
         """One warning per engine the first time a stream capture did not close and its work ran eagerly instead (vv_stat(ctx, 4) > 0):
