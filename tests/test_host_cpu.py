@@ -681,3 +681,39 @@ def test_bench_checkpoint_hook_resolves_model_directories(tmp_path, monkeypatch)
     (tmp_path / "config.json").write_text(json.dumps(CONFIGS["1.5b"]))
     save_file({"x": torch.zeros(1)}, str(tmp_path / "model.safetensors"))
     assert bench.find_checkpoint("1.5b") == str(tmp_path) and bench.find_checkpoint("0.5b-streaming") is None
+
+
+def test_engine_sync_refuses_captured_graphs_that_hold_memset_nodes():
+    """Round 6: a memset node of a replayed hipGraph filled with stale words on this runtime, so the library captures kernel
+    launches only and Engine.sync() -- where every generate() ends -- raises when vv_stat(ctx, 5) says otherwise.  Host logic only: the
+    engine object is built around a stub of the C library."""
+    import pytest
+    from vibevoice_amd.engine import Engine
+
+    class Lib:
+        def __init__(self, foreign):
+            self.foreign = foreign
+
+        def vv_check(self, ctx, stream):
+            return 0
+
+        def vv_stat(self, ctx, what):
+            return {4: 0, 5: self.foreign}.get(what, 0)
+
+        def vv_destroy(self, ctx):
+            return None
+
+    class Stream:
+        cuda_stream = 0
+
+        def synchronize(self):
+            return None
+
+    def make(foreign):
+        e = object.__new__(Engine)
+        e.stream, e.lib, e._ctx, e._fallback_warned = Stream(), Lib(foreign), 1, False
+        return e
+
+    make(0).sync()
+    with pytest.raises(RuntimeError, match="memset / memcpy node"):
+        make(2).sync()
