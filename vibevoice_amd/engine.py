@@ -186,7 +186,7 @@ class Engine:
             self._chk(self.lib.vv_check(self._ctx, self._s), "vv_check")
             self._warn_capture_fallbacks()
             n = int(self.lib.vv_stat(self._ctx, 5))
-            if n:
+            if n and os.environ.get("VVHIP_ALLOW_FOREIGN_NODES") != "1":      # the escape: A/B runs against library builds from before round 6
                 # an invariant of the library, checked where every generate() ends: a memset node of a replayed hipGraph was seen to
                 # fill with stale words on this runtime, so captured sequences hold kernel launches only
                 raise RuntimeError(f"vibevoice_amd: {n} memset / memcpy node(s) inside this engine's captured hipGraphs -- a copy or fill "
