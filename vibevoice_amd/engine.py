@@ -6,6 +6,7 @@ inside libvvhip.so.  There is no fallback path: constructing an Engine without
 the shared library or without a GPU raises.
 """
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence
 
