@@ -402,6 +402,9 @@ class VibeVoiceForConditionalGenerationInference:
         # as ONE engine call (vv_codec_chain_batch); the sampler enqueued speculatively behind the LM pass
         self.concurrent_codecs = True
         self.batched_codecs = hasattr(engine, "codec_chain_batch")
+        # one utterance's decode -> semantic re-encode as ONE engine call (one captured sequence instead of two: a graph-to-graph transition
+        # costs ~7 us against ~1.5 us between two kernels of one graph); VVHIP_CHAIN_SINGLE=0: the two calls (the A/B of round 6)
+        self.chain_single = os.environ.get("VVHIP_CHAIN_SINGLE", "1") != "0"
         self.speculate_sampling = True
         self.last_stats = {}
 
@@ -1080,7 +1083,7 @@ class VibeVoiceForConditionalGenerationInference:
                     e.codec_reset(u.slot)
         if diff:
             # ---- codec decode, semantic encode, connectors (:636-672) ----
-            if len(diff) > 1 and self.batched_codecs:
+            if self.batched_codecs and (len(diff) > 1 or self.chain_single):
                 # the reference decodes / re-encodes the step's diffusion rows as one batch (:636-672): one engine call, the
                 # weight-heavy tokenizer stages read their weights once for all rows
                 e.codec_chain_batch([u.slot for u in diff], self._latent[:n], self._audio[:n],
@@ -1438,6 +1441,7 @@ class VibeVoiceForConditionalGenerationInference:
         m.set_ddpm_inference_steps(self.ddpm_inference_steps)
         m._sched_cfg = dict(self._sched_cfg)
         m.concurrent_codecs, m.batched_codecs, m.speculate_sampling = self.concurrent_codecs, self.batched_codecs, self.speculate_sampling
+        m.chain_single = self.chain_single
         return m
 
     def generate_interleaved(self, requests: List[dict], lanes: int = 2, audio_streamer=None, **kwargs) -> List[VibeVoiceGenerationOutput]:
