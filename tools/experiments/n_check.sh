@@ -9,4 +9,4 @@ for f in ("r06_torchrun_n1","r06_shared_gpu_n2_controlflow"):
         print(f, d["n_gpus"], d["value"], d["ms_per_step"], "parity", (d.get("parity") or {}).get("within_bounds"), "c3", c3.get("value"), c3.get("ms_per_step"), "rccl" in d["extra"] and bool(d["extra"]["rccl"]))
     except Exception as e: print(f, "ERR", repr(e)[:200])
 PY
-tail -3 $O/t1.err $O/d2.err | cut -c1-200
+tail -n 3 $O/t1.err $O/d2.err | cut -c1-200
