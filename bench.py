@@ -812,6 +812,9 @@ def bench_decode(args, spec, ctx, with_cpu, with_roofline, with_parity=False):
                    "parallelism": f"utterance-dp{world}"},
         "roofline": roof, "cpu_baseline": cpu, "gpu_eager_baseline": eager, "parity": parity, "parity_long": parity_long,
         "extra": {"frames_timed": frames, "weights_load_s": round(load_s, 2), "libvvhip_build_id": _build_id(),
+                  # hipGraph executables this engine holds, captures that fell back to eager runs, nodes of the captured graphs that are not
+                  # kernel launches (0 by construction: DESIGN.md section 8, the memset node of a replayed graph)
+                  "captured_graphs": {"executables": eng.stat(1), "capture_fallbacks": eng.stat(4), "non_kernel_nodes": eng.stat(5)},
                   "weights_broadcast": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in bc.items()},
                   "weights_source": (f"checkpoint {ckpt}" if ckpt else "synthetic (seeded N(0, 0.02^2) at the config's shapes)"),
                   "per_rank_ms_per_step": per_rank_ms, "rccl": rccl, "warmup_s": round(warm_s, 3), "first_audio": first_audio,
